@@ -1,0 +1,562 @@
+// TEST INFRASTRUCTURE ONLY ("Oracle B") -- never shipped, never linked into the product.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+//
+// A plain CPU restatement of the reference's depth-filter path, one function per
+// reference kernel / host method, each citing the reference file:line it follows
+// (paths relative to /root/reference).  Arithmetic is fp32 evaluated exactly as the
+// reference's expressions are written (operation order, float/double promotions),
+// no FMA contraction, IEEE / and sqrt.  Pinning:
+//   * built with -DRMD_ORACLE_LIBM=1 (glibc expf/sinf/acosf) this file must agree BIT
+//     FOR BIT with Oracle A = the reference's own sources run through oracle/cuda_shim
+//     (tests/test_oracle_pin.py) -- that pins the restatement to the reference;
+//   * built without it, the three transcendentals come from rmd_math.h, the header the
+//     HIP kernels compile too, and the HIP path must agree bit for bit with this file.
+// TV-L1: the reference kernel races across 16x16 tiles; the semantics
+// restated here are "all duals, then all primals", which equals the reference kernel
+// executed with its blocks serialised in row-major order (what Oracle A does).
+#include <float.h>
+#include <math.h>
+#include <omp.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "rmd_math.h"
+
+#ifndef RMD_PATCH_SIDE
+#define RMD_PATCH_SIDE 5
+#endif
+#ifndef RMD_MAX_EXTENT
+#define RMD_MAX_EXTENT 100
+#endif
+
+#ifdef RMD_ORACLE_LIBM
+#define ORC_EXPF expf
+#define ORC_SINF sinf
+#define ORC_ACOSF acosf
+#else
+#define ORC_EXPF rmd_expf
+#define ORC_SINF rmd_sinf
+#define ORC_ACOSF rmd_acosf
+#endif
+
+namespace {
+
+const int SIDE = RMD_PATCH_SIDE;
+const int OFFSET = -RMD_PATCH_SIDE / 2;  // mvs_device_data.cuh:42 (C truncation)
+const int AREA = RMD_PATCH_SIDE * RMD_PATCH_SIDE;  // mvs_device_data.cuh:43
+
+enum { UPDATE = 0, CONVERGED = 1, BORDER = 2, DIVERGED = 3, NO_MATCH = 4, NOT_VISIBLE = 5 };  // seed_matrix.cuh:33-41
+
+struct V3 { float x, y, z; };
+struct V2 { float x, y; };
+
+inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // helper_math.h:1248-1251
+inline float dot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }              // helper_math.h:1244-1247
+inline float norm(V3 v) { return sqrtf(dot(v, v)); }                        // helper_vector_types.cuh:23-28
+inline float norm(V2 v) { return sqrtf(dot(v, v)); }
+inline V3 normalize(V3 v) {  // helper_math.h:1309-1313
+  const float inv = rmd_rsqrtf(dot(v, v));
+  return V3{v.x * inv, v.y * inv, v.z * inv};
+}
+inline V2 normalize(V2 v) {  // helper_math.h:1304-1308
+  const float inv = rmd_rsqrtf(dot(v, v));
+  return V2{v.x * inv, v.y * inv};
+}
+inline V3 scale(V3 v, float s) { return V3{v.x * s, v.y * s, v.z * s}; }
+
+// se3.cuh: 3x4 row-major [R|t]
+struct Pose { float d[12]; };
+inline Pose pose_inverse(const Pose& p) {  // se3.cuh:78-95
+  Pose r;
+  const float* d = p.d;
+  r.d[0] = d[0]; r.d[1] = d[4]; r.d[2] = d[8];
+  r.d[4] = d[1]; r.d[5] = d[5]; r.d[6] = d[9];
+  r.d[8] = d[2]; r.d[9] = d[6]; r.d[10] = d[10];
+  r.d[3] = -d[0] * d[3] - d[4] * d[7] - d[8] * d[11];
+  r.d[7] = -d[1] * d[3] - d[5] * d[7] - d[9] * d[11];
+  r.d[11] = -d[2] * d[3] - d[6] * d[7] - d[10] * d[11];
+  return r;
+}
+inline Pose pose_compose(const Pose& l, const Pose& r) {  // se3.cuh:144-162
+  Pose o;
+  for (int row = 0; row < 3; ++row) {
+    const float l0 = l.d[4 * row], l1 = l.d[4 * row + 1], l2 = l.d[4 * row + 2], lt = l.d[4 * row + 3];
+    for (int col = 0; col < 3; ++col) o.d[4 * row + col] = l0 * r.d[col] + l1 * r.d[4 + col] + l2 * r.d[8 + col];
+    o.d[4 * row + 3] = lt + l0 * r.d[3] + l1 * r.d[7] + l2 * r.d[11];
+  }
+  return o;
+}
+inline V3 pose_rotate(const Pose& p, V3 v) {  // se3.cuh:109-115
+  return V3{p.d[0] * v.x + p.d[1] * v.y + p.d[2] * v.z, p.d[4] * v.x + p.d[5] * v.y + p.d[6] * v.z,
+            p.d[8] * v.x + p.d[9] * v.y + p.d[10] * v.z};
+}
+inline V3 pose_translation(const Pose& p) { return V3{p.d[3], p.d[7], p.d[11]}; }
+inline V3 pose_apply(const Pose& p, V3 v) {  // se3.cuh:164-168: translate(rotate(p))
+  const V3 r = pose_rotate(p, v);
+  return V3{r.x + p.d[3], r.y + p.d[7], r.z + p.d[11]};
+}
+
+struct Camera {  // pinhole_camera.cuh:27-63
+  float fx, fy, cx, cy;
+  V3 cam2world(float u, float v) const { return V3{(u - cx) / fx, (v - cy) / fy, 1.0f}; }
+  V2 world2cam(V3 p) const { return V2{fx * p.x / p.z + cx, fy * p.y / p.z + cy}; }
+  float one_pix_angle() const { return atan2f(1.0f, 2.0f * fx) * 2.0f; }
+};
+
+inline long clampi(long v, long lo, long hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// One fetch through a clamp-addressed, linear-filtered, unnormalised texture
+// (texture_memory.cuh:45-66) under the filter rule of rmd_math.h.
+float tex_linear(const float* plane, int w, int h, float x, float y) {
+  if (!(isfinite(x) && isfinite(y))) return rmd_nanf();
+  const float xb = x - 0.5f, yb = y - 0.5f;
+  const float fi = floorf(xb), fj = floorf(yb);
+  const float a = xb - fi, b = yb - fj;
+  const float wmax = static_cast<float>(w - 1), hmax = static_cast<float>(h - 1);
+  const long i0 = fi < 0.0f ? 0 : (fi > wmax ? w - 1 : static_cast<long>(fi));
+  const long j0 = fj < 0.0f ? 0 : (fj > hmax ? h - 1 : static_cast<long>(fj));
+  const long i1 = (fi + 1.0f) < 0.0f ? 0 : ((fi + 1.0f) > wmax ? w - 1 : static_cast<long>(fi + 1.0f));
+  const long j1 = (fj + 1.0f) < 0.0f ? 0 : ((fj + 1.0f) > hmax ? h - 1 : static_cast<long>(fj + 1.0f));
+  const float t00 = plane[j0 * w + i0], t10 = plane[j0 * w + i1], t01 = plane[j1 * w + i0], t11 = plane[j1 * w + i1];
+  const float h0 = a == 0.0f ? t00 : rmd_lerp(a, t00, t10);
+  const float h1 = a == 0.0f ? t01 : rmd_lerp(a, t01, t11);
+  return b == 0.0f ? h0 : rmd_lerp(b, h0, h1);
+}
+
+struct Seeds {
+  int w, h;
+  Camera cam;
+  std::vector<float> ref, cur, sum_templ, denom, mu, sigma_sq, a, b, match;  // match: 2 floats / pixel
+  std::vector<int> conv;
+  float min_depth, max_depth, avg_depth, depth_range, sigma_sq_max;  // mvs_device_data.cuh:30-37
+  float eta_inlier, eta_outlier, epsilon;
+  Pose T_world_ref;
+  float dist_from_ref;
+  // statistics of the last update(): seeds that entered the search, NCC evaluations done
+  long long last_live_seeds, last_ncc_evals, last_steps;
+};
+
+// seed_init.cu:27-61
+void seed_init(Seeds& s) {
+  const int w = s.w, h = s.h;
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      float sum_t = 0.0f, sum_t_sq = 0.0f;
+      for (int py = 0; py < SIDE; ++py)
+        for (int px = 0; px < SIDE; ++px) {
+          const float t = s.ref[clampi(y + OFFSET + py, 0, h - 1) * w + clampi(x + OFFSET + px, 0, w - 1)];
+          sum_t += t;
+          sum_t_sq += t * t;
+        }
+      const size_t i = static_cast<size_t>(y) * w + x;
+      s.sum_templ[i] = sum_t;
+      s.denom[i] = static_cast<float>(static_cast<double>(AREA) * sum_t_sq - static_cast<double>(sum_t) * sum_t);
+      s.mu[i] = s.avg_depth;
+      s.sigma_sq[i] = s.sigma_sq_max;
+      s.a[i] = 10.0f;
+      s.b[i] = 10.0f;
+    }
+}
+
+// seed_check.cu:28-67
+void seed_check(Seeds& s) {
+  const int w = s.w, h = s.h;
+  const size_t x_hi = static_cast<size_t>(w) - SIDE - 1, y_hi = static_cast<size_t>(h) - SIDE - 1;  // size_t, as written
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      const size_t i = static_cast<size_t>(y) * w + x;
+      if (static_cast<size_t>(x) > x_hi || static_cast<size_t>(y) > y_hi || x < SIDE || y < SIDE) {
+        s.conv[i] = BORDER;
+        continue;
+      }
+      const float sig = s.sigma_sq[i], a = s.a[i], b = s.b[i];
+      if ((a / (a + b)) > s.eta_inlier && sig < s.epsilon) s.conv[i] = CONVERGED;
+      else if ((a - 1) / (a + b - 2) < s.eta_outlier) s.conv[i] = DIVERGED;
+      else s.conv[i] = UPDATE;
+    }
+}
+
+// epipolar_match.cu:37-140
+void epipolar_match(Seeds& s, const Pose& T_curr_ref) {
+  const int w = s.w, h = s.h;
+  long long live = 0, evals = 0, steps = 0;
+#pragma omp parallel for schedule(dynamic, 2) reduction(+ : live, evals, steps)
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      const size_t i = static_cast<size_t>(y) * w + x;
+      const int state = s.conv[i];
+      if (state == BORDER || state == CONVERGED || state == DIVERGED) continue;
+      ++live;
+      const float mu = s.mu[i];
+      const float sigma = sqrtf(s.sigma_sq[i]);
+      const V3 f_ref = normalize(s.cam.cam2world(static_cast<float>(x), static_cast<float>(y)));
+      const V2 px_mean = s.cam.world2cam(pose_apply(T_curr_ref, scale(f_ref, mu)));
+      const float d_lo = mu - 3.0f * sigma;
+      const V2 px_min = s.cam.world2cam(pose_apply(T_curr_ref, scale(f_ref, d_lo > 0.01f ? d_lo : 0.01f)));
+      const V2 px_max = s.cam.world2cam(pose_apply(T_curr_ref, scale(f_ref, mu + (3.0f * sigma))));
+      const V2 epi_line = V2{px_max.x - px_min.x, px_max.y - px_min.y};
+      const V2 epi_dir = normalize(epi_line);
+      const float len = norm(epi_line);
+      const float max_extent = static_cast<float>(RMD_MAX_EXTENT);
+      const float half_length = 0.5f * (len < max_extent ? len : max_extent);
+      const float sum_templ = s.sum_templ[i], denom = s.denom[i];
+      float best_ncc = -1.0f;
+      V2 best_px = V2{0.0f, 0.0f};
+      bool have_best = false;
+      for (float l = -half_length; l <= half_length; l += 0.7f) {
+        ++steps;
+        const V2 px = V2{px_mean.x + l * epi_dir.x, px_mean.y + l * epi_dir.y};
+        if (px.x >= static_cast<float>(w - SIDE) || px.y >= static_cast<float>(h - SIDE) ||
+            px.x < static_cast<float>(SIDE) || px.y < static_cast<float>(SIDE))
+          continue;
+        ++evals;
+        float sum_img = 0.0f, sum_img_sq = 0.0f, sum_img_templ = 0.0f;
+        for (int py = 0; py < SIDE; ++py)
+          for (int pxi = 0; pxi < SIDE; ++pxi) {
+            const float templ = s.ref[clampi(y + OFFSET + py, 0, h - 1) * w + clampi(x + OFFSET + pxi, 0, w - 1)];
+            const float img = tex_linear(s.cur.data(), w, h, px.x + static_cast<float>(OFFSET + pxi) + 0.5f,
+                                         px.y + static_cast<float>(OFFSET + py) + 0.5f);
+            sum_img += img;
+            sum_img_sq += img * img;
+            sum_img_templ += img * templ;
+          }
+        const float num = static_cast<float>(AREA) * sum_img_templ - sum_img * sum_templ;
+        const float den = (static_cast<float>(AREA) * sum_img_sq - sum_img * sum_img) * denom;
+        const float ncc = num * rmd_rsqrtf(den + FLT_MIN);
+        if (ncc > best_ncc) {
+          best_px = px;
+          best_ncc = ncc;
+          have_best = true;
+        }
+      }
+      if (best_ncc < 0.5f) {
+        s.conv[i] = NO_MATCH;
+      } else {
+        (void)have_best;
+        s.match[2 * i] = best_px.x;
+        s.match[2 * i + 1] = best_px.y;
+        s.conv[i] = UPDATE;
+      }
+    }
+  s.last_live_seeds = live;
+  s.last_ncc_evals = evals;
+  s.last_steps = steps;
+}
+
+// triangulation.cu:29-50
+V3 triangulate(V3 f_ref, V3 f_cur, const Pose& T_ref_curr) {
+  const V3 t = pose_translation(T_ref_curr);
+  const V3 f2 = pose_rotate(T_ref_curr, f_cur);
+  const float bx = dot(t, f_ref), by = dot(t, f2);
+  const float A0 = dot(f_ref, f_ref);
+  const float A2 = dot(f_ref, f2);
+  const float A1 = -A2;
+  const float A3 = dot(V3{-f2.x, -f2.y, -f2.z}, f2);
+  const float det = A0 * A3 - A1 * A2;
+  const float l0 = (A3 * bx - A1 * by) / det;
+  const float l1 = (-A2 * bx + A0 * by) / det;
+  const V3 xm = V3{l0 * f_ref.x, l0 * f_ref.y, l0 * f_ref.z};
+  const V3 xn = V3{t.x + l1 * f2.x, t.y + l1 * f2.y, t.z + l1 * f2.z};
+  return V3{(xm.x + xn.x) / 2.0f, (xm.y + xn.y) / 2.0f, (xm.z + xn.z) / 2.0f};
+}
+
+// triangulation.cu:52-68
+float triangulation_uncertainty(float z, V3 f_ref, V3 t, float one_pix_angle) {
+  const V3 a = V3{f_ref.x * z - t.x, f_ref.y * z - t.y, f_ref.z * z - t.z};
+  const float t_norm = norm(t);
+  const float a_norm = norm(a);
+  const float alpha = ORC_ACOSF(dot(f_ref, t) / t_norm);
+  const float beta = ORC_ACOSF((-dot(a, t)) / (t_norm * a_norm));
+  const float beta_plus = beta + one_pix_angle;
+  const float gamma_plus = static_cast<float>(RMD_PI_D - static_cast<double>(alpha) - static_cast<double>(beta_plus));
+  const float z_plus = t_norm * ORC_SINF(beta_plus) / ORC_SINF(gamma_plus);
+  return z_plus - z;
+}
+
+// seed_update.cu:30-37
+float normpdf(float x, float mu, float sigma_sq) {
+  const float e = ORC_EXPF(-(x - mu) * (x - mu) / (2.0f * sigma_sq));
+  const float two_pi_ss = static_cast<float>(static_cast<double>(2.0f) * RMD_PI_D * static_cast<double>(sigma_sq));
+  return e * rmd_rsqrtf(two_pi_ss);
+}
+
+// seed_update.cu:39-121
+void seed_update(Seeds& s, const Pose& T_ref_curr) {
+  const int w = s.w, h = s.h;
+  const float one_pix = s.cam.one_pix_angle();
+  const V3 t = pose_translation(T_ref_curr);
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      const size_t i = static_cast<size_t>(y) * w + x;
+      const int state = s.conv[i];
+      if (state == CONVERGED || state == DIVERGED) continue;
+      if (state == UPDATE) {
+        const float mu = s.mu[i], sigma_sq = s.sigma_sq[i], a = s.a[i], b = s.b[i];
+        const V3 f_ref = normalize(s.cam.cam2world(static_cast<float>(x), static_cast<float>(y)));
+        const V3 f_epi = normalize(s.cam.cam2world(s.match[2 * i], s.match[2 * i + 1]));
+        const V3 P = triangulate(f_ref, f_epi, T_ref_curr);
+        if (P.z < 0.0f) continue;
+        const float depth = norm(P);
+        const float tau = triangulation_uncertainty(depth, f_ref, t, one_pix);
+        const float tau_sq = tau * tau;
+        const float s_sq = (tau_sq * sigma_sq) / (tau_sq + sigma_sq);
+        const float m = s_sq * (mu / sigma_sq + depth / tau_sq);
+        float c1 = (a / (a + b)) * normpdf(depth, mu, sigma_sq + tau_sq);
+        float c2 = (b / (a + b)) * (1.0f / s.depth_range);
+        const float norm_const = c1 + c2;
+        c1 = c1 / norm_const;
+        c2 = c2 / norm_const;
+        const float f = c1 * ((a + 1.0f) / (a + b + 1.0f)) + c2 * (a / (a + b + 1.0f));
+        const float e = c1 * (((a + 1.0f) * (a + 2.0f)) / ((a + b + 1.0f) * (a + b + 2.0f))) +
+                        c2 * (a * (a + 1.0f) / ((a + b + 1.0f) * (a + b + 2.0f)));
+        if (isnan(c1 * m)) continue;
+        const float mu_prime = c1 * m + c2 * mu;
+        s.sigma_sq[i] = c1 * (s_sq + m * m) + c2 * (sigma_sq + mu * mu) - mu_prime * mu_prime;
+        s.mu[i] = mu_prime;
+        const float a_prime = (e - f) / (f - e / f);
+        s.a[i] = a_prime;
+        s.b[i] = a_prime * (1.0f - f) / f;
+      } else if (state == NO_MATCH) {
+        s.b[i] = s.b[i] + 1.0f;
+      }
+    }
+}
+
+struct Denoiser {
+  int w, h;
+  float L, tau, sigma, theta;  // depthmap_denoiser.cu:124-141
+  float large_sigma_sq;
+  std::vector<float> u, u_head, g, px, py, px_new, py_new;
+};
+
+}  // namespace
+
+extern "C" {
+
+int orc_patch_side(void) { return SIDE; }
+int orc_max_extent(void) { return RMD_MAX_EXTENT; }
+int orc_uses_libm(void) {
+#ifdef RMD_ORACLE_LIBM
+  return 1;
+#else
+  return 0;
+#endif
+}
+void orc_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int orc_max_threads(void) { return omp_get_max_threads(); }
+
+// ---- rmd::SeedMatrix (seed_matrix.cu) -------------------------------------------------
+void* orc_seeds_create(int w, int h, float fx, float fy, float cx, float cy) {  // seed_matrix.cu:28-80
+  if (w <= 0 || h <= 0) return nullptr;
+  Seeds* s = new Seeds();
+  s->w = w; s->h = h;
+  s->cam = Camera{fx, fy, cx, cy};
+  const size_t n = static_cast<size_t>(w) * h;
+  s->ref.assign(n, 0.0f); s->cur.assign(n, 0.0f); s->sum_templ.assign(n, 0.0f); s->denom.assign(n, 0.0f);
+  s->mu.assign(n, 0.0f); s->sigma_sq.assign(n, 0.0f); s->a.assign(n, 0.0f); s->b.assign(n, 0.0f);
+  s->match.assign(2 * n, 0.0f);
+  s->conv.assign(n, 0);
+  s->dist_from_ref = 0.0f;
+  s->last_live_seeds = s->last_ncc_evals = s->last_steps = 0;
+  memset(&s->T_world_ref, 0, sizeof(Pose));
+  return s;
+}
+void orc_seeds_destroy(void* s) { delete static_cast<Seeds*>(s); }
+
+int orc_seeds_set_reference(void* sp, const float* img, const float* T_curr_world, float min_depth, float max_depth) {
+  // seed_matrix.cu:87-118
+  Seeds& s = *static_cast<Seeds*>(sp);
+  memcpy(s.ref.data(), img, s.ref.size() * sizeof(float));
+  s.min_depth = min_depth;
+  s.max_depth = max_depth;
+  s.avg_depth = (min_depth + max_depth) / 2.0f;
+  s.depth_range = max_depth - min_depth;
+  s.sigma_sq_max = s.depth_range * s.depth_range / 36.0f;
+  s.eta_inlier = 0.7f;
+  s.eta_outlier = 0.05f;
+  s.epsilon = s.depth_range / 1000.0f;
+  Pose T;
+  memcpy(T.d, T_curr_world, sizeof(T.d));
+  s.T_world_ref = pose_inverse(T);
+  seed_init(s);
+  return 0;
+}
+
+int orc_seeds_update(void* sp, const float* img, const float* T_curr_world) {  // seed_matrix.cu:120-158
+  Seeds& s = *static_cast<Seeds*>(sp);
+  Pose T;
+  memcpy(T.d, T_curr_world, sizeof(T.d));
+  const Pose T_curr_ref = pose_compose(T, s.T_world_ref);
+  s.dist_from_ref = norm(pose_translation(T_curr_ref));
+  memcpy(s.cur.data(), img, s.cur.size() * sizeof(float));
+  seed_check(s);
+  epipolar_match(s, T_curr_ref);
+  seed_update(s, pose_inverse(T_curr_ref));
+  return 0;
+}
+
+// plane ids as RMD_HIP_PLANE_* in include/rmd_hip.h
+int orc_seeds_download(void* sp, int plane, void* dst) {  // seed_matrix.cu:160-168,205-230
+  Seeds& s = *static_cast<Seeds*>(sp);
+  const size_t n = static_cast<size_t>(s.w) * s.h;
+  const void* src = nullptr;
+  size_t bytes = n * 4;
+  switch (plane) {
+    case 0: src = s.mu.data(); break;
+    case 1: src = s.sigma_sq.data(); break;
+    case 2: src = s.a.data(); break;
+    case 3: src = s.b.data(); break;
+    case 4: src = s.conv.data(); break;
+    case 5: src = s.sum_templ.data(); break;
+    case 6: src = s.denom.data(); break;
+    case 7: src = s.match.data(); bytes = n * 8; break;
+    default: return -1;
+  }
+  memcpy(dst, src, bytes);
+  return 0;
+}
+int orc_seeds_upload(void* sp, int plane, const float* src) {  // test hook, mirrors ref_seeds_upload
+  Seeds& s = *static_cast<Seeds*>(sp);
+  const size_t bytes = static_cast<size_t>(s.w) * s.h * 4;
+  switch (plane) {
+    case 0: memcpy(s.mu.data(), src, bytes); return 0;
+    case 1: memcpy(s.sigma_sq.data(), src, bytes); return 0;
+    case 2: memcpy(s.a.data(), src, bytes); return 0;
+    case 3: memcpy(s.b.data(), src, bytes); return 0;
+    default: return -1;
+  }
+}
+unsigned long orc_seeds_converged_count(void* sp) {  // seed_matrix.cu:195-198
+  Seeds& s = *static_cast<Seeds*>(sp);
+  unsigned long c = 0;
+  for (int v : s.conv) c += (v == CONVERGED);
+  return c;
+}
+float orc_seeds_dist_from_ref(void* sp) { return static_cast<Seeds*>(sp)->dist_from_ref; }
+void orc_seeds_last_stats(void* sp, long long* out3) {
+  Seeds& s = *static_cast<Seeds*>(sp);
+  out3[0] = s.last_live_seeds; out3[1] = s.last_ncc_evals; out3[2] = s.last_steps;
+}
+
+// ---- rmd::DepthmapDenoiser (depthmap_denoiser.cu) --------------------------------------
+void* orc_denoiser_create(int w, int h) {  // depthmap_denoiser.cu:124-169
+  if (w <= 0 || h <= 0) return nullptr;
+  Denoiser* d = new Denoiser();
+  d->w = w; d->h = h;
+  d->L = sqrtf(8.0f);
+  d->tau = 0.02f;
+  d->sigma = (1 / (d->L * d->L)) / d->tau;
+  d->theta = 0.5f;
+  d->large_sigma_sq = -1.0f;  // the reference leaves it uninitialised; see ref_driver.cpp
+  const size_t n = static_cast<size_t>(w) * h;
+  d->u.assign(n, 0.0f); d->u_head.assign(n, 0.0f); d->g.assign(n, 0.0f);
+  d->px.assign(n, 0.0f); d->py.assign(n, 0.0f); d->px_new.assign(n, 0.0f); d->py_new.assign(n, 0.0f);
+  return d;
+}
+void orc_denoiser_destroy(void* d) { delete static_cast<Denoiser*>(d); }
+void orc_denoiser_set_large_sigma_sq(void* d, float depth_range) {  // depthmap_denoiser.cu:226-229
+  static_cast<Denoiser*>(d)->large_sigma_sq = depth_range * depth_range / 72.0f;
+}
+void orc_denoiser_constants(void* dp, float* out4) {
+  Denoiser* d = static_cast<Denoiser*>(dp);
+  out4[0] = d->L; out4[1] = d->tau; out4[2] = d->sigma; out4[3] = d->theta;
+}
+
+// depthmap_denoiser.cu:179-224 (host), :45-59 (weights), :61-118 (one primal-dual iteration)
+int orc_denoiser_denoise_planes(void* dp, const float* mu, const float* sigma_sq, const float* a, const float* b,
+                                float* out, float lambda, int iterations) {
+  Denoiser& d = *static_cast<Denoiser*>(dp);
+  if (d.large_sigma_sq < 0.0f) return -2;  // the reference prints to cerr and returns (:189-193)
+  const int w = d.w, h = d.h;
+  const size_t n = static_cast<size_t>(w) * h;
+  const float large = d.large_sigma_sq, tau = d.tau, sigma = d.sigma, theta = d.theta;
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < n; ++i) {
+    const float E_pi = a[i] / (a[i] + b[i]);
+    const float v = (E_pi * sigma_sq[i] + (1.0f - E_pi) * large) / large;
+    d.g[i] = v > 1.0f ? v : 1.0f;
+    d.u[i] = mu[i];
+    d.u_head[i] = mu[i];
+    d.px[i] = 0.0f;
+    d.py[i] = 0.0f;
+  }
+  for (int it = 0; it < iterations; ++it) {
+    // dual step for every pixel (:73-83)
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x) {
+        const size_t i = static_cast<size_t>(y) * w + x;
+        const float g = d.g[i], cu = d.u[i];
+        const int xe = x + 1 < w - 1 ? x + 1 : w - 1, ys = y + 1 < h - 1 ? y + 1 : h - 1;
+        const float gx = d.u_head[static_cast<size_t>(y) * w + xe] - cu;
+        const float gy = d.u_head[static_cast<size_t>(ys) * w + x] - cu;
+        const float tx = g * gx * sigma + d.px[i];
+        const float ty = g * gy * sigma + d.py[i];
+        const float mag = sqrtf(tx * tx + ty * ty);
+        const float den = 1.0f > mag ? 1.0f : mag;
+        d.px_new[i] = tx / den;
+        d.py_new[i] = ty / den;
+      }
+    // primal step for every pixel (:87-115)
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; ++y)
+      for (int x = 0; x < w; ++x) {
+        const size_t i = static_cast<size_t>(y) * w + x;
+        const float noisy = mu[i], old_u = d.u[i], g = d.g[i];
+        float cpx = d.px_new[i], cpy = d.py_new[i];
+        float wpx = d.px_new[static_cast<size_t>(y) * w + (x - 1 > 0 ? x - 1 : 0)];
+        float npy = d.py_new[static_cast<size_t>(y - 1 > 0 ? y - 1 : 0) * w + x];
+        if (x == 0) wpx = 0.0f;
+        else if (x >= w - 1) cpx = 0.0f;
+        if (y == 0) npy = 0.0f;
+        else if (y >= h - 1) cpy = 0.0f;
+        const float divergence = cpx - wpx + cpy - npy;
+        const float temp_u = old_u + tau * g * divergence;
+        float nu;
+        if ((temp_u - noisy) > (tau * lambda)) nu = temp_u - tau * lambda;
+        else if ((temp_u - noisy) < (-tau * lambda)) nu = temp_u + tau * lambda;
+        else nu = noisy;
+        d.u[i] = nu;
+        d.u_head[i] = nu + theta * (nu - old_u);
+      }
+    d.px.swap(d.px_new);
+    d.py.swap(d.py_new);
+  }
+  memcpy(out, d.u.data(), n * sizeof(float));
+  return 0;
+}
+int orc_denoiser_denoise(void* dp, void* sp, float* out, float lambda, int iterations) {
+  Seeds& s = *static_cast<Seeds*>(sp);
+  return orc_denoiser_denoise_planes(dp, s.mu.data(), s.sigma_sq.data(), s.a.data(), s.b.data(), out, lambda, iterations);
+}
+
+// ---- rmd::ImageReducer (reduction.cu) --------------------------------------------------
+// The reference sums in a block-tree order in fp32; its own test (reduction_test.cpp:24-70)
+// only requires agreement with a double-accumulated sum to 4 ulp, which is the semantics here.
+float orc_reduce_sum_f32(const float* img, int w, int h) {
+  double acc = 0.0;
+  const size_t n = static_cast<size_t>(w) * h;
+  for (size_t i = 0; i < n; ++i) acc += img[i];
+  return static_cast<float>(acc);
+}
+unsigned long orc_reduce_count_eq_i32(const int* img, int w, int h, int value) {  // reduction_kernels.cu:107-159
+  unsigned long c = 0;
+  const size_t n = static_cast<size_t>(w) * h;
+  for (size_t i = 0; i < n; ++i) c += (img[i] == value);
+  return c;
+}
+
+// ---- primitives, for the arithmetic-contract tests ---------------------------------------
+float orc_math_expf(float x) { return rmd_expf(x); }
+float orc_math_sinf(float x) { return rmd_sinf(x); }
+float orc_math_acosf(float x) { return rmd_acosf(x); }
+float orc_math_rsqrtf(float x) { return rmd_rsqrtf(x); }
+float orc_math_lerp(float t, float a, float b) { return rmd_lerp(t, a, b); }
+float orc_tex_linear(const float* plane, int w, int h, float x, float y) { return tex_linear(plane, w, h, x, y); }
+
+}  // extern "C"
