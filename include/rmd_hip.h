@@ -1,0 +1,172 @@
+/*
+ * librmd_hip.so -- C ABI of the MI355X-native REMODE depth-filter path.
+ *
+ * This is the drop-in boundary.  The reference exposes the path as C++ classes compiled
+ * by nvcc into the static library `rpg_open_remode_cuda` (CMakeLists.txt:92-107):
+ *     rmd::SeedMatrix        include/rmd/seed_matrix.cuh:45-109,  src/seed_matrix.cu
+ *     rmd::DepthmapDenoiser  include/rmd/depthmap_denoiser.cuh:27-54, src/depthmap_denoiser.cu
+ *     rmd::ImageReducer<T>   include/rmd/reduction.cuh:26-62,    src/reduction.cu
+ *     rmd::DeviceImage<T>    include/rmd/device_image.cuh:34-180
+ *     rmd::checkCudaDevice   include/rmd/check_cuda_device.cuh:24, src/check_cuda_device.cu
+ * Each entry point below replaces one method of those classes (cited per function).  The
+ * C++ headers under include/rmd/ in THIS repository re-create the classes, name for name,
+ * as thin inline wrappers over this ABI, so the reference's host code (src/depthmap.cpp,
+ * src/depthmap_node.cpp, the gtest sources) compiles against them unchanged -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns RMD_HIP_OK (0) or a negative RMD_HIP_ERR_*; a description of the
+ *     last failure on the calling thread is available from rmd_hip_last_error();
+ *   - handles are opaque, own their device memory and a HIP stream, are bound to the device
+ *     that was current when they were created, and may be used from one thread at a time;
+ *     distinct handles are fully independent (no process-global state, unlike the reference's
+ *     texture references / __constant__ symbols, texture_memory.cuh:27-42);
+ *   - host images are contiguous row-major W x H, borrowed for the duration of the call;
+ *   - poses cross as 12 floats, the row-major 3x4 [R|t] of rmd::SE3<float>::data
+ *     (se3.cuh:141, matrix.cuh:34);
+ *   - `update` may leave device work in flight on return exactly like the reference
+ *     (seed_matrix.cu:155-157); every download / count / denoise synchronises first.
+ */
+#ifndef RMD_HIP_H
+#define RMD_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RMD_HIP_OK 0
+#define RMD_HIP_ERR_INVALID_ARG (-1) /* null handle, bad size, unsupported patch side, ... */
+#define RMD_HIP_ERR_RUNTIME (-2)     /* a HIP runtime call failed (rmd::CudaException in the reference) */
+#define RMD_HIP_ERR_NOT_READY (-3)   /* e.g. denoise() before set_large_sigma_sq(), update() before set_reference() */
+#define RMD_HIP_ERR_NO_DEVICE (-4)   /* no usable gfx950 device */
+
+/* rmd::ConvergenceStates (seed_matrix.cuh:33-41) */
+#define RMD_HIP_STATE_UPDATE 0
+#define RMD_HIP_STATE_CONVERGED 1
+#define RMD_HIP_STATE_BORDER 2
+#define RMD_HIP_STATE_DIVERGED 3
+#define RMD_HIP_STATE_NO_MATCH 4
+#define RMD_HIP_STATE_NOT_VISIBLE 5
+
+/* planes of a SeedMatrix (seed_matrix.cuh:89-97) */
+#define RMD_HIP_PLANE_MU 0               /* f32  depth estimate                         */
+#define RMD_HIP_PLANE_SIGMA_SQ 1         /* f32  variance of the depth estimate         */
+#define RMD_HIP_PLANE_A 2                /* f32  Beta a                                 */
+#define RMD_HIP_PLANE_B 3                /* f32  Beta b                                 */
+#define RMD_HIP_PLANE_CONVERGENCE 4      /* i32  RMD_HIP_STATE_*                        */
+#define RMD_HIP_PLANE_SUM_TEMPL 5        /* f32  NCC template sum                       */
+#define RMD_HIP_PLANE_CONST_TEMPL_DENOM 6 /* f32 NCC template denominator              */
+#define RMD_HIP_PLANE_EPIPOLAR_MATCHES 7 /* f32x2 matched pixel in the current frame   */
+#define RMD_HIP_PLANE_REF_IMG 8          /* f32  reference image                        */
+#define RMD_HIP_PLANE_CURR_IMG 9         /* f32  current image                          */
+#define RMD_HIP_NUM_PLANES 10
+
+/* element kinds of rmd::DeviceImage<T> */
+#define RMD_HIP_KIND_F32 0
+#define RMD_HIP_KIND_I32 1
+#define RMD_HIP_KIND_F32X2 2
+
+typedef struct rmd_hip_image rmd_hip_image_t;
+typedef struct rmd_hip_seeds rmd_hip_seeds_t;
+typedef struct rmd_hip_denoiser rmd_hip_denoiser_t;
+
+/* ---- library ------------------------------------------------------------------------ */
+const char* rmd_hip_last_error(void);
+int rmd_hip_version(void);
+
+/* ---- device selection: rmd::checkCudaDevice (check_cuda_device.cu:23-117) ------------- */
+int rmd_hip_device_count(int* count);
+int rmd_hip_set_device(int device_id);
+int rmd_hip_device_name(int device_id, char* buf, size_t buf_len);
+
+/* ---- rmd::DeviceImage<T> (device_image.cuh) ------------------------------------------- */
+/* ctor :38-65 (pitched allocation) / dtor :124-132 */
+int rmd_hip_image_create(int kind, int width, int height, rmd_hip_image_t** out);
+int rmd_hip_image_destroy(rmd_hip_image_t* img);
+/* setDevData :93-105 / getDevData :109-121 / zero :141-151 / operator= :154-171 */
+int rmd_hip_image_upload(rmd_hip_image_t* img, const void* host_row_major);
+int rmd_hip_image_download(const rmd_hip_image_t* img, void* host_row_major);
+int rmd_hip_image_zero(rmd_hip_image_t* img);
+int rmd_hip_image_copy(rmd_hip_image_t* dst, const rmd_hip_image_t* src);
+/* public fields width/height/pitch/stride/data :174-179 (data is a device pointer) */
+int rmd_hip_image_info(const rmd_hip_image_t* img, int* kind, int* width, int* height, size_t* pitch_bytes,
+                       size_t* stride_elems, void** device_data);
+
+/* ---- rmd::SeedMatrix (seed_matrix.cu) -------------------------------------------------- */
+/* ctor :28-80.  patch_side = RMD_CORR_PATCH_SIDE (3, 5, 7 or 9; CMakeLists.txt:50-51),
+ * max_extent = RMD_MAX_EXTENT_EPIPOLAR_SEARCH (CMakeLists.txt:52-53); both compile-time in the reference. */
+int rmd_hip_seeds_create(int width, int height, float fx, float fy, float cx, float cy, int patch_side, int max_extent,
+                         rmd_hip_seeds_t** out);
+int rmd_hip_seeds_destroy(rmd_hip_seeds_t* s);
+/* setReferenceImage :87-118 */
+int rmd_hip_seeds_set_reference(rmd_hip_seeds_t* s, const float* host_img, const float* T_curr_world, float min_depth,
+                                float max_depth);
+/* update :120-158 (check -> epipolar match -> triangulate + fuse) */
+int rmd_hip_seeds_update(rmd_hip_seeds_t* s, const float* host_img, const float* T_curr_world);
+/* same two calls for a frame that is already resident in device memory (row stride in elements);
+ * the frame is copied device-to-device into the handle's own image plane on the handle's stream */
+int rmd_hip_seeds_set_reference_device(rmd_hip_seeds_t* s, const float* dev_img, size_t stride_elems,
+                                       const float* T_curr_world, float min_depth, float max_depth);
+int rmd_hip_seeds_update_device(rmd_hip_seeds_t* s, const float* dev_img, size_t stride_elems,
+                                const float* T_curr_world);
+/* downloadDepthmap/downloadConvergence :160-168 and the RMD_BUILD_TESTS downloads :205-230 */
+int rmd_hip_seeds_download(const rmd_hip_seeds_t* s, int plane, void* host_dst);
+/* test hook: overwrite mu / sigma_sq / a / b (planes 0..3) */
+int rmd_hip_seeds_upload(rmd_hip_seeds_t* s, int plane, const float* host_src);
+/* getMu/getSigmaSq/getA/getB/getConvergence :170-193: a borrowed view, valid while `s` lives */
+int rmd_hip_seeds_plane(const rmd_hip_seeds_t* s, int plane, const rmd_hip_image_t** view);
+/* getConvergedCount :195-198 (count of CONVERGED in the convergence plane) */
+int rmd_hip_seeds_converged_count(const rmd_hip_seeds_t* s, size_t* count);
+/* getDistFromRef :200-203 */
+int rmd_hip_seeds_dist_from_ref(const rmd_hip_seeds_t* s, float* dist);
+/* blocks until all work queued by this handle has finished */
+int rmd_hip_seeds_sync(const rmd_hip_seeds_t* s);
+
+/* knobs (not in the reference) */
+#define RMD_HIP_OPT_MATCHER 0      /* 0 = per-pixel kernel, 1 = tile-cooperative kernel (default) */
+#define RMD_HIP_OPT_TIMING 1       /* 1 = bracket every kernel with HIP events on the handle's stream */
+#define RMD_HIP_OPT_COLLECT_STATS 2 /* 1 = count live seeds / search steps / NCC evaluations per update */
+int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value);
+/* kernels of the seed path, for rmd_hip_seeds_timing */
+#define RMD_HIP_STAGE_SEED_INIT 0
+#define RMD_HIP_STAGE_UPDATE 1  /* fused seed_check + epipolar_match + seed_update */
+#define RMD_HIP_STAGE_COUNT 2
+#define RMD_HIP_NUM_SEED_STAGES 3
+/* accumulated device time and launch count of one stage since the last reset (needs RMD_HIP_OPT_TIMING) */
+int rmd_hip_seeds_timing(const rmd_hip_seeds_t* s, int stage, double* total_ms, long* launches);
+int rmd_hip_seeds_timing_reset(rmd_hip_seeds_t* s);
+/* out[0..2] = live seeds, epipolar steps visited, NCC evaluations of the last update (needs COLLECT_STATS) */
+int rmd_hip_seeds_last_stats(const rmd_hip_seeds_t* s, long long* out3);
+
+/* ---- rmd::DepthmapDenoiser (depthmap_denoiser.cu) --------------------------------------- */
+int rmd_hip_denoiser_create(int width, int height, rmd_hip_denoiser_t** out); /* ctor :143-169 */
+int rmd_hip_denoiser_destroy(rmd_hip_denoiser_t* d);
+int rmd_hip_denoiser_set_large_sigma_sq(rmd_hip_denoiser_t* d, float depth_range); /* :226-229 */
+/* denoise :179-224.  Returns RMD_HIP_ERR_NOT_READY if set_large_sigma_sq was never called
+ * (the reference prints to cerr and returns, :189-193). */
+int rmd_hip_denoiser_denoise(rmd_hip_denoiser_t* d, const rmd_hip_image_t* mu, const rmd_hip_image_t* sigma_sq,
+                             const rmd_hip_image_t* a, const rmd_hip_image_t* b, float* host_denoised, float lambda,
+                             int iterations);
+/* as above but leaves the result in device memory (view valid until the next denoise); host_denoised may be NULL */
+int rmd_hip_denoiser_result(const rmd_hip_denoiser_t* d, const rmd_hip_image_t** view);
+/* L, tau, sigma, theta of denoise::DeviceData (depthmap_denoiser.cu:124-141) */
+int rmd_hip_denoiser_constants(const rmd_hip_denoiser_t* d, float* out4);
+#define RMD_HIP_DENOISE_OPT_TIMING 1
+#define RMD_HIP_DENOISE_OPT_ITERS_PER_LAUNCH 2 /* temporal blocking depth, 1..8 */
+int rmd_hip_denoiser_set_option(rmd_hip_denoiser_t* d, int option, int value);
+/* accumulated device time / launches of the TV iteration kernel since the last denoise() started */
+int rmd_hip_denoiser_timing(const rmd_hip_denoiser_t* d, double* total_ms, long* launches);
+
+/* ---- rmd::ImageReducer<T> (reduction.cu) ------------------------------------------------ */
+int rmd_hip_reduce_sum_f32(const rmd_hip_image_t* img, float* sum);                    /* sum :81-130 */
+int rmd_hip_reduce_count_eq_i32(const rmd_hip_image_t* img, int value, size_t* count); /* countEqual :133-183 */
+
+/* ---- arithmetic-contract self test (device side of csrc/rmd_math.h) ---------------------- */
+/* op: 0 expf, 1 sinf, 2 acosf, 3 rsqrtf, 4 sqrtf, 5 x/y, 6 lerp(t=x, a=y, b=z); n host floats in, n out */
+int rmd_hip_math_eval(int op, const float* x, const float* y, const float* z, float* out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RMD_HIP_H */

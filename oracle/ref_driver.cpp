@@ -27,6 +27,17 @@
 #include <cuda_runtime.h>
 #include <shim_launch.h>
 
+#ifdef RMD_REF_USE_SHARED_MATH
+// Variant "ref_rmd": the reference's sources with the three libm transcendentals on the path
+// (seed_update.cu:36 expf; triangulation.cu:63-66 acosf, sinf) taken from csrc/rmd_math.h -- the
+// header the HIP kernels compile -- instead of glibc.  Nothing else changes.  This is the oracle the
+// HIP path must equal bit for bit; the plain build ("ref") measures what that substitution moves.
+#include "rmd_math.h"
+#define expf rmd_expf
+#define sinf rmd_sinf
+#define acosf rmd_acosf
+#endif
+
 #define private public  // the driver reaches into the reference classes' buffers (test hooks)
 // reduction.cu first: it explicitly specialises ImageReducer<int>::countEqual, which
 // seed_matrix.cu uses (separate translation units in the reference's own build).
@@ -56,6 +67,13 @@ extern "C" {
 
 int ref_patch_side(void) { return RMD_CORR_PATCH_SIDE; }
 int ref_max_extent(void) { return RMD_MAX_EXTENT_EPIPOLAR_SEARCH; }
+int ref_uses_shared_math(void) {
+#ifdef RMD_REF_USE_SHARED_MATH
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 void* ref_seeds_create(int w, int h, float fx, float fy, float cx, float cy) {
   return new rmd::SeedMatrix(static_cast<size_t>(w), static_cast<size_t>(h), rmd::PinholeCamera(fx, fy, cx, cy));

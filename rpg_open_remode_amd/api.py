@@ -1,0 +1,408 @@
+"""Host-side mirror of the reference's C++ interface for the depth-filter path, over the C ABI.
+
+Class and method names, argument order and error behaviour follow the reference so that the
+parity tests read like the reference's own tests (test/seed_matrix_test.cpp, test/reduction_test.cpp,
+test/dataset_main.cpp):
+
+    rmd::PinholeCamera      include/rmd/pinhole_camera.cuh:27-63
+    rmd::SE3<float>         include/rmd/se3.cuh:27-168
+    rmd::DeviceImage<T>     include/rmd/device_image.cuh:34-180
+    rmd::SeedMatrix         include/rmd/seed_matrix.cuh:45-109
+    rmd::DepthmapDenoiser   include/rmd/depthmap_denoiser.cuh:27-54
+    rmd::ImageReducer<T>    include/rmd/reduction.cuh:26-62
+    rmd::Depthmap           include/rmd/depthmap.h:34-129   (numpy arrays instead of cv::Mat)
+    rmd::checkCudaDevice    include/rmd/check_cuda_device.cuh:24
+
+Everything computes on the GPU through librmd_hip.so; nothing here falls back to the CPU.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import RmdHipError, check
+
+__all__ = ["PinholeCamera", "SE3", "DeviceImage", "SeedMatrix", "DepthmapDenoiser", "ImageReducer", "Depthmap",
+           "ConvergenceStates", "checkCudaDevice", "RmdHipError"]
+
+PLANE_MU, PLANE_SIGMA_SQ, PLANE_A, PLANE_B, PLANE_CONVERGENCE = 0, 1, 2, 3, 4
+PLANE_SUM_TEMPL, PLANE_CONST_TEMPL_DENOM, PLANE_EPIPOLAR_MATCHES, PLANE_REF_IMG, PLANE_CURR_IMG = 5, 6, 7, 8, 9
+KIND_F32, KIND_I32, KIND_F32X2 = 0, 1, 2
+OPT_MATCHER, OPT_TIMING, OPT_COLLECT_STATS = 0, 1, 2
+STAGE_SEED_INIT, STAGE_UPDATE, STAGE_COUNT = 0, 1, 2
+DENOISE_OPT_TIMING, DENOISE_OPT_ITERS_PER_LAUNCH = 1, 2
+
+
+class ConvergenceStates:  # seed_matrix.cuh:33-41
+    UPDATE, CONVERGED, BORDER, DIVERGED, NO_MATCH, NOT_VISIBLE = range(6)
+
+
+def checkCudaDevice(device=0, verbose=False):
+    """check_cuda_device.cu:23-117: enumerate devices, select `device` (the reference's --device=N)."""
+    L = _lib.lib()
+    n = ctypes.c_int(0)
+    if L.rmd_hip_device_count(ctypes.byref(n)) != _lib.OK:
+        if verbose:
+            print("ERROR: no HIP-capable device found.")
+        return False
+    if verbose:
+        buf = ctypes.create_string_buffer(256)
+        for d in range(n.value):
+            L.rmd_hip_device_name(d, buf, 256)
+            print(f"Device {d} - {buf.value.decode()}")
+    if L.rmd_hip_set_device(int(device)) != _lib.OK:
+        if verbose:
+            print(f"ERROR: invalid device ID specified. Please specify a value in [0, {n.value - 1}].")
+        return False
+    return True
+
+
+class PinholeCamera:
+    def __init__(self, fx=0.0, fy=0.0, cx=0.0, cy=0.0):
+        self.fx, self.fy, self.cx, self.cy = float(fx), float(fy), float(cx), float(cy)
+
+
+class SE3:
+    """3x4 row-major [R|t], float32 (se3.cuh).  Host arithmetic in float32, in the reference's order."""
+
+    def __init__(self, *args):
+        self.data = np.zeros(12, np.float32)
+        if len(args) == 7:  # (qw, qx, qy, qz, tx, ty, tz), se3.cuh:38-66
+            f = np.float32
+            qw, qx, qy, qz, tx, ty, tz = (f(a) for a in args)
+            x, y, z = f(2) * qx, f(2) * qy, f(2) * qz
+            wx, wy, wz = x * qw, y * qw, z * qw
+            xx, xy, xz = x * qx, y * qx, z * qx
+            yy, yz, zz = y * qy, z * qy, z * qz
+            d = self.data
+            d[0], d[1], d[2] = f(1) - (yy + zz), xy - wz, xz + wy
+            d[4], d[5], d[6] = xy + wz, f(1) - (xx + zz), yz - wx
+            d[8], d[9], d[10] = xz - wy, yz + wx, f(1) - (xx + yy)
+            d[3], d[7], d[11] = tx, ty, tz
+        elif len(args) == 2:  # (r[9] row-major, t[3]), se3.cuh:68-77
+            r, t = np.asarray(args[0], np.float32).reshape(3, 3), np.asarray(args[1], np.float32).reshape(3)
+            m = self.data.reshape(3, 4)
+            m[:, :3], m[:, 3] = r, t
+        elif len(args) == 1:
+            self.data[:] = np.asarray(args[0], np.float32).reshape(12)
+        elif len(args) != 0:
+            raise TypeError("SE3(): 0, 1, 2 or 7 arguments")
+
+    def inv(self):  # se3.cuh:78-95
+        d, r = self.data, SE3()
+        o = r.data
+        for i in range(3):
+            for j in range(3):
+                o[4 * i + j] = d[4 * j + i]
+            o[4 * i + 3] = -d[i] * d[3] - d[4 + i] * d[7] - d[8 + i] * d[11]
+        return r
+
+    def __mul__(self, rhs):  # se3.cuh:144-162
+        l, r, out = self.data, rhs.data, SE3()
+        o = out.data
+        for row in range(3):
+            l0, l1, l2, lt = l[4 * row], l[4 * row + 1], l[4 * row + 2], l[4 * row + 3]
+            for col in range(3):
+                o[4 * row + col] = l0 * r[col] + l1 * r[4 + col] + l2 * r[8 + col]
+            o[4 * row + 3] = lt + l0 * r[3] + l1 * r[7] + l2 * r[11]
+        return out
+
+    def getTranslation(self):
+        return self.data[[3, 7, 11]].copy()
+
+
+def _as_pose(T):
+    return np.ascontiguousarray(T.data if isinstance(T, SE3) else T, np.float32).reshape(12)
+
+
+_KIND_OF = {np.dtype(np.float32): KIND_F32, np.dtype(np.int32): KIND_I32}
+
+
+class DeviceImage:
+    """rmd::DeviceImage<T>: a pitched 2-D device buffer.  dtype float32, int32, or 'float2'."""
+
+    def __init__(self, width, height, dtype=np.float32, _view=None):
+        self._owns = _view is None
+        if _view is not None:
+            self.ptr = _view
+        else:
+            kind = KIND_F32X2 if dtype == "float2" else _KIND_OF[np.dtype(dtype)]
+            h = ctypes.c_void_p()
+            check(_lib.lib().rmd_hip_image_create(kind, int(width), int(height), ctypes.byref(h)))
+            self.ptr = h.value
+        k, w, hh = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        pitch, stride, data = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_void_p()
+        check(_lib.lib().rmd_hip_image_info(self.ptr, ctypes.byref(k), ctypes.byref(w), ctypes.byref(hh),
+                                            ctypes.byref(pitch), ctypes.byref(stride), ctypes.byref(data)))
+        self.kind, self.width, self.height = k.value, w.value, hh.value
+        self.pitch, self.stride, self.data = pitch.value, stride.value, data.value
+
+    def _host_shape(self):
+        return (self.height, self.width, 2) if self.kind == KIND_F32X2 else (self.height, self.width)
+
+    def _host_dtype(self):
+        return np.int32 if self.kind == KIND_I32 else np.float32
+
+    def setDevData(self, host):  # device_image.cuh:93-105
+        arr = np.ascontiguousarray(host, self._host_dtype())
+        assert arr.shape == self._host_shape(), (arr.shape, self._host_shape())
+        check(_lib.lib().rmd_hip_image_upload(self.ptr, arr.ctypes.data))
+
+    def getDevData(self):  # device_image.cuh:109-121
+        out = np.empty(self._host_shape(), self._host_dtype())
+        check(_lib.lib().rmd_hip_image_download(self.ptr, out.ctypes.data))
+        return out
+
+    def zero(self):  # device_image.cuh:141-151
+        check(_lib.lib().rmd_hip_image_zero(self.ptr))
+
+    def assign(self, other):  # operator=, device_image.cuh:154-171
+        check(_lib.lib().rmd_hip_image_copy(self.ptr, other.ptr))
+        return self
+
+    def close(self):
+        if self._owns and self.ptr:
+            _lib.lib().rmd_hip_image_destroy(self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ImageReducer:
+    """rmd::ImageReducer<T>.  The launch-shape arguments of the reference constructor are accepted and ignored."""
+
+    def __init__(self, num_threads_per_block=None, num_blocks_per_grid=None):
+        pass
+
+    def sum(self, img):  # reduction.cu:81-130
+        out = ctypes.c_float()
+        check(_lib.lib().rmd_hip_reduce_sum_f32(img.ptr, ctypes.byref(out)))
+        return float(out.value)
+
+    def countEqual(self, img, value):  # reduction.cu:133-183
+        out = ctypes.c_size_t()
+        check(_lib.lib().rmd_hip_reduce_count_eq_i32(img.ptr, int(value), ctypes.byref(out)))
+        return int(out.value)
+
+
+class SeedMatrix:
+    def __init__(self, width, height, cam, patch_side=5, max_extent=100):
+        self.width, self.height, self.patch_side = int(width), int(height), int(patch_side)
+        h = ctypes.c_void_p()
+        check(_lib.lib().rmd_hip_seeds_create(self.width, self.height, cam.fx, cam.fy, cam.cx, cam.cy, int(patch_side),
+                                              int(max_extent), ctypes.byref(h)))
+        self.ptr = h.value
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            _lib.lib().rmd_hip_seeds_destroy(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- seed_matrix.cu:87-158 ---
+    def setReferenceImage(self, host_ref_img, T_curr_world, min_depth, max_depth):
+        img = np.ascontiguousarray(host_ref_img, np.float32)
+        assert img.shape == (self.height, self.width)
+        T = _as_pose(T_curr_world)
+        check(_lib.lib().rmd_hip_seeds_set_reference(self.ptr, img.ctypes.data, T.ctypes.data, float(min_depth), float(max_depth)))
+        return True
+
+    def update(self, host_curr_img, T_curr_world):
+        img = np.ascontiguousarray(host_curr_img, np.float32)
+        assert img.shape == (self.height, self.width)
+        T = _as_pose(T_curr_world)
+        check(_lib.lib().rmd_hip_seeds_update(self.ptr, img.ctypes.data, T.ctypes.data))
+        return True
+
+    def setReferenceImageDevice(self, dev_ptr, stride_elems, T_curr_world, min_depth, max_depth):
+        T = _as_pose(T_curr_world)
+        check(_lib.lib().rmd_hip_seeds_set_reference_device(self.ptr, dev_ptr, int(stride_elems), T.ctypes.data,
+                                                            float(min_depth), float(max_depth)))
+        return True
+
+    def updateDevice(self, dev_ptr, stride_elems, T_curr_world):
+        T = _as_pose(T_curr_world)
+        check(_lib.lib().rmd_hip_seeds_update_device(self.ptr, dev_ptr, int(stride_elems), T.ctypes.data))
+        return True
+
+    # --- downloads, seed_matrix.cu:160-168,205-230 ---
+    def download(self, plane):
+        if plane == PLANE_CONVERGENCE:
+            out = np.empty((self.height, self.width), np.int32)
+        elif plane == PLANE_EPIPOLAR_MATCHES:
+            out = np.empty((self.height, self.width, 2), np.float32)
+        else:
+            out = np.empty((self.height, self.width), np.float32)
+        check(_lib.lib().rmd_hip_seeds_download(self.ptr, int(plane), out.ctypes.data))
+        return out
+
+    def downloadDepthmap(self): return self.download(PLANE_MU)
+    def downloadConvergence(self): return self.download(PLANE_CONVERGENCE)
+    def downloadSigmaSq(self): return self.download(PLANE_SIGMA_SQ)
+    def downloadA(self): return self.download(PLANE_A)
+    def downloadB(self): return self.download(PLANE_B)
+    def downloadSumTempl(self): return self.download(PLANE_SUM_TEMPL)
+    def downloadConstTemplDenom(self): return self.download(PLANE_CONST_TEMPL_DENOM)
+    def downloadEpipolarMatches(self): return self.download(PLANE_EPIPOLAR_MATCHES)
+
+    def upload(self, plane, arr):
+        arr = np.ascontiguousarray(arr, np.float32)
+        assert arr.shape == (self.height, self.width)
+        check(_lib.lib().rmd_hip_seeds_upload(self.ptr, int(plane), arr.ctypes.data))
+
+    def state(self):
+        return {p: self.download(p) for p in range(8)}
+
+    # --- getters, seed_matrix.cu:170-203 ---
+    def _plane(self, plane):
+        v = ctypes.c_void_p()
+        check(_lib.lib().rmd_hip_seeds_plane(self.ptr, int(plane), ctypes.byref(v)))
+        img = DeviceImage(0, 0, _view=v.value)
+        img._keepalive = self
+        return img
+
+    def getMu(self): return self._plane(PLANE_MU)
+    def getSigmaSq(self): return self._plane(PLANE_SIGMA_SQ)
+    def getA(self): return self._plane(PLANE_A)
+    def getB(self): return self._plane(PLANE_B)
+    def getConvergence(self): return self._plane(PLANE_CONVERGENCE)
+
+    def getConvergedCount(self):
+        out = ctypes.c_size_t()
+        check(_lib.lib().rmd_hip_seeds_converged_count(self.ptr, ctypes.byref(out)))
+        return int(out.value)
+
+    def getDistFromRef(self):
+        out = ctypes.c_float()
+        check(_lib.lib().rmd_hip_seeds_dist_from_ref(self.ptr, ctypes.byref(out)))
+        return float(out.value)
+
+    # --- extras ---
+    def sync(self):
+        check(_lib.lib().rmd_hip_seeds_sync(self.ptr))
+
+    def setOption(self, option, value):
+        check(_lib.lib().rmd_hip_seeds_set_option(self.ptr, int(option), int(value)))
+
+    def timing(self, stage):
+        ms, n = ctypes.c_double(), ctypes.c_long()
+        check(_lib.lib().rmd_hip_seeds_timing(self.ptr, int(stage), ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    def timingReset(self):
+        check(_lib.lib().rmd_hip_seeds_timing_reset(self.ptr))
+
+    def lastStats(self):
+        out = np.zeros(3, np.int64)
+        check(_lib.lib().rmd_hip_seeds_last_stats(self.ptr, out.ctypes.data))
+        return {"live_seeds": int(out[0]), "steps": int(out[1]), "ncc_evals": int(out[2])}
+
+
+class DepthmapDenoiser:
+    def __init__(self, width, height):
+        self.width, self.height = int(width), int(height)
+        h = ctypes.c_void_p()
+        check(_lib.lib().rmd_hip_denoiser_create(self.width, self.height, ctypes.byref(h)))
+        self.ptr = h.value
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            _lib.lib().rmd_hip_denoiser_destroy(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def setLargeSigmaSq(self, depth_range):  # depthmap_denoiser.cu:226-229
+        check(_lib.lib().rmd_hip_denoiser_set_large_sigma_sq(self.ptr, float(depth_range)))
+
+    def denoise(self, mu, sigma_sq, a, b, lam, iterations, download=True):  # depthmap_denoiser.cu:179-224
+        out = np.empty((self.height, self.width), np.float32) if download else None
+        check(_lib.lib().rmd_hip_denoiser_denoise(self.ptr, mu.ptr, sigma_sq.ptr, a.ptr, b.ptr,
+                                                  out.ctypes.data if download else None, float(lam), int(iterations)))
+        return out
+
+    def constants(self):
+        out = np.zeros(4, np.float32)
+        check(_lib.lib().rmd_hip_denoiser_constants(self.ptr, out.ctypes.data))
+        return out
+
+    def setOption(self, option, value):
+        check(_lib.lib().rmd_hip_denoiser_set_option(self.ptr, int(option), int(value)))
+
+    def timing(self):
+        ms, n = ctypes.c_double(), ctypes.c_long()
+        check(_lib.lib().rmd_hip_denoiser_timing(self.ptr, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+
+class Depthmap:
+    """rmd::Depthmap (depthmap.h:34-129, depthmap.cpp) with numpy uint8 images in place of cv::Mat.
+    Constructor argument order is the reference's: (width, height, fx, cx, fy, cy)."""
+
+    def __init__(self, width, height, fx, cx, fy, cy, patch_side=5, max_extent=100):
+        self.width_, self.height_ = int(width), int(height)
+        self.fx_, self.fy_, self.cx_, self.cy_ = fx, fy, cx, cy
+        self.seeds_ = SeedMatrix(width, height, PinholeCamera(fx, fy, cx, cy), patch_side, max_extent)
+        self.denoiser_ = DepthmapDenoiser(width, height)
+        self.output_depth_32fc1_ = np.zeros((self.height_, self.width_), np.float32)
+        self.output_convergence_int_ = np.zeros((self.height_, self.width_), np.int32)
+        self.ref_img_8uc1_ = None
+        self.T_world_ref_ = SE3()
+
+    @staticmethod
+    def _input_image(img_8uc1):  # depthmap.cpp:95-106 (undistortion is outside this path)
+        img = np.asarray(img_8uc1)
+        if img.dtype != np.uint8:
+            raise TypeError("Depthmap expects 8-bit gray images (CV_8UC1)")
+        return (img.astype(np.float32) * np.float32(1.0 / 255.0)).astype(np.float32)
+
+    def setReferenceImage(self, img_curr, T_curr_world, min_depth, max_depth):  # depthmap.cpp:63-83
+        self.denoiser_.setLargeSigmaSq(max_depth - min_depth)
+        ret = self.seeds_.setReferenceImage(self._input_image(img_curr), T_curr_world, min_depth, max_depth)
+        self.ref_img_8uc1_ = np.array(img_curr, copy=True)
+        self.T_world_ref_ = (T_curr_world if isinstance(T_curr_world, SE3) else SE3(T_curr_world)).inv()
+        return ret
+
+    def update(self, img_curr, T_curr_world):  # depthmap.cpp:85-93
+        self.seeds_.update(self._input_image(img_curr), T_curr_world)
+
+    def downloadDepthmap(self):
+        self.output_depth_32fc1_ = self.seeds_.downloadDepthmap()
+
+    def downloadDenoisedDepthmap(self, lam, iterations):  # depthmap.cpp:113-123
+        self.output_depth_32fc1_ = self.denoiser_.denoise(self.seeds_.getMu(), self.seeds_.getSigmaSq(), self.seeds_.getA(),
+                                                          self.seeds_.getB(), lam, iterations)
+
+    def getDepthmap(self): return self.output_depth_32fc1_
+
+    def downloadConvergenceMap(self):
+        self.output_convergence_int_ = self.seeds_.downloadConvergence()
+
+    def getConvergenceMap(self): return self.output_convergence_int_
+    def getReferenceImage(self): return self.ref_img_8uc1_
+    def getConvergedCount(self): return self.seeds_.getConvergedCount()
+
+    def getConvergedPercentage(self):  # depthmap.cpp:152-156
+        return float(np.float32(self.getConvergedCount()) / np.float32(self.width_ * self.height_) * np.float32(100.0))
+
+    def getDistFromRef(self): return self.seeds_.getDistFromRef()
+    def getT_world_ref(self): return self.T_world_ref_
+    def getWidth(self): return self.width_
+    def getHeight(self): return self.height_
+    def getFx(self): return self.fx_
+    def getFy(self): return self.fy_
+    def getCx(self): return self.cx_
+    def getCy(self): return self.cy_

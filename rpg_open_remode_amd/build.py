@@ -1,0 +1,86 @@
+"""Builds every native artefact of the repository, in-tree.
+
+  rpg_open_remode_amd/librmd_hip.so     HIP kernels + C ABI, hipcc --offload-arch=gfx950 (cross-compiles without a GPU)
+  rpg_open_remode_amd/librmd_synth.so   synthetic sequence generator (host only)
+  oracle/libremode_oracle*_s{3,5,7,9}.so  CPU oracle B (test infrastructure)
+  oracle/_ref/libremode_ref_s{3,5,7,9}.so CPU oracle A, only where /root/reference exists
+
+Run as `python -m rpg_open_remode_amd.build` or through __graft_entry__.build().
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # arithmetic contract (csrc/rmd_math.h): no contraction, IEEE fp32 divide / sqrt
+    "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
+]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd, cwd=None, verbose=False):
+    if verbose:
+        print("+", " ".join(cmd), flush=True)
+    res = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"build step failed ({' '.join(cmd)}):\n{res.stdout}")
+    if verbose and res.stdout.strip():
+        print(res.stdout)
+    return res.stdout
+
+
+def hipcc_path():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def build_hip(force=False, verbose=False, extra_flags=()):
+    out = os.path.join(HERE, "librmd_hip.so")
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h"))]
+    srcs.append(os.path.join(ROOT, "include", "rmd_hip.h"))
+    if force or _newer(out, srcs):
+        _run([hipcc_path(), *HIPCC_FLAGS, *extra_flags, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+              os.path.join(CSRC, "rmd_capi.hip"), "-o", out], verbose=verbose)
+    return out
+
+
+def build_synth(force=False, verbose=False):
+    out = os.path.join(HERE, "librmd_synth.so")
+    src = os.path.join(CSRC, "synth.cpp")
+    if force or _newer(out, [src]):
+        _run(["g++", "-O2", "-fPIC", "-shared", "-fopenmp", src, "-o", out], verbose=verbose)
+    return out
+
+
+def build_oracles(force=False, verbose=False):
+    odir = os.path.join(ROOT, "oracle")
+    if force:
+        _run(["make", "-C", odir, "clean"], verbose=verbose)
+    _run(["make", "-C", odir, "port"], verbose=verbose)
+    if os.path.isdir("/root/reference/src"):
+        _run(["make", "-C", odir, "ref"], verbose=verbose)
+
+
+def build_all(force=False, verbose=False):
+    build_hip(force, verbose)
+    build_synth(force, verbose)
+    build_oracles(force, verbose)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)
+    print("build OK")

@@ -1,0 +1,808 @@
+// librmd_hip.so: C ABI (include/rmd_hip.h) over the HIP kernels.  Host orchestration of
+// rmd::SeedMatrix (seed_matrix.cu:28-230), rmd::DepthmapDenoiser (depthmap_denoiser.cu:124-229),
+// rmd::ImageReducer (reduction.cu) and rmd::DeviceImage (device_image.cuh), redesigned around
+// per-handle HIP streams, kernarg parameter blocks and pinned staging instead of the reference's
+// default stream, device-resident descriptor structs and global texture references.
+#include "rmd_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "rmd_kernels.hpp"
+#include "rmd_matcher.hpp"
+
+#define RMD_HIP_VERSION_NUMBER 100
+
+namespace {
+
+thread_local char g_last_error[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                      \
+  do {                                                                                                     \
+    const hipError_t e_ = (expr);                                                                          \
+    if (e_ != hipSuccess)                                                                                  \
+      return fail(RMD_HIP_ERR_RUNTIME, "%s failed: %s (%d) at %s:%d", #expr, hipGetErrorString(e_),       \
+                  static_cast<int>(e_), __FILE__, __LINE__);                                               \
+  } while (0)
+
+#define TRY(expr)             \
+  do {                        \
+    const int rc_ = (expr);   \
+    if (rc_ != RMD_HIP_OK) return rc_; \
+  } while (0)
+
+size_t kind_size(int kind) { return kind == RMD_HIP_KIND_F32X2 ? 8 : 4; }
+
+// Poses on the host: se3.cuh:78-95 (inverse), :144-162 (compose), operation order preserved.
+rmdk::Pose pose_inverse(const rmdk::Pose& p) {
+  rmdk::Pose r;
+  const float* d = p.d;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r.d[4 * i + j] = d[4 * j + i];
+  for (int i = 0; i < 3; ++i) r.d[4 * i + 3] = -d[i] * d[3] - d[4 + i] * d[7] - d[8 + i] * d[11];
+  return r;
+}
+rmdk::Pose pose_compose(const rmdk::Pose& l, const rmdk::Pose& r) {
+  rmdk::Pose o;
+  for (int row = 0; row < 3; ++row) {
+    const float l0 = l.d[4 * row], l1 = l.d[4 * row + 1], l2 = l.d[4 * row + 2], lt = l.d[4 * row + 3];
+    for (int col = 0; col < 3; ++col) o.d[4 * row + col] = l0 * r.d[col] + l1 * r.d[4 + col] + l2 * r.d[8 + col];
+    o.d[4 * row + 3] = lt + l0 * r.d[3] + l1 * r.d[7] + l2 * r.d[11];
+  }
+  return o;
+}
+
+struct StageTimer {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  std::vector<hipEvent_t> pool;
+  double total_ms = 0.0;
+  long launches = 0;
+  hipEvent_t get() {
+    if (!pool.empty()) {
+      hipEvent_t e = pool.back();
+      pool.pop_back();
+      return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+  void drain() {  // caller has synchronised the stream
+    for (auto& pr : pending) {
+      float ms = 0.0f;
+      if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) total_ms += ms;
+      ++launches;
+      pool.push_back(pr.first);
+      pool.push_back(pr.second);
+    }
+    pending.clear();
+  }
+  void reset() { total_ms = 0.0; launches = 0; }
+  void destroy() {
+    for (auto& pr : pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto e : pool) (void)hipEventDestroy(e);
+    pending.clear();
+    pool.clear();
+  }
+};
+
+struct ScopedStage {
+  StageTimer* t;
+  hipStream_t stream;
+  hipEvent_t start = nullptr;
+  ScopedStage(StageTimer* timer, hipStream_t s) : t(timer), stream(s) {
+    if (t) {
+      start = t->get();
+      (void)hipEventRecord(start, stream);
+    }
+  }
+  ~ScopedStage() {
+    if (t) {
+      hipEvent_t stop = t->get();
+      (void)hipEventRecord(stop, stream);
+      t->pending.emplace_back(start, stop);
+    }
+  }
+};
+
+}  // namespace
+
+// ---- rmd::DeviceImage<T> -------------------------------------------------------------------
+struct rmd_hip_image {
+  int kind = 0, width = 0, height = 0, device = 0;
+  size_t pitch = 0;   // bytes
+  size_t stride = 0;  // elements
+  void* data = nullptr;
+  bool owns = false;
+  hipStream_t owner_stream = nullptr;  // stream of the handle that writes this image (views), else null
+};
+
+namespace {
+
+int image_alloc(rmd_hip_image* img, int kind, int width, int height) {
+  if (width <= 0 || height <= 0 || kind < 0 || kind > RMD_HIP_KIND_F32X2)
+    return fail(RMD_HIP_ERR_INVALID_ARG, "image: bad kind/size (%d, %dx%d)", kind, width, height);
+  const size_t es = kind_size(kind);
+  // rows padded to 256 B so that every row starts on a full HBM burst / 64-lane dword access
+  const size_t pitch = (static_cast<size_t>(width) * es + 255) / 256 * 256;
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, pitch * height));
+  HIP_TRY(hipMemset(p, 0, pitch * height));
+  img->kind = kind; img->width = width; img->height = height;
+  img->pitch = pitch; img->stride = pitch / es; img->data = p; img->owns = true;
+  (void)hipGetDevice(&img->device);
+  return RMD_HIP_OK;
+}
+
+}  // namespace
+
+// ---- rmd::SeedMatrix ------------------------------------------------------------------------
+struct rmd_hip_seeds {
+  int width = 0, height = 0, patch_side = 5, device = 0;
+  rmd_hip_image planes[RMD_HIP_NUM_PLANES];
+  rmdk::SeedParams P;
+  rmdk::Pose T_world_ref;
+  float dist_from_ref = 0.0f;
+  bool has_reference = false;
+  hipStream_t stream = nullptr;
+  unsigned long long* d_scalars = nullptr;  // [0] count result, [1..3] stats
+  unsigned long long* h_scalars = nullptr;  // pinned mirror
+  int opt_matcher = 1, opt_timing = 0, opt_stats = 0;
+  StageTimer timers[RMD_HIP_NUM_SEED_STAGES];
+  long long last_stats[3] = {0, 0, 0};
+  bool stats_pending = false;
+  rmdk::MatcherWorkspace matcher_ws;
+};
+
+namespace {
+
+bool side_supported(int s) { return s == 3 || s == 5 || s == 7 || s == 9; }
+
+template <typename F>
+int dispatch_side(int side, F&& f) {
+  switch (side) {
+    case 3: return f(std::integral_constant<int, 3>());
+    case 5: return f(std::integral_constant<int, 5>());
+    case 7: return f(std::integral_constant<int, 7>());
+    case 9: return f(std::integral_constant<int, 9>());
+    default: return fail(RMD_HIP_ERR_INVALID_ARG, "unsupported patch side %d (3, 5, 7, 9)", side);
+  }
+}
+
+int seeds_sync(const rmd_hip_seeds* s) {
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  rmd_hip_seeds* m = const_cast<rmd_hip_seeds*>(s);
+  for (auto& t : m->timers) t.drain();
+  if (m->stats_pending) {
+    for (int k = 0; k < 3; ++k) m->last_stats[k] = static_cast<long long>(m->h_scalars[1 + k]);
+    m->stats_pending = false;
+  }
+  return RMD_HIP_OK;
+}
+
+int seeds_bind_device(const rmd_hip_seeds* s) {
+  int cur = -1;
+  HIP_TRY(hipGetDevice(&cur));
+  if (cur != s->device) HIP_TRY(hipSetDevice(s->device));
+  return RMD_HIP_OK;
+}
+
+int seeds_launch_init(rmd_hip_seeds* s) {
+  const dim3 block(64, 4), grid((s->width + 63) / 64, (s->height + 3) / 4);
+  ScopedStage st(s->opt_timing ? &s->timers[RMD_HIP_STAGE_SEED_INIT] : nullptr, s->stream);
+  return dispatch_side(s->patch_side, [&](auto side) {
+    hipLaunchKernelGGL((rmdk::seed_init_kernel<decltype(side)::value>), grid, block, 0, s->stream, s->P);
+    HIP_TRY(hipGetLastError());
+    return RMD_HIP_OK;
+  });
+}
+
+int seeds_launch_update(rmd_hip_seeds* s) {
+  rmdk::SeedParams P = s->P;
+  if (s->opt_stats) {
+    HIP_TRY(hipMemsetAsync(s->d_scalars + 1, 0, 3 * sizeof(unsigned long long), s->stream));
+    P.stats = s->d_scalars + 1;
+  } else {
+    P.stats = nullptr;
+  }
+  int rc;
+  {
+    ScopedStage st(s->opt_timing ? &s->timers[RMD_HIP_STAGE_UPDATE] : nullptr, s->stream);
+    rc = dispatch_side(s->patch_side, [&](auto side) {
+      constexpr int SIDE = decltype(side)::value;
+      if (s->opt_matcher == 0) {
+        const dim3 block(64, 4), grid((s->width + 63) / 64, (s->height + 3) / 4);
+        hipLaunchKernelGGL((rmdk::seed_update_pixel_kernel<SIDE>), grid, block, 0, s->stream, P);
+      } else {
+        rmdk::launch_seed_update_tile<SIDE>(P, s->matcher_ws, s->stream);
+      }
+      HIP_TRY(hipGetLastError());
+      return RMD_HIP_OK;
+    });
+  }
+  TRY(rc);
+  if (s->opt_stats) {
+    HIP_TRY(hipMemcpyAsync(s->h_scalars + 1, s->d_scalars + 1, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                           s->stream));
+    s->stats_pending = true;
+  }
+  return RMD_HIP_OK;
+}
+
+// common tail of setReferenceImage (seed_matrix.cu:95-113) once the frame is in planes[REF_IMG]
+int seeds_after_reference(rmd_hip_seeds* s, const float* T_curr_world, float min_depth, float max_depth) {
+  rmdk::SeedParams& P = s->P;
+  P.avg_depth = (min_depth + max_depth) / 2.0f;
+  P.depth_range = max_depth - min_depth;
+  P.sigma_sq_max = P.depth_range * P.depth_range / 36.0f;
+  P.eta_inlier = 0.7f;
+  P.eta_outlier = 0.05f;
+  P.epsilon = P.depth_range / 1000.0f;
+  rmdk::Pose T;
+  memcpy(T.d, T_curr_world, sizeof(T.d));
+  s->T_world_ref = pose_inverse(T);
+  TRY(seeds_launch_init(s));
+  s->has_reference = true;
+  // the reference synchronises here (seed_matrix.cu:113); so do we: the host image is borrowed
+  return seeds_sync(s);
+}
+
+// common tail of update (seed_matrix.cu:124-157) once the frame is in planes[CURR_IMG]
+int seeds_after_frame(rmd_hip_seeds* s, const float* T_curr_world) {
+  rmdk::Pose T;
+  memcpy(T.d, T_curr_world, sizeof(T.d));
+  const rmdk::Pose T_curr_ref = pose_compose(T, s->T_world_ref);
+  const float tx = T_curr_ref.d[3], ty = T_curr_ref.d[7], tz = T_curr_ref.d[11];
+  s->dist_from_ref = sqrtf(tx * tx + ty * ty + tz * tz);
+  s->P.T_curr_ref = T_curr_ref;
+  s->P.T_ref_curr = pose_inverse(T_curr_ref);
+  return seeds_launch_update(s);
+}
+
+}  // namespace
+
+// ---- rmd::DepthmapDenoiser ------------------------------------------------------------------
+struct rmd_hip_denoiser {
+  int width = 0, height = 0, device = 0;
+  rmd_hip_image u[2], u_head[2], p[2], g;
+  float L, tau, sigma, theta;
+  float large_sigma_sq = -1.0f;
+  hipStream_t stream = nullptr;
+  int result_index = 0;
+  int opt_timing = 0, opt_iters_per_launch = 1;
+  StageTimer timer;
+};
+
+extern "C" {
+
+const char* rmd_hip_last_error(void) { return g_last_error; }
+int rmd_hip_version(void) { return RMD_HIP_VERSION_NUMBER; }
+
+// ---- device selection (check_cuda_device.cu:23-117) -------------------------------------------
+int rmd_hip_device_count(int* count) {
+  if (!count) return fail(RMD_HIP_ERR_INVALID_ARG, "device_count: null output");
+  int n = 0;
+  const hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) {
+    *count = 0;
+    return fail(RMD_HIP_ERR_NO_DEVICE, "no HIP device: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return RMD_HIP_OK;
+}
+int rmd_hip_set_device(int device_id) {
+  int n = 0;
+  TRY(rmd_hip_device_count(&n));
+  if (device_id < 0 || device_id >= n)
+    return fail(RMD_HIP_ERR_INVALID_ARG, "invalid device id %d: specify a value in [0, %d]", device_id, n - 1);
+  HIP_TRY(hipSetDevice(device_id));
+  return RMD_HIP_OK;
+}
+int rmd_hip_device_name(int device_id, char* buf, size_t buf_len) {
+  if (!buf || buf_len == 0) return fail(RMD_HIP_ERR_INVALID_ARG, "device_name: null buffer");
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+  snprintf(buf, buf_len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return RMD_HIP_OK;
+}
+
+// ---- DeviceImage ----------------------------------------------------------------------------
+int rmd_hip_image_create(int kind, int width, int height, rmd_hip_image_t** out) {
+  if (!out) return fail(RMD_HIP_ERR_INVALID_ARG, "image_create: null output");
+  rmd_hip_image* img = new (std::nothrow) rmd_hip_image();
+  if (!img) return fail(RMD_HIP_ERR_RUNTIME, "image_create: out of host memory");
+  const int rc = image_alloc(img, kind, width, height);
+  if (rc != RMD_HIP_OK) {
+    delete img;
+    return rc;
+  }
+  *out = img;
+  return RMD_HIP_OK;
+}
+int rmd_hip_image_destroy(rmd_hip_image_t* img) {
+  if (!img) return RMD_HIP_OK;
+  if (img->owns && img->data) (void)hipFree(img->data);  // destructors must not throw (device_image.cuh:124-132 does)
+  delete img;
+  return RMD_HIP_OK;
+}
+int rmd_hip_image_upload(rmd_hip_image_t* img, const void* host) {
+  if (!img || !host) return fail(RMD_HIP_ERR_INVALID_ARG, "image_upload: null argument");
+  if (img->owner_stream) HIP_TRY(hipStreamSynchronize(img->owner_stream));
+  const size_t row = static_cast<size_t>(img->width) * kind_size(img->kind);
+  HIP_TRY(hipMemcpy2D(img->data, img->pitch, host, row, row, img->height, hipMemcpyHostToDevice));
+  return RMD_HIP_OK;
+}
+int rmd_hip_image_download(const rmd_hip_image_t* img, void* host) {
+  if (!img || !host) return fail(RMD_HIP_ERR_INVALID_ARG, "image_download: null argument");
+  if (img->owner_stream) HIP_TRY(hipStreamSynchronize(img->owner_stream));
+  const size_t row = static_cast<size_t>(img->width) * kind_size(img->kind);
+  HIP_TRY(hipMemcpy2D(host, row, img->data, img->pitch, row, img->height, hipMemcpyDeviceToHost));
+  return RMD_HIP_OK;
+}
+int rmd_hip_image_zero(rmd_hip_image_t* img) {
+  if (!img) return fail(RMD_HIP_ERR_INVALID_ARG, "image_zero: null image");
+  if (img->owner_stream) HIP_TRY(hipStreamSynchronize(img->owner_stream));
+  HIP_TRY(hipMemset(img->data, 0, img->pitch * img->height));
+  return RMD_HIP_OK;
+}
+int rmd_hip_image_copy(rmd_hip_image_t* dst, const rmd_hip_image_t* src) {
+  if (!dst || !src) return fail(RMD_HIP_ERR_INVALID_ARG, "image_copy: null argument");
+  if (dst == src) return RMD_HIP_OK;
+  if (dst->kind != src->kind || dst->width != src->width || dst->height != src->height)
+    return fail(RMD_HIP_ERR_INVALID_ARG, "image_copy: shape mismatch");
+  if (src->owner_stream) HIP_TRY(hipStreamSynchronize(src->owner_stream));
+  if (dst->owner_stream) HIP_TRY(hipStreamSynchronize(dst->owner_stream));
+  const size_t row = static_cast<size_t>(src->width) * kind_size(src->kind);
+  HIP_TRY(hipMemcpy2D(dst->data, dst->pitch, src->data, src->pitch, row, src->height, hipMemcpyDeviceToDevice));
+  return RMD_HIP_OK;
+}
+int rmd_hip_image_info(const rmd_hip_image_t* img, int* kind, int* width, int* height, size_t* pitch_bytes,
+                       size_t* stride_elems, void** device_data) {
+  if (!img) return fail(RMD_HIP_ERR_INVALID_ARG, "image_info: null image");
+  if (kind) *kind = img->kind;
+  if (width) *width = img->width;
+  if (height) *height = img->height;
+  if (pitch_bytes) *pitch_bytes = img->pitch;
+  if (stride_elems) *stride_elems = img->stride;
+  if (device_data) *device_data = img->data;
+  return RMD_HIP_OK;
+}
+
+// ---- SeedMatrix -----------------------------------------------------------------------------
+int rmd_hip_seeds_destroy(rmd_hip_seeds_t* s) {
+  if (!s) return RMD_HIP_OK;
+  (void)hipSetDevice(s->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  for (auto& t : s->timers) t.destroy();
+  for (auto& pl : s->planes)
+    if (pl.owns && pl.data) (void)hipFree(pl.data);
+  s->matcher_ws.release();
+  if (s->d_scalars) (void)hipFree(s->d_scalars);
+  if (s->h_scalars) (void)hipHostFree(s->h_scalars);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_seeds_create(int width, int height, float fx, float fy, float cx, float cy, int patch_side, int max_extent,
+                         rmd_hip_seeds_t** out) {
+  if (!out) return fail(RMD_HIP_ERR_INVALID_ARG, "seeds_create: null output");
+  *out = nullptr;
+  if (width <= 0 || height <= 0) return fail(RMD_HIP_ERR_INVALID_ARG, "seeds_create: bad size %dx%d", width, height);
+  if (!side_supported(patch_side))
+    return fail(RMD_HIP_ERR_INVALID_ARG, "seeds_create: unsupported patch side %d (3, 5, 7, 9)", patch_side);
+  if (max_extent <= 0 || max_extent > 100)
+    return fail(RMD_HIP_ERR_INVALID_ARG, "seeds_create: max_extent %d outside (0, 100]", max_extent);
+  int ndev = 0;
+  TRY(rmd_hip_device_count(&ndev));
+  rmd_hip_seeds* s = new (std::nothrow) rmd_hip_seeds();
+  if (!s) return fail(RMD_HIP_ERR_RUNTIME, "seeds_create: out of host memory");
+  s->width = width; s->height = height; s->patch_side = patch_side;
+  (void)hipGetDevice(&s->device);
+  auto bail = [&](int rc) { rmd_hip_seeds_destroy(s); return rc; };
+  if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: hipStreamCreate failed"));
+  for (int p = 0; p < RMD_HIP_NUM_PLANES; ++p) {
+    const int kind = p == RMD_HIP_PLANE_CONVERGENCE ? RMD_HIP_KIND_I32
+                     : p == RMD_HIP_PLANE_EPIPOLAR_MATCHES ? RMD_HIP_KIND_F32X2 : RMD_HIP_KIND_F32;
+    const int rc = image_alloc(&s->planes[p], kind, width, height);
+    if (rc != RMD_HIP_OK) return bail(rc);
+    s->planes[p].owner_stream = s->stream;
+  }
+  if (hipMalloc(reinterpret_cast<void**>(&s->d_scalars), 4 * sizeof(unsigned long long)) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&s->h_scalars), 4 * sizeof(unsigned long long)) != hipSuccess)
+    return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: scalar buffers"));
+  (void)hipMemset(s->d_scalars, 0, 4 * sizeof(unsigned long long));
+  memset(s->h_scalars, 0, 4 * sizeof(unsigned long long));
+  rmdk::SeedParams& P = s->P;
+  memset(&P, 0, sizeof(P));
+  P.w = width; P.h = height;
+  P.stride = static_cast<int>(s->planes[RMD_HIP_PLANE_MU].stride);
+  P.stride2 = static_cast<int>(s->planes[RMD_HIP_PLANE_EPIPOLAR_MATCHES].stride);
+  P.ref = static_cast<const float*>(s->planes[RMD_HIP_PLANE_REF_IMG].data);
+  P.cur = static_cast<const float*>(s->planes[RMD_HIP_PLANE_CURR_IMG].data);
+  P.sum_templ = static_cast<float*>(s->planes[RMD_HIP_PLANE_SUM_TEMPL].data);
+  P.denom = static_cast<float*>(s->planes[RMD_HIP_PLANE_CONST_TEMPL_DENOM].data);
+  P.mu = static_cast<float*>(s->planes[RMD_HIP_PLANE_MU].data);
+  P.sigma_sq = static_cast<float*>(s->planes[RMD_HIP_PLANE_SIGMA_SQ].data);
+  P.a = static_cast<float*>(s->planes[RMD_HIP_PLANE_A].data);
+  P.b = static_cast<float*>(s->planes[RMD_HIP_PLANE_B].data);
+  P.conv = static_cast<int*>(s->planes[RMD_HIP_PLANE_CONVERGENCE].data);
+  P.match = static_cast<float2*>(s->planes[RMD_HIP_PLANE_EPIPOLAR_MATCHES].data);
+  P.cam = rmdk::Cam{fx, fy, cx, cy};
+  P.one_pix_angle = atan2f(1.0f, 2.0f * fx) * 2.0f;  // pinhole_camera.cuh:56-59
+  P.max_extent = static_cast<float>(max_extent);
+  const int rcw = s->matcher_ws.allocate(width, height);
+  if (rcw != 0) return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: matcher workspace"));
+  *out = s;
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_seeds_set_reference(rmd_hip_seeds_t* s, const float* host_img, const float* T_curr_world, float min_depth,
+                                float max_depth) {
+  if (!s || !host_img || !T_curr_world) return fail(RMD_HIP_ERR_INVALID_ARG, "set_reference: null argument");
+  TRY(seeds_bind_device(s));
+  const rmd_hip_image& im = s->planes[RMD_HIP_PLANE_REF_IMG];
+  const size_t row = static_cast<size_t>(s->width) * 4;
+  HIP_TRY(hipMemcpy2DAsync(im.data, im.pitch, host_img, row, row, s->height, hipMemcpyHostToDevice, s->stream));
+  return seeds_after_reference(s, T_curr_world, min_depth, max_depth);
+}
+
+int rmd_hip_seeds_set_reference_device(rmd_hip_seeds_t* s, const float* dev_img, size_t stride_elems,
+                                       const float* T_curr_world, float min_depth, float max_depth) {
+  if (!s || !dev_img || !T_curr_world) return fail(RMD_HIP_ERR_INVALID_ARG, "set_reference_device: null argument");
+  if (stride_elems < static_cast<size_t>(s->width)) return fail(RMD_HIP_ERR_INVALID_ARG, "set_reference_device: stride < width");
+  TRY(seeds_bind_device(s));
+  const rmd_hip_image& im = s->planes[RMD_HIP_PLANE_REF_IMG];
+  const size_t row = static_cast<size_t>(s->width) * 4;
+  HIP_TRY(hipMemcpy2DAsync(im.data, im.pitch, dev_img, stride_elems * 4, row, s->height, hipMemcpyDeviceToDevice, s->stream));
+  return seeds_after_reference(s, T_curr_world, min_depth, max_depth);
+}
+
+int rmd_hip_seeds_update(rmd_hip_seeds_t* s, const float* host_img, const float* T_curr_world) {
+  if (!s || !host_img || !T_curr_world) return fail(RMD_HIP_ERR_INVALID_ARG, "update: null argument");
+  if (!s->has_reference) return fail(RMD_HIP_ERR_NOT_READY, "update: setReferenceImage has not been called");
+  TRY(seeds_bind_device(s));
+  const rmd_hip_image& im = s->planes[RMD_HIP_PLANE_CURR_IMG];
+  const size_t row = static_cast<size_t>(s->width) * 4;
+  // pageable source: the runtime stages it and returns once the host buffer may be reused
+  HIP_TRY(hipMemcpy2DAsync(im.data, im.pitch, host_img, row, row, s->height, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return seeds_after_frame(s, T_curr_world);
+}
+
+int rmd_hip_seeds_update_device(rmd_hip_seeds_t* s, const float* dev_img, size_t stride_elems, const float* T_curr_world) {
+  if (!s || !dev_img || !T_curr_world) return fail(RMD_HIP_ERR_INVALID_ARG, "update_device: null argument");
+  if (!s->has_reference) return fail(RMD_HIP_ERR_NOT_READY, "update_device: setReferenceImage has not been called");
+  if (stride_elems < static_cast<size_t>(s->width)) return fail(RMD_HIP_ERR_INVALID_ARG, "update_device: stride < width");
+  TRY(seeds_bind_device(s));
+  const rmd_hip_image& im = s->planes[RMD_HIP_PLANE_CURR_IMG];
+  const size_t row = static_cast<size_t>(s->width) * 4;
+  HIP_TRY(hipMemcpy2DAsync(im.data, im.pitch, dev_img, stride_elems * 4, row, s->height, hipMemcpyDeviceToDevice, s->stream));
+  return seeds_after_frame(s, T_curr_world);
+}
+
+int rmd_hip_seeds_download(const rmd_hip_seeds_t* s, int plane, void* host_dst) {
+  if (!s || !host_dst) return fail(RMD_HIP_ERR_INVALID_ARG, "seeds_download: null argument");
+  if (plane < 0 || plane >= RMD_HIP_NUM_PLANES) return fail(RMD_HIP_ERR_INVALID_ARG, "seeds_download: bad plane %d", plane);
+  TRY(seeds_bind_device(s));
+  TRY(seeds_sync(s));
+  const rmd_hip_image& im = s->planes[plane];
+  const size_t row = static_cast<size_t>(im.width) * kind_size(im.kind);
+  HIP_TRY(hipMemcpy2D(host_dst, row, im.data, im.pitch, row, im.height, hipMemcpyDeviceToHost));
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_seeds_upload(rmd_hip_seeds_t* s, int plane, const float* host_src) {
+  if (!s || !host_src) return fail(RMD_HIP_ERR_INVALID_ARG, "seeds_upload: null argument");
+  if (plane < RMD_HIP_PLANE_MU || plane > RMD_HIP_PLANE_B) return fail(RMD_HIP_ERR_INVALID_ARG, "seeds_upload: plane %d", plane);
+  TRY(seeds_bind_device(s));
+  TRY(seeds_sync(s));
+  const rmd_hip_image& im = s->planes[plane];
+  const size_t row = static_cast<size_t>(im.width) * 4;
+  HIP_TRY(hipMemcpy2D(im.data, im.pitch, host_src, row, row, im.height, hipMemcpyHostToDevice));
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_seeds_plane(const rmd_hip_seeds_t* s, int plane, const rmd_hip_image_t** view) {
+  if (!s || !view) return fail(RMD_HIP_ERR_INVALID_ARG, "seeds_plane: null argument");
+  if (plane < 0 || plane >= RMD_HIP_NUM_PLANES) return fail(RMD_HIP_ERR_INVALID_ARG, "seeds_plane: bad plane %d", plane);
+  *view = &s->planes[plane];
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_seeds_converged_count(const rmd_hip_seeds_t* s, size_t* count) {
+  if (!s || !count) return fail(RMD_HIP_ERR_INVALID_ARG, "converged_count: null argument");
+  TRY(seeds_bind_device(s));
+  rmd_hip_seeds* m = const_cast<rmd_hip_seeds*>(s);
+  HIP_TRY(hipMemsetAsync(m->d_scalars, 0, sizeof(unsigned long long), m->stream));
+  {
+    ScopedStage st(m->opt_timing ? &m->timers[RMD_HIP_STAGE_COUNT] : nullptr, m->stream);
+    const dim3 block(256), grid((s->width + 255) / 256, s->height < 64 ? s->height : 64);
+    hipLaunchKernelGGL(rmdk::count_eq_kernel, grid, block, 0, m->stream,
+                       static_cast<const int*>(s->planes[RMD_HIP_PLANE_CONVERGENCE].data), s->width, s->height,
+                       s->P.stride, static_cast<int>(RMD_HIP_STATE_CONVERGED), m->d_scalars);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipMemcpyAsync(m->h_scalars, m->d_scalars, sizeof(unsigned long long), hipMemcpyDeviceToHost, m->stream));
+  TRY(seeds_sync(s));
+  *count = static_cast<size_t>(m->h_scalars[0]);
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_seeds_dist_from_ref(const rmd_hip_seeds_t* s, float* dist) {
+  if (!s || !dist) return fail(RMD_HIP_ERR_INVALID_ARG, "dist_from_ref: null argument");
+  *dist = s->dist_from_ref;
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_seeds_sync(const rmd_hip_seeds_t* s) {
+  if (!s) return fail(RMD_HIP_ERR_INVALID_ARG, "seeds_sync: null handle");
+  TRY(seeds_bind_device(s));
+  return seeds_sync(s);
+}
+
+int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value) {
+  if (!s) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: null handle");
+  switch (option) {
+    case RMD_HIP_OPT_MATCHER:
+      if (value != 0 && value != 1) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: matcher %d", value);
+      s->opt_matcher = value;
+      return RMD_HIP_OK;
+    case RMD_HIP_OPT_TIMING: s->opt_timing = value != 0; return RMD_HIP_OK;
+    case RMD_HIP_OPT_COLLECT_STATS: s->opt_stats = value != 0; return RMD_HIP_OK;
+    default: return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: unknown option %d", option);
+  }
+}
+
+int rmd_hip_seeds_timing(const rmd_hip_seeds_t* s, int stage, double* total_ms, long* launches) {
+  if (!s || stage < 0 || stage >= RMD_HIP_NUM_SEED_STAGES) return fail(RMD_HIP_ERR_INVALID_ARG, "seeds_timing: bad argument");
+  TRY(seeds_bind_device(s));
+  TRY(seeds_sync(s));
+  if (total_ms) *total_ms = s->timers[stage].total_ms;
+  if (launches) *launches = s->timers[stage].launches;
+  return RMD_HIP_OK;
+}
+int rmd_hip_seeds_timing_reset(rmd_hip_seeds_t* s) {
+  if (!s) return fail(RMD_HIP_ERR_INVALID_ARG, "timing_reset: null handle");
+  TRY(seeds_bind_device(s));
+  TRY(seeds_sync(s));
+  for (auto& t : s->timers) t.reset();
+  return RMD_HIP_OK;
+}
+int rmd_hip_seeds_last_stats(const rmd_hip_seeds_t* s, long long* out3) {
+  if (!s || !out3) return fail(RMD_HIP_ERR_INVALID_ARG, "last_stats: null argument");
+  TRY(seeds_bind_device(s));
+  TRY(seeds_sync(s));
+  for (int k = 0; k < 3; ++k) out3[k] = s->last_stats[k];
+  return RMD_HIP_OK;
+}
+
+// ---- DepthmapDenoiser -----------------------------------------------------------------------
+int rmd_hip_denoiser_destroy(rmd_hip_denoiser_t* d) {
+  if (!d) return RMD_HIP_OK;
+  (void)hipSetDevice(d->device);
+  if (d->stream) (void)hipStreamSynchronize(d->stream);
+  d->timer.destroy();
+  rmd_hip_image* all[] = {&d->u[0], &d->u[1], &d->u_head[0], &d->u_head[1], &d->p[0], &d->p[1], &d->g};
+  for (auto* im : all)
+    if (im->owns && im->data) (void)hipFree(im->data);
+  if (d->stream) (void)hipStreamDestroy(d->stream);
+  delete d;
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_denoiser_create(int width, int height, rmd_hip_denoiser_t** out) {
+  if (!out) return fail(RMD_HIP_ERR_INVALID_ARG, "denoiser_create: null output");
+  *out = nullptr;
+  if (width <= 0 || height <= 0) return fail(RMD_HIP_ERR_INVALID_ARG, "denoiser_create: bad size %dx%d", width, height);
+  int ndev = 0;
+  TRY(rmd_hip_device_count(&ndev));
+  rmd_hip_denoiser* d = new (std::nothrow) rmd_hip_denoiser();
+  if (!d) return fail(RMD_HIP_ERR_RUNTIME, "denoiser_create: out of host memory");
+  d->width = width; d->height = height;
+  (void)hipGetDevice(&d->device);
+  // denoise::DeviceData constructor, depthmap_denoiser.cu:124-141
+  d->L = sqrtf(8.0f);
+  d->tau = 0.02f;
+  d->sigma = (1 / (d->L * d->L)) / d->tau;
+  d->theta = 0.5f;
+  auto bail = [&](int rc) { rmd_hip_denoiser_destroy(d); return rc; };
+  if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(fail(RMD_HIP_ERR_RUNTIME, "denoiser_create: hipStreamCreate failed"));
+  rmd_hip_image* f32[] = {&d->u[0], &d->u[1], &d->u_head[0], &d->u_head[1], &d->g};
+  for (auto* im : f32) {
+    const int rc = image_alloc(im, RMD_HIP_KIND_F32, width, height);
+    if (rc != RMD_HIP_OK) return bail(rc);
+    im->owner_stream = d->stream;
+  }
+  for (int k = 0; k < 2; ++k) {
+    const int rc = image_alloc(&d->p[k], RMD_HIP_KIND_F32X2, width, height);
+    if (rc != RMD_HIP_OK) return bail(rc);
+    d->p[k].owner_stream = d->stream;
+  }
+  *out = d;
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_denoiser_set_large_sigma_sq(rmd_hip_denoiser_t* d, float depth_range) {
+  if (!d) return fail(RMD_HIP_ERR_INVALID_ARG, "set_large_sigma_sq: null handle");
+  d->large_sigma_sq = depth_range * depth_range / 72.0f;
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_denoiser_constants(const rmd_hip_denoiser_t* d, float* out4) {
+  if (!d || !out4) return fail(RMD_HIP_ERR_INVALID_ARG, "denoiser_constants: null argument");
+  out4[0] = d->L; out4[1] = d->tau; out4[2] = d->sigma; out4[3] = d->theta;
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_denoiser_set_option(rmd_hip_denoiser_t* d, int option, int value) {
+  if (!d) return fail(RMD_HIP_ERR_INVALID_ARG, "denoiser_set_option: null handle");
+  switch (option) {
+    case RMD_HIP_DENOISE_OPT_TIMING: d->opt_timing = value != 0; return RMD_HIP_OK;
+    case RMD_HIP_DENOISE_OPT_ITERS_PER_LAUNCH:
+      if (value < 1 || value > 8) return fail(RMD_HIP_ERR_INVALID_ARG, "iters_per_launch %d outside 1..8", value);
+      d->opt_iters_per_launch = value;
+      return RMD_HIP_OK;
+    default: return fail(RMD_HIP_ERR_INVALID_ARG, "denoiser_set_option: unknown option %d", option);
+  }
+}
+
+int rmd_hip_denoiser_denoise(rmd_hip_denoiser_t* d, const rmd_hip_image_t* mu, const rmd_hip_image_t* sigma_sq,
+                             const rmd_hip_image_t* a, const rmd_hip_image_t* b, float* host_denoised, float lambda,
+                             int iterations) {
+  if (!d || !mu || !sigma_sq || !a || !b) return fail(RMD_HIP_ERR_INVALID_ARG, "denoise: null argument");
+  if (iterations < 0) return fail(RMD_HIP_ERR_INVALID_ARG, "denoise: negative iteration count");
+  if (d->large_sigma_sq < 0.0f) return fail(RMD_HIP_ERR_NOT_READY, "denoise: setLargeSigmaSq must be called before this method");
+  const rmd_hip_image_t* ins[4] = {mu, sigma_sq, a, b};
+  for (auto* im : ins) {
+    if (im->kind != RMD_HIP_KIND_F32 || im->width != d->width || im->height != d->height || im->stride != mu->stride)
+      return fail(RMD_HIP_ERR_INVALID_ARG, "denoise: input planes must be f32 %dx%d with one common stride", d->width, d->height);
+  }
+  int cur = -1;
+  HIP_TRY(hipGetDevice(&cur));
+  if (cur != d->device) HIP_TRY(hipSetDevice(d->device));
+  // inputs may still be written by their owner (the SeedMatrix's last kernel is left in flight)
+  for (auto* im : ins)
+    if (im->owner_stream && im->owner_stream != d->stream) HIP_TRY(hipStreamSynchronize(im->owner_stream));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  d->timer.drain();
+  d->timer.reset();
+
+  rmdk::TvParams P;
+  P.w = d->width; P.h = d->height;
+  P.stride = static_cast<int>(d->g.stride);
+  P.stride2 = static_cast<int>(d->p[0].stride);
+  P.mu = static_cast<const float*>(mu->data);
+  P.sigma_sq = static_cast<const float*>(sigma_sq->data);
+  P.a = static_cast<const float*>(a->data);
+  P.b = static_cast<const float*>(b->data);
+  P.in_stride = static_cast<int>(mu->stride);
+  P.g = static_cast<float*>(d->g.data);
+  P.large_sigma_sq = d->large_sigma_sq;
+  P.tau = d->tau; P.sigma = d->sigma; P.theta = d->theta; P.lambda = lambda;
+
+  {
+    const dim3 block(64, 4), grid((d->width + 63) / 64, (d->height + 3) / 4);
+    hipLaunchKernelGGL(rmdk::tv_prepare_kernel, grid, block, 0, d->stream, P, static_cast<float*>(d->u[0].data),
+                       static_cast<float*>(d->u_head[0].data), static_cast<float2*>(d->p[0].data));
+    HIP_TRY(hipGetLastError());
+  }
+  int cur_buf = 0;
+  {
+    const dim3 block(rmdk::TV_TX, rmdk::TV_TY);
+    const dim3 grid((d->width + rmdk::TV_TX - 1) / rmdk::TV_TX, (d->height + rmdk::TV_TY - 1) / rmdk::TV_TY);
+    for (int it = 0; it < iterations; ++it) {
+      const int nxt = cur_buf ^ 1;
+      ScopedStage st(d->opt_timing ? &d->timer : nullptr, d->stream);
+      hipLaunchKernelGGL(rmdk::tv_iterate_kernel, grid, block, 0, d->stream, P,
+                         static_cast<const float*>(d->u[cur_buf].data), static_cast<const float*>(d->u_head[cur_buf].data),
+                         static_cast<const float2*>(d->p[cur_buf].data), static_cast<float*>(d->u[nxt].data),
+                         static_cast<float*>(d->u_head[nxt].data), static_cast<float2*>(d->p[nxt].data));
+      cur_buf = nxt;
+    }
+    HIP_TRY(hipGetLastError());
+  }
+  d->result_index = cur_buf;
+  if (host_denoised) {
+    const rmd_hip_image& r = d->u[cur_buf];
+    const size_t row = static_cast<size_t>(r.width) * 4;
+    HIP_TRY(hipMemcpy2DAsync(host_denoised, row, r.data, r.pitch, row, r.height, hipMemcpyDeviceToHost, d->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  d->timer.drain();
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_denoiser_result(const rmd_hip_denoiser_t* d, const rmd_hip_image_t** view) {
+  if (!d || !view) return fail(RMD_HIP_ERR_INVALID_ARG, "denoiser_result: null argument");
+  *view = &d->u[d->result_index];
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_denoiser_timing(const rmd_hip_denoiser_t* d, double* total_ms, long* launches) {
+  if (!d) return fail(RMD_HIP_ERR_INVALID_ARG, "denoiser_timing: null handle");
+  if (total_ms) *total_ms = d->timer.total_ms;
+  if (launches) *launches = d->timer.launches;
+  return RMD_HIP_OK;
+}
+
+// ---- ImageReducer ---------------------------------------------------------------------------
+int rmd_hip_reduce_sum_f32(const rmd_hip_image_t* img, float* sum) {
+  if (!img || !sum) return fail(RMD_HIP_ERR_INVALID_ARG, "reduce_sum: null argument");
+  if (img->kind != RMD_HIP_KIND_F32) return fail(RMD_HIP_ERR_INVALID_ARG, "reduce_sum: image is not f32");
+  if (img->owner_stream) HIP_TRY(hipStreamSynchronize(img->owner_stream));
+  const dim3 block(256), grid((img->width + 255) / 256 < 8 ? (img->width + 255) / 256 : 8, img->height < 64 ? img->height : 64);
+  const int nparts = grid.x * grid.y;
+  double* d_parts = nullptr;
+  float* d_out = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_parts), nparts * sizeof(double)));
+  if (hipMalloc(reinterpret_cast<void**>(&d_out), sizeof(float)) != hipSuccess) {
+    (void)hipFree(d_parts);
+    return fail(RMD_HIP_ERR_RUNTIME, "reduce_sum: hipMalloc failed");
+  }
+  hipLaunchKernelGGL(rmdk::sum_partial_kernel, grid, block, 0, nullptr, static_cast<const float*>(img->data), img->width,
+                     img->height, static_cast<int>(img->stride), d_parts);
+  hipLaunchKernelGGL(rmdk::sum_final_kernel, dim3(1), dim3(64), 0, nullptr, d_parts, nparts, d_out);
+  const hipError_t e = hipMemcpy(sum, d_out, sizeof(float), hipMemcpyDeviceToHost);
+  (void)hipFree(d_parts);
+  (void)hipFree(d_out);
+  if (e != hipSuccess) return fail(RMD_HIP_ERR_RUNTIME, "reduce_sum: %s", hipGetErrorString(e));
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_reduce_count_eq_i32(const rmd_hip_image_t* img, int value, size_t* count) {
+  if (!img || !count) return fail(RMD_HIP_ERR_INVALID_ARG, "reduce_count_eq: null argument");
+  if (img->kind != RMD_HIP_KIND_I32) return fail(RMD_HIP_ERR_INVALID_ARG, "reduce_count_eq: image is not i32");
+  if (img->owner_stream) HIP_TRY(hipStreamSynchronize(img->owner_stream));
+  unsigned long long* d_out = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), sizeof(unsigned long long)));
+  (void)hipMemset(d_out, 0, sizeof(unsigned long long));
+  const dim3 block(256), grid((img->width + 255) / 256, img->height < 64 ? img->height : 64);
+  hipLaunchKernelGGL(rmdk::count_eq_kernel, grid, block, 0, nullptr, static_cast<const int*>(img->data), img->width,
+                     img->height, static_cast<int>(img->stride), value, d_out);
+  unsigned long long h = 0;
+  const hipError_t e = hipMemcpy(&h, d_out, sizeof(h), hipMemcpyDeviceToHost);
+  (void)hipFree(d_out);
+  if (e != hipSuccess) return fail(RMD_HIP_ERR_RUNTIME, "reduce_count_eq: %s", hipGetErrorString(e));
+  *count = static_cast<size_t>(h);
+  return RMD_HIP_OK;
+}
+
+// ---- arithmetic-contract self test ----------------------------------------------------------
+int rmd_hip_math_eval(int op, const float* x, const float* y, const float* z, float* out, size_t n) {
+  if (!x || !out || n == 0 || op < 0 || op > 6) return fail(RMD_HIP_ERR_INVALID_ARG, "math_eval: bad argument");
+  if ((op == 5 && !y) || (op == 6 && (!y || !z))) return fail(RMD_HIP_ERR_INVALID_ARG, "math_eval: missing operand");
+  float *dx = nullptr, *dy = nullptr, *dz = nullptr, *dout = nullptr;
+  const size_t bytes = n * sizeof(float);
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dx), bytes));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dy), bytes));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dz), bytes));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dout), bytes));
+  (void)hipMemcpy(dx, x, bytes, hipMemcpyHostToDevice);
+  (void)hipMemcpy(dy, y ? y : x, bytes, hipMemcpyHostToDevice);
+  (void)hipMemcpy(dz, z ? z : x, bytes, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(rmdk::math_eval_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, op, dx, dy,
+                     dz, dout, n);
+  const hipError_t e = hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
+  (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dz); (void)hipFree(dout);
+  if (e != hipSuccess) return fail(RMD_HIP_ERR_RUNTIME, "math_eval: %s", hipGetErrorString(e));
+  return RMD_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,377 @@
+// HIP kernels of the depth-filter path (gfx950 / CDNA4, wave64).
+//
+//   seed_init_kernel          <- src/seed_init.cu:27-61
+//   seed_update_pixel_kernel  <- src/seed_check.cu:28-67 + src/epipolar_match.cu:37-140 +
+//                                src/seed_update.cu:39-121, fused, one lane per pixel
+//   (seed_update_tile_kernel, the production matcher, lives in rmd_matcher.hpp)
+//   count_eq_kernel / sum_*   <- src/reduction_kernels.cu:57-159
+//   tv_prepare_kernel         <- src/depthmap_denoiser.cu:45-59 + :215-217
+//   tv_iterate_kernel         <- src/depthmap_denoiser.cu:61-118
+//
+// No textures, no __constant__ symbols, no process-global state: everything a kernel needs
+// arrives as a by-value parameter block in kernarg SGPRs.
+#ifndef RMD_KERNELS_HPP
+#define RMD_KERNELS_HPP
+
+#include <float.h>
+
+#include "rmd_device.hpp"
+
+namespace rmdk {
+
+enum : int { ST_UPDATE = 0, ST_CONVERGED = 1, ST_BORDER = 2, ST_DIVERGED = 3, ST_NO_MATCH = 4, ST_NOT_VISIBLE = 5 };
+
+// Parameter block of the seed kernels (the reference's mvs::DeviceData, mvs_device_data.cuh:46-106,
+// minus the pointer-to-descriptor indirection).
+struct SeedParams {
+  int w, h;
+  int stride;   // elements, shared by every f32/i32 plane of one SeedMatrix
+  int stride2;  // float2 elements, epipolar_matches plane
+  const float* ref;
+  const float* cur;
+  float* sum_templ;
+  float* denom;
+  float* mu;
+  float* sigma_sq;
+  float* a;
+  float* b;
+  int* conv;
+  float2* match;
+  Cam cam;
+  float one_pix_angle;
+  float avg_depth, depth_range, sigma_sq_max;
+  float eta_inlier, eta_outlier, epsilon;
+  float max_extent;
+  Pose T_curr_ref;
+  Pose T_ref_curr;
+  unsigned long long* stats;  // [0] live seeds, [1] steps visited, [2] NCC evaluations; may be null
+};
+
+// ------------------------------------------------------------------------------------------
+// seed_init.cu:27-61 -- NCC template statistics + prior.  Runs once per reference frame.
+template <int SIDE>
+__global__ __launch_bounds__(256) void seed_init_kernel(SeedParams P) {
+  constexpr int OFFSET = -SIDE / 2;
+  constexpr int AREA = SIDE * SIDE;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= P.w || y >= P.h) return;
+  float sum_t = 0.0f, sum_t_sq = 0.0f;
+#pragma unroll
+  for (int py = 0; py < SIDE; ++py) {
+    const int yy = clampi(y + OFFSET + py, 0, P.h - 1);
+#pragma unroll
+    for (int px = 0; px < SIDE; ++px) {
+      const float t = P.ref[yy * P.stride + clampi(x + OFFSET + px, 0, P.w - 1)];
+      sum_t += t;
+      sum_t_sq += t * t;
+    }
+  }
+  const int i = y * P.stride + x;
+  P.sum_templ[i] = sum_t;
+  P.denom[i] = static_cast<float>(static_cast<double>(AREA) * sum_t_sq - static_cast<double>(sum_t) * sum_t);
+  P.mu[i] = P.avg_depth;
+  P.sigma_sq[i] = P.sigma_sq_max;
+  P.a[i] = 10.0f;
+  P.b[i] = 10.0f;
+}
+
+// ------------------------------------------------------------------------------------------
+// seed_check.cu:28-67 as a function of one pixel's state
+RMDK_D int seed_check(const SeedParams& P, int x, int y, float sigma_sq, float a, float b, int side) {
+  // the reference compares in size_t: width - SIDE - 1 wraps for tiny images
+  const size_t x_hi = static_cast<size_t>(P.w) - side - 1, y_hi = static_cast<size_t>(P.h) - side - 1;
+  if (static_cast<size_t>(x) > x_hi || static_cast<size_t>(y) > y_hi || x < side || y < side) return ST_BORDER;
+  if ((a / (a + b)) > P.eta_inlier && sigma_sq < P.epsilon) return ST_CONVERGED;
+  if ((a - 1) / (a + b - 2) < P.eta_outlier) return ST_DIVERGED;
+  return ST_UPDATE;
+}
+
+// Epipolar segment of one seed in the current frame (epipolar_match.cu:59-75)
+struct Segment {
+  F2 mean;   // projection of mu
+  F2 dir;    // unit direction (NaN for a zero-length segment)
+  float half_length;
+};
+RMDK_D Segment epipolar_segment(const SeedParams& P, int x, int y, float mu, float sigma_sq) {
+  const float sigma = sqrtf(sigma_sq);
+  const F3 f_ref = normalize3(cam2world(P.cam, static_cast<float>(x), static_cast<float>(y)));
+  Segment s;
+  s.mean = world2cam(P.cam, pose_apply(P.T_curr_ref, scale3(f_ref, mu)));
+  const float d_lo = mu - 3.0f * sigma;
+  const F2 px_min = world2cam(P.cam, pose_apply(P.T_curr_ref, scale3(f_ref, d_lo > 0.01f ? d_lo : 0.01f)));
+  const F2 px_max = world2cam(P.cam, pose_apply(P.T_curr_ref, scale3(f_ref, mu + (3.0f * sigma))));
+  const F2 line = F2{px_max.x - px_min.x, px_max.y - px_min.y};
+  s.dir = normalize2(line);
+  const float len = norm2(line);
+  s.half_length = 0.5f * (len < P.max_extent ? len : P.max_extent);
+  return s;
+}
+
+// seed_update.cu:58-119 for one pixel whose state (after matching) is `state`
+RMDK_D void seed_fuse(const SeedParams& P, int x, int y, int i, int state, float mu, float sigma_sq, float a, float b,
+                      F2 match) {
+  if (state == ST_UPDATE) {
+    const F3 f_ref = normalize3(cam2world(P.cam, static_cast<float>(x), static_cast<float>(y)));
+    const F3 f_epi = normalize3(cam2world(P.cam, match.x, match.y));
+    const F3 pt = triangulate(f_ref, f_epi, P.T_ref_curr);
+    if (pt.z < 0.0f) return;
+    const float depth = norm3(pt);
+    const float tau = triangulation_uncertainty(depth, f_ref, pose_translation(P.T_ref_curr), P.one_pix_angle);
+    const float tau_sq = tau * tau;
+    const float s_sq = (tau_sq * sigma_sq) / (tau_sq + sigma_sq);
+    const float m = s_sq * (mu / sigma_sq + depth / tau_sq);
+    float c1 = (a / (a + b)) * normpdf(depth, mu, sigma_sq + tau_sq);
+    float c2 = (b / (a + b)) * (1.0f / P.depth_range);
+    const float norm_const = c1 + c2;
+    c1 = c1 / norm_const;
+    c2 = c2 / norm_const;
+    const float f = c1 * ((a + 1.0f) / (a + b + 1.0f)) + c2 * (a / (a + b + 1.0f));
+    const float e = c1 * (((a + 1.0f) * (a + 2.0f)) / ((a + b + 1.0f) * (a + b + 2.0f))) +
+                    c2 * (a * (a + 1.0f) / ((a + b + 1.0f) * (a + b + 2.0f)));
+    if (isnan(c1 * m)) return;
+    const float mu_prime = c1 * m + c2 * mu;
+    P.sigma_sq[i] = c1 * (s_sq + m * m) + c2 * (sigma_sq + mu * mu) - mu_prime * mu_prime;
+    P.mu[i] = mu_prime;
+    const float a_prime = (e - f) / (f - e / f);
+    P.a[i] = a_prime;
+    P.b[i] = a_prime * (1.0f - f) / f;
+  } else if (state == ST_NO_MATCH) {
+    P.b[i] = b + 1.0f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused check + match + update, one lane per pixel, all image reads straight from global
+// memory (L1/L2).  Simple and exact; kept as the A/B baseline and small-image path.
+template <int SIDE>
+__global__ __launch_bounds__(256) void seed_update_pixel_kernel(SeedParams P) {
+  constexpr int OFFSET = -SIDE / 2;
+  constexpr float AREA = static_cast<float>(SIDE * SIDE);
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= P.w || y >= P.h) return;
+  const int i = y * P.stride + x;
+  const float mu = P.mu[i], sigma_sq = P.sigma_sq[i], a = P.a[i], b = P.b[i];
+  int state = seed_check(P, x, y, sigma_sq, a, b, SIDE);
+  if (state != ST_UPDATE) {
+    P.conv[i] = state;
+    return;
+  }
+  const Segment seg = epipolar_segment(P, x, y, mu, sigma_sq);
+  const float sum_templ = P.sum_templ[i], denom = P.denom[i];
+  float best_ncc = -1.0f;
+  F2 best_px = F2{0.0f, 0.0f};
+  unsigned steps = 0, evals = 0;
+  for (float l = -seg.half_length; l <= seg.half_length; l += 0.7f) {
+    ++steps;
+    const F2 px = F2{seg.mean.x + l * seg.dir.x, seg.mean.y + l * seg.dir.y};
+    if (px.x >= static_cast<float>(P.w - SIDE) || px.y >= static_cast<float>(P.h - SIDE) ||
+        px.x < static_cast<float>(SIDE) || px.y < static_cast<float>(SIDE))
+      continue;
+    ++evals;
+    float sum_img = 0.0f, sum_img_sq = 0.0f, sum_img_templ = 0.0f;
+    for (int py = 0; py < SIDE; ++py) {
+      const float cy = px.y + static_cast<float>(OFFSET + py) + 0.5f;
+      const float* ref_row = P.ref + clampi(y + OFFSET + py, 0, P.h - 1) * P.stride;
+      for (int pxi = 0; pxi < SIDE; ++pxi) {
+        const float templ = ref_row[clampi(x + OFFSET + pxi, 0, P.w - 1)];
+        const float img = tex_linear_global(P.cur, P.w, P.h, P.stride, px.x + static_cast<float>(OFFSET + pxi) + 0.5f, cy);
+        sum_img += img;
+        sum_img_sq += img * img;
+        sum_img_templ += img * templ;
+      }
+    }
+    const float num = AREA * sum_img_templ - sum_img * sum_templ;
+    const float den = (AREA * sum_img_sq - sum_img * sum_img) * denom;
+    const float ncc = num * rmd_rsqrtf(den + FLT_MIN);
+    if (ncc > best_ncc) {
+      best_px = px;
+      best_ncc = ncc;
+    }
+  }
+  if (best_ncc < 0.5f) {
+    state = ST_NO_MATCH;
+  } else {
+    P.match[y * P.stride2 + x] = make_float2(best_px.x, best_px.y);
+  }
+  P.conv[i] = state;
+  if (P.stats) {
+    atomicAdd(&P.stats[0], 1ull);
+    atomicAdd(&P.stats[1], static_cast<unsigned long long>(steps));
+    atomicAdd(&P.stats[2], static_cast<unsigned long long>(evals));
+  }
+  seed_fuse(P, x, y, i, state, mu, sigma_sq, a, b, best_px);
+}
+
+// ------------------------------------------------------------------------------------------
+// Reductions (reduction_kernels.cu:57-159): wave-level shuffles, one atomic / one partial per block.
+RMDK_D unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+RMDK_D double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void count_eq_kernel(const int* __restrict__ img, int w, int h, int stride, int value,
+                                                       unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long wave_part[4];
+  unsigned long long c = 0;
+  for (int y = blockIdx.y; y < h; y += gridDim.y) {
+    const int* row = img + static_cast<size_t>(y) * stride;
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < w; x += gridDim.x * blockDim.x) c += (row[x] == value);
+  }
+  c = wave_sum_u64(c);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_part[wave] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long t = wave_part[0] + wave_part[1] + wave_part[2] + wave_part[3];
+    if (t) atomicAdd(out, t);
+  }
+}
+
+// pass 1: one fp64 partial per block, in a fixed order; pass 2: one block folds the partials.
+__global__ __launch_bounds__(256) void sum_partial_kernel(const float* __restrict__ img, int w, int h, int stride,
+                                                          double* __restrict__ partials) {
+  __shared__ double wave_part[4];
+  double acc = 0.0;
+  for (int y = blockIdx.y; y < h; y += gridDim.y) {
+    const float* row = img + static_cast<size_t>(y) * stride;
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < w; x += gridDim.x * blockDim.x) acc += static_cast<double>(row[x]);
+  }
+  acc = wave_sum_f64(acc);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    partials[blockIdx.y * gridDim.x + blockIdx.x] = ((wave_part[0] + wave_part[1]) + wave_part[2]) + wave_part[3];
+}
+__global__ __launch_bounds__(64) void sum_final_kernel(const double* __restrict__ partials, int n, float* __restrict__ out) {
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) acc += partials[i];
+  acc = wave_sum_f64(acc);
+  if (threadIdx.x == 0) *out = static_cast<float>(acc);
+}
+
+// ------------------------------------------------------------------------------------------
+// TV-L1 denoiser.
+struct TvParams {
+  int w, h;
+  int stride;   // f32 planes
+  int stride2;  // float2 plane
+  const float* mu;
+  const float* sigma_sq;
+  const float* a;
+  const float* b;
+  int in_stride;  // stride of the four input planes (they belong to the SeedMatrix)
+  float* g;
+  float large_sigma_sq;
+  float tau, sigma, theta, lambda;
+};
+
+// depthmap_denoiser.cu:45-59 (weights) fused with the re-initialisation at :215-217
+__global__ __launch_bounds__(256) void tv_prepare_kernel(TvParams P, float* __restrict__ u, float* __restrict__ u_head,
+                                                         float2* __restrict__ p) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= P.w || y >= P.h) return;
+  const int ii = y * P.in_stride + x;
+  const float a = P.a[ii], b = P.b[ii];
+  const float E_pi = a / (a + b);
+  const float v = (E_pi * P.sigma_sq[ii] + (1.0f - E_pi) * P.large_sigma_sq) / P.large_sigma_sq;
+  const int i = y * P.stride + x;
+  P.g[i] = v > 1.0f ? v : 1.0f;
+  const float m = P.mu[ii];
+  u[i] = m;
+  u_head[i] = m;
+  p[y * P.stride2 + x] = make_float2(0.0f, 0.0f);
+}
+
+// dual step of one pixel (depthmap_denoiser.cu:73-83), reading the previous iterate
+RMDK_D float2 tv_dual(const TvParams& P, const float* __restrict__ u, const float* __restrict__ u_head,
+                      const float2* __restrict__ p, int x, int y) {
+  const int i = y * P.stride + x;
+  const float g = P.g[i], cu = u[i];
+  const int xe = x + 1 < P.w - 1 ? x + 1 : P.w - 1;
+  const int ys = y + 1 < P.h - 1 ? y + 1 : P.h - 1;
+  const float gx = u_head[y * P.stride + xe] - cu;
+  const float gy = u_head[ys * P.stride + x] - cu;
+  const float2 po = p[y * P.stride2 + x];
+  const float tx = g * gx * P.sigma + po.x;
+  const float ty = g * gy * P.sigma + po.y;
+  const float mag = sqrtf(tx * tx + ty * ty);
+  const float den = 1.0f > mag ? 1.0f : mag;
+  return make_float2(tx / den, ty / den);
+}
+
+// One primal-dual iteration (depthmap_denoiser.cu:61-118) with "all duals, then all primals"
+// semantics: the block evaluates the dual for its TX x TY tile plus the one-pixel west column
+// and north row it needs, keeps them in LDS, then runs the primal step.  Iterates are
+// ping-ponged between (u,u_head,p)_in and _out so there is no inter-block race.
+constexpr int TV_TX = 64, TV_TY = 4;
+__global__ __launch_bounds__(TV_TX* TV_TY) void tv_iterate_kernel(TvParams P, const float* __restrict__ u_in,
+                                                                  const float* __restrict__ uh_in,
+                                                                  const float2* __restrict__ p_in, float* __restrict__ u_out,
+                                                                  float* __restrict__ uh_out, float2* __restrict__ p_out) {
+  __shared__ float2 sp[TV_TY + 1][TV_TX + 1];
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int x0 = blockIdx.x * TV_TX, y0 = blockIdx.y * TV_TY;
+  const int x = x0 + tx, y = y0 + ty;
+  const bool inside = x < P.w && y < P.h;
+  if (inside) sp[ty + 1][tx + 1] = tv_dual(P, u_in, uh_in, p_in, x, y);
+  const int t = ty * TV_TX + tx;
+  if (t < TV_TY) {  // west halo column
+    const int yy = y0 + t;
+    if (x0 > 0 && yy < P.h) sp[t + 1][0] = tv_dual(P, u_in, uh_in, p_in, x0 - 1, yy);
+  } else if (t >= 64 && t < 64 + TV_TX) {  // north halo row (a different wave than the west column)
+    const int xx = x0 + (t - 64);
+    if (y0 > 0 && xx < P.w) sp[0][t - 64 + 1] = tv_dual(P, u_in, uh_in, p_in, xx, y0 - 1);
+  }
+  __syncthreads();
+  if (!inside) return;
+  const int i = y * P.stride + x;
+  const float noisy = P.mu[y * P.in_stride + x], old_u = u_in[i], g = P.g[i];
+  float2 cp = sp[ty + 1][tx + 1];
+  float wpx = sp[ty + 1][tx].x;
+  float npy = sp[ty][tx + 1].y;
+  if (x == 0) wpx = 0.0f;
+  else if (x >= P.w - 1) cp.x = 0.0f;
+  if (y == 0) npy = 0.0f;
+  else if (y >= P.h - 1) cp.y = 0.0f;
+  const float divergence = cp.x - wpx + cp.y - npy;
+  const float temp_u = old_u + P.tau * g * divergence;
+  float nu;
+  if ((temp_u - noisy) > (P.tau * P.lambda)) nu = temp_u - P.tau * P.lambda;
+  else if ((temp_u - noisy) < (-P.tau * P.lambda)) nu = temp_u + P.tau * P.lambda;
+  else nu = noisy;
+  u_out[i] = nu;
+  uh_out[i] = nu + P.theta * (nu - old_u);
+  p_out[y * P.stride2 + x] = sp[ty + 1][tx + 1];
+}
+
+// ------------------------------------------------------------------------------------------
+// device side of the arithmetic contract, for the self test
+__global__ void math_eval_kernel(int op, const float* x, const float* y, const float* z, float* out, size_t n) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float r;
+  switch (op) {
+    case 0: r = rmd_expf(x[i]); break;
+    case 1: r = rmd_sinf(x[i]); break;
+    case 2: r = rmd_acosf(x[i]); break;
+    case 3: r = rmd_rsqrtf(x[i]); break;
+    case 4: r = sqrtf(x[i]); break;
+    case 5: r = x[i] / y[i]; break;
+    default: r = rmd_lerp(x[i], y[i], z[i]); break;
+  }
+  out[i] = r;
+}
+
+}  // namespace rmdk
+
+#endif  // RMD_KERNELS_HPP

@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_libs():
+    """Build whatever native library is missing (cross-compiles on CPU; a no-op when prebuilt files travelled here)."""
+    from rpg_open_remode_amd import build
+    need = [os.path.join(ROOT, "rpg_open_remode_amd", "librmd_hip.so"),
+            os.path.join(ROOT, "rpg_open_remode_amd", "librmd_synth.so"),
+            os.path.join(ROOT, "oracle", "libremode_oracle_s5.so")]
+    if not all(os.path.exists(p) for p in need):
+        build.build_all()
+    yield
+
+
+def has_gpu():
+    import ctypes
+    from rpg_open_remode_amd import _lib
+    n = ctypes.c_int(0)
+    return _lib.lib().rmd_hip_device_count(ctypes.byref(n)) == 0 and n.value > 0

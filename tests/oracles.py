@@ -1,6 +1,7 @@
 """ctypes bindings for the two CPU oracles (test infrastructure only).
 
-  OracleLib("ref", side)       -> oracle/_ref/libremode_ref_s<side>.so     Oracle A: the reference's own sources on CPU
+  OracleLib("ref", side)       -> oracle/_ref/libremode_ref_s<side>.so     Oracle A: the reference's own sources on CPU (glibc libm)
+  OracleLib("ref_rmd", side)   -> oracle/_ref/libremode_ref_rmd_s<side>.so Oracle A with expf/sinf/acosf from csrc/rmd_math.h
   OracleLib("port", side)      -> oracle/libremode_oracle_s<side>.so       Oracle B: our restatement, rmd_math.h transcendentals
   OracleLib("port_libm", side) -> oracle/libremode_oracle_libm_s<side>.so  Oracle B with glibc transcendentals (== A bit for bit)
 
@@ -23,6 +24,8 @@ _c_f, _c_i, _c_p = ctypes.c_float, ctypes.c_int, ctypes.c_void_p
 def lib_path(kind, side):
     if kind == "ref":
         return os.path.join(ORACLE_DIR, "_ref", f"libremode_ref_s{side}.so")
+    if kind == "ref_rmd":
+        return os.path.join(ORACLE_DIR, "_ref", f"libremode_ref_rmd_s{side}.so")
     if kind == "port":
         return os.path.join(ORACLE_DIR, f"libremode_oracle_s{side}.so")
     if kind == "port_libm":
@@ -47,7 +50,7 @@ class OracleLib:
 
     def _init(self, kind, side):
         self.kind, self.side = kind, side
-        self.prefix = "ref_" if kind == "ref" else "orc_"
+        self.prefix = "ref_" if kind.startswith("ref") else "orc_"
         path = lib_path(kind, side)
         if not os.path.exists(path):
             raise RuntimeError(f"oracle library {path} missing (run `make -C oracle`)")
@@ -77,7 +80,7 @@ class OracleLib:
         f("reduce_count_eq_i32").argtypes = [_c_p, _c_i, _c_i, _c_i]
         f("patch_side").restype = _c_i
         assert f("patch_side")() == side
-        if kind != "ref":
+        if not kind.startswith("ref"):
             L.orc_seeds_last_stats.argtypes = [_c_p, _c_p]
             L.orc_set_num_threads.argtypes = [_c_i]
             L.orc_max_threads.restype = _c_i

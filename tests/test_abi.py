@@ -1,0 +1,67 @@
+"""CPU-only checks of the drop-in boundary: librmd_hip.so loads, exports every symbol of include/rmd_hip.h,
+and reports errors the way the header says (no compute calls here)."""
+import ctypes
+import os
+
+from rpg_open_remode_amd import _lib
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = _lib.lib()
+    declared = _lib.header_functions()
+    assert len(declared) >= 35
+    missing = [n for n in declared if not hasattr(L, n)]
+    assert not missing, f"declared in rmd_hip.h but not exported: {missing}"
+
+
+def test_python_binding_covers_the_header():
+    assert sorted(_lib.SIGNATURES) == _lib.header_functions()
+
+
+def test_version_and_error_string():
+    L = _lib.lib()
+    assert L.rmd_hip_version() >= 100
+    assert L.rmd_hip_seeds_create(64, 48, 1.0, 1.0, 1.0, 1.0, 5, 100, None) == _lib.ERR_INVALID_ARG
+    assert b"null output" in L.rmd_hip_last_error()
+
+
+def test_argument_validation_precedes_device_use():
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    # unsupported patch side, bad size, bad extent: rejected before any HIP call
+    assert L.rmd_hip_seeds_create(64, 48, 1.0, 1.0, 1.0, 1.0, 4, 100, ctypes.byref(h)) == _lib.ERR_INVALID_ARG
+    assert L.rmd_hip_seeds_create(0, 48, 1.0, 1.0, 1.0, 1.0, 5, 100, ctypes.byref(h)) == _lib.ERR_INVALID_ARG
+    assert L.rmd_hip_seeds_create(64, 48, 1.0, 1.0, 1.0, 1.0, 5, 1000, ctypes.byref(h)) == _lib.ERR_INVALID_ARG
+    assert L.rmd_hip_image_create(7, 8, 8, ctypes.byref(h)) == _lib.ERR_INVALID_ARG
+    assert L.rmd_hip_seeds_update(None, None, None) == _lib.ERR_INVALID_ARG
+    assert L.rmd_hip_denoiser_denoise(None, None, None, None, None, None, 0.5, 1) == _lib.ERR_INVALID_ARG
+    # destroying null handles is a no-op, as deleting a null pointer is
+    assert L.rmd_hip_seeds_destroy(None) == 0 and L.rmd_hip_denoiser_destroy(None) == 0 and L.rmd_hip_image_destroy(None) == 0
+
+
+def test_device_count_reports_absence_cleanly():
+    L = _lib.lib()
+    n = ctypes.c_int(-1)
+    rc = L.rmd_hip_device_count(ctypes.byref(n))
+    assert rc in (_lib.OK, _lib.ERR_NO_DEVICE)
+    if rc == _lib.ERR_NO_DEVICE:
+        assert n.value == 0
+        h = ctypes.c_void_p()
+        # no silent CPU path: creating a handle without a GPU is an error
+        assert L.rmd_hip_seeds_create(64, 48, 1.0, 1.0, 1.0, 1.0, 5, 100, ctypes.byref(h)) == _lib.ERR_NO_DEVICE
+        assert L.rmd_hip_denoiser_create(64, 48, ctypes.byref(h)) == _lib.ERR_NO_DEVICE
+
+
+def test_product_never_touches_the_oracle():
+    """The product path must not import, link or execute anything under oracle/."""
+    root = _lib.ROOT
+    pkg = os.path.join(root, "rpg_open_remode_amd")
+    offenders = []
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                for needle in ("libremode_oracle", "libremode_ref", "import oracles", "oracle/_ref", "#include \"remode_oracle"):
+                    if needle in text and f != "build.py":
+                        offenders.append((f, needle))
+    assert not offenders, offenders
