@@ -46,6 +46,7 @@
 #include RMD_REF_DENOISER_CU
 #undef private
 
+#include <omp.h>
 #include <new>
 
 // Dynamic shared memory of the reduction kernels (reduction_kernels.cu:37-55 declares
@@ -66,6 +67,8 @@ rmd::SE3<float> se3_from_rowmajor(const float* T) {
 extern "C" {
 
 int ref_patch_side(void) { return RMD_CORR_PATCH_SIDE; }
+int ref_max_threads(void) { return omp_get_max_threads(); }
+void ref_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 int ref_max_extent(void) { return RMD_MAX_EXTENT_EPIPOLAR_SEARCH; }
 int ref_uses_shared_math(void) {
 #ifdef RMD_REF_USE_SHARED_MATH

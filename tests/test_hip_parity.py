@@ -1,0 +1,329 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same seeded inputs.
+
+Bar: BIT-EXACT on every plane (mu, sigma^2, a, b, convergence, template statistics, epipolar matches) against
+  * Oracle B (oracle/remode_oracle.cpp, default build), and, where oracle/_ref travelled,
+  * Oracle A "ref_rmd" = the reference's own sources with only expf/sinf/acosf taken from csrc/rmd_math.h.
+NaNs compare equal to NaNs; nothing else is tolerated.  Float tolerance appears in exactly one place: the fp32
+image sum (reduction_test.cpp:24-70 allows 4 ulp against a double sum; so do we).
+"""
+import numpy as np
+import pytest
+
+import oracles as O
+from common import PLANE_NAMES, assert_states_equal, random_state, rmse, sequence
+from rpg_open_remode_amd import api
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip_seeds(seq, side, matcher):
+    s = api.SeedMatrix(seq.width, seq.height, api.PinholeCamera(*seq.K), patch_side=side)
+    s.setOption(api.OPT_MATCHER, matcher)
+    return s
+
+
+def _oracle_seeds(kind, seq, side):
+    return O.Seeds(O.OracleLib(kind, side), seq.width, seq.height, seq.K)
+
+
+def _compare_run(seq, side, matcher, n_updates, oracle_kind="port", state0=None, check_every=1):
+    hip = _hip_seeds(seq, side, matcher)
+    orc = _oracle_seeds(oracle_kind, seq, side)
+    hip.setReferenceImage(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    orc.set_reference(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    assert_states_equal(orc.state(), hip.state(), "after setReferenceImage")
+    if state0 is not None:
+        for p, arr in enumerate(state0):
+            hip.upload(p, arr)
+            orc.upload(p, arr)
+    for k in range(1, n_updates + 1):
+        hip.update(seq.images[k], seq.T_curr_world[k])
+        orc.update(seq.images[k], seq.T_curr_world[k])
+        if k % check_every == 0 or k == n_updates:
+            assert_states_equal(orc.state(), hip.state(), f"side {side} matcher {matcher} update {k}")
+    assert hip.getConvergedCount() == orc.converged_count()
+    assert hip.getDistFromRef() == orc.dist_from_ref()
+    return hip, orc
+
+
+def test_device_is_gfx950():
+    assert api.checkCudaDevice(0)
+    import ctypes
+    from rpg_open_remode_amd import _lib
+    buf = ctypes.create_string_buffer(256)
+    _lib.check(_lib.lib().rmd_hip_device_name(0, buf, 256))
+    assert b"gfx950" in buf.value, buf.value
+
+
+@pytest.mark.parametrize("matcher", [0, 1])
+@pytest.mark.parametrize("side", [3, 5, 7, 9])
+def test_sequence_bit_exact_vs_port(side, matcher):
+    _compare_run(sequence(320, 240, 13), side, matcher, 12)
+
+
+@pytest.mark.parametrize("matcher", [0, 1])
+def test_sequence_bit_exact_vs_reference_sources(matcher):
+    if not O.available("ref_rmd", 5):
+        pytest.skip("oracle/_ref not present")
+    _compare_run(sequence(160, 120, 9), 5, matcher, 8, oracle_kind="ref_rmd")
+    _compare_run(sequence(160, 120, 9), 9, matcher, 8, oracle_kind="ref_rmd")
+
+
+@pytest.mark.parametrize("matcher", [0, 1])
+@pytest.mark.parametrize("side", [5, 9])
+def test_long_sequence_through_convergence(side, matcher):
+    hip, orc = _compare_run(sequence(160, 120, 45), side, matcher, 44, check_every=11)
+    assert hip.getConvergedCount() > 0.3 * 160 * 120
+
+
+@pytest.mark.parametrize("matcher", [0, 1])
+@pytest.mark.parametrize("side", [5, 9])
+def test_adversarial_seed_states(side, matcher):
+    """NaN / Inf / negative / huge state planes, searches at the 100 px cap, depths behind the camera"""
+    seq = sequence(192, 144, 4)
+    rng = np.random.default_rng(4321 + side)
+    st0 = random_state(seq.width, seq.height, seq, rng, side)
+    hip, orc = _compare_run(seq, side, matcher, 3, state0=st0)
+    conv = hip.downloadConvergence()
+    for st in range(5):
+        assert (conv == st).any(), f"state {st} never produced"
+
+
+@pytest.mark.parametrize("matcher", [0, 1])
+@pytest.mark.parametrize("wh", [(101, 67), (64, 48), (257, 33), (40, 200)])
+def test_ragged_sizes(wh, matcher):
+    """widths/heights that are not multiples of any tile, pitched rows (stride != width)"""
+    w, h = wh
+    _compare_run(sequence(w, h, 5), 5, matcher, 4)
+
+
+@pytest.mark.parametrize("matcher", [0, 1])
+def test_tiny_images_are_all_border(matcher):
+    for (w, h) in ((10, 10), (11, 30), (18, 18)):
+        seq = sequence(w, h, 3)
+        hip, _ = _compare_run(seq, 5, matcher, 2)
+        conv = hip.downloadConvergence()
+        if w <= 10 or h <= 10:
+            assert np.all(conv == api.ConvergenceStates.BORDER)
+
+
+@pytest.mark.parametrize("matcher", [0, 1])
+def test_identity_pose_reference_kat(matcher):
+    """test/epipolar_test.cpp:206-220 on the GPU: zero-length segments -> NO_MATCH, the rest match themselves"""
+    seq = sequence(320, 240, 2)
+    hip = _hip_seeds(seq, 5, matcher)
+    orc = _oracle_seeds("port", seq, 5)
+    for s in (hip,):
+        s.setReferenceImage(seq.images[0], seq.T_curr_world[0], 0.4, 1.8)
+        s.update(seq.images[0], seq.T_curr_world[0])
+    orc.set_reference(seq.images[0], seq.T_curr_world[0], 0.4, 1.8)
+    orc.update(seq.images[0], seq.T_curr_world[0])
+    assert_states_equal(orc.state(), hip.state(), "identity pose")
+    conv, match = hip.downloadConvergence(), hip.downloadEpipolarMatches()
+    upd = conv == api.ConvergenceStates.UPDATE
+    yy, xx = np.mgrid[0:seq.height, 0:seq.width]
+    assert upd.sum() > 100 and (conv == api.ConvergenceStates.NO_MATCH).sum() > 100
+    assert np.max(np.abs(match[..., 0][upd] - xx[upd])) < 0.01 and np.max(np.abs(match[..., 1][upd] - yy[upd])) < 0.01
+
+
+def test_reference_kat_seed_matrix_init_and_check_on_gpu():
+    """test/seed_matrix_test.cpp:99-110 and :219-241"""
+    seq = sequence(320, 240, 21)
+    s = _hip_seeds(seq, 5, 1)
+    s.setReferenceImage(seq.images[0], seq.T_curr_world[0], 0.4, 1.8)
+    avg = np.float32((np.float32(0.4) + np.float32(1.8)) / np.float32(2.0))
+    assert np.all(s.downloadDepthmap() == avg) and np.all(s.downloadA() == 10.0) and np.all(s.downloadB() == 10.0)
+    s.update(seq.images[0], seq.T_curr_world[20])
+    conv = s.downloadConvergence()
+    h, w = conv.shape
+    yy, xx = np.mgrid[0:h, 0:w]
+    border = (yy > h - 5 - 1) | (yy < 5) | (xx > w - 5 - 1) | (xx < 5)
+    assert np.all(conv[border] == api.ConvergenceStates.BORDER)
+    assert np.all(np.isin(conv[~border], [0, 1, 3, 4, 5]))
+
+
+def test_two_instances_are_independent():
+    """the reference's global texture references allow ONE live SeedMatrix per process (texture_memory.cuh:27-42)"""
+    sa, sb = sequence(160, 120, 5, seed=0), sequence(128, 96, 5, seed=3)
+    ha, hb = _hip_seeds(sa, 5, 1), _hip_seeds(sb, 9, 1)
+    oa, ob = _oracle_seeds("port", sa, 5), _oracle_seeds("port", sb, 9)
+    for h, o, s in ((ha, oa, sa), (hb, ob, sb)):
+        h.setReferenceImage(s.images[0], s.T_curr_world[0], s.min_depth, s.max_depth)
+        o.set_reference(s.images[0], s.T_curr_world[0], s.min_depth, s.max_depth)
+    for k in range(1, 5):  # interleaved
+        ha.update(sa.images[k], sa.T_curr_world[k])
+        hb.update(sb.images[k], sb.T_curr_world[k])
+        oa.update(sa.images[k], sa.T_curr_world[k])
+        ob.update(sb.images[k], sb.T_curr_world[k])
+    assert_states_equal(oa.state(), ha.state(), "instance A")
+    assert_states_equal(ob.state(), hb.state(), "instance B")
+
+
+def test_device_resident_frames_equal_host_frames():
+    import torch
+    seq = sequence(160, 120, 6)
+    h1, h2 = _hip_seeds(seq, 5, 1), _hip_seeds(seq, 5, 1)
+    frames = [torch.from_numpy(im).cuda() for im in seq.images]
+    torch.cuda.synchronize()
+    h1.setReferenceImage(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    h2.setReferenceImageDevice(frames[0].data_ptr(), seq.width, seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    for k in range(1, 6):
+        h1.update(seq.images[k], seq.T_curr_world[k])
+        h2.updateDevice(frames[k].data_ptr(), seq.width, seq.T_curr_world[k])
+    assert_states_equal(h1.state(), h2.state(), "device-resident input")
+
+
+def test_error_paths():
+    seq = sequence(64, 48, 2)
+    s = _hip_seeds(seq, 5, 1)
+    with pytest.raises(api.RmdHipError) as e:
+        s.update(seq.images[1], seq.T_curr_world[1])  # no reference yet
+    assert e.value.code == -3
+    d = api.DepthmapDenoiser(seq.width, seq.height)
+    s.setReferenceImage(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    with pytest.raises(api.RmdHipError) as e:
+        d.denoise(s.getMu(), s.getSigmaSq(), s.getA(), s.getB(), 0.5, 3)  # setLargeSigmaSq not called
+    assert e.value.code == -3
+    with pytest.raises(api.RmdHipError):
+        api.SeedMatrix(64, 48, api.PinholeCamera(*seq.K), patch_side=4)
+
+
+# ---------------------------------------------------------------------------------------------- denoiser
+@pytest.mark.parametrize("wh", [(160, 120), (101, 67), (64, 5), (3, 70)])
+@pytest.mark.parametrize("iters_per_launch", [1, 4])
+def test_denoiser_bit_exact(wh, iters_per_launch):
+    w, h = wh
+    seq = sequence(max(w, 24), max(h, 24), 8)
+    rng = np.random.default_rng(w * 1000 + h)
+    lo, hi = seq.min_depth, seq.max_depth
+    mu = rng.uniform(lo, hi, (h, w)).astype(np.float32)
+    sig = (10.0 ** rng.uniform(-6, -1, (h, w))).astype(np.float32)
+    a = rng.uniform(1, 30, (h, w)).astype(np.float32)
+    b = rng.uniform(1, 30, (h, w)).astype(np.float32)
+    imgs = []
+    for arr in (mu, sig, a, b):
+        im = api.DeviceImage(w, h, np.float32)
+        im.setDevData(arr)
+        imgs.append(im)
+    d = api.DepthmapDenoiser(w, h)
+    d.setOption(api.DENOISE_OPT_ITERS_PER_LAUNCH, iters_per_launch)
+    d.setLargeSigmaSq(hi - lo)
+    ol = O.OracleLib("port", 5)
+    od = O.Denoiser(ol, w, h)
+    od.set_large_sigma_sq(hi - lo)
+    assert np.array_equal(d.constants(), od.constants())
+    for lam, iters in ((0.5, 1), (0.5, 2), (0.5, 37), (0.2, 200)):
+        got = d.denoise(*imgs, lam, iters)
+        exp = np.empty((h, w), np.float32)
+        rc = ol.lib.orc_denoiser_denoise_planes(od.ptr, mu.ctypes.data, sig.ctypes.data, a.ctypes.data, b.ctypes.data,
+                                                exp.ctypes.data, lam, iters)
+        assert rc == 0
+        assert O.planes_equal(exp, got), f"{w}x{h} lambda {lam} iters {iters}: {O.count_mismatch(exp, got)} pixels differ"
+
+
+def test_denoiser_after_sequence_matches_oracle_and_reference_kernel():
+    seq = sequence(160, 120, 25)
+    hip, orc = _compare_run(seq, 5, 1, 24, check_every=24)
+    d = api.DepthmapDenoiser(seq.width, seq.height)
+    d.setLargeSigmaSq(seq.max_depth - seq.min_depth)
+    got = d.denoise(hip.getMu(), hip.getSigmaSq(), hip.getA(), hip.getB(), 0.5, 60)
+    od = O.Denoiser(orc.o, seq.width, seq.height)
+    od.set_large_sigma_sq(seq.max_depth - seq.min_depth)
+    assert O.planes_equal(od.denoise(orc, 0.5, 60), got)
+    if O.available("ref_rmd", 5):  # the reference's own TV kernel, barriers emulated with fibres
+        ref = _oracle_seeds("ref_rmd", seq, 5)
+        ref.set_reference(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+        for k in range(1, 25):
+            ref.update(seq.images[k], seq.T_curr_world[k])
+        rd = O.Denoiser(ref.o, seq.width, seq.height)
+        rd.set_large_sigma_sq(seq.max_depth - seq.min_depth)
+        assert O.planes_equal(rd.denoise(ref, 0.5, 60), got)
+
+
+# ---------------------------------------------------------------------------------------------- reductions, images
+def test_reductions_reference_kat():
+    """test/reduction_test.cpp:24-122 at its own size (752x480)"""
+    rng = np.random.default_rng(11)
+    w, h = 752, 480
+    img = rng.random((h, w), dtype=np.float32)
+    di = api.DeviceImage(w, h, np.float32)
+    di.setDevData(img)
+    red = api.ImageReducer()
+    expect = np.float32(img.astype(np.float64).sum())
+    assert abs(red.sum(di) - expect) <= 4 * np.spacing(expect)
+    ints = rng.integers(0, 256, (h, w), dtype=np.int32)
+    ii = api.DeviceImage(w, h, np.int32)
+    ii.setDevData(ints)
+    assert red.countEqual(ii, 2) == int((ints == 2).sum())
+    for (ww, hh) in ((1, 1), (63, 1), (1, 300), (1000, 3)):
+        a = rng.integers(0, 3, (hh, ww), dtype=np.int32)
+        im = api.DeviceImage(ww, hh, np.int32)
+        im.setDevData(a)
+        assert red.countEqual(im, 1) == int((a == 1).sum())
+        f = rng.random((hh, ww), dtype=np.float32)
+        fm = api.DeviceImage(ww, hh, np.float32)
+        fm.setDevData(f)
+        e = np.float32(f.astype(np.float64).sum())
+        assert abs(red.sum(fm) - e) <= 4 * np.spacing(e)
+
+
+def test_device_image_round_trips():
+    """test/device_image_test.cpp:27-156: upload/download float, float2; device-to-device copy; zero"""
+    rng = np.random.default_rng(5)
+    for (w, h) in ((640, 480), (101, 7)):
+        f = rng.random((h, w), dtype=np.float32)
+        a = api.DeviceImage(w, h, np.float32)
+        a.setDevData(f)
+        assert np.array_equal(a.getDevData(), f)
+        f2 = rng.random((h, w, 2), dtype=np.float32)
+        b = api.DeviceImage(w, h, "float2")
+        b.setDevData(f2)
+        assert np.array_equal(b.getDevData(), f2)
+        c = api.DeviceImage(w, h, np.float32)
+        c.assign(a)
+        assert np.array_equal(c.getDevData(), f)
+        c.zero()
+        assert not c.getDevData().any()
+        assert a.pitch % 256 == 0 and a.stride * 4 == a.pitch
+
+
+# ---------------------------------------------------------------------------------------------- arithmetic contract
+def test_device_math_equals_host_math_bit_for_bit():
+    import ctypes
+    from rpg_open_remode_amd import _lib
+    ol = O.OracleLib("port", 5).lib
+    rng = np.random.default_rng(2024)
+    n = 1 << 18
+
+    def dev(op, x, y=None, z=None):
+        out = np.empty_like(x)
+        _lib.check(_lib.lib().rmd_hip_math_eval(op, x.ctypes.data, None if y is None else y.ctypes.data,
+                                                None if z is None else z.ctypes.data, out.ctypes.data, x.size))
+        return out
+
+    def host(fn, *arrs):
+        return np.array([fn(*[float(v) for v in vals]) for vals in zip(*arrs)], np.float32)
+
+    specials = np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, np.inf, -np.inf, np.nan, 1e-38, 1e-45, 3.4e38, 88.7, -103.9, -87.3],
+                        np.float32)
+    cases = {
+        0: np.concatenate([rng.uniform(-110, 90, n).astype(np.float32), specials]),
+        1: np.concatenate([rng.uniform(-8, 8, n).astype(np.float32), rng.uniform(-1e5, 1e5, 4096).astype(np.float32), specials]),
+        2: np.concatenate([rng.uniform(-1.001, 1.001, n).astype(np.float32), specials]),
+        3: np.concatenate([(10.0 ** rng.uniform(-40, 38, n)).astype(np.float32), specials]),
+    }
+    fns = {0: ol.orc_math_expf, 1: ol.orc_math_sinf, 2: ol.orc_math_acosf, 3: ol.orc_math_rsqrtf}
+    for op, x in cases.items():
+        x = x[:: max(1, x.size // 60000)].copy()  # keep the host loop short
+        got, exp = dev(op, x), host(fns[op], x)
+        bad = ~((got == exp) | (np.isnan(got) & np.isnan(exp)))
+        assert not bad.any(), f"op {op}: {bad.sum()} mismatches, e.g. x={x[bad][:4]} dev={got[bad][:4]} host={exp[bad][:4]}"
+    # IEEE sqrt and divide on the device (the contract relies on them being correctly rounded)
+    x = np.concatenate([(10.0 ** rng.uniform(-44, 38, n)).astype(np.float32), specials])
+    y = np.concatenate([(10.0 ** rng.uniform(-20, 20, n)).astype(np.float32) * rng.choice([-1, 1], n).astype(np.float32), specials[::-1]])
+    with np.errstate(all="ignore"):
+        assert O.planes_equal(dev(4, x), np.sqrt(x))
+        assert O.planes_equal(dev(5, x, y), x / y)
+    t = rng.random(60000).astype(np.float32)
+    a, b = rng.random(60000).astype(np.float32), rng.random(60000).astype(np.float32)
+    assert O.planes_equal(dev(6, t, a, b), host(ol.orc_math_lerp, t, a, b))
