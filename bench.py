@@ -92,8 +92,13 @@ def main():
 
     # one independent sequence per rank (scene / trajectory seed = rank), rendered on the host, then made resident
     seq = synth.Sequence(WIDTH, HEIGHT, FRAMES, seed=rank)
-    frames = [torch.from_numpy(im).to(device) for im in seq.images]
-    torch.cuda.synchronize()
+    # device-resident frames, allocated through the library's own rmd::DeviceImage (not torch: PyTorch-ROCm ships a
+    # private HIP runtime; torch is used here for torch.distributed only)
+    frames = []
+    for im in seq.images:
+        d = api.DeviceImage(WIDTH, HEIGHT, np.float32)
+        d.setDevData(im)
+        frames.append(d)
 
     def new_seeds():
         s = api.SeedMatrix(WIDTH, HEIGHT, api.PinholeCamera(*seq.K), patch_side=SIDE)
@@ -101,7 +106,7 @@ def main():
         return s
 
     def set_ref(s):
-        s.setReferenceImageDevice(frames[0].data_ptr(), WIDTH, seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+        s.setReferenceImageDevice(frames[0].data, frames[0].stride, seq.T_curr_world[0], seq.min_depth, seq.max_depth)
 
     def run_updates(s, first, count):
         """`count` consecutive steps starting at step index `first` of the endless loop ref, 1..199, ref, 1..199, ..."""
@@ -110,7 +115,7 @@ def main():
             k = i % per_pass
             if k == 0 and i != 0:
                 set_ref(s)
-            s.updateDevice(frames[k + 1].data_ptr(), WIDTH, seq.T_curr_world[k + 1])
+            s.updateDevice(frames[k + 1].data, frames[k + 1].stride, seq.T_curr_world[k + 1])
 
     # warm-up: W untimed steps on a scratch instance (clocks, code objects, allocator)
     scratch = new_seeds()
@@ -120,7 +125,6 @@ def main():
 
     seeds = new_seeds()
     seeds.setOption(api.OPT_TIMING, 1)
-    seeds.setOption(api.OPT_COLLECT_STATS, 1)
     set_ref(seeds)
     seeds.sync()
     seeds.timingReset()
@@ -184,6 +188,19 @@ def main():
             s2.sync()
             return WIDTH * HEIGHT * n / (time.perf_counter() - ts) / 1e6
 
+        # search statistics of the timed workload (separate pass, diagnostics counters on)
+        s3 = new_seeds()
+        s3.setOption(api.OPT_COLLECT_STATS, 1)
+        set_ref(s3)
+        tot = {"live_seeds": 0, "steps": 0, "ncc_evals": 0}
+        for i in range(min(args.steps, FRAMES - 1)):
+            s3.updateDevice(frames[i + 1].data, frames[i + 1].stride, seq.T_curr_world[i + 1])
+            st = s3.lastStats()
+            for key in tot:
+                tot[key] += st[key]
+        n_st = max(1, min(args.steps, FRAMES - 1))
+        search_stats = {k: round(v / n_st, 1) for k, v in tot.items()}
+
         cpu = None
         if args.cpu_seconds > 0:
             try:
@@ -201,7 +218,7 @@ def main():
                                    f"updates per pass, NCC patch side {SIDE} (half-patch 4), max epipolar extent 100 px; "
                                    f"one independent sequence per GPU",
                        "frames_resident_in_hbm": True, "matcher": "tile" if args.matcher else "pixel",
-                       "converged_seeds_at_end": converged, "seed_stats_last_update": seeds.lastStats()},
+                       "converged_seeds_at_end": converged, "mean_per_update": search_stats},
             "roofline": roofline, "roofline_denoiser": roofline_tv, "cpu_baseline": cpu,
             "per_rank": [{"elapsed_s": round(e, 6), "mpix": u / 1e6} for e, u in per_rank],
         }

@@ -126,6 +126,20 @@ def test_identity_pose_reference_kat(matcher):
     assert np.max(np.abs(match[..., 0][upd] - xx[upd])) < 0.01 and np.max(np.abs(match[..., 1][upd] - yy[upd])) < 0.01
 
 
+@pytest.mark.parametrize("matcher", [0, 1])
+def test_search_statistics_equal_the_oracle(matcher):
+    """live seeds, search-loop iterations and NCC evaluations per update: same work as the reference does"""
+    seq = sequence(192, 144, 8)
+    hip, orc = _hip_seeds(seq, 5, matcher), _oracle_seeds("port", seq, 5)
+    hip.setOption(api.OPT_COLLECT_STATS, 1)
+    hip.setReferenceImage(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    orc.set_reference(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    for k in range(1, 8):
+        hip.update(seq.images[k], seq.T_curr_world[k])
+        orc.update(seq.images[k], seq.T_curr_world[k])
+        assert hip.lastStats() == orc.last_stats(), f"update {k}"
+
+
 def test_reference_kat_seed_matrix_init_and_check_on_gpu():
     """test/seed_matrix_test.cpp:99-110 and :219-241"""
     seq = sequence(320, 240, 21)
@@ -160,16 +174,18 @@ def test_two_instances_are_independent():
 
 
 def test_device_resident_frames_equal_host_frames():
-    import torch
     seq = sequence(160, 120, 6)
     h1, h2 = _hip_seeds(seq, 5, 1), _hip_seeds(seq, 5, 1)
-    frames = [torch.from_numpy(im).cuda() for im in seq.images]
-    torch.cuda.synchronize()
+    frames = []
+    for im in seq.images:
+        d = api.DeviceImage(seq.width, seq.height, np.float32)
+        d.setDevData(im)
+        frames.append(d)
     h1.setReferenceImage(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
-    h2.setReferenceImageDevice(frames[0].data_ptr(), seq.width, seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    h2.setReferenceImageDevice(frames[0].data, frames[0].stride, seq.T_curr_world[0], seq.min_depth, seq.max_depth)
     for k in range(1, 6):
         h1.update(seq.images[k], seq.T_curr_world[k])
-        h2.updateDevice(frames[k].data_ptr(), seq.width, seq.T_curr_world[k])
+        h2.updateDevice(frames[k].data, frames[k].stride, seq.T_curr_world[k])
     assert_states_equal(h1.state(), h2.state(), "device-resident input")
 
 
