@@ -82,10 +82,45 @@ RMDK_D bool axis_params(float p, int (&idx)[SIDE], float (&wgt)[SIDE]) {
   return regular;
 }
 
-// One NCC evaluation at px for the seed whose reference-patch origin in the LDS tile is ref_org.
-// win: LDS window of the current image, origin (wx0, wy0), row stride WS; or global fallback.
+// Sums of one NCC evaluation over a REGULAR footprint: texel rows j0 .. j0+SIDE, columns i0 .. i0+SIDE,
+// read from `base` (pointing at texel (i0, j0)) with row stride CT_STRIDE (compile time, LDS window)
+// or rt_stride (run time, global memory).  Separable filter: SIDE+1 horizontal lerps per texel row are
+// shared by the two patch rows that straddle it.
+template <int SIDE, int CT_STRIDE>
+RMDK_D void ncc_sums_regular(const float* __restrict__ base, int rt_stride, const float (&ax)[SIDE], const float (&ay)[SIDE],
+                             const float* __restrict__ ref_patch, int ref_stride, float& sum_img, float& sum_img_sq,
+                             float& sum_img_templ) {
+  float hprev[SIDE], hcur[SIDE];
+#pragma unroll
+  for (int r = 0; r <= SIDE; ++r) {
+    const float* row = CT_STRIDE > 0 ? base + r * CT_STRIDE : base + r * rt_stride;
+    float t[SIDE + 1];
+#pragma unroll
+    for (int c = 0; c <= SIDE; ++c) t[c] = row[c];
+#pragma unroll
+    for (int k = 0; k < SIDE; ++k) hcur[k] = rmd_lerp(ax[k], t[k], t[k + 1]);
+    if (r > 0) {
+      const float by = ay[r - 1];
+#pragma unroll
+      for (int k = 0; k < SIDE; ++k) {
+        const float img = rmd_lerp(by, hprev[k], hcur[k]);
+        const float templ = ref_patch[(r - 1) * ref_stride + k];
+        sum_img += img;
+        sum_img_sq += img * img;
+        sum_img_templ += img * templ;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < SIDE; ++k) hprev[k] = hcur[k];
+  }
+}
+
+// One NCC evaluation at px.  Three sources for the current-image samples, same arithmetic in all:
+//   1. the LDS window staged for this tile, when the footprint lies inside it;
+//   2. global memory (L1/L2) with the same regular footprint, for seeds that wandered off the window;
+//   3. per-sample fetches, only when the replayed roundings make the footprint irregular.
 template <int SIDE, int WS>
-RMDK_D float ncc_at(const SeedParams& P, F2 px, const float* __restrict__ win, int wx0, int wy0, bool use_window,
+RMDK_D float ncc_at(const SeedParams& P, F2 px, const float* __restrict__ win, int wx0, int wy0, int wx1, int wy1,
                     const float* __restrict__ ref_patch, int ref_stride, float sum_templ, float denom) {
   constexpr int OFFSET = -SIDE / 2;
   constexpr float AREA = static_cast<float>(SIDE * SIDE);
@@ -94,34 +129,17 @@ RMDK_D float ncc_at(const SeedParams& P, F2 px, const float* __restrict__ win, i
   float ax[SIDE], ay[SIDE];
   const bool reg_x = axis_params<SIDE>(px.x, ix, ax);
   const bool reg_y = axis_params<SIDE>(px.y, iy, ay);
-  if (use_window && reg_x && reg_y) {
-    // fast path: texel rows iy[0] .. iy[0]+SIDE, columns ix[0] .. ix[0]+SIDE, all inside the image
-    // (the guard keeps px in [SIDE, dim-SIDE)) and inside the staged window.
-    const float* base = win + (iy[0] - wy0) * WS + (ix[0] - wx0);
-    float hprev[SIDE], hcur[SIDE];
-#pragma unroll
-    for (int r = 0; r <= SIDE; ++r) {
-      float t[SIDE + 1];
-#pragma unroll
-      for (int c = 0; c <= SIDE; ++c) t[c] = base[r * WS + c];
-#pragma unroll
-      for (int k = 0; k < SIDE; ++k) hcur[k] = rmd_lerp(ax[k], t[k], t[k + 1]);
-      if (r > 0) {
-        const float by = ay[r - 1];
-#pragma unroll
-        for (int k = 0; k < SIDE; ++k) {
-          const float img = rmd_lerp(by, hprev[k], hcur[k]);
-          const float templ = ref_patch[(r - 1) * ref_stride + k];
-          sum_img += img;
-          sum_img_sq += img * img;
-          sum_img_templ += img * templ;
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < SIDE; ++k) hprev[k] = hcur[k];
+  if (reg_x && reg_y) {
+    // the guard keeps px in [SIDE, dim-SIDE), so rows iy[0]..iy[0]+SIDE and columns ix[0]..ix[0]+SIDE are in the image
+    const bool in_window = ix[0] >= wx0 && iy[0] >= wy0 && ix[0] + SIDE <= wx1 && iy[0] + SIDE <= wy1;
+    if (in_window) {
+      ncc_sums_regular<SIDE, WS>(win + (iy[0] - wy0) * WS + (ix[0] - wx0), 0, ax, ay, ref_patch, ref_stride, sum_img,
+                                 sum_img_sq, sum_img_templ);
+    } else {
+      ncc_sums_regular<SIDE, 0>(P.cur + iy[0] * P.stride + ix[0], P.stride, ax, ay, ref_patch, ref_stride, sum_img,
+                                sum_img_sq, sum_img_templ);
     }
   } else {
-    // general path (irregular rounding at an integer boundary, or window not staged): per-sample fetches
     for (int m = 0; m < SIDE; ++m) {
       const float cy = px.y + static_cast<float>(OFFSET + m) + 0.5f;
       for (int k = 0; k < SIDE; ++k) {
@@ -151,9 +169,9 @@ struct TileSmem {
   unsigned long long best[TILE_PIX];
   int prefix[TILE_PIX + 1];
   unsigned short i_first[TILE_PIX];
-  float red_f[4][4];
+  float red_f[4][8];
   int red_i[4];
-  int win_org[4];  // wx0, wy0, use_window
+  int win_box[4];  // wx0, wy0, wx1, wy1 (inclusive texel bounds of the staged window; wx1 < wx0 if none)
 };
 
 template <int SIDE, int WS, int WROWS>
@@ -213,20 +231,28 @@ __global__ __launch_bounds__(TILE_PIX) void seed_update_tile_kernel(SeedParams P
   S.best[tid] = 0ull;
   if (live) { S.sum_templ[tid] = P.sum_templ[gi]; S.denom[tid] = P.denom[gi]; }
 
-  // ---- phase 1: workgroup scan of step counts + bounding box of sample positions ------------
+  // ---- phase 1: workgroup scan of step counts; where do the tile's samples fall? ---------------
   int incl = n_valid;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     const int v = __shfl_up(incl, off, 64);
     if (lane >= off) incl += v;
   }
+  // step-weighted centroid of the seeds' sample positions (placement heuristic only; not part of any result)
+  float cw = static_cast<float>(n_valid);
+  float cxw = n_valid ? cw * 0.5f * (bb_x0 + bb_x1) : 0.0f;
+  float cyw = n_valid ? cw * 0.5f * (bb_y0 + bb_y1) : 0.0f;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     bb_x0 = fminf(bb_x0, __shfl_xor(bb_x0, off, 64)); bb_y0 = fminf(bb_y0, __shfl_xor(bb_y0, off, 64));
     bb_x1 = fmaxf(bb_x1, __shfl_xor(bb_x1, off, 64)); bb_y1 = fmaxf(bb_y1, __shfl_xor(bb_y1, off, 64));
+    cw += __shfl_xor(cw, off, 64); cxw += __shfl_xor(cxw, off, 64); cyw += __shfl_xor(cyw, off, 64);
   }
   if (lane == 63) S.red_i[wave] = incl;
-  if (lane == 0) { S.red_f[wave][0] = bb_x0; S.red_f[wave][1] = bb_y0; S.red_f[wave][2] = bb_x1; S.red_f[wave][3] = bb_y1; }
+  if (lane == 0) {
+    S.red_f[wave][0] = bb_x0; S.red_f[wave][1] = bb_y0; S.red_f[wave][2] = bb_x1; S.red_f[wave][3] = bb_y1;
+    S.red_f[wave][4] = cw; S.red_f[wave][5] = cxw; S.red_f[wave][6] = cyw;
+  }
   __syncthreads();
   int wave_off = 0;
 #pragma unroll
@@ -235,40 +261,49 @@ __global__ __launch_bounds__(TILE_PIX) void seed_update_tile_kernel(SeedParams P
   S.prefix[tid] = wave_off + incl - n_valid;  // exclusive
   if (tid == 0) {
     S.prefix[TILE_PIX] = total;
-    const float fx0 = fminf(fminf(S.red_f[0][0], S.red_f[1][0]), fminf(S.red_f[2][0], S.red_f[3][0]));
-    const float fy0 = fminf(fminf(S.red_f[0][1], S.red_f[1][1]), fminf(S.red_f[2][1], S.red_f[3][1]));
-    const float fx1 = fmaxf(fmaxf(S.red_f[0][2], S.red_f[1][2]), fmaxf(S.red_f[2][2], S.red_f[3][2]));
-    const float fy1 = fmaxf(fmaxf(S.red_f[0][3], S.red_f[1][3]), fmaxf(S.red_f[2][3], S.red_f[3][3]));
-    int use = 0, wx0 = 0, wy0 = 0, ww = 0, wh = 0;
+    int wx0 = 0, wy0 = 0, wx1 = -1, wy1 = -1;
     if (total > 0) {
-      // texels touched by a sample at p: floor(p) - HALF .. floor(p) + HALF + 1, +-1 for the replayed roundings
+      const float fx0 = fminf(fminf(S.red_f[0][0], S.red_f[1][0]), fminf(S.red_f[2][0], S.red_f[3][0]));
+      const float fy0 = fminf(fminf(S.red_f[0][1], S.red_f[1][1]), fminf(S.red_f[2][1], S.red_f[3][1]));
+      const float fx1 = fmaxf(fmaxf(S.red_f[0][2], S.red_f[1][2]), fmaxf(S.red_f[2][2], S.red_f[3][2]));
+      const float fy1 = fmaxf(fmaxf(S.red_f[0][3], S.red_f[1][3]), fmaxf(S.red_f[2][3], S.red_f[3][3]));
+      // texels touched by a sample at p: floor(p) - HALF .. floor(p) + HALF + 1, +1 for the replayed roundings
       wx0 = max(static_cast<int>(floorf(fx0)) - HALF - 1, 0);
       wy0 = max(static_cast<int>(floorf(fy0)) - HALF - 1, 0);
-      const int wx1 = min(static_cast<int>(floorf(fx1)) + HALF + 2, P.w - 1);
-      const int wy1 = min(static_cast<int>(floorf(fy1)) + HALF + 2, P.h - 1);
-      ww = wx1 - wx0 + 1; wh = wy1 - wy0 + 1;
-      use = (ww <= WS && wh <= WROWS) ? 1 : 0;
+      wx1 = min(static_cast<int>(floorf(fx1)) + HALF + 2, P.w - 1);
+      wy1 = min(static_cast<int>(floorf(fy1)) + HALF + 2, P.h - 1);
+      const int need_w = wx1 - wx0 + 1, need_h = wy1 - wy0 + 1;
       if (feedback) {
-        atomicMax(&feedback[0], static_cast<unsigned int>(ww));
-        atomicMax(&feedback[1], static_cast<unsigned int>(wh));
-        if (!use) atomicAdd(&feedback[2], 1u);
+        atomicMax(&feedback[0], static_cast<unsigned int>(need_w));
+        atomicMax(&feedback[1], static_cast<unsigned int>(need_h));
+      }
+      if (need_w > WS || need_h > WROWS) {
+        // a few seeds wandered off: centre the window on where most samples are; the rest read global memory
+        const float w_sum = S.red_f[0][4] + S.red_f[1][4] + S.red_f[2][4] + S.red_f[3][4];
+        const float cx = (S.red_f[0][5] + S.red_f[1][5] + S.red_f[2][5] + S.red_f[3][5]) / w_sum;
+        const float cy = (S.red_f[0][6] + S.red_f[1][6] + S.red_f[2][6] + S.red_f[3][6]) / w_sum;
+        if (need_w > WS) {
+          wx0 = min(max(static_cast<int>(cx) - WS / 2, 0), max(P.w - WS, 0));
+          wx1 = min(wx0 + WS - 1, P.w - 1);
+        }
+        if (need_h > WROWS) {
+          wy0 = min(max(static_cast<int>(cy) - WROWS / 2, 0), max(P.h - WROWS, 0));
+          wy1 = min(wy0 + WROWS - 1, P.h - 1);
+        }
+        if (feedback) atomicAdd(&feedback[2], 1u);
       }
     }
-    S.win_org[0] = wx0; S.win_org[1] = wy0; S.win_org[2] = use; S.win_org[3] = (wh << 16) | ww;
+    S.win_box[0] = wx0; S.win_box[1] = wy0; S.win_box[2] = wx1; S.win_box[3] = wy1;
   }
   __syncthreads();
 
   // ---- phase 2: stage the current-image window and the reference tile into LDS ----------------
-  const int wx0 = S.win_org[0], wy0 = S.win_org[1];
-  const bool use_window = S.win_org[2] != 0;
+  const int wx0 = S.win_box[0], wy0 = S.win_box[1], wx1 = S.win_box[2], wy1 = S.win_box[3];
   if (total > 0) {
-    if (use_window) {
-      const int ww = S.win_org[3] & 0xffff, wh = S.win_org[3] >> 16;
-      // one wave per row, lanes along the row: coalesced dword loads
-      for (int r = wave; r < wh; r += 4) {
-        const float* src = P.cur + (wy0 + r) * P.stride + wx0;
-        for (int c = lane; c < ww; c += 64) S.win[r * WS + c] = src[c];
-      }
+    const int ww = wx1 - wx0 + 1, wh = wy1 - wy0 + 1;
+    for (int r = wave; r < wh; r += 4) {  // one wave per row, lanes along the row: coalesced dword loads
+      const float* src = P.cur + (wy0 + r) * P.stride + wx0;
+      for (int c = lane; c < ww; c += 64) S.win[r * WS + c] = src[c];
     }
     for (int i = tid; i < Smem::REF_H * Smem::REF_W; i += TILE_PIX) {
       const int ry = i / Smem::REF_W, rx = i - ry * Smem::REF_W;
@@ -278,27 +313,40 @@ __global__ __launch_bounds__(TILE_PIX) void seed_update_tile_kernel(SeedParams P
   __syncthreads();
 
   // ---- phase 3: the tile's (seed, step) work items, dealt round-robin to the lanes -------------
-  for (int k = tid; k < total; k += TILE_PIX) {
-    int lo = 0, hi = TILE_PIX;  // last p with prefix[p] <= k
+  const int rounds = (total + TILE_PIX - 1) / TILE_PIX;
+  for (int rd = 0; rd < rounds; ++rd) {
+    const int k = rd * TILE_PIX + tid;
+    int p = -1;
+    unsigned long long key = 0ull;
+    if (k < total) {
+      int lo = 0, hi = TILE_PIX;  // last p with prefix[p] <= k
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int mid = (lo + hi) >> 1;
-      if (S.prefix[mid] <= k) lo = mid; else hi = mid;
+      for (int it = 0; it < 8; ++it) {
+        const int mid = (lo + hi) >> 1;
+        if (S.prefix[mid] <= k) lo = mid; else hi = mid;
+      }
+      p = lo;
+      const int j = k - S.prefix[p];
+      float l = S.l_first[p];
+      for (int q = 0; q < j; ++q) l += 0.7f;  // the reference accumulates l; replay it
+      const F2 px = F2{S.mean_x[p] + l * S.dir_x[p], S.mean_y[p] + l * S.dir_y[p]};
+      const int ptx = p & (TILE_W - 1), pty = p >> 4;
+      const float ncc = ncc_at<SIDE, WS>(P, px, S.win, wx0, wy0, wx1, wy1, S.ref + pty * Smem::REF_W + ptx, Smem::REF_W,
+                                        S.sum_templ[p], S.denom[p]);
+      if (ncc > -1.0f) {  // NaN and anything the reference's "ncc > best_ncc" would never accept are dropped
+        const unsigned int step = static_cast<unsigned int>(S.i_first[p]) + static_cast<unsigned int>(j);
+        key = (static_cast<unsigned long long>(orderable_f32(ncc + 0.0f)) << 32) | (0xffffffffu - step);
+      }
     }
-    const int p = lo;
-    const int j = k - S.prefix[p];
-    float l = S.l_first[p];
-    for (int q = 0; q < j; ++q) l += 0.7f;  // the reference accumulates l; replay it
-    const F2 px = F2{S.mean_x[p] + l * S.dir_x[p], S.mean_y[p] + l * S.dir_y[p]};
-    const int ptx = p & (TILE_W - 1), pty = p >> 4;
-    const float ncc = ncc_at<SIDE, WS>(P, px, S.win, wx0, wy0, use_window, S.ref + pty * Smem::REF_W + ptx, Smem::REF_W,
-                                      S.sum_templ[p], S.denom[p]);
-    if (ncc > -1.0f) {  // NaN and anything the reference's "ncc > best_ncc" would never accept are dropped
-      const unsigned int step = static_cast<unsigned int>(S.i_first[p]) + static_cast<unsigned int>(j);
-      const unsigned long long key =
-          (static_cast<unsigned long long>(orderable_f32(ncc + 0.0f)) << 32) | (0xffffffffu - step);
-      atomicMax(&S.best[p], key);
+    // seeds occupy runs of consecutive lanes: segmented max towards the run's first lane, then one LDS atomic per run
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned long long okey = __shfl_down(key, off, 64);
+      const int op = __shfl_down(p, off, 64);
+      if (lane + off < 64 && op == p && okey > key) key = okey;
     }
+    const int prev_p = __shfl_up(p, 1, 64);
+    if (p >= 0 && key != 0ull && (lane == 0 || prev_p != p)) atomicMax(&S.best[p], key);
   }
   __syncthreads();
 
