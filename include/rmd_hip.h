@@ -138,6 +138,11 @@ int rmd_hip_seeds_timing(const rmd_hip_seeds_t* s, int stage, double* total_ms, 
 int rmd_hip_seeds_timing_reset(rmd_hip_seeds_t* s);
 /* out[0..2] = live seeds, epipolar steps visited, NCC evaluations of the last update (needs COLLECT_STATS) */
 int rmd_hip_seeds_last_stats(const rmd_hip_seeds_t* s, long long* out3);
+/* tile-kernel diagnostics of the last update (needs COLLECT_STATS): [0..2] as last_stats, [3..5] NCC evaluations served
+ * from the LDS window / regular global reads / per-sample reads, [6] max work items of a tile, [7..9] summed workgroup
+ * cycles in setup / staging / search, [11] max workgroup cycles, [12] tiles with work, [13] search rounds,
+ * [14] max setup cycles, [15] max search cycles */
+int rmd_hip_seeds_last_diagnostics(const rmd_hip_seeds_t* s, long long* out16);
 
 /* ---- rmd::DepthmapDenoiser (depthmap_denoiser.cu) --------------------------------------- */
 int rmd_hip_denoiser_create(int width, int height, rmd_hip_denoiser_t** out); /* ctor :143-169 */

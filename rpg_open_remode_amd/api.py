@@ -307,6 +307,15 @@ class SeedMatrix:
         return {"live_seeds": int(out[0]), "steps": int(out[1]), "ncc_evals": int(out[2])}
 
 
+    def lastDiagnostics(self):
+        out = np.zeros(16, np.int64)
+        check(_lib.lib().rmd_hip_seeds_last_diagnostics(self.ptr, out.ctypes.data))
+        names = ["live_seeds", "steps", "ncc_evals", "evals_lds", "evals_global", "evals_irregular", "max_tile_items",
+                 "cycles_setup", "cycles_stage", "cycles_search", "_10", "max_wg_cycles", "tiles_with_work", "rounds",
+                 "max_setup_cycles", "max_search_cycles"]
+        return {n: int(v) for n, v in zip(names, out) if not n.startswith("_")}
+
+
 class DepthmapDenoiser:
     def __init__(self, width, height):
         self.width, self.height = int(width), int(height)

@@ -152,18 +152,18 @@ int image_alloc(rmd_hip_image* img, int kind, int width, int height) {
 
 // ---- rmd::SeedMatrix ------------------------------------------------------------------------
 struct rmd_hip_seeds {
-  int width = 0, height = 0, patch_side = 5, device = 0;
+  int width = 0, height = 0, patch_side = 5, device = 0, num_cus = 256;
   rmd_hip_image planes[RMD_HIP_NUM_PLANES];
   rmdk::SeedParams P;
   rmdk::Pose T_world_ref;
   float dist_from_ref = 0.0f;
   bool has_reference = false;
   hipStream_t stream = nullptr;
-  unsigned long long* d_scalars = nullptr;  // [0] count result, [1..3] stats
+  unsigned long long* d_scalars = nullptr;  // [0] count result, [1..16] diagnostics
   unsigned long long* h_scalars = nullptr;  // pinned mirror
   int opt_matcher = 1, opt_timing = 0, opt_stats = 0;
   StageTimer timers[RMD_HIP_NUM_SEED_STAGES];
-  long long last_stats[3] = {0, 0, 0};
+  long long last_stats[16] = {0};
   bool stats_pending = false;
   rmdk::MatcherWorkspace matcher_ws;
 };
@@ -188,7 +188,7 @@ int seeds_sync(const rmd_hip_seeds* s) {
   rmd_hip_seeds* m = const_cast<rmd_hip_seeds*>(s);
   for (auto& t : m->timers) t.drain();
   if (m->stats_pending) {
-    for (int k = 0; k < 3; ++k) m->last_stats[k] = static_cast<long long>(m->h_scalars[1 + k]);
+    for (int k = 0; k < 16; ++k) m->last_stats[k] = static_cast<long long>(m->h_scalars[1 + k]);
     m->stats_pending = false;
   }
   return RMD_HIP_OK;
@@ -214,7 +214,7 @@ int seeds_launch_init(rmd_hip_seeds* s) {
 int seeds_launch_update(rmd_hip_seeds* s) {
   rmdk::SeedParams P = s->P;
   if (s->opt_stats) {
-    HIP_TRY(hipMemsetAsync(s->d_scalars + 1, 0, 3 * sizeof(unsigned long long), s->stream));
+    HIP_TRY(hipMemsetAsync(s->d_scalars + 1, 0, 16 * sizeof(unsigned long long), s->stream));
     P.stats = s->d_scalars + 1;
   } else {
     P.stats = nullptr;
@@ -228,7 +228,7 @@ int seeds_launch_update(rmd_hip_seeds* s) {
         const dim3 block(64, 4), grid((s->width + 63) / 64, (s->height + 3) / 4);
         hipLaunchKernelGGL((rmdk::seed_update_pixel_kernel<SIDE>), grid, block, 0, s->stream, P);
       } else {
-        rmdk::launch_seed_update_tile<SIDE>(P, s->matcher_ws, s->stream);
+        HIP_TRY(rmdk::launch_seed_update_tile<SIDE>(P, s->matcher_ws, s->stream, s->num_cus));
       }
       HIP_TRY(hipGetLastError());
       return RMD_HIP_OK;
@@ -236,7 +236,7 @@ int seeds_launch_update(rmd_hip_seeds* s) {
   }
   TRY(rc);
   if (s->opt_stats) {
-    HIP_TRY(hipMemcpyAsync(s->h_scalars + 1, s->d_scalars + 1, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+    HIP_TRY(hipMemcpyAsync(s->h_scalars + 1, s->d_scalars + 1, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                            s->stream));
     s->stats_pending = true;
   }
@@ -423,11 +423,11 @@ int rmd_hip_seeds_create(int width, int height, float fx, float fy, float cx, fl
     if (rc != RMD_HIP_OK) return bail(rc);
     s->planes[p].owner_stream = s->stream;
   }
-  if (hipMalloc(reinterpret_cast<void**>(&s->d_scalars), 4 * sizeof(unsigned long long)) != hipSuccess ||
-      hipHostMalloc(reinterpret_cast<void**>(&s->h_scalars), 4 * sizeof(unsigned long long)) != hipSuccess)
+  if (hipMalloc(reinterpret_cast<void**>(&s->d_scalars), 17 * sizeof(unsigned long long)) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&s->h_scalars), 17 * sizeof(unsigned long long)) != hipSuccess)
     return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: scalar buffers"));
-  (void)hipMemset(s->d_scalars, 0, 4 * sizeof(unsigned long long));
-  memset(s->h_scalars, 0, 4 * sizeof(unsigned long long));
+  (void)hipMemset(s->d_scalars, 0, 17 * sizeof(unsigned long long));
+  memset(s->h_scalars, 0, 17 * sizeof(unsigned long long));
   rmdk::SeedParams& P = s->P;
   memset(&P, 0, sizeof(P));
   P.w = width; P.h = height;
@@ -446,8 +446,10 @@ int rmd_hip_seeds_create(int width, int height, float fx, float fy, float cx, fl
   P.cam = rmdk::Cam{fx, fy, cx, cy};
   P.one_pix_angle = atan2f(1.0f, 2.0f * fx) * 2.0f;  // pinhole_camera.cuh:56-59
   P.max_extent = static_cast<float>(max_extent);
-  const int rcw = s->matcher_ws.allocate(width, height);
+  const int rcw = s->matcher_ws.allocate(width, height, P.stride);
   if (rcw != 0) return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: matcher workspace"));
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) s->num_cus = prop.multiProcessorCount;
   *out = s;
   return RMD_HIP_OK;
 }
@@ -589,6 +591,13 @@ int rmd_hip_seeds_last_stats(const rmd_hip_seeds_t* s, long long* out3) {
   TRY(seeds_bind_device(s));
   TRY(seeds_sync(s));
   for (int k = 0; k < 3; ++k) out3[k] = s->last_stats[k];
+  return RMD_HIP_OK;
+}
+int rmd_hip_seeds_last_diagnostics(const rmd_hip_seeds_t* s, long long* out16) {
+  if (!s || !out16) return fail(RMD_HIP_ERR_INVALID_ARG, "last_diagnostics: null argument");
+  TRY(seeds_bind_device(s));
+  TRY(seeds_sync(s));
+  for (int k = 0; k < 16; ++k) out16[k] = s->last_stats[k];
   return RMD_HIP_OK;
 }
 

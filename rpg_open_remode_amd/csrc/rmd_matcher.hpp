@@ -1,24 +1,30 @@
-// Tile-cooperative fused seed update: seed_check (src/seed_check.cu:28-67) + epipolar NCC search
+// The production seed update: seed_check (src/seed_check.cu:28-67) + epipolar NCC search
 // (src/epipolar_match.cu:37-140) + triangulation and Bayesian fusion (src/seed_update.cu:39-121,
-// src/triangulation.cu) in ONE launch per frame.  This is the production kernel.
+// src/triangulation.cu) as a three-kernel, load-balanced pipeline on one stream:
+//
+//   seed_setup_kernel     one 256-thread workgroup per 16x16 tile of seeds, one lane per seed.
+//                         State check; epipolar segment; ONE walk of the search loop to find the
+//                         contiguous run of steps whose patch lies inside the image.  Writes the
+//                         per-seed search descriptor, the tile's total work and the image window its
+//                         samples fall into, and appends fixed-size WORK UNITS (tile, item range) to
+//                         a device queue.
+//   seed_search_kernel    persistent workgroups pull units from the queue (one returning atomic per
+//                         unit), so a tile whose seeds all search 143 steps is spread over many CUs
+//                         while converged tiles cost nothing.  Per unit: stage the tile's window of
+//                         the current image and its reference-image tile in LDS (batched, coalesced
+//                         loads), deal the unit's (seed, step) pairs round-robin to the 256 lanes, one
+//                         NCC evaluation per pair with the separable bilinear filter of rmd_math.h
+//                         ((SIDE+1)^2 LDS reads feed SIDE*(SIDE+1) + SIDE^2 lerps instead of 4*SIDE^2
+//                         texel fetches), segmented wave max, one 64-bit atomic max per seed run on
+//                         {orderable(ncc), ~step} (ties -> lowest step, as the reference's strict '>').
+//   seed_finalize_kernel  one lane per seed: decode the arg-max, match coordinates, triangulation,
+//                         posterior update.
 //
 // Why not one lane per pixel (the reference's shape, kept in rmd_kernels.hpp as the A/B baseline):
-// the per-seed trip count of the search varies from 0 (converged / diverged / border seeds) to 143
-// steps, so a wave64 idles at the pace of its longest lane, and every lane gathers its own
-// (SIDE+1)^2 texels per step through the vector memory path.  Here a 256-thread workgroup owns a
-// 16x16 tile of seeds and
-//   1. every lane sets up ITS seed (state check, epipolar segment, the contiguous run of steps
-//      whose patch lies inside the image) and the workgroup prefix-sums the step counts;
-//   2. the bounding box of all sample positions of the tile (plus patch halo) is staged ONCE from
-//      the current image into LDS with coalesced row loads, next to the reference-image tile;
-//   3. the tile's (seed, step) pairs are dealt round-robin to the 256 lanes, so lanes stay busy
-//      whatever the per-seed trip counts are, and neighbouring lanes walk neighbouring steps of
-//      the same segment (LDS-friendly).  One work item = one NCC evaluation with the separable
-//      bilinear filter of rmd_math.h: (SIDE+1)^2 LDS reads feed SIDE*(SIDE+1) horizontal and
-//      SIDE^2 vertical lerps instead of 4*SIDE^2 texel fetches;
-//   4. the per-seed arg-max (ties -> lowest step, as the reference's strict '>' does) is an LDS
-//      64-bit atomic max on {orderable(ncc), ~step};
-//   5. every lane finishes ITS seed: match coordinates, triangulation, posterior update.
+// the per-seed trip count varies from 0 (converged / diverged / border) to 143, so a wave64 idles at
+// the pace of its longest lane and every lane gathers its own texels through the vector memory path.
+// Why not one fused kernel per tile (the first version of this file): kernel time was the time of
+// the heaviest tile (max workgroup 0.6-2.5 M cycles vs 0.1 M average on the benchmark sequence).
 // Results are bit-identical to the reference semantics (tests/test_hip_parity.py).
 #ifndef RMD_MATCHER_HPP
 #define RMD_MATCHER_HPP
@@ -28,25 +34,66 @@
 namespace rmdk {
 
 constexpr int TILE_W = 16, TILE_H = 16, TILE_PIX = TILE_W * TILE_H;
-constexpr int MAX_STEPS = 160;  // > floor(100 / 0.7) + 1 = 143 iterations of the search loop
+constexpr int UNIT_ITEMS = 4 * TILE_PIX;  // NCC evaluations per work unit (4 rounds of the 256 lanes)
+constexpr int MAX_ITEMS_PER_TILE = TILE_PIX * 144;
+
+// per-tile record written by seed_setup, read by seed_search
+struct TileInfo {
+  int total;               // NCC evaluations of the tile
+  int wx0, wy0, wx1, wy1;  // inclusive texel box of the current image staged for the tile
+  int pad[3];
+};
 
 struct MatcherWorkspace {
-  // device: [0] max window width seen, [1] max window height seen, [2] tiles that fell back to global reads
-  unsigned int* d_feedback = nullptr;
-  unsigned int* h_feedback = nullptr;  // pinned mirror, read one frame late
-  int allocate(int, int) {
-    if (hipMalloc(reinterpret_cast<void**>(&d_feedback), 4 * sizeof(unsigned int)) != hipSuccess) return -1;
-    if (hipHostMalloc(reinterpret_cast<void**>(&h_feedback), 4 * sizeof(unsigned int)) != hipSuccess) return -1;
-    (void)hipMemset(d_feedback, 0, 4 * sizeof(unsigned int));
-    h_feedback[0] = h_feedback[1] = h_feedback[2] = h_feedback[3] = 0;
+  int tiles_x = 0, tiles_y = 0, stride = 0;
+  float2* d_mean = nullptr;   // per seed: projection of mu into the current frame
+  float2* d_dir = nullptr;    // per seed: unit direction of the epipolar segment
+  float* d_lfirst = nullptr;  // per seed: accumulated l at the first in-image step
+  unsigned int* d_packed = nullptr;      // per seed: first in-image step << 16 | number of in-image steps
+  unsigned long long* d_best = nullptr;  // per seed: arg-max key
+  TileInfo* d_tiles = nullptr;
+  uint2* d_units = nullptr;         // (tile, first item)
+  unsigned int* d_queue = nullptr;  // [0] units appended, [1] next unit, [2] widest / [3] tallest window, [4] off-window tiles
+  int max_units = 0;
+  int allocate(int w, int h, int stride_elems) {
+    tiles_x = (w + TILE_W - 1) / TILE_W;
+    tiles_y = (h + TILE_H - 1) / TILE_H;
+    stride = stride_elems;
+    const size_t n = static_cast<size_t>(stride) * h;
+    max_units = tiles_x * tiles_y * ((MAX_ITEMS_PER_TILE + UNIT_ITEMS - 1) / UNIT_ITEMS);
+    if (hipMalloc(reinterpret_cast<void**>(&d_mean), n * sizeof(float2)) != hipSuccess) return -1;
+    if (hipMalloc(reinterpret_cast<void**>(&d_dir), n * sizeof(float2)) != hipSuccess) return -1;
+    if (hipMalloc(reinterpret_cast<void**>(&d_lfirst), n * sizeof(float)) != hipSuccess) return -1;
+    if (hipMalloc(reinterpret_cast<void**>(&d_packed), n * sizeof(unsigned int)) != hipSuccess) return -1;
+    if (hipMalloc(reinterpret_cast<void**>(&d_best), n * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (hipMalloc(reinterpret_cast<void**>(&d_tiles), static_cast<size_t>(tiles_x) * tiles_y * sizeof(TileInfo)) != hipSuccess) return -1;
+    if (hipMalloc(reinterpret_cast<void**>(&d_units), static_cast<size_t>(max_units) * sizeof(uint2)) != hipSuccess) return -1;
+    if (hipMalloc(reinterpret_cast<void**>(&d_queue), 8 * sizeof(unsigned int)) != hipSuccess) return -1;
+    (void)hipMemset(d_packed, 0, n * sizeof(unsigned int));
+    (void)hipMemset(d_best, 0, n * sizeof(unsigned long long));
+    (void)hipMemset(d_queue, 0, 8 * sizeof(unsigned int));
     return 0;
   }
   void release() {
-    if (d_feedback) (void)hipFree(d_feedback);
-    if (h_feedback) (void)hipHostFree(h_feedback);
-    d_feedback = nullptr;
-    h_feedback = nullptr;
+    void* all[] = {d_mean, d_dir, d_lfirst, d_packed, d_best, d_tiles, d_units, d_queue};
+    for (void* p : all)
+      if (p) (void)hipFree(p);
+    d_mean = d_dir = nullptr; d_lfirst = nullptr; d_packed = nullptr; d_best = nullptr;
+    d_tiles = nullptr; d_units = nullptr; d_queue = nullptr;
   }
+};
+
+// device view of the workspace
+struct MatcherArgs {
+  float2* mean;
+  float2* dir;
+  float* lfirst;
+  unsigned int* packed;
+  unsigned long long* best;
+  TileInfo* tiles;
+  uint2* units;
+  unsigned int* queue;
+  int tiles_x;
 };
 
 RMDK_D unsigned int orderable_f32(float f) {
@@ -116,12 +163,12 @@ RMDK_D void ncc_sums_regular(const float* __restrict__ base, int rt_stride, cons
 }
 
 // One NCC evaluation at px.  Three sources for the current-image samples, same arithmetic in all:
-//   1. the LDS window staged for this tile, when the footprint lies inside it;
-//   2. global memory (L1/L2) with the same regular footprint, for seeds that wandered off the window;
-//   3. per-sample fetches, only when the replayed roundings make the footprint irregular.
+//   0. the LDS window staged for this tile, when the footprint lies inside it;
+//   1. global memory (L1/L2) with the same regular footprint, for seeds that wandered off the window;
+//   2. per-sample fetches, only when the replayed roundings make the footprint irregular.
 template <int SIDE, int WS>
 RMDK_D float ncc_at(const SeedParams& P, F2 px, const float* __restrict__ win, int wx0, int wy0, int wx1, int wy1,
-                    const float* __restrict__ ref_patch, int ref_stride, float sum_templ, float denom) {
+                    const float* __restrict__ ref_patch, int ref_stride, float sum_templ, float denom, int& path) {
   constexpr int OFFSET = -SIDE / 2;
   constexpr float AREA = static_cast<float>(SIDE * SIDE);
   float sum_img = 0.0f, sum_img_sq = 0.0f, sum_img_templ = 0.0f;
@@ -132,6 +179,7 @@ RMDK_D float ncc_at(const SeedParams& P, F2 px, const float* __restrict__ win, i
   if (reg_x && reg_y) {
     // the guard keeps px in [SIDE, dim-SIDE), so rows iy[0]..iy[0]+SIDE and columns ix[0]..ix[0]+SIDE are in the image
     const bool in_window = ix[0] >= wx0 && iy[0] >= wy0 && ix[0] + SIDE <= wx1 && iy[0] + SIDE <= wy1;
+    path = in_window ? 0 : 1;
     if (in_window) {
       ncc_sums_regular<SIDE, WS>(win + (iy[0] - wy0) * WS + (ix[0] - wx0), 0, ax, ay, ref_patch, ref_stride, sum_img,
                                  sum_img_sq, sum_img_templ);
@@ -140,6 +188,7 @@ RMDK_D float ncc_at(const SeedParams& P, F2 px, const float* __restrict__ win, i
                                 sum_img_sq, sum_img_templ);
     }
   } else {
+    path = 2;
     for (int m = 0; m < SIDE; ++m) {
       const float cy = px.y + static_cast<float>(OFFSET + m) + 0.5f;
       for (int k = 0; k < SIDE; ++k) {
@@ -157,57 +206,38 @@ RMDK_D float ncc_at(const SeedParams& P, F2 px, const float* __restrict__ win, i
   return num * rmd_rsqrtf(den + FLT_MIN);
 }
 
+// ------------------------------------------------------------------------------------------------
+// stage 1: per-tile setup
 template <int SIDE, int WS, int WROWS>
-struct TileSmem {
-  static constexpr int HALF = SIDE / 2;
-  static constexpr int REF_W = TILE_W + SIDE - 1, REF_H = TILE_H + SIDE - 1;
-  float win[WROWS * WS];
-  float ref[REF_H * REF_W];
-  float mean_x[TILE_PIX], mean_y[TILE_PIX], dir_x[TILE_PIX], dir_y[TILE_PIX];
-  float l_first[TILE_PIX];
-  float sum_templ[TILE_PIX], denom[TILE_PIX];
-  unsigned long long best[TILE_PIX];
-  int prefix[TILE_PIX + 1];
-  unsigned short i_first[TILE_PIX];
-  float red_f[4][8];
-  int red_i[4];
-  int win_box[4];  // wx0, wy0, wx1, wy1 (inclusive texel bounds of the staged window; wx1 < wx0 if none)
-};
-
-template <int SIDE, int WS, int WROWS>
-__global__ __launch_bounds__(TILE_PIX) void seed_update_tile_kernel(SeedParams P, unsigned int* __restrict__ feedback) {
-  using Smem = TileSmem<SIDE, WS, WROWS>;
+__global__ __launch_bounds__(TILE_PIX) void seed_setup_kernel(SeedParams P, MatcherArgs M) {
   constexpr int HALF = SIDE / 2;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  Smem& S = *reinterpret_cast<Smem*>(smem_raw);
-
+  __shared__ float red_f[4][8];
+  __shared__ int red_i[4];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int tx = tid & (TILE_W - 1), ty = tid >> 4;
-  const int x0 = blockIdx.x * TILE_W, y0 = blockIdx.y * TILE_H;
-  const int x = x0 + tx, y = y0 + ty;
+  const int x = blockIdx.x * TILE_W + tx, y = blockIdx.y * TILE_H + ty;
   const bool in_image = x < P.w && y < P.h;
   const int gi = y * P.stride + x;
 
-  // ---- phase 0: per-seed setup ----------------------------------------------------------------
-  float mu = 0.0f, sigma_sq = 0.0f, a = 0.0f, b = 0.0f;
   int state = ST_BORDER;
+  float mu = 0.0f, sigma_sq = 0.0f;
   if (in_image) {
-    mu = P.mu[gi]; sigma_sq = P.sigma_sq[gi]; a = P.a[gi]; b = P.b[gi];
-    state = seed_check(P, x, y, sigma_sq, a, b, SIDE);
+    mu = P.mu[gi]; sigma_sq = P.sigma_sq[gi];
+    state = seed_check(P, x, y, sigma_sq, P.a[gi], P.b[gi], SIDE);
+    P.conv[gi] = state;  // final for BORDER / CONVERGED / DIVERGED; UPDATE seeds are settled by seed_finalize
   }
   const bool live = in_image && state == ST_UPDATE;
-  Segment seg;
-  seg.mean = F2{0.0f, 0.0f}; seg.dir = F2{0.0f, 0.0f}; seg.half_length = 0.0f;
   int n_valid = 0, i_first = 0;
   float l_first = 0.0f;
   unsigned int n_steps = 0, n_evals = 0;
   float bb_x0 = INFINITY, bb_y0 = INFINITY, bb_x1 = -INFINITY, bb_y1 = -INFINITY;
   if (live) {
-    seg = epipolar_segment(P, x, y, mu, sigma_sq);
+    const Segment seg = epipolar_segment(P, x, y, mu, sigma_sq);
     const bool finite = isfinite(seg.mean.x) && isfinite(seg.mean.y) && isfinite(seg.dir.x) && isfinite(seg.dir.y);
     // walk the search loop once (epipolar_match.cu:88): count the steps and find the run of steps that
     // pass the in-image guard.  The guard region is convex and px is monotone in l, so that run is contiguous.
+    // A non-finite position yields NaN sums in the reference and never becomes a candidate: no work.
     int i = 0;
     for (float l = -seg.half_length; l <= seg.half_length; l += 0.7f, ++i) {
       const F2 px = F2{seg.mean.x + l * seg.dir.x, seg.mean.y + l * seg.dir.y};
@@ -222,136 +252,33 @@ __global__ __launch_bounds__(TILE_PIX) void seed_update_tile_kernel(SeedParams P
       }
     }
     n_steps = static_cast<unsigned int>(i);
-    // a non-finite position yields NaN sums in the reference and never becomes a candidate: no work
+    M.best[gi] = 0ull;
+    if (n_valid > 0) {
+      M.mean[gi] = make_float2(seg.mean.x, seg.mean.y);
+      M.dir[gi] = make_float2(seg.dir.x, seg.dir.y);
+      M.lfirst[gi] = l_first;
+    }
   }
-  S.mean_x[tid] = seg.mean.x; S.mean_y[tid] = seg.mean.y;
-  S.dir_x[tid] = seg.dir.x; S.dir_y[tid] = seg.dir.y;
-  S.l_first[tid] = l_first;
-  S.i_first[tid] = static_cast<unsigned short>(i_first);
-  S.best[tid] = 0ull;
-  if (live) { S.sum_templ[tid] = P.sum_templ[gi]; S.denom[tid] = P.denom[gi]; }
+  if (in_image) M.packed[gi] = (static_cast<unsigned int>(i_first) << 16) | static_cast<unsigned int>(n_valid);
 
-  // ---- phase 1: workgroup scan of step counts; where do the tile's samples fall? ---------------
-  int incl = n_valid;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int v = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += v;
-  }
-  // step-weighted centroid of the seeds' sample positions (placement heuristic only; not part of any result)
+  // tile totals: work, bounding box and step-weighted centroid of the sample positions
+  int tot = n_valid;
   float cw = static_cast<float>(n_valid);
   float cxw = n_valid ? cw * 0.5f * (bb_x0 + bb_x1) : 0.0f;
   float cyw = n_valid ? cw * 0.5f * (bb_y0 + bb_y1) : 0.0f;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
+    tot += __shfl_xor(tot, off, 64);
     bb_x0 = fminf(bb_x0, __shfl_xor(bb_x0, off, 64)); bb_y0 = fminf(bb_y0, __shfl_xor(bb_y0, off, 64));
     bb_x1 = fmaxf(bb_x1, __shfl_xor(bb_x1, off, 64)); bb_y1 = fmaxf(bb_y1, __shfl_xor(bb_y1, off, 64));
     cw += __shfl_xor(cw, off, 64); cxw += __shfl_xor(cxw, off, 64); cyw += __shfl_xor(cyw, off, 64);
   }
-  if (lane == 63) S.red_i[wave] = incl;
   if (lane == 0) {
-    S.red_f[wave][0] = bb_x0; S.red_f[wave][1] = bb_y0; S.red_f[wave][2] = bb_x1; S.red_f[wave][3] = bb_y1;
-    S.red_f[wave][4] = cw; S.red_f[wave][5] = cxw; S.red_f[wave][6] = cyw;
+    red_i[wave] = tot;
+    red_f[wave][0] = bb_x0; red_f[wave][1] = bb_y0; red_f[wave][2] = bb_x1; red_f[wave][3] = bb_y1;
+    red_f[wave][4] = cw; red_f[wave][5] = cxw; red_f[wave][6] = cyw;
   }
-  __syncthreads();
-  int wave_off = 0;
-#pragma unroll
-  for (int wv = 0; wv < 4; ++wv) wave_off += (wv < wave) ? S.red_i[wv] : 0;
-  const int total = S.red_i[0] + S.red_i[1] + S.red_i[2] + S.red_i[3];
-  S.prefix[tid] = wave_off + incl - n_valid;  // exclusive
-  if (tid == 0) {
-    S.prefix[TILE_PIX] = total;
-    int wx0 = 0, wy0 = 0, wx1 = -1, wy1 = -1;
-    if (total > 0) {
-      const float fx0 = fminf(fminf(S.red_f[0][0], S.red_f[1][0]), fminf(S.red_f[2][0], S.red_f[3][0]));
-      const float fy0 = fminf(fminf(S.red_f[0][1], S.red_f[1][1]), fminf(S.red_f[2][1], S.red_f[3][1]));
-      const float fx1 = fmaxf(fmaxf(S.red_f[0][2], S.red_f[1][2]), fmaxf(S.red_f[2][2], S.red_f[3][2]));
-      const float fy1 = fmaxf(fmaxf(S.red_f[0][3], S.red_f[1][3]), fmaxf(S.red_f[2][3], S.red_f[3][3]));
-      // texels touched by a sample at p: floor(p) - HALF .. floor(p) + HALF + 1, +1 for the replayed roundings
-      wx0 = max(static_cast<int>(floorf(fx0)) - HALF - 1, 0);
-      wy0 = max(static_cast<int>(floorf(fy0)) - HALF - 1, 0);
-      wx1 = min(static_cast<int>(floorf(fx1)) + HALF + 2, P.w - 1);
-      wy1 = min(static_cast<int>(floorf(fy1)) + HALF + 2, P.h - 1);
-      const int need_w = wx1 - wx0 + 1, need_h = wy1 - wy0 + 1;
-      if (feedback) {
-        atomicMax(&feedback[0], static_cast<unsigned int>(need_w));
-        atomicMax(&feedback[1], static_cast<unsigned int>(need_h));
-      }
-      if (need_w > WS || need_h > WROWS) {
-        // a few seeds wandered off: centre the window on where most samples are; the rest read global memory
-        const float w_sum = S.red_f[0][4] + S.red_f[1][4] + S.red_f[2][4] + S.red_f[3][4];
-        const float cx = (S.red_f[0][5] + S.red_f[1][5] + S.red_f[2][5] + S.red_f[3][5]) / w_sum;
-        const float cy = (S.red_f[0][6] + S.red_f[1][6] + S.red_f[2][6] + S.red_f[3][6]) / w_sum;
-        if (need_w > WS) {
-          wx0 = min(max(static_cast<int>(cx) - WS / 2, 0), max(P.w - WS, 0));
-          wx1 = min(wx0 + WS - 1, P.w - 1);
-        }
-        if (need_h > WROWS) {
-          wy0 = min(max(static_cast<int>(cy) - WROWS / 2, 0), max(P.h - WROWS, 0));
-          wy1 = min(wy0 + WROWS - 1, P.h - 1);
-        }
-        if (feedback) atomicAdd(&feedback[2], 1u);
-      }
-    }
-    S.win_box[0] = wx0; S.win_box[1] = wy0; S.win_box[2] = wx1; S.win_box[3] = wy1;
-  }
-  __syncthreads();
-
-  // ---- phase 2: stage the current-image window and the reference tile into LDS ----------------
-  const int wx0 = S.win_box[0], wy0 = S.win_box[1], wx1 = S.win_box[2], wy1 = S.win_box[3];
-  if (total > 0) {
-    const int ww = wx1 - wx0 + 1, wh = wy1 - wy0 + 1;
-    for (int r = wave; r < wh; r += 4) {  // one wave per row, lanes along the row: coalesced dword loads
-      const float* src = P.cur + (wy0 + r) * P.stride + wx0;
-      for (int c = lane; c < ww; c += 64) S.win[r * WS + c] = src[c];
-    }
-    for (int i = tid; i < Smem::REF_H * Smem::REF_W; i += TILE_PIX) {
-      const int ry = i / Smem::REF_W, rx = i - ry * Smem::REF_W;
-      S.ref[i] = P.ref[clampi(y0 - HALF + ry, 0, P.h - 1) * P.stride + clampi(x0 - HALF + rx, 0, P.w - 1)];
-    }
-  }
-  __syncthreads();
-
-  // ---- phase 3: the tile's (seed, step) work items, dealt round-robin to the lanes -------------
-  const int rounds = (total + TILE_PIX - 1) / TILE_PIX;
-  for (int rd = 0; rd < rounds; ++rd) {
-    const int k = rd * TILE_PIX + tid;
-    int p = -1;
-    unsigned long long key = 0ull;
-    if (k < total) {
-      int lo = 0, hi = TILE_PIX;  // last p with prefix[p] <= k
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int mid = (lo + hi) >> 1;
-        if (S.prefix[mid] <= k) lo = mid; else hi = mid;
-      }
-      p = lo;
-      const int j = k - S.prefix[p];
-      float l = S.l_first[p];
-      for (int q = 0; q < j; ++q) l += 0.7f;  // the reference accumulates l; replay it
-      const F2 px = F2{S.mean_x[p] + l * S.dir_x[p], S.mean_y[p] + l * S.dir_y[p]};
-      const int ptx = p & (TILE_W - 1), pty = p >> 4;
-      const float ncc = ncc_at<SIDE, WS>(P, px, S.win, wx0, wy0, wx1, wy1, S.ref + pty * Smem::REF_W + ptx, Smem::REF_W,
-                                        S.sum_templ[p], S.denom[p]);
-      if (ncc > -1.0f) {  // NaN and anything the reference's "ncc > best_ncc" would never accept are dropped
-        const unsigned int step = static_cast<unsigned int>(S.i_first[p]) + static_cast<unsigned int>(j);
-        key = (static_cast<unsigned long long>(orderable_f32(ncc + 0.0f)) << 32) | (0xffffffffu - step);
-      }
-    }
-    // seeds occupy runs of consecutive lanes: segmented max towards the run's first lane, then one LDS atomic per run
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const unsigned long long okey = __shfl_down(key, off, 64);
-      const int op = __shfl_down(p, off, 64);
-      if (lane + off < 64 && op == p && okey > key) key = okey;
-    }
-    const int prev_p = __shfl_up(p, 1, 64);
-    if (p >= 0 && key != 0ull && (lane == 0 || prev_p != p)) atomicMax(&S.best[p], key);
-  }
-  __syncthreads();
-
-  // ---- phase 4: every lane finishes its own seed ---------------------------------------------
-  if (P.stats) {  // diagnostics: one atomic triple per wave
+  if (P.stats) {  // diagnostics
     const unsigned long long s_live = wave_sum_u64(live ? 1ull : 0ull);
     const unsigned long long s_steps = wave_sum_u64(static_cast<unsigned long long>(n_steps));
     const unsigned long long s_evals = wave_sum_u64(static_cast<unsigned long long>(n_evals));
@@ -361,38 +288,264 @@ __global__ __launch_bounds__(TILE_PIX) void seed_update_tile_kernel(SeedParams P
       atomicAdd(&P.stats[2], s_evals);
     }
   }
-  if (!in_image) return;
-  F2 best_px = F2{0.0f, 0.0f};
-  if (live) {
-    const unsigned long long key = S.best[tid];
-    float best_ncc = -1.0f;
-    if (key != 0ull) {
-      best_ncc = from_orderable_f32(static_cast<unsigned int>(key >> 32));
-      const int step = static_cast<int>(0xffffffffu - static_cast<unsigned int>(key & 0xffffffffu));
-      float l = l_first;
-      for (int q = i_first; q < step; ++q) l += 0.7f;
-      best_px = F2{seg.mean.x + l * seg.dir.x, seg.mean.y + l * seg.dir.y};
+  __syncthreads();
+  if (tid != 0) return;
+  const int total = red_i[0] + red_i[1] + red_i[2] + red_i[3];
+  TileInfo ti;
+  ti.total = total; ti.wx0 = 0; ti.wy0 = 0; ti.wx1 = -1; ti.wy1 = -1; ti.pad[0] = ti.pad[1] = ti.pad[2] = 0;
+  const int tile = blockIdx.y * M.tiles_x + blockIdx.x;
+  if (total > 0) {
+    const float fx0 = fminf(fminf(red_f[0][0], red_f[1][0]), fminf(red_f[2][0], red_f[3][0]));
+    const float fy0 = fminf(fminf(red_f[0][1], red_f[1][1]), fminf(red_f[2][1], red_f[3][1]));
+    const float fx1 = fmaxf(fmaxf(red_f[0][2], red_f[1][2]), fmaxf(red_f[2][2], red_f[3][2]));
+    const float fy1 = fmaxf(fmaxf(red_f[0][3], red_f[1][3]), fmaxf(red_f[2][3], red_f[3][3]));
+    // texels touched by a sample at p: floor(p) - HALF .. floor(p) + HALF + 1, +1 for the replayed roundings
+    ti.wx0 = max(static_cast<int>(floorf(fx0)) - HALF - 1, 0);
+    ti.wy0 = max(static_cast<int>(floorf(fy0)) - HALF - 1, 0);
+    ti.wx1 = min(static_cast<int>(floorf(fx1)) + HALF + 2, P.w - 1);
+    ti.wy1 = min(static_cast<int>(floorf(fy1)) + HALF + 2, P.h - 1);
+    const int need_w = ti.wx1 - ti.wx0 + 1, need_h = ti.wy1 - ti.wy0 + 1;
+    atomicMax(&M.queue[2], static_cast<unsigned int>(need_w));
+    atomicMax(&M.queue[3], static_cast<unsigned int>(need_h));
+    if (need_w > WS || need_h > WROWS) {
+      // a few seeds wandered off: centre the window on where most samples are; the rest read global memory
+      const float w_sum = red_f[0][4] + red_f[1][4] + red_f[2][4] + red_f[3][4];
+      const float cx = (red_f[0][5] + red_f[1][5] + red_f[2][5] + red_f[3][5]) / w_sum;
+      const float cy = (red_f[0][6] + red_f[1][6] + red_f[2][6] + red_f[3][6]) / w_sum;
+      if (need_w > WS) {
+        ti.wx0 = min(max(static_cast<int>(cx) - WS / 2, 0), max(P.w - WS, 0));
+        ti.wx1 = min(ti.wx0 + WS - 1, P.w - 1);
+      }
+      if (need_h > WROWS) {
+        ti.wy0 = min(max(static_cast<int>(cy) - WROWS / 2, 0), max(P.h - WROWS, 0));
+        ti.wy1 = min(ti.wy0 + WROWS - 1, P.h - 1);
+      }
+      atomicAdd(&M.queue[4], 1u);
     }
-    if (best_ncc < 0.5f) {
-      state = ST_NO_MATCH;
-    } else {
-      P.match[y * P.stride2 + x] = make_float2(best_px.x, best_px.y);
-    }
+    const unsigned int n_units = static_cast<unsigned int>((total + UNIT_ITEMS - 1) / UNIT_ITEMS);
+    const unsigned int base = atomicAdd(&M.queue[0], n_units);
+    for (unsigned int u = 0; u < n_units; ++u) M.units[base + u] = make_uint2(static_cast<unsigned int>(tile), u * UNIT_ITEMS);
   }
-  P.conv[gi] = state;
-  if (live) seed_fuse(P, x, y, gi, state, mu, sigma_sq, a, b, best_px);
+  M.tiles[tile] = ti;
 }
 
+// ------------------------------------------------------------------------------------------------
+// stage 2: persistent search workgroups
+template <int SIDE, int WS, int WROWS>
+struct SearchSmem {
+  static constexpr int HALF = SIDE / 2;
+  static constexpr int REF_W = TILE_W + SIDE - 1, REF_H = TILE_H + SIDE - 1;
+  float win[WROWS * WS];
+  float ref[REF_H * REF_W];
+  float mean_x[TILE_PIX], mean_y[TILE_PIX], dir_x[TILE_PIX], dir_y[TILE_PIX];
+  float l_first[TILE_PIX];
+  float sum_templ[TILE_PIX], denom[TILE_PIX];
+  int prefix[TILE_PIX + 1];
+  unsigned short i_first[TILE_PIX];
+  int red_i[4];
+  unsigned int unit[2];
+};
+
+template <int SIDE, int WS, int WROWS>
+__global__ __launch_bounds__(TILE_PIX) void seed_search_kernel(SeedParams P, MatcherArgs M) {
+  using Smem = SearchSmem<SIDE, WS, WROWS>;
+  constexpr int HALF = SIDE / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Smem& S = *reinterpret_cast<Smem*>(smem_raw);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int tx = tid & (TILE_W - 1), ty = tid >> 4;
+  const unsigned int n_units = M.queue[0];
+  unsigned int n_path[3] = {0, 0, 0};
+  unsigned long long t_stage = 0, t_search = 0;
+  unsigned int my_units = 0;
+
+  for (;;) {
+    const long long t0 = P.stats ? clock64() : 0;
+    __syncthreads();  // previous unit's LDS is no longer read
+    if (tid == 0) S.unit[0] = atomicAdd(&M.queue[1], 1u);
+    __syncthreads();
+    const unsigned int u = S.unit[0];
+    if (u >= n_units) break;
+    ++my_units;
+    const uint2 unit = M.units[u];
+    const int tile = static_cast<int>(unit.x);
+    const int first = static_cast<int>(unit.y);
+    const TileInfo ti = M.tiles[tile];
+    const int tile_y = tile / M.tiles_x, tile_x = tile - tile_y * M.tiles_x;
+    const int x0 = tile_x * TILE_W, y0 = tile_y * TILE_H;
+    const int x = x0 + tx, y = y0 + ty;
+    const bool in_image = x < P.w && y < P.h;
+    const int gi = y * P.stride + x;
+
+    // per-seed descriptors of the tile -> LDS; exclusive prefix of the step counts
+    const unsigned int packed = in_image ? M.packed[gi] : 0u;
+    const int n_valid = static_cast<int>(packed & 0xffffu);
+    if (n_valid > 0) {
+      const float2 m = M.mean[gi], d = M.dir[gi];
+      S.mean_x[tid] = m.x; S.mean_y[tid] = m.y; S.dir_x[tid] = d.x; S.dir_y[tid] = d.y;
+      S.l_first[tid] = M.lfirst[gi];
+      S.sum_templ[tid] = P.sum_templ[gi]; S.denom[tid] = P.denom[gi];
+    }
+    S.i_first[tid] = static_cast<unsigned short>(packed >> 16);
+    int incl = n_valid;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += v;
+    }
+    if (lane == 63) S.red_i[wave] = incl;
+
+    // stage the window of the current image (batches of independent loads) and the reference tile
+    const int wx0 = ti.wx0, wy0 = ti.wy0, wx1 = ti.wx1, wy1 = ti.wy1;
+    const int ww = wx1 - wx0 + 1, wh = wy1 - wy0 + 1;
+    {
+      const int n_el = ww * wh;
+      const float inv_ww = 1.0f / static_cast<float>(ww);
+      for (int e0 = tid; e0 < n_el; e0 += TILE_PIX * 8) {
+        float v[8];
+        int dst[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int e = e0 + q * TILE_PIX;
+          int r = static_cast<int>(static_cast<float>(e) * inv_ww);  // e / ww, fixed up below (e < 2^14)
+          int c = e - r * ww;
+          if (c < 0) { --r; c += ww; } else if (c >= ww) { ++r; c -= ww; }
+          dst[q] = r * WS + c;
+          v[q] = e < n_el ? P.cur[(wy0 + r) * P.stride + wx0 + c] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (e0 + q * TILE_PIX < n_el) S.win[dst[q]] = v[q];
+      }
+      for (int i = tid; i < Smem::REF_H * Smem::REF_W; i += TILE_PIX) {
+        const int ry = i / Smem::REF_W, rx = i - ry * Smem::REF_W;
+        S.ref[i] = P.ref[clampi(y0 - HALF + ry, 0, P.h - 1) * P.stride + clampi(x0 - HALF + rx, 0, P.w - 1)];
+      }
+    }
+    __syncthreads();
+    int wave_off = 0;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) wave_off += (wv < wave) ? S.red_i[wv] : 0;
+    S.prefix[tid] = wave_off + incl - n_valid;  // exclusive
+    if (tid == 0) S.prefix[TILE_PIX] = ti.total;
+    __syncthreads();
+    const long long t1 = P.stats ? clock64() : 0;
+
+    // the unit's (seed, step) work items, dealt round-robin to the lanes
+    const int last = min(first + UNIT_ITEMS, ti.total);
+    for (int k0 = first; k0 < last; k0 += TILE_PIX) {
+      const int k = k0 + tid;
+      int p = -1;
+      unsigned long long key = 0ull;
+      if (k < last) {
+        int lo = 0, hi = TILE_PIX;  // last p with prefix[p] <= k
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int mid = (lo + hi) >> 1;
+          if (S.prefix[mid] <= k) lo = mid; else hi = mid;
+        }
+        p = lo;
+        const int j = k - S.prefix[p];
+        float l = S.l_first[p];
+        for (int q = 0; q < j; ++q) l += 0.7f;  // the reference accumulates l; replay it
+        const F2 px = F2{S.mean_x[p] + l * S.dir_x[p], S.mean_y[p] + l * S.dir_y[p]};
+        const int ptx = p & (TILE_W - 1), pty = p >> 4;
+        int path = 0;
+        const float ncc = ncc_at<SIDE, WS>(P, px, S.win, wx0, wy0, wx1, wy1, S.ref + pty * Smem::REF_W + ptx, Smem::REF_W,
+                                          S.sum_templ[p], S.denom[p], path);
+        n_path[0] += path == 0; n_path[1] += path == 1; n_path[2] += path == 2;
+        if (ncc > -1.0f) {  // NaN and anything the reference's "ncc > best_ncc" would never accept are dropped
+          const unsigned int step = static_cast<unsigned int>(S.i_first[p]) + static_cast<unsigned int>(j);
+          key = (static_cast<unsigned long long>(orderable_f32(ncc + 0.0f)) << 32) | (0xffffffffu - step);
+        }
+      }
+      // seeds occupy runs of consecutive lanes: segmented max towards the run's first lane, then one atomic per run
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long okey = __shfl_down(key, off, 64);
+        const int op = __shfl_down(p, off, 64);
+        if (lane + off < 64 && op == p && okey > key) key = okey;
+      }
+      const int prev_p = __shfl_up(p, 1, 64);
+      if (p >= 0 && key != 0ull && (lane == 0 || prev_p != p)) {
+        const int py = y0 + (p >> 4), pxx = x0 + (p & (TILE_W - 1));
+        atomicMax(&M.best[py * P.stride + pxx], key);
+      }
+    }
+    if (P.stats) {
+      const long long t2 = clock64();
+      t_stage += static_cast<unsigned long long>(t1 - t0);
+      t_search += static_cast<unsigned long long>(t2 - t1);
+    }
+  }
+  if (P.stats) {
+    const unsigned long long s0 = wave_sum_u64(n_path[0]), s1 = wave_sum_u64(n_path[1]), s2 = wave_sum_u64(n_path[2]);
+    if (lane == 0) {
+      if (s0) atomicAdd(&P.stats[3], s0);
+      if (s1) atomicAdd(&P.stats[4], s1);
+      if (s2) atomicAdd(&P.stats[5], s2);
+    }
+    if (tid == 0) {
+      atomicAdd(&P.stats[8], t_stage);
+      atomicAdd(&P.stats[9], t_search);
+      atomicMax(&P.stats[11], t_stage + t_search);
+      atomicAdd(&P.stats[13], static_cast<unsigned long long>(my_units));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 3: per-seed finalisation (epipolar_match.cu:131-139 + seed_update.cu:39-121)
+__global__ __launch_bounds__(256) void seed_finalize_kernel(SeedParams P, MatcherArgs M) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= P.w || y >= P.h) return;
+  const int gi = y * P.stride + x;
+  int state = P.conv[gi];
+  if (state != ST_UPDATE) return;  // BORDER / CONVERGED / DIVERGED were settled by seed_setup
+  const unsigned long long key = M.best[gi];
+  F2 best_px = F2{0.0f, 0.0f};
+  float best_ncc = -1.0f;
+  if (key != 0ull) {
+    best_ncc = from_orderable_f32(static_cast<unsigned int>(key >> 32));
+    const int step = static_cast<int>(0xffffffffu - static_cast<unsigned int>(key & 0xffffffffu));
+    const int i_first = static_cast<int>(M.packed[gi] >> 16);
+    float l = M.lfirst[gi];
+    for (int q = i_first; q < step; ++q) l += 0.7f;
+    const float2 m = M.mean[gi], d = M.dir[gi];
+    best_px = F2{m.x + l * d.x, m.y + l * d.y};
+  }
+  if (best_ncc < 0.5f) {
+    state = ST_NO_MATCH;
+    P.conv[gi] = state;
+  } else {
+    P.match[y * P.stride2 + x] = make_float2(best_px.x, best_px.y);
+  }
+  seed_fuse(P, x, y, gi, state, P.mu[gi], P.sigma_sq[gi], P.a[gi], P.b[gi], best_px);
+}
+
+// ------------------------------------------------------------------------------------------------
 template <int SIDE>
-inline void launch_seed_update_tile(const SeedParams& P, MatcherWorkspace& ws, hipStream_t stream) {
+inline hipError_t launch_seed_update_tile(const SeedParams& P, MatcherWorkspace& ws, hipStream_t stream, int num_cus) {
   // window geometry: rows of 133 floats (covers 16 + 100 + SIDE + 3 texels; odd stride spreads LDS banks)
   constexpr int WS = 133, WROWS = 104;
-  using Smem = TileSmem<SIDE, WS, WROWS>;
-  const dim3 block(TILE_PIX), grid((P.w + TILE_W - 1) / TILE_W, (P.h + TILE_H - 1) / TILE_H);
-  auto kernel = seed_update_tile_kernel<SIDE, WS, WROWS>;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            static_cast<int>(sizeof(Smem)));
-  hipLaunchKernelGGL(kernel, grid, block, sizeof(Smem), stream, P, ws.d_feedback);
+  using Smem = SearchSmem<SIDE, WS, WROWS>;
+  MatcherArgs M;
+  M.mean = ws.d_mean; M.dir = ws.d_dir; M.lfirst = ws.d_lfirst; M.packed = ws.d_packed; M.best = ws.d_best;
+  M.tiles = ws.d_tiles; M.units = ws.d_units; M.queue = ws.d_queue; M.tiles_x = ws.tiles_x;
+  hipError_t e = hipMemsetAsync(ws.d_queue, 0, 8 * sizeof(unsigned int), stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((seed_setup_kernel<SIDE, WS, WROWS>), dim3(ws.tiles_x, ws.tiles_y), dim3(TILE_PIX), 0, stream, P, M);
+  auto search = seed_search_kernel<SIDE, WS, WROWS>;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(search), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          static_cast<int>(sizeof(Smem)));
+  if (e != hipSuccess) return e;
+  const int wg_per_cu = static_cast<int>((160 * 1024) / sizeof(Smem));
+  const int grid = num_cus * (wg_per_cu > 0 ? wg_per_cu : 1);
+  hipLaunchKernelGGL(search, dim3(grid), dim3(TILE_PIX), sizeof(Smem), stream, P, M);
+  hipLaunchKernelGGL(seed_finalize_kernel, dim3((P.w + 63) / 64, (P.h + 3) / 4), dim3(64, 4), 0, stream, P, M);
+  return hipGetLastError();
 }
 
 }  // namespace rmdk
