@@ -104,8 +104,10 @@ int rmd_hip_seeds_set_reference(rmd_hip_seeds_t* s, const float* host_img, const
                                 float max_depth);
 /* update :120-158 (check -> epipolar match -> triangulate + fuse) */
 int rmd_hip_seeds_update(rmd_hip_seeds_t* s, const float* host_img, const float* T_curr_world);
-/* same two calls for a frame that is already resident in device memory (row stride in elements);
- * the frame is copied device-to-device into the handle's own image plane on the handle's stream */
+/* same two calls for a frame that is already resident in device memory (row stride in elements).
+ * set_reference_device copies the frame into the handle's own plane.  update_device reads the caller's buffer IN
+ * PLACE (zero copy): it must stay valid and unmodified until the next call on this handle that synchronises
+ * (download / converged_count / sync / denoise) or until the next update has been issued and synchronised. */
 int rmd_hip_seeds_set_reference_device(rmd_hip_seeds_t* s, const float* dev_img, size_t stride_elems,
                                        const float* T_curr_world, float min_depth, float max_depth);
 int rmd_hip_seeds_update_device(rmd_hip_seeds_t* s, const float* dev_img, size_t stride_elems,

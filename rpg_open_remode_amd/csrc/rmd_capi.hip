@@ -435,6 +435,7 @@ int rmd_hip_seeds_create(int width, int height, float fx, float fy, float cx, fl
   P.stride2 = static_cast<int>(s->planes[RMD_HIP_PLANE_EPIPOLAR_MATCHES].stride);
   P.ref = static_cast<const float*>(s->planes[RMD_HIP_PLANE_REF_IMG].data);
   P.cur = static_cast<const float*>(s->planes[RMD_HIP_PLANE_CURR_IMG].data);
+  P.cur_stride = P.stride;
   P.sum_templ = static_cast<float*>(s->planes[RMD_HIP_PLANE_SUM_TEMPL].data);
   P.denom = static_cast<float*>(s->planes[RMD_HIP_PLANE_CONST_TEMPL_DENOM].data);
   P.mu = static_cast<float*>(s->planes[RMD_HIP_PLANE_MU].data);
@@ -484,6 +485,8 @@ int rmd_hip_seeds_update(rmd_hip_seeds_t* s, const float* host_img, const float*
   // pageable source: the runtime stages it and returns once the host buffer may be reused
   HIP_TRY(hipMemcpy2DAsync(im.data, im.pitch, host_img, row, row, s->height, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  s->P.cur = static_cast<const float*>(im.data);
+  s->P.cur_stride = s->P.stride;
   return seeds_after_frame(s, T_curr_world);
 }
 
@@ -492,9 +495,9 @@ int rmd_hip_seeds_update_device(rmd_hip_seeds_t* s, const float* dev_img, size_t
   if (!s->has_reference) return fail(RMD_HIP_ERR_NOT_READY, "update_device: setReferenceImage has not been called");
   if (stride_elems < static_cast<size_t>(s->width)) return fail(RMD_HIP_ERR_INVALID_ARG, "update_device: stride < width");
   TRY(seeds_bind_device(s));
-  const rmd_hip_image& im = s->planes[RMD_HIP_PLANE_CURR_IMG];
-  const size_t row = static_cast<size_t>(s->width) * 4;
-  HIP_TRY(hipMemcpy2DAsync(im.data, im.pitch, dev_img, stride_elems * 4, row, s->height, hipMemcpyDeviceToDevice, s->stream));
+  // zero copy: the kernels read the caller's buffer in place (see the header for the lifetime rule)
+  s->P.cur = dev_img;
+  s->P.cur_stride = static_cast<int>(stride_elems);
   return seeds_after_frame(s, T_curr_world);
 }
 

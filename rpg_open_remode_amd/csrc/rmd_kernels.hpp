@@ -27,6 +27,7 @@ struct SeedParams {
   int w, h;
   int stride;   // elements, shared by every f32/i32 plane of one SeedMatrix
   int stride2;  // float2 elements, epipolar_matches plane
+  int cur_stride;  // elements, current image (may be a caller-owned device buffer)
   const float* ref;
   const float* cur;
   float* sum_templ;
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void seed_update_pixel_kernel(SeedParams P) {
       const float* ref_row = P.ref + clampi(y + OFFSET + py, 0, P.h - 1) * P.stride;
       for (int pxi = 0; pxi < SIDE; ++pxi) {
         const float templ = ref_row[clampi(x + OFFSET + pxi, 0, P.w - 1)];
-        const float img = tex_linear_global(P.cur, P.w, P.h, P.stride, px.x + static_cast<float>(OFFSET + pxi) + 0.5f, cy);
+        const float img = tex_linear_global(P.cur, P.w, P.h, P.cur_stride, px.x + static_cast<float>(OFFSET + pxi) + 0.5f, cy);
         sum_img += img;
         sum_img_sq += img * img;
         sum_img_templ += img * templ;

@@ -1,6 +1,6 @@
 // The production seed update: seed_check (src/seed_check.cu:28-67) + epipolar NCC search
 // (src/epipolar_match.cu:37-140) + triangulation and Bayesian fusion (src/seed_update.cu:39-121,
-// src/triangulation.cu) as a three-kernel, load-balanced pipeline on one stream:
+// src/triangulation.cu) as a load-balanced pipeline of small kernels on one stream:
 //
 //   seed_setup_kernel     one 256-thread workgroup per 16x16 tile of seeds, one lane per seed.
 //                         State check; epipolar segment; ONE walk of the search loop to find the
@@ -8,6 +8,8 @@
 //                         per-seed search descriptor, the tile's total work and the image window its
 //                         samples fall into, and appends fixed-size WORK UNITS (tile, item range) to
 //                         a device queue.
+//   seed_plan_kernel      one workgroup: exclusive scan of the tiles' unit counts -> compact unit list (keeps every
+//                         atomic out of seed_setup: 1200 tiles x 3 atomics on shared words cost 40 us per frame).
 //   seed_search_kernel    persistent workgroups pull units from the queue (one returning atomic per
 //                         unit), so a tile whose seeds all search 143 steps is spread over many CUs
 //                         while converged tiles cost nothing.  Per unit: stage the tile's window of
@@ -41,7 +43,8 @@ constexpr int MAX_ITEMS_PER_TILE = TILE_PIX * 144;
 struct TileInfo {
   int total;               // NCC evaluations of the tile
   int wx0, wy0, wx1, wy1;  // inclusive texel box of the current image staged for the tile
-  int pad[3];
+  int need_w, need_h;      // size of the box that would hold every sample of the tile
+  int off_window;          // 1 if that box did not fit and the window was centred on the bulk of the samples
 };
 
 struct MatcherWorkspace {
@@ -53,8 +56,15 @@ struct MatcherWorkspace {
   unsigned long long* d_best = nullptr;  // per seed: arg-max key
   TileInfo* d_tiles = nullptr;
   uint2* d_units = nullptr;         // (tile, first item)
-  unsigned int* d_queue = nullptr;  // [0] units appended, [1] next unit, [2] widest / [3] tallest window, [4] off-window tiles
+  // two banks of 8 counters, used alternately frame by frame so that nobody has to memset between frames (the
+  // finalize kernel of frame k clears the bank of frame k+1):
+  //   [0] units appended, [1] units handed out beyond the static first round, [2] widest / [3] tallest window needed,
+  //   [4] tiles whose samples did not fit the window
+  unsigned int* d_queue = nullptr;
+  unsigned int* h_feedback = nullptr;  // pinned, written by the finalize kernel: [0] units of the last frame, [1..3] as [2..4] above
   int max_units = 0;
+  int parity = 0;
+  bool attr_set = false;
   int allocate(int w, int h, int stride_elems) {
     tiles_x = (w + TILE_W - 1) / TILE_W;
     tiles_y = (h + TILE_H - 1) / TILE_H;
@@ -68,16 +78,21 @@ struct MatcherWorkspace {
     if (hipMalloc(reinterpret_cast<void**>(&d_best), n * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_tiles), static_cast<size_t>(tiles_x) * tiles_y * sizeof(TileInfo)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_units), static_cast<size_t>(max_units) * sizeof(uint2)) != hipSuccess) return -1;
-    if (hipMalloc(reinterpret_cast<void**>(&d_queue), 8 * sizeof(unsigned int)) != hipSuccess) return -1;
+    if (hipMalloc(reinterpret_cast<void**>(&d_queue), 16 * sizeof(unsigned int)) != hipSuccess) return -1;
+    if (hipHostMalloc(reinterpret_cast<void**>(&h_feedback), 4 * sizeof(unsigned int)) != hipSuccess) return -1;
     (void)hipMemset(d_packed, 0, n * sizeof(unsigned int));
     (void)hipMemset(d_best, 0, n * sizeof(unsigned long long));
-    (void)hipMemset(d_queue, 0, 8 * sizeof(unsigned int));
+    (void)hipMemset(d_queue, 0, 16 * sizeof(unsigned int));
+    h_feedback[0] = 0xffffffffu;  // unknown
+    h_feedback[1] = h_feedback[2] = h_feedback[3] = 0;
     return 0;
   }
   void release() {
     void* all[] = {d_mean, d_dir, d_lfirst, d_packed, d_best, d_tiles, d_units, d_queue};
     for (void* p : all)
       if (p) (void)hipFree(p);
+    if (h_feedback) (void)hipHostFree(h_feedback);
+    h_feedback = nullptr;
     d_mean = d_dir = nullptr; d_lfirst = nullptr; d_packed = nullptr; d_best = nullptr;
     d_tiles = nullptr; d_units = nullptr; d_queue = nullptr;
   }
@@ -92,7 +107,9 @@ struct MatcherArgs {
   unsigned long long* best;
   TileInfo* tiles;
   uint2* units;
-  unsigned int* queue;
+  unsigned int* queue;       // this frame's counter bank
+  unsigned int* queue_next;  // next frame's bank, cleared by seed_finalize
+  unsigned int* feedback;    // pinned host memory
   int tiles_x;
 };
 
@@ -184,7 +201,7 @@ RMDK_D float ncc_at(const SeedParams& P, F2 px, const float* __restrict__ win, i
       ncc_sums_regular<SIDE, WS>(win + (iy[0] - wy0) * WS + (ix[0] - wx0), 0, ax, ay, ref_patch, ref_stride, sum_img,
                                  sum_img_sq, sum_img_templ);
     } else {
-      ncc_sums_regular<SIDE, 0>(P.cur + iy[0] * P.stride + ix[0], P.stride, ax, ay, ref_patch, ref_stride, sum_img,
+      ncc_sums_regular<SIDE, 0>(P.cur + iy[0] * P.cur_stride + ix[0], P.cur_stride, ax, ay, ref_patch, ref_stride, sum_img,
                                 sum_img_sq, sum_img_templ);
     }
   } else {
@@ -193,7 +210,7 @@ RMDK_D float ncc_at(const SeedParams& P, F2 px, const float* __restrict__ win, i
       const float cy = px.y + static_cast<float>(OFFSET + m) + 0.5f;
       for (int k = 0; k < SIDE; ++k) {
         const float cx = px.x + static_cast<float>(OFFSET + k) + 0.5f;
-        const float img = tex_linear_global(P.cur, P.w, P.h, P.stride, cx, cy);
+        const float img = tex_linear_global(P.cur, P.w, P.h, P.cur_stride, cx, cy);
         const float templ = ref_patch[m * ref_stride + k];
         sum_img += img;
         sum_img_sq += img * img;
@@ -234,24 +251,65 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_kernel(SeedParams P, Matc
   float bb_x0 = INFINITY, bb_y0 = INFINITY, bb_x1 = -INFINITY, bb_y1 = -INFINITY;
   if (live) {
     const Segment seg = epipolar_segment(P, x, y, mu, sigma_sq);
+    const float half = seg.half_length;
     const bool finite = isfinite(seg.mean.x) && isfinite(seg.mean.y) && isfinite(seg.dir.x) && isfinite(seg.dir.y);
-    // walk the search loop once (epipolar_match.cu:88): count the steps and find the run of steps that
-    // pass the in-image guard.  The guard region is convex and px is monotone in l, so that run is contiguous.
+    // Which steps of the search loop (epipolar_match.cu:88: l = -half; l <= half; l += 0.7f) pass the in-image guard?
+    // px(l) = mean + l*dir is monotone per axis and the guard region is a box, so they form ONE contiguous run.
+    // Real-arithmetic bounds [la, lb] of that run tell where to look; the float sequence l_i itself has no closed
+    // form, so it is replayed (one add per step), and the exact guard is evaluated only around the two ends.
     // A non-finite position yields NaN sums in the reference and never becomes a candidate: no work.
-    int i = 0;
-    for (float l = -seg.half_length; l <= seg.half_length; l += 0.7f, ++i) {
-      const F2 px = F2{seg.mean.x + l * seg.dir.x, seg.mean.y + l * seg.dir.y};
-      if (!px_outside(P, px, SIDE)) {
-        ++n_evals;  // what the reference would evaluate (NaN positions pass its guard too)
-        if (finite) {
-          if (n_valid == 0) { i_first = i; l_first = l; }
-          ++n_valid;
-          bb_x0 = fminf(bb_x0, px.x); bb_x1 = fmaxf(bb_x1, px.x);
-          bb_y0 = fminf(bb_y0, px.y); bb_y1 = fmaxf(bb_y1, px.y);
+    if (finite) {
+      float la = -half, lb = half;
+      bool empty = false;
+      const float lo_x = static_cast<float>(SIDE), hi_x = static_cast<float>(P.w - SIDE);
+      const float lo_y = static_cast<float>(SIDE), hi_y = static_cast<float>(P.h - SIDE);
+      if (seg.dir.x > 0.0f) { la = fmaxf(la, (lo_x - seg.mean.x) / seg.dir.x); lb = fminf(lb, (hi_x - seg.mean.x) / seg.dir.x); }
+      else if (seg.dir.x < 0.0f) { la = fmaxf(la, (hi_x - seg.mean.x) / seg.dir.x); lb = fminf(lb, (lo_x - seg.mean.x) / seg.dir.x); }
+      else empty = empty || !(seg.mean.x >= lo_x && seg.mean.x < hi_x);
+      if (seg.dir.y > 0.0f) { la = fmaxf(la, (lo_y - seg.mean.y) / seg.dir.y); lb = fminf(lb, (hi_y - seg.mean.y) / seg.dir.y); }
+      else if (seg.dir.y < 0.0f) { la = fmaxf(la, (hi_y - seg.mean.y) / seg.dir.y); lb = fminf(lb, (lo_y - seg.mean.y) / seg.dir.y); }
+      else empty = empty || !(seg.mean.y >= lo_y && seg.mean.y < hi_y);
+      // the estimates are good to ~1e-3 of a step; everything within 2 steps of them is checked exactly
+      if (!empty && la <= lb + 1.5f) {
+        const int i_a = max(static_cast<int>(floorf((la + half) * (1.0f / 0.7f))) - 2, 0);
+        int i = 0;
+        float l = -half;
+        for (; i < i_a && l <= half; ++i) l += 0.7f;  // replay
+        F2 px_first = F2{0.0f, 0.0f}, px_last = F2{0.0f, 0.0f};
+        for (; l <= half && l <= lb + 1.5f; l += 0.7f, ++i) {  // exact scan for the first in-image step
+          const F2 px = F2{seg.mean.x + l * seg.dir.x, seg.mean.y + l * seg.dir.y};
+          if (!px_outside(P, px, SIDE)) { n_valid = 1; i_first = i; l_first = l; px_first = px; px_last = px; break; }
+        }
+        if (n_valid) {
+          const int i_b = max(static_cast<int>(floorf((lb + half) * (1.0f / 0.7f))) - 2, i_first);
+          for (; i < i_b && l <= half; ++i) l += 0.7f;  // replay across the interior of the run (in-image by convexity)
+          int i_last = i_first;
+          if (l <= half && i > i_first) {  // the replayed position: still in the run unless the estimate overshot
+            const F2 px = F2{seg.mean.x + l * seg.dir.x, seg.mean.y + l * seg.dir.y};
+            if (!px_outside(P, px, SIDE)) { i_last = i; px_last = px; }
+            else {  // overshoot (cannot happen within the error bounds, kept for safety): rescan from the first step
+              i = i_first; l = l_first;
+            }
+          } else if (i > i_first) { i = i_first; l = l_first; }
+          for (l += 0.7f, ++i; l <= half; l += 0.7f, ++i) {  // exact scan for the last in-image step
+            const F2 px = F2{seg.mean.x + l * seg.dir.x, seg.mean.y + l * seg.dir.y};
+            if (px_outside(P, px, SIDE)) break;
+            i_last = i; px_last = px;
+          }
+          n_valid = i_last - i_first + 1;
+          bb_x0 = fminf(px_first.x, px_last.x); bb_x1 = fmaxf(px_first.x, px_last.x);
+          bb_y0 = fminf(px_first.y, px_last.y); bb_y1 = fmaxf(px_first.y, px_last.y);
         }
       }
     }
-    n_steps = static_cast<unsigned int>(i);
+    if (P.stats) {  // diagnostics only: the full walk, counting what the reference would visit / evaluate
+      int i = 0;
+      for (float l = -half; l <= half; l += 0.7f, ++i) {
+        const F2 px = F2{seg.mean.x + l * seg.dir.x, seg.mean.y + l * seg.dir.y};
+        if (!px_outside(P, px, SIDE)) ++n_evals;  // NaN positions pass the reference's guard too
+      }
+      n_steps = static_cast<unsigned int>(i);
+    }
     M.best[gi] = 0ull;
     if (n_valid > 0) {
       M.mean[gi] = make_float2(seg.mean.x, seg.mean.y);
@@ -292,7 +350,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_kernel(SeedParams P, Matc
   if (tid != 0) return;
   const int total = red_i[0] + red_i[1] + red_i[2] + red_i[3];
   TileInfo ti;
-  ti.total = total; ti.wx0 = 0; ti.wy0 = 0; ti.wx1 = -1; ti.wy1 = -1; ti.pad[0] = ti.pad[1] = ti.pad[2] = 0;
+  ti.total = total; ti.wx0 = 0; ti.wy0 = 0; ti.wx1 = -1; ti.wy1 = -1; ti.need_w = 0; ti.need_h = 0; ti.off_window = 0;
   const int tile = blockIdx.y * M.tiles_x + blockIdx.x;
   if (total > 0) {
     const float fx0 = fminf(fminf(red_f[0][0], red_f[1][0]), fminf(red_f[2][0], red_f[3][0]));
@@ -304,29 +362,79 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_kernel(SeedParams P, Matc
     ti.wy0 = max(static_cast<int>(floorf(fy0)) - HALF - 1, 0);
     ti.wx1 = min(static_cast<int>(floorf(fx1)) + HALF + 2, P.w - 1);
     ti.wy1 = min(static_cast<int>(floorf(fy1)) + HALF + 2, P.h - 1);
-    const int need_w = ti.wx1 - ti.wx0 + 1, need_h = ti.wy1 - ti.wy0 + 1;
-    atomicMax(&M.queue[2], static_cast<unsigned int>(need_w));
-    atomicMax(&M.queue[3], static_cast<unsigned int>(need_h));
-    if (need_w > WS || need_h > WROWS) {
+    ti.need_w = ti.wx1 - ti.wx0 + 1;
+    ti.need_h = ti.wy1 - ti.wy0 + 1;
+    if (ti.need_w > WS || ti.need_h > WROWS) {
       // a few seeds wandered off: centre the window on where most samples are; the rest read global memory
       const float w_sum = red_f[0][4] + red_f[1][4] + red_f[2][4] + red_f[3][4];
       const float cx = (red_f[0][5] + red_f[1][5] + red_f[2][5] + red_f[3][5]) / w_sum;
       const float cy = (red_f[0][6] + red_f[1][6] + red_f[2][6] + red_f[3][6]) / w_sum;
-      if (need_w > WS) {
+      if (ti.need_w > WS) {
         ti.wx0 = min(max(static_cast<int>(cx) - WS / 2, 0), max(P.w - WS, 0));
         ti.wx1 = min(ti.wx0 + WS - 1, P.w - 1);
       }
-      if (need_h > WROWS) {
+      if (ti.need_h > WROWS) {
         ti.wy0 = min(max(static_cast<int>(cy) - WROWS / 2, 0), max(P.h - WROWS, 0));
         ti.wy1 = min(ti.wy0 + WROWS - 1, P.h - 1);
       }
-      atomicAdd(&M.queue[4], 1u);
+      ti.off_window = 1;
     }
-    const unsigned int n_units = static_cast<unsigned int>((total + UNIT_ITEMS - 1) / UNIT_ITEMS);
-    const unsigned int base = atomicAdd(&M.queue[0], n_units);
-    for (unsigned int u = 0; u < n_units; ++u) M.units[base + u] = make_uint2(static_cast<unsigned int>(tile), u * UNIT_ITEMS);
   }
-  M.tiles[tile] = ti;
+  M.tiles[tile] = ti;  // no atomics here: seed_plan turns the per-tile totals into the unit queue
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 1b: one workgroup turns the per-tile totals into the work-unit list (exclusive scan) and the feedback maxima
+constexpr int PLAN_THREADS = 1024;
+__global__ __launch_bounds__(PLAN_THREADS) void seed_plan_kernel(MatcherArgs M, int n_tiles) {
+  __shared__ int wave_tot[PLAN_THREADS / 64];
+  __shared__ int carry_s;
+  __shared__ int red_max[3][PLAN_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  int m_w = 0, m_h = 0, n_off = 0;
+  __syncthreads();
+  for (int chunk = 0; chunk < n_tiles; chunk += PLAN_THREADS) {
+    const int t = chunk + tid;
+    int n_u = 0;
+    if (t < n_tiles) {
+      const TileInfo ti = M.tiles[t];
+      n_u = (ti.total + UNIT_ITEMS - 1) / UNIT_ITEMS;
+      m_w = max(m_w, ti.need_w); m_h = max(m_h, ti.need_h); n_off += ti.off_window;
+    }
+    int incl = n_u;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += v;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int wave_off = 0, block_tot = 0;
+    for (int wv = 0; wv < PLAN_THREADS / 64; ++wv) {
+      const int v = wave_tot[wv];
+      wave_off += wv < wave ? v : 0;
+      block_tot += v;
+    }
+    const int base = carry_s + wave_off + incl - n_u;
+    for (int u = 0; u < n_u; ++u) M.units[base + u] = make_uint2(static_cast<unsigned int>(t), static_cast<unsigned int>(u * UNIT_ITEMS));
+    __syncthreads();
+    if (tid == 0) carry_s += block_tot;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    m_w = max(m_w, __shfl_xor(m_w, off, 64)); m_h = max(m_h, __shfl_xor(m_h, off, 64)); n_off += __shfl_xor(n_off, off, 64);
+  }
+  if (lane == 0) { red_max[0][wave] = m_w; red_max[1][wave] = m_h; red_max[2][wave] = n_off; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int wv = 1; wv < PLAN_THREADS / 64; ++wv) { m_w = max(m_w, red_max[0][wv]); m_h = max(m_h, red_max[1][wv]); n_off += red_max[2][wv]; }
+    M.queue[0] = static_cast<unsigned int>(carry_s);
+    M.queue[2] = static_cast<unsigned int>(m_w);
+    M.queue[3] = static_cast<unsigned int>(m_h);
+    M.queue[4] = static_cast<unsigned int>(n_off);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -360,12 +468,10 @@ __global__ __launch_bounds__(TILE_PIX) void seed_search_kernel(SeedParams P, Mat
   unsigned long long t_stage = 0, t_search = 0;
   unsigned int my_units = 0;
 
-  for (;;) {
+  // unit blockIdx.x is ours for free; further units come from the shared counter (one returning atomic each)
+  unsigned int u = blockIdx.x;
+  for (;; ) {
     const long long t0 = P.stats ? clock64() : 0;
-    __syncthreads();  // previous unit's LDS is no longer read
-    if (tid == 0) S.unit[0] = atomicAdd(&M.queue[1], 1u);
-    __syncthreads();
-    const unsigned int u = S.unit[0];
     if (u >= n_units) break;
     ++my_units;
     const uint2 unit = M.units[u];
@@ -412,7 +518,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_search_kernel(SeedParams P, Mat
           int c = e - r * ww;
           if (c < 0) { --r; c += ww; } else if (c >= ww) { ++r; c -= ww; }
           dst[q] = r * WS + c;
-          v[q] = e < n_el ? P.cur[(wy0 + r) * P.stride + wx0 + c] : 0.0f;
+          v[q] = e < n_el ? P.cur[(wy0 + r) * P.cur_stride + wx0 + c] : 0.0f;
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q)
@@ -478,6 +584,10 @@ __global__ __launch_bounds__(TILE_PIX) void seed_search_kernel(SeedParams P, Mat
       t_stage += static_cast<unsigned long long>(t1 - t0);
       t_search += static_cast<unsigned long long>(t2 - t1);
     }
+    __syncthreads();  // this unit's LDS is no longer read
+    if (tid == 0) S.unit[0] = gridDim.x + atomicAdd(&M.queue[1], 1u);
+    __syncthreads();
+    u = S.unit[0];
   }
   if (P.stats) {
     const unsigned long long s0 = wave_sum_u64(n_path[0]), s1 = wave_sum_u64(n_path[1]), s2 = wave_sum_u64(n_path[2]);
@@ -500,6 +610,10 @@ __global__ __launch_bounds__(TILE_PIX) void seed_search_kernel(SeedParams P, Mat
 __global__ __launch_bounds__(256) void seed_finalize_kernel(SeedParams P, MatcherArgs M) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x == 0 && y == 0) {  // housekeeping: feedback for the host's next launch, and a clean counter bank for it
+    M.feedback[0] = M.queue[0]; M.feedback[1] = M.queue[2]; M.feedback[2] = M.queue[3]; M.feedback[3] = M.queue[4];
+    for (int k = 0; k < 8; ++k) M.queue_next[k] = 0u;
+  }
   if (x >= P.w || y >= P.h) return;
   const int gi = y * P.stride + x;
   int state = P.conv[gi];
@@ -533,16 +647,30 @@ inline hipError_t launch_seed_update_tile(const SeedParams& P, MatcherWorkspace&
   using Smem = SearchSmem<SIDE, WS, WROWS>;
   MatcherArgs M;
   M.mean = ws.d_mean; M.dir = ws.d_dir; M.lfirst = ws.d_lfirst; M.packed = ws.d_packed; M.best = ws.d_best;
-  M.tiles = ws.d_tiles; M.units = ws.d_units; M.queue = ws.d_queue; M.tiles_x = ws.tiles_x;
-  hipError_t e = hipMemsetAsync(ws.d_queue, 0, 8 * sizeof(unsigned int), stream);
-  if (e != hipSuccess) return e;
+  M.tiles = ws.d_tiles; M.units = ws.d_units; M.tiles_x = ws.tiles_x;
+  M.queue = ws.d_queue + 8 * ws.parity;
+  M.queue_next = ws.d_queue + 8 * (ws.parity ^ 1);
+  M.feedback = ws.h_feedback;
+  ws.parity ^= 1;
   hipLaunchKernelGGL((seed_setup_kernel<SIDE, WS, WROWS>), dim3(ws.tiles_x, ws.tiles_y), dim3(TILE_PIX), 0, stream, P, M);
+  hipLaunchKernelGGL(seed_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, stream, M, ws.tiles_x * ws.tiles_y);
   auto search = seed_search_kernel<SIDE, WS, WROWS>;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(search), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          static_cast<int>(sizeof(Smem)));
-  if (e != hipSuccess) return e;
+  if (!ws.attr_set) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(search), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             static_cast<int>(sizeof(Smem)));
+    if (e != hipSuccess) return e;
+    ws.attr_set = true;
+  }
+  // Persistent grid: as many workgroups as fit the chip, but no more than the work of the previous frame suggests
+  // (the unit count is read back through pinned memory, one or two frames late; any grid size is correct).
   const int wg_per_cu = static_cast<int>((160 * 1024) / sizeof(Smem));
-  const int grid = num_cus * (wg_per_cu > 0 ? wg_per_cu : 1);
+  const int resident = num_cus * (wg_per_cu > 0 ? wg_per_cu : 1);
+  const unsigned int prev_units = ws.h_feedback[0];
+  int grid = resident;
+  if (prev_units != 0xffffffffu) {
+    const long long want = static_cast<long long>(prev_units) + prev_units / 4 + 16;
+    grid = want < resident ? static_cast<int>(want) : resident;
+  }
   hipLaunchKernelGGL(search, dim3(grid), dim3(TILE_PIX), sizeof(Smem), stream, P, M);
   hipLaunchKernelGGL(seed_finalize_kernel, dim3((P.w + 63) / 64, (P.h + 3) / 4), dim3(64, 4), 0, stream, P, M);
   return hipGetLastError();

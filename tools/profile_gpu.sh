@@ -14,6 +14,7 @@ cd /tmp
 echo "== kernel trace + stats: bench.py $BENCH_ARGS"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python "$ROOT/bench.py" $BENCH_ARGS > "$SUM/bench_under_trace.json" 2> "$OUT/trace.err"
 PMC_ARGS="--steps 40 --warmup 2 --cpu-seconds 0"
+if [ "${PMC:-1}" = "1" ]; then
 echo "== PMC pass 1 (SQ)"
 timeout 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --output-format csv -d "$OUT/pmc_sq" -- python "$ROOT/bench.py" $PMC_ARGS > /dev/null 2> "$OUT/pmc_sq.err"
 echo "== PMC pass 2 (SQ waits)"
@@ -22,6 +23,7 @@ echo "== PMC pass 3 (FETCH_SIZE)"
 timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python "$ROOT/bench.py" $PMC_ARGS > /dev/null 2> "$OUT/pmc_fetch.err"
 echo "== PMC pass 4 (WRITE_SIZE)"
 timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python "$ROOT/bench.py" $PMC_ARGS > /dev/null 2> "$OUT/pmc_write.err"
+fi
 cd "$ROOT"
 python tools/summarize_rocprof.py "$OUT" "$SUM" "$TAG"
 ls -la "$SUM"
