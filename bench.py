@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample (0 disables)")
     ap.add_argument("--matcher", type=int, default=1, help="0 per-pixel kernel, 1 tile kernel")
+    ap.add_argument("--window", type=int, default=0, help="search LDS window: 0 auto, 1 small, 2 large")
     return ap.parse_args()
 
 
@@ -76,7 +77,7 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"), os.path.abspath(__file__),
                "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
-               "--cpu-seconds", str(args.cpu_seconds), "--matcher", str(args.matcher)]
+               "--cpu-seconds", str(args.cpu_seconds), "--matcher", str(args.matcher), "--window", str(args.window)]
         sys.exit(subprocess.call(cmd))
 
     import torch
@@ -103,6 +104,7 @@ def main():
     def new_seeds():
         s = api.SeedMatrix(WIDTH, HEIGHT, api.PinholeCamera(*seq.K), patch_side=SIDE)
         s.setOption(api.OPT_MATCHER, args.matcher)
+        s.setOption(api.OPT_WINDOW, args.window)
         return s
 
     def set_ref(s):
@@ -124,7 +126,7 @@ def main():
     scratch.sync()
 
     seeds = new_seeds()
-    seeds.setOption(api.OPT_TIMING, 1)
+    seeds.setOption(api.OPT_TIMING, 2)  # one HIP event pair around the timed region, on the stream the kernels run on
     set_ref(seeds)
     seeds.sync()
     seeds.timingReset()

@@ -127,8 +127,10 @@ int rmd_hip_seeds_sync(const rmd_hip_seeds_t* s);
 
 /* knobs (not in the reference) */
 #define RMD_HIP_OPT_MATCHER 0      /* 0 = per-pixel kernel, 1 = tile-cooperative kernel (default) */
-#define RMD_HIP_OPT_TIMING 1       /* 1 = bracket every kernel with HIP events on the handle's stream */
+#define RMD_HIP_OPT_TIMING 1       /* 1 = bracket every update with HIP events on the handle's stream; 2 = one event pair
+                                      around everything between timing_reset and the timing query (no markers in between) */
 #define RMD_HIP_OPT_COLLECT_STATS 2 /* 1 = count live seeds / search steps / NCC evaluations per update */
+#define RMD_HIP_OPT_WINDOW 3       /* search-kernel LDS window: 0 = chosen per frame from feedback, 1 = small, 2 = large */
 int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value);
 /* kernels of the seed path, for rmd_hip_seeds_timing */
 #define RMD_HIP_STAGE_SEED_INIT 0

@@ -161,7 +161,9 @@ struct rmd_hip_seeds {
   hipStream_t stream = nullptr;
   unsigned long long* d_scalars = nullptr;  // [0] count result, [1..16] diagnostics
   unsigned long long* h_scalars = nullptr;  // pinned mirror
-  int opt_matcher = 1, opt_timing = 0, opt_stats = 0;
+  int opt_matcher = 1, opt_timing = 0, opt_stats = 0, opt_window = 0;
+  hipEvent_t region_start = nullptr, region_stop = nullptr;
+  long region_updates = 0;
   StageTimer timers[RMD_HIP_NUM_SEED_STAGES];
   long long last_stats[16] = {0};
   bool stats_pending = false;
@@ -220,15 +222,16 @@ int seeds_launch_update(rmd_hip_seeds* s) {
     P.stats = nullptr;
   }
   int rc;
+  if (s->opt_timing == 2) ++s->region_updates;
   {
-    ScopedStage st(s->opt_timing ? &s->timers[RMD_HIP_STAGE_UPDATE] : nullptr, s->stream);
+    ScopedStage st(s->opt_timing == 1 ? &s->timers[RMD_HIP_STAGE_UPDATE] : nullptr, s->stream);
     rc = dispatch_side(s->patch_side, [&](auto side) {
       constexpr int SIDE = decltype(side)::value;
       if (s->opt_matcher == 0) {
         const dim3 block(64, 4), grid((s->width + 63) / 64, (s->height + 3) / 4);
         hipLaunchKernelGGL((rmdk::seed_update_pixel_kernel<SIDE>), grid, block, 0, s->stream, P);
       } else {
-        HIP_TRY(rmdk::launch_seed_update_tile<SIDE>(P, s->matcher_ws, s->stream, s->num_cus));
+        HIP_TRY(rmdk::launch_seed_update_tile<SIDE>(P, s->matcher_ws, s->stream, s->num_cus, s->opt_window));
       }
       HIP_TRY(hipGetLastError());
       return RMD_HIP_OK;
@@ -388,6 +391,8 @@ int rmd_hip_seeds_destroy(rmd_hip_seeds_t* s) {
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   for (auto& t : s->timers) t.destroy();
+  if (s->region_start) (void)hipEventDestroy(s->region_start);
+  if (s->region_stop) (void)hipEventDestroy(s->region_stop);
   for (auto& pl : s->planes)
     if (pl.owns && pl.data) (void)hipFree(pl.data);
   s->matcher_ws.release();
@@ -568,7 +573,14 @@ int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value) {
       if (value != 0 && value != 1) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: matcher %d", value);
       s->opt_matcher = value;
       return RMD_HIP_OK;
-    case RMD_HIP_OPT_TIMING: s->opt_timing = value != 0; return RMD_HIP_OK;
+    case RMD_HIP_OPT_TIMING:
+      if (value < 0 || value > 2) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: timing mode %d", value);
+      s->opt_timing = value;
+      return RMD_HIP_OK;
+    case RMD_HIP_OPT_WINDOW:
+      if (value < 0 || value > 2) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: window %d", value);
+      s->opt_window = value;
+      return RMD_HIP_OK;
     case RMD_HIP_OPT_COLLECT_STATS: s->opt_stats = value != 0; return RMD_HIP_OK;
     default: return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: unknown option %d", option);
   }
@@ -577,6 +589,19 @@ int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value) {
 int rmd_hip_seeds_timing(const rmd_hip_seeds_t* s, int stage, double* total_ms, long* launches) {
   if (!s || stage < 0 || stage >= RMD_HIP_NUM_SEED_STAGES) return fail(RMD_HIP_ERR_INVALID_ARG, "seeds_timing: bad argument");
   TRY(seeds_bind_device(s));
+  if (s->opt_timing == 2 && stage == RMD_HIP_STAGE_UPDATE) {
+    // region mode: ONE event pair around everything queued since timing_reset (no per-launch markers in the stream)
+    rmd_hip_seeds* m = const_cast<rmd_hip_seeds*>(s);
+    if (!m->region_start) return fail(RMD_HIP_ERR_NOT_READY, "seeds_timing: call timing_reset first");
+    if (!m->region_stop) HIP_TRY(hipEventCreate(&m->region_stop));
+    HIP_TRY(hipEventRecord(m->region_stop, m->stream));
+    HIP_TRY(hipEventSynchronize(m->region_stop));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, m->region_start, m->region_stop));
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = m->region_updates;
+    return RMD_HIP_OK;
+  }
   TRY(seeds_sync(s));
   if (total_ms) *total_ms = s->timers[stage].total_ms;
   if (launches) *launches = s->timers[stage].launches;
@@ -587,6 +612,11 @@ int rmd_hip_seeds_timing_reset(rmd_hip_seeds_t* s) {
   TRY(seeds_bind_device(s));
   TRY(seeds_sync(s));
   for (auto& t : s->timers) t.reset();
+  if (s->opt_timing == 2) {
+    if (!s->region_start) HIP_TRY(hipEventCreate(&s->region_start));
+    HIP_TRY(hipEventRecord(s->region_start, s->stream));
+    s->region_updates = 0;
+  }
   return RMD_HIP_OK;
 }
 int rmd_hip_seeds_last_stats(const rmd_hip_seeds_t* s, long long* out3) {

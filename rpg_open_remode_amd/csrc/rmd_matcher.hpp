@@ -36,7 +36,8 @@
 namespace rmdk {
 
 constexpr int TILE_W = 16, TILE_H = 16, TILE_PIX = TILE_W * TILE_H;
-constexpr int UNIT_ITEMS = 4 * TILE_PIX;  // NCC evaluations per work unit (4 rounds of the 256 lanes)
+constexpr int MAX_UNIT_ROUNDS = 4;  // a work unit is 1..4 rounds of the 256 lanes (chosen per frame by seed_plan)
+constexpr int MIN_UNIT_ITEMS = TILE_PIX;
 constexpr int MAX_ITEMS_PER_TILE = TILE_PIX * 144;
 
 // per-tile record written by seed_setup, read by seed_search
@@ -59,18 +60,18 @@ struct MatcherWorkspace {
   // two banks of 8 counters, used alternately frame by frame so that nobody has to memset between frames (the
   // finalize kernel of frame k clears the bank of frame k+1):
   //   [0] units appended, [1] units handed out beyond the static first round, [2] widest / [3] tallest window needed,
-  //   [4] tiles whose samples did not fit the window
+  //   [4] tiles whose samples did not fit the window, [5] items per unit of this frame
   unsigned int* d_queue = nullptr;
   unsigned int* h_feedback = nullptr;  // pinned, written by the finalize kernel: [0] units of the last frame, [1..3] as [2..4] above
   int max_units = 0;
   int parity = 0;
-  bool attr_set = false;
+  bool attr_set_small = false, attr_set_large = false;
   int allocate(int w, int h, int stride_elems) {
     tiles_x = (w + TILE_W - 1) / TILE_W;
     tiles_y = (h + TILE_H - 1) / TILE_H;
     stride = stride_elems;
     const size_t n = static_cast<size_t>(stride) * h;
-    max_units = tiles_x * tiles_y * ((MAX_ITEMS_PER_TILE + UNIT_ITEMS - 1) / UNIT_ITEMS);
+    max_units = tiles_x * tiles_y * ((MAX_ITEMS_PER_TILE + MIN_UNIT_ITEMS - 1) / MIN_UNIT_ITEMS);
     if (hipMalloc(reinterpret_cast<void**>(&d_mean), n * sizeof(float2)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_dir), n * sizeof(float2)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_lfirst), n * sizeof(float)) != hipSuccess) return -1;
@@ -244,6 +245,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_kernel(SeedParams P, Matc
     state = seed_check(P, x, y, sigma_sq, P.a[gi], P.b[gi], SIDE);
     P.conv[gi] = state;  // final for BORDER / CONVERGED / DIVERGED; UPDATE seeds are settled by seed_finalize
   }
+
   const bool live = in_image && state == ST_UPDATE;
   int n_valid = 0, i_first = 0;
   float l_first = 0.0f;
@@ -386,22 +388,46 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_kernel(SeedParams P, Matc
 // ------------------------------------------------------------------------------------------------
 // stage 1b: one workgroup turns the per-tile totals into the work-unit list (exclusive scan) and the feedback maxima
 constexpr int PLAN_THREADS = 1024;
-__global__ __launch_bounds__(PLAN_THREADS) void seed_plan_kernel(MatcherArgs M, int n_tiles) {
+__global__ __launch_bounds__(PLAN_THREADS) void seed_plan_kernel(MatcherArgs M, int n_tiles, int target_units) {
   __shared__ int wave_tot[PLAN_THREADS / 64];
   __shared__ int carry_s;
-  __shared__ int red_max[3][PLAN_THREADS / 64];
+  __shared__ int red_s[4][PLAN_THREADS / 64];
+  __shared__ int unit_items_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) carry_s = 0;
-  int m_w = 0, m_h = 0, n_off = 0;
+  // pass 1: total work and the feedback maxima
+  int m_w = 0, m_h = 0, n_off = 0, items = 0;
+  for (int t = tid; t < n_tiles; t += PLAN_THREADS) {
+    const TileInfo ti = M.tiles[t];
+    m_w = max(m_w, ti.need_w); m_h = max(m_h, ti.need_h); n_off += ti.off_window; items += ti.total;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    m_w = max(m_w, __shfl_xor(m_w, off, 64)); m_h = max(m_h, __shfl_xor(m_h, off, 64));
+    n_off += __shfl_xor(n_off, off, 64); items += __shfl_xor(items, off, 64);
+  }
+  if (lane == 0) { red_s[0][wave] = m_w; red_s[1][wave] = m_h; red_s[2][wave] = n_off; red_s[3][wave] = items; }
   __syncthreads();
+  if (tid == 0) {
+    for (int wv = 1; wv < PLAN_THREADS / 64; ++wv) {
+      m_w = max(m_w, red_s[0][wv]); m_h = max(m_h, red_s[1][wv]); n_off += red_s[2][wv]; items += red_s[3][wv];
+    }
+    // unit size: small when there is little work (latency: more workgroups, fewer rounds each), up to
+    // MAX_UNIT_ROUNDS rounds when there is plenty (amortises the per-unit staging)
+    int rounds = (items + target_units * TILE_PIX - 1) / (target_units * TILE_PIX);
+    rounds = min(max(rounds, 1), MAX_UNIT_ROUNDS);
+    unit_items_s = rounds * TILE_PIX;
+    carry_s = 0;
+    M.queue[2] = static_cast<unsigned int>(m_w);
+    M.queue[3] = static_cast<unsigned int>(m_h);
+    M.queue[4] = static_cast<unsigned int>(n_off);
+    M.queue[5] = static_cast<unsigned int>(rounds * TILE_PIX);
+  }
+  __syncthreads();
+  const int unit_items = unit_items_s;
+  // pass 2: exclusive scan of the tiles' unit counts -> compact unit list
   for (int chunk = 0; chunk < n_tiles; chunk += PLAN_THREADS) {
     const int t = chunk + tid;
-    int n_u = 0;
-    if (t < n_tiles) {
-      const TileInfo ti = M.tiles[t];
-      n_u = (ti.total + UNIT_ITEMS - 1) / UNIT_ITEMS;
-      m_w = max(m_w, ti.need_w); m_h = max(m_h, ti.need_h); n_off += ti.off_window;
-    }
+    const int n_u = t < n_tiles ? (M.tiles[t].total + unit_items - 1) / unit_items : 0;
     int incl = n_u;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -417,24 +443,12 @@ __global__ __launch_bounds__(PLAN_THREADS) void seed_plan_kernel(MatcherArgs M, 
       block_tot += v;
     }
     const int base = carry_s + wave_off + incl - n_u;
-    for (int u = 0; u < n_u; ++u) M.units[base + u] = make_uint2(static_cast<unsigned int>(t), static_cast<unsigned int>(u * UNIT_ITEMS));
+    for (int u = 0; u < n_u; ++u) M.units[base + u] = make_uint2(static_cast<unsigned int>(t), static_cast<unsigned int>(u * unit_items));
     __syncthreads();
     if (tid == 0) carry_s += block_tot;
     __syncthreads();
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    m_w = max(m_w, __shfl_xor(m_w, off, 64)); m_h = max(m_h, __shfl_xor(m_h, off, 64)); n_off += __shfl_xor(n_off, off, 64);
-  }
-  if (lane == 0) { red_max[0][wave] = m_w; red_max[1][wave] = m_h; red_max[2][wave] = n_off; }
-  __syncthreads();
-  if (tid == 0) {
-    for (int wv = 1; wv < PLAN_THREADS / 64; ++wv) { m_w = max(m_w, red_max[0][wv]); m_h = max(m_h, red_max[1][wv]); n_off += red_max[2][wv]; }
-    M.queue[0] = static_cast<unsigned int>(carry_s);
-    M.queue[2] = static_cast<unsigned int>(m_w);
-    M.queue[3] = static_cast<unsigned int>(m_h);
-    M.queue[4] = static_cast<unsigned int>(n_off);
-  }
+  if (tid == 0) M.queue[0] = static_cast<unsigned int>(carry_s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -464,6 +478,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_search_kernel(SeedParams P, Mat
   const int lane = tid & 63, wave = tid >> 6;
   const int tx = tid & (TILE_W - 1), ty = tid >> 4;
   const unsigned int n_units = M.queue[0];
+  const int unit_items = static_cast<int>(M.queue[5]);
   unsigned int n_path[3] = {0, 0, 0};
   unsigned long long t_stage = 0, t_search = 0;
   unsigned int my_units = 0;
@@ -539,7 +554,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_search_kernel(SeedParams P, Mat
     const long long t1 = P.stats ? clock64() : 0;
 
     // the unit's (seed, step) work items, dealt round-robin to the lanes
-    const int last = min(first + UNIT_ITEMS, ti.total);
+    const int last = min(first + unit_items, ti.total);
     for (int k0 = first; k0 < last; k0 += TILE_PIX) {
       const int k = k0 + tid;
       int p = -1;
@@ -640,10 +655,8 @@ __global__ __launch_bounds__(256) void seed_finalize_kernel(SeedParams P, Matche
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int SIDE>
-inline hipError_t launch_seed_update_tile(const SeedParams& P, MatcherWorkspace& ws, hipStream_t stream, int num_cus) {
-  // window geometry: rows of 133 floats (covers 16 + 100 + SIDE + 3 texels; odd stride spreads LDS banks)
-  constexpr int WS = 133, WROWS = 104;
+template <int SIDE, int WS, int WROWS>
+inline hipError_t launch_seed_pipeline(const SeedParams& P, MatcherWorkspace& ws, hipStream_t stream, int num_cus, bool& attr_set) {
   using Smem = SearchSmem<SIDE, WS, WROWS>;
   MatcherArgs M;
   M.mean = ws.d_mean; M.dir = ws.d_dir; M.lfirst = ws.d_lfirst; M.packed = ws.d_packed; M.best = ws.d_best;
@@ -652,19 +665,20 @@ inline hipError_t launch_seed_update_tile(const SeedParams& P, MatcherWorkspace&
   M.queue_next = ws.d_queue + 8 * (ws.parity ^ 1);
   M.feedback = ws.h_feedback;
   ws.parity ^= 1;
+  // Persistent grid: as many workgroups as fit the chip, but no more than the work of the previous frame suggests
+  // (the unit count is read back through pinned memory, one or two frames late; any grid size is correct).
+  const int by_lds = static_cast<int>((160 * 1024) / sizeof(Smem));
+  const int wg_per_cu = by_lds < 4 ? (by_lds > 0 ? by_lds : 1) : 4;  // >4 x 256 threads gain nothing at this register count
+  const int resident = num_cus * wg_per_cu;
   hipLaunchKernelGGL((seed_setup_kernel<SIDE, WS, WROWS>), dim3(ws.tiles_x, ws.tiles_y), dim3(TILE_PIX), 0, stream, P, M);
-  hipLaunchKernelGGL(seed_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, stream, M, ws.tiles_x * ws.tiles_y);
+  hipLaunchKernelGGL(seed_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, stream, M, ws.tiles_x * ws.tiles_y, resident);
   auto search = seed_search_kernel<SIDE, WS, WROWS>;
-  if (!ws.attr_set) {
+  if (!attr_set) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(search), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              static_cast<int>(sizeof(Smem)));
     if (e != hipSuccess) return e;
-    ws.attr_set = true;
+    attr_set = true;
   }
-  // Persistent grid: as many workgroups as fit the chip, but no more than the work of the previous frame suggests
-  // (the unit count is read back through pinned memory, one or two frames late; any grid size is correct).
-  const int wg_per_cu = static_cast<int>((160 * 1024) / sizeof(Smem));
-  const int resident = num_cus * (wg_per_cu > 0 ? wg_per_cu : 1);
   const unsigned int prev_units = ws.h_feedback[0];
   int grid = resident;
   if (prev_units != 0xffffffffu) {
@@ -674,6 +688,22 @@ inline hipError_t launch_seed_update_tile(const SeedParams& P, MatcherWorkspace&
   hipLaunchKernelGGL(search, dim3(grid), dim3(TILE_PIX), sizeof(Smem), stream, P, M);
   hipLaunchKernelGGL(seed_finalize_kernel, dim3((P.w + 63) / 64, (P.h + 3) / 4), dim3(64, 4), 0, stream, P, M);
   return hipGetLastError();
+}
+
+// Two LDS window geometries for the search kernel (odd row strides spread the LDS banks):
+//   small  69 x 64 texels: searches up to ~40 px; 4 workgroups per CU
+//   large 133 x 104 texels: holds a 16x16 tile's worst case (100 px search, any direction); 2 workgroups per CU
+// The host picks per frame from the previous frame's widest / tallest tile window (pinned feedback); a wrong guess only
+// sends the overflowing samples to the global-memory path.
+template <int SIDE>
+inline hipError_t launch_seed_update_tile(const SeedParams& P, MatcherWorkspace& ws, hipStream_t stream, int num_cus,
+                                          int force_window) {
+  const unsigned int need_w = ws.h_feedback[1], need_h = ws.h_feedback[2];
+  bool small = ws.h_feedback[0] != 0xffffffffu && need_w + 6 <= 69 && need_h + 6 <= 64;
+  if (force_window == 1) small = true;
+  if (force_window == 2) small = false;
+  if (small) return launch_seed_pipeline<SIDE, 69, 64>(P, ws, stream, num_cus, ws.attr_set_small);
+  return launch_seed_pipeline<SIDE, 133, 104>(P, ws, stream, num_cus, ws.attr_set_large);
 }
 
 }  // namespace rmdk

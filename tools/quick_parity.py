@@ -11,6 +11,7 @@ seq = synth.Sequence(w, h, n, seed=0)
 cam = api.PinholeCamera(*seq.K)
 a, b = api.SeedMatrix(w, h, cam, patch_side=side), api.SeedMatrix(w, h, cam, patch_side=side)
 a.setOption(api.OPT_MATCHER, 0); b.setOption(api.OPT_MATCHER, 1)
+b.setOption(api.OPT_WINDOW, int(os.environ.get("RMD_WINDOW", "0")))
 for s in (a, b):
     s.setOption(api.OPT_TIMING, 1)
     s.setReferenceImage(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
