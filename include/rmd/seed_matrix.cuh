@@ -1,0 +1,106 @@
+// rmd::SeedMatrix (reference: include/rmd/seed_matrix.cuh:45-109, src/seed_matrix.cu) as an inline wrapper over
+// librmd_hip.so.  Same constructor, methods, return conventions (bool always true, exceptions on runtime errors).
+// RMD_CORR_PATCH_SIDE / RMD_MAX_EXTENT_EPIPOLAR_SEARCH keep their role as compile-time knobs of the consumer
+// (CMakeLists.txt:50-53); they are forwarded to the library, which holds all four patch sizes.
+#ifndef SEED_MATRIX_CUH
+#define SEED_MATRIX_CUH
+
+#include <rmd/device_image.cuh>
+#include <rmd/pinhole_camera.cuh>
+#include <rmd/reduction.cuh>
+#include <rmd/se3.cuh>
+
+#ifndef RMD_CORR_PATCH_SIDE
+#define RMD_CORR_PATCH_SIDE 5
+#endif
+#define RMD_CORR_PATCH_OFFSET -RMD_CORR_PATCH_SIDE / 2
+#define RMD_CORR_PATCH_AREA RMD_CORR_PATCH_SIDE* RMD_CORR_PATCH_SIDE
+#ifndef RMD_MAX_EXTENT_EPIPOLAR_SEARCH
+#define RMD_MAX_EXTENT_EPIPOLAR_SEARCH 100
+#endif
+
+namespace rmd {
+
+namespace ConvergenceStates {
+enum ConvergenceState { UPDATE = 0, CONVERGED, BORDER, DIVERGED, NO_MATCH, NOT_VISIBLE };
+}
+typedef ConvergenceStates::ConvergenceState ConvergenceState;
+
+class SeedMatrix {
+ public:
+  SeedMatrix(const size_t& width, const size_t& height, const PinholeCamera& cam) : handle_(NULL), mu_(NULL), sigma_(NULL), a_(NULL), b_(NULL), conv_(NULL) {
+    detail::throw_on_error(rmd_hip_seeds_create(static_cast<int>(width), static_cast<int>(height), cam.fx, cam.fy, cam.cx, cam.cy,
+                                                RMD_CORR_PATCH_SIDE, RMD_MAX_EXTENT_EPIPOLAR_SEARCH, &handle_),
+                           "SeedMatrix: unable to create");
+    mu_ = view<float>(RMD_HIP_PLANE_MU);
+    sigma_ = view<float>(RMD_HIP_PLANE_SIGMA_SQ);
+    a_ = view<float>(RMD_HIP_PLANE_A);
+    b_ = view<float>(RMD_HIP_PLANE_B);
+    conv_ = view<int>(RMD_HIP_PLANE_CONVERGENCE);
+  }
+  ~SeedMatrix() {
+    delete mu_; delete sigma_; delete a_; delete b_; delete conv_;
+    rmd_hip_seeds_destroy(handle_);
+  }
+
+  bool setReferenceImage(float* host_ref_img_align_row_maj, const SE3<float>& T_curr_world, const float& min_depth, const float& max_depth) {
+    detail::throw_on_error(rmd_hip_seeds_set_reference(handle_, host_ref_img_align_row_maj, T_curr_world.data.data, min_depth, max_depth),
+                           "SeedMatrix: setReferenceImage failed");
+    return true;
+  }
+  bool update(float* host_curr_img_align_row_maj, const SE3<float>& T_curr_world) {
+    detail::throw_on_error(rmd_hip_seeds_update(handle_, host_curr_img_align_row_maj, T_curr_world.data.data), "SeedMatrix: update failed");
+    return true;
+  }
+
+  void downloadDepthmap(float* host_depthmap_align_row_maj) const { download(RMD_HIP_PLANE_MU, host_depthmap_align_row_maj); }
+  void downloadConvergence(int* host_align_row_maj) const { download(RMD_HIP_PLANE_CONVERGENCE, host_align_row_maj); }
+
+  const DeviceImage<float>& getMu() const { return *mu_; }
+  const DeviceImage<float>& getSigmaSq() const { return *sigma_; }
+  const DeviceImage<float>& getA() const { return *a_; }
+  const DeviceImage<float>& getB() const { return *b_; }
+  const DeviceImage<int>& getConvergence() const { return *conv_; }
+
+  size_t getConvergedCount() const {
+    size_t n = 0;
+    detail::throw_on_error(rmd_hip_seeds_converged_count(handle_, &n), "SeedMatrix: getConvergedCount failed");
+    return n;
+  }
+  float getDistFromRef() const {
+    float d = 0.0f;
+    detail::throw_on_error(rmd_hip_seeds_dist_from_ref(handle_, &d), "SeedMatrix: getDistFromRef failed");
+    return d;
+  }
+
+#if RMD_BUILD_TESTS
+  void downloadSigmaSq(float* host_align_row_maj) const { download(RMD_HIP_PLANE_SIGMA_SQ, host_align_row_maj); }
+  void downloadA(float* host_align_row_maj) const { download(RMD_HIP_PLANE_A, host_align_row_maj); }
+  void downloadB(float* host_align_row_maj) const { download(RMD_HIP_PLANE_B, host_align_row_maj); }
+  void downloadSumTempl(float* host_align_row_maj) const { download(RMD_HIP_PLANE_SUM_TEMPL, host_align_row_maj); }
+  void downloadConstTemplDenom(float* host_align_row_maj) const { download(RMD_HIP_PLANE_CONST_TEMPL_DENOM, host_align_row_maj); }
+  void downloadEpipolarMatches(float2* host_align_row_maj) const { download(RMD_HIP_PLANE_EPIPOLAR_MATCHES, host_align_row_maj); }
+#endif
+
+  rmd_hip_seeds_t* handle() const { return handle_; }
+
+ private:
+  SeedMatrix(const SeedMatrix&);
+  SeedMatrix& operator=(const SeedMatrix&);
+  void download(int plane, void* dst) const {
+    detail::throw_on_error(rmd_hip_seeds_download(handle_, plane, dst), "SeedMatrix: download failed");
+  }
+  template <typename T>
+  DeviceImage<T>* view(int plane) const {
+    const rmd_hip_image_t* v = NULL;
+    detail::throw_on_error(rmd_hip_seeds_plane(handle_, plane, &v), "SeedMatrix: plane view failed");
+    return new DeviceImage<T>(v);
+  }
+  rmd_hip_seeds_t* handle_;
+  DeviceImage<float>*mu_, *sigma_, *a_, *b_;
+  DeviceImage<int>* conv_;
+};
+
+}  // namespace rmd
+
+#endif  // SEED_MATRIX_CUH

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Per-kernel breakdown of the TIMED pass of bench.py from a rocprofv3 kernel trace (skips warm-up and diagnostics passes).
+usage: trace_breakdown.py <prof_dir> [warmup=10] [steps=199]"""
+import csv, glob, sys
+from collections import defaultdict
+d = sys.argv[1]; warm = int(sys.argv[2]) if len(sys.argv) > 2 else 10; steps = int(sys.argv[3]) if len(sys.argv) > 3 else 199
+f = glob.glob(d + '/trace/**/*kernel_trace.csv', recursive=True)[0]
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
+per = defaultdict(list)
+for r in rows:
+    for k in ('seed_search', 'seed_setup', 'seed_finalize', 'seed_plan'):
+        if k in r['Kernel_Name']:
+            per[k].append((int(r['Start_Timestamp']), int(r['End_Timestamp'])))
+out = []
+for k in ('seed_setup', 'seed_plan', 'seed_search', 'seed_finalize'):
+    t = per[k][warm:warm + steps]
+    dd = [(e - s) / 1e3 for s, e in t]
+    out.append(f"{k:14s} avg {sum(dd)/len(dd):7.2f}  min {min(dd):7.2f}  max {max(dd):7.2f} us  (n={len(dd)})")
+su, fi = per['seed_setup'][warm:warm + steps], per['seed_finalize'][warm:warm + steps]
+span = [(fi[i][1] - su[i][0]) / 1e3 for i in range(steps)]
+gap = [(su[i + 1][0] - fi[i][1]) / 1e3 for i in range(steps - 1)]
+out.append(f"frame span (setup start -> finalize end) avg {sum(span)/steps:.2f} us; idle between frames avg {sum(gap)/(steps-1):.2f} us; "
+           f"whole timed pass {(fi[-1][1]-su[0][0])/1e3/steps:.2f} us/frame")
+for i in (0, 4, 9, 19, 39, 59, 99, 149, steps - 1):
+    out.append(f"  frame {i+1:3d}: " + "  ".join(f"{k[5:]} {(per[k][warm+i][1]-per[k][warm+i][0])/1e3:6.1f}" for k in ('seed_setup', 'seed_plan', 'seed_search', 'seed_finalize')))
+print("\n".join(out))
