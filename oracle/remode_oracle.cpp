@@ -558,5 +558,17 @@ float orc_math_acosf(float x) { return rmd_acosf(x); }
 float orc_math_rsqrtf(float x) { return rmd_rsqrtf(x); }
 float orc_math_lerp(float t, float a, float b) { return rmd_lerp(t, a, b); }
 float orc_tex_linear(const float* plane, int w, int h, float x, float y) { return tex_linear(plane, w, h, x, y); }
+// op as rmd_hip_math_eval: 0 expf, 1 sinf, 2 acosf, 3 rsqrtf, 6 lerp(t = x, a = y, b = z)
+void orc_math_eval_array(int op, const float* x, const float* y, const float* z, float* out, long n) {
+  for (long i = 0; i < n; ++i) {
+    switch (op) {
+      case 0: out[i] = rmd_expf(x[i]); break;
+      case 1: out[i] = rmd_sinf(x[i]); break;
+      case 2: out[i] = rmd_acosf(x[i]); break;
+      case 3: out[i] = rmd_rsqrtf(x[i]); break;
+      default: out[i] = rmd_lerp(x[i], y[i], z[i]); break;
+    }
+  }
+}
 
 }  // extern "C"

@@ -54,6 +54,9 @@ class OracleLib:
         path = lib_path(kind, side)
         if not os.path.exists(path):
             raise RuntimeError(f"oracle library {path} missing (run `make -C oracle`)")
+        # the oracles are OpenMP code run on small images: a few threads beat the 100+ of a GPU host
+        os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         self.lib = L = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
         p = self.prefix
         f = lambda name: getattr(L, p + name)
@@ -90,6 +93,8 @@ class OracleLib:
             L.orc_math_lerp.restype, L.orc_math_lerp.argtypes = _c_f, [_c_f, _c_f, _c_f]
             L.orc_tex_linear.restype, L.orc_tex_linear.argtypes = _c_f, [_c_p, _c_i, _c_i, _c_f, _c_f]
             L.orc_denoiser_denoise_planes.argtypes = [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_f, _c_i]
+            L.orc_math_eval_array.argtypes = [_c_i, _c_p, _c_p, _c_p, _c_p, ctypes.c_long]
+            L.orc_math_eval_array.restype = None
 
     def fn(self, name):
         return getattr(self.lib, self.prefix + name)

@@ -317,8 +317,11 @@ def test_device_math_equals_host_math_bit_for_bit():
                                                 None if z is None else z.ctypes.data, out.ctypes.data, x.size))
         return out
 
-    def host(fn, *arrs):
-        return np.array([fn(*[float(v) for v in vals]) for vals in zip(*arrs)], np.float32)
+    def host(op, x, y=None, z=None):
+        out = np.empty_like(x)
+        ol.orc_math_eval_array(op, x.ctypes.data, None if y is None else y.ctypes.data, None if z is None else z.ctypes.data,
+                               out.ctypes.data, x.size)
+        return out
 
     specials = np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, np.inf, -np.inf, np.nan, 1e-38, 1e-45, 3.4e38, 88.7, -103.9, -87.3],
                         np.float32)
@@ -328,10 +331,9 @@ def test_device_math_equals_host_math_bit_for_bit():
         2: np.concatenate([rng.uniform(-1.001, 1.001, n).astype(np.float32), specials]),
         3: np.concatenate([(10.0 ** rng.uniform(-40, 38, n)).astype(np.float32), specials]),
     }
-    fns = {0: ol.orc_math_expf, 1: ol.orc_math_sinf, 2: ol.orc_math_acosf, 3: ol.orc_math_rsqrtf}
     for op, x in cases.items():
-        x = x[:: max(1, x.size // 60000)].copy()  # keep the host loop short
-        got, exp = dev(op, x), host(fns[op], x)
+        x = np.ascontiguousarray(x)
+        got, exp = dev(op, x), host(op, x)
         bad = ~((got == exp) | (np.isnan(got) & np.isnan(exp)))
         assert not bad.any(), f"op {op}: {bad.sum()} mismatches, e.g. x={x[bad][:4]} dev={got[bad][:4]} host={exp[bad][:4]}"
     # IEEE sqrt and divide on the device (the contract relies on them being correctly rounded)
@@ -342,4 +344,4 @@ def test_device_math_equals_host_math_bit_for_bit():
         assert O.planes_equal(dev(5, x, y), x / y)
     t = rng.random(60000).astype(np.float32)
     a, b = rng.random(60000).astype(np.float32), rng.random(60000).astype(np.float32)
-    assert O.planes_equal(dev(6, t, a, b), host(ol.orc_math_lerp, t, a, b))
+    assert O.planes_equal(dev(6, t, a, b), host(6, t, a, b))
