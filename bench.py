@@ -50,11 +50,6 @@ def cpu_baseline(seq, budget_s, gpu_sample_fn):
     import oracles as O
     kind = "reference" if O.available("ref", SIDE) else "port"
     olib = O.OracleLib("ref" if kind == "reference" else "port", SIDE)
-    n_host = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    if kind == "reference":
-        olib.lib.ref_set_num_threads(n_host)
-    else:
-        olib.lib.orc_set_num_threads(n_host)
     cores = olib.lib.ref_max_threads() if kind == "reference" else olib.lib.orc_max_threads()
     s = O.Seeds(olib, seq.width, seq.height, seq.K)
     s.set_reference(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)

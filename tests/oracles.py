@@ -54,9 +54,6 @@ class OracleLib:
         path = lib_path(kind, side)
         if not os.path.exists(path):
             raise RuntimeError(f"oracle library {path} missing (run `make -C oracle`)")
-        # the oracles are OpenMP code run on small images: a few threads beat the 100+ of a GPU host
-        os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
-        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         self.lib = L = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
         p = self.prefix
         f = lambda name: getattr(L, p + name)

@@ -61,7 +61,7 @@ def main():
             lines.append(f"{n:60s} {len(v):6d} {sum(v) / len(v):10.2f} {v2[len(v2) // 2]:10.2f} {v2[-1]:10.2f}  {'/'.join(str(x) for x in res[n])}")
     # --- counters
     counters = {}
-    for sub in ("pmc_sq", "pmc_wait", "pmc_fetch", "pmc_write"):
+    for sub in sorted(os.listdir(raw)):
         for f in find(raw, sub, "*counter_collection.csv"):
             with open(f) as fh:
                 rows = list(csv.DictReader(fh))
