@@ -28,7 +28,7 @@ __all__ = ["PinholeCamera", "SE3", "DeviceImage", "SeedMatrix", "DepthmapDenoise
 PLANE_MU, PLANE_SIGMA_SQ, PLANE_A, PLANE_B, PLANE_CONVERGENCE = 0, 1, 2, 3, 4
 PLANE_SUM_TEMPL, PLANE_CONST_TEMPL_DENOM, PLANE_EPIPOLAR_MATCHES, PLANE_REF_IMG, PLANE_CURR_IMG = 5, 6, 7, 8, 9
 KIND_F32, KIND_I32, KIND_F32X2 = 0, 1, 2
-OPT_MATCHER, OPT_TIMING, OPT_COLLECT_STATS, OPT_WINDOW = 0, 1, 2, 3
+OPT_MATCHER, OPT_TIMING, OPT_COLLECT_STATS, OPT_WINDOW, OPT_LAZY_FINALIZE = 0, 1, 2, 3, 4
 STAGE_SEED_INIT, STAGE_UPDATE, STAGE_COUNT = 0, 1, 2
 DENOISE_OPT_TIMING, DENOISE_OPT_ITERS_PER_LAUNCH = 1, 2
 

@@ -129,9 +129,19 @@ struct rmd_hip_image {
   void* data = nullptr;
   bool owns = false;
   hipStream_t owner_stream = nullptr;  // stream of the handle that writes this image (views), else null
+  struct rmd_hip_seeds* owner_seeds = nullptr;  // SeedMatrix whose plane this is: observers must let it settle first
 };
 
 namespace {
+
+int seeds_sync(const rmd_hip_seeds* s);
+
+// wait until the owner of an image (if any) has settled it
+int image_settle(const rmd_hip_image* img) {
+  if (img->owner_seeds) return seeds_sync(img->owner_seeds);
+  if (img->owner_stream) HIP_TRY(hipStreamSynchronize(img->owner_stream));
+  return RMD_HIP_OK;
+}
 
 int image_alloc(rmd_hip_image* img, int kind, int width, int height) {
   if (width <= 0 || height <= 0 || kind < 0 || kind > RMD_HIP_KIND_F32X2)
@@ -141,7 +151,10 @@ int image_alloc(rmd_hip_image* img, int kind, int width, int height) {
   const size_t pitch = (static_cast<size_t>(width) * es + 255) / 256 * 256;
   void* p = nullptr;
   HIP_TRY(hipMalloc(&p, pitch * height));
+  // hipMemset runs on the null stream; the handles' kernels run on non-blocking streams that do NOT order against it,
+  // so the fill must have completed before the buffer is handed out
   HIP_TRY(hipMemset(p, 0, pitch * height));
+  HIP_TRY(hipStreamSynchronize(nullptr));
   img->kind = kind; img->width = width; img->height = height;
   img->pitch = pitch; img->stride = pitch / es; img->data = p; img->owns = true;
   (void)hipGetDevice(&img->device);
@@ -164,6 +177,11 @@ struct rmd_hip_seeds {
   int opt_matcher = 1, opt_timing = 0, opt_stats = 0, opt_window = 0;
   hipEvent_t region_start = nullptr, region_stop = nullptr;
   long region_updates = 0;
+  // deferred finalisation of the last tile-pipeline update (see rmd_matcher.hpp): pending until the next update()
+  // fuses it or an observer forces it
+  bool finalize_pending = false;
+  rmdk::SeedParams P_pending;
+  int opt_lazy = 1;
   StageTimer timers[RMD_HIP_NUM_SEED_STAGES];
   long long last_stats[16] = {0};
   bool stats_pending = false;
@@ -185,9 +203,19 @@ int dispatch_side(int side, F&& f) {
   }
 }
 
+int seeds_flush(rmd_hip_seeds* s) {
+  if (s->finalize_pending) {
+    s->finalize_pending = false;
+    HIP_TRY(rmdk::launch_seed_finalize(s->P_pending, s->matcher_ws, s->stream));
+  }
+  return RMD_HIP_OK;
+}
+
+// every observer of the seed state goes through here: settle deferred work, then wait for the stream
 int seeds_sync(const rmd_hip_seeds* s) {
-  HIP_TRY(hipStreamSynchronize(s->stream));
   rmd_hip_seeds* m = const_cast<rmd_hip_seeds*>(s);
+  TRY(seeds_flush(m));
+  HIP_TRY(hipStreamSynchronize(s->stream));
   for (auto& t : m->timers) t.drain();
   if (m->stats_pending) {
     for (int k = 0; k < 16; ++k) m->last_stats[k] = static_cast<long long>(m->h_scalars[1 + k]);
@@ -228,10 +256,17 @@ int seeds_launch_update(rmd_hip_seeds* s) {
     rc = dispatch_side(s->patch_side, [&](auto side) {
       constexpr int SIDE = decltype(side)::value;
       if (s->opt_matcher == 0) {
+        TRY(seeds_flush(s));
         const dim3 block(64, 4), grid((s->width + 63) / 64, (s->height + 3) / 4);
         hipLaunchKernelGGL((rmdk::seed_update_pixel_kernel<SIDE>), grid, block, 0, s->stream, P);
       } else {
-        HIP_TRY(rmdk::launch_seed_update_tile<SIDE>(P, s->matcher_ws, s->stream, s->num_cus, s->opt_window));
+        const bool fuse = s->finalize_pending;
+        const rmdk::Pose T_prev = fuse ? s->P_pending.T_ref_curr : P.T_ref_curr;
+        HIP_TRY(rmdk::launch_seed_update_tile<SIDE>(P, s->matcher_ws, s->stream, s->num_cus, s->opt_window, fuse, T_prev));
+        s->P_pending = P;
+        s->P_pending.stats = nullptr;
+        s->finalize_pending = true;
+        if (!s->opt_lazy || s->opt_stats) TRY(seeds_flush(s));
       }
       HIP_TRY(hipGetLastError());
       return RMD_HIP_OK;
@@ -248,6 +283,7 @@ int seeds_launch_update(rmd_hip_seeds* s) {
 
 // common tail of setReferenceImage (seed_matrix.cu:95-113) once the frame is in planes[REF_IMG]
 int seeds_after_reference(rmd_hip_seeds* s, const float* T_curr_world, float min_depth, float max_depth) {
+  TRY(seeds_flush(s));  // a deferred finalisation of the old reference must not run after the re-initialisation
   rmdk::SeedParams& P = s->P;
   P.avg_depth = (min_depth + max_depth) / 2.0f;
   P.depth_range = max_depth - min_depth;
@@ -344,22 +380,23 @@ int rmd_hip_image_destroy(rmd_hip_image_t* img) {
 }
 int rmd_hip_image_upload(rmd_hip_image_t* img, const void* host) {
   if (!img || !host) return fail(RMD_HIP_ERR_INVALID_ARG, "image_upload: null argument");
-  if (img->owner_stream) HIP_TRY(hipStreamSynchronize(img->owner_stream));
+  TRY(image_settle(img));
   const size_t row = static_cast<size_t>(img->width) * kind_size(img->kind);
   HIP_TRY(hipMemcpy2D(img->data, img->pitch, host, row, row, img->height, hipMemcpyHostToDevice));
   return RMD_HIP_OK;
 }
 int rmd_hip_image_download(const rmd_hip_image_t* img, void* host) {
   if (!img || !host) return fail(RMD_HIP_ERR_INVALID_ARG, "image_download: null argument");
-  if (img->owner_stream) HIP_TRY(hipStreamSynchronize(img->owner_stream));
+  TRY(image_settle(img));
   const size_t row = static_cast<size_t>(img->width) * kind_size(img->kind);
   HIP_TRY(hipMemcpy2D(host, row, img->data, img->pitch, row, img->height, hipMemcpyDeviceToHost));
   return RMD_HIP_OK;
 }
 int rmd_hip_image_zero(rmd_hip_image_t* img) {
   if (!img) return fail(RMD_HIP_ERR_INVALID_ARG, "image_zero: null image");
-  if (img->owner_stream) HIP_TRY(hipStreamSynchronize(img->owner_stream));
+  TRY(image_settle(img));
   HIP_TRY(hipMemset(img->data, 0, img->pitch * img->height));
+  HIP_TRY(hipStreamSynchronize(nullptr));
   return RMD_HIP_OK;
 }
 int rmd_hip_image_copy(rmd_hip_image_t* dst, const rmd_hip_image_t* src) {
@@ -367,8 +404,8 @@ int rmd_hip_image_copy(rmd_hip_image_t* dst, const rmd_hip_image_t* src) {
   if (dst == src) return RMD_HIP_OK;
   if (dst->kind != src->kind || dst->width != src->width || dst->height != src->height)
     return fail(RMD_HIP_ERR_INVALID_ARG, "image_copy: shape mismatch");
-  if (src->owner_stream) HIP_TRY(hipStreamSynchronize(src->owner_stream));
-  if (dst->owner_stream) HIP_TRY(hipStreamSynchronize(dst->owner_stream));
+  TRY(image_settle(src));
+  TRY(image_settle(dst));
   const size_t row = static_cast<size_t>(src->width) * kind_size(src->kind);
   HIP_TRY(hipMemcpy2D(dst->data, dst->pitch, src->data, src->pitch, row, src->height, hipMemcpyDeviceToDevice));
   return RMD_HIP_OK;
@@ -427,6 +464,7 @@ int rmd_hip_seeds_create(int width, int height, float fx, float fy, float cx, fl
     const int rc = image_alloc(&s->planes[p], kind, width, height);
     if (rc != RMD_HIP_OK) return bail(rc);
     s->planes[p].owner_stream = s->stream;
+    s->planes[p].owner_seeds = s;
   }
   if (hipMalloc(reinterpret_cast<void**>(&s->d_scalars), 17 * sizeof(unsigned long long)) != hipSuccess ||
       hipHostMalloc(reinterpret_cast<void**>(&s->h_scalars), 17 * sizeof(unsigned long long)) != hipSuccess)
@@ -456,6 +494,7 @@ int rmd_hip_seeds_create(int width, int height, float fx, float fy, float cx, fl
   if (rcw != 0) return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: matcher workspace"));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) s->num_cus = prop.multiProcessorCount;
+  if (hipDeviceSynchronize() != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: device synchronisation failed"));  // all fills done
   *out = s;
   return RMD_HIP_OK;
 }
@@ -539,6 +578,7 @@ int rmd_hip_seeds_converged_count(const rmd_hip_seeds_t* s, size_t* count) {
   if (!s || !count) return fail(RMD_HIP_ERR_INVALID_ARG, "converged_count: null argument");
   TRY(seeds_bind_device(s));
   rmd_hip_seeds* m = const_cast<rmd_hip_seeds*>(s);
+  TRY(seeds_flush(m));
   HIP_TRY(hipMemsetAsync(m->d_scalars, 0, sizeof(unsigned long long), m->stream));
   {
     ScopedStage st(m->opt_timing ? &m->timers[RMD_HIP_STAGE_COUNT] : nullptr, m->stream);
@@ -577,6 +617,9 @@ int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value) {
       if (value < 0 || value > 2) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: timing mode %d", value);
       s->opt_timing = value;
       return RMD_HIP_OK;
+    case RMD_HIP_OPT_LAZY_FINALIZE:
+      s->opt_lazy = value != 0;
+      return RMD_HIP_OK;
     case RMD_HIP_OPT_WINDOW:
       if (value < 0 || value > 2) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: window %d", value);
       s->opt_window = value;
@@ -594,6 +637,7 @@ int rmd_hip_seeds_timing(const rmd_hip_seeds_t* s, int stage, double* total_ms, 
     rmd_hip_seeds* m = const_cast<rmd_hip_seeds*>(s);
     if (!m->region_start) return fail(RMD_HIP_ERR_NOT_READY, "seeds_timing: call timing_reset first");
     if (!m->region_stop) HIP_TRY(hipEventCreate(&m->region_stop));
+    TRY(seeds_flush(m));  // the deferred finalisation of the last update belongs to the region
     HIP_TRY(hipEventRecord(m->region_stop, m->stream));
     HIP_TRY(hipEventSynchronize(m->region_stop));
     float ms = 0.0f;
@@ -677,6 +721,7 @@ int rmd_hip_denoiser_create(int width, int height, rmd_hip_denoiser_t** out) {
     if (rc != RMD_HIP_OK) return bail(rc);
     d->p[k].owner_stream = d->stream;
   }
+  if (hipDeviceSynchronize() != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "denoiser_create: device synchronisation failed"));
   *out = d;
   return RMD_HIP_OK;
 }
@@ -721,7 +766,7 @@ int rmd_hip_denoiser_denoise(rmd_hip_denoiser_t* d, const rmd_hip_image_t* mu, c
   if (cur != d->device) HIP_TRY(hipSetDevice(d->device));
   // inputs may still be written by their owner (the SeedMatrix's last kernel is left in flight)
   for (auto* im : ins)
-    if (im->owner_stream && im->owner_stream != d->stream) HIP_TRY(hipStreamSynchronize(im->owner_stream));
+    if (im->owner_seeds || (im->owner_stream && im->owner_stream != d->stream)) TRY(image_settle(im));
   HIP_TRY(hipStreamSynchronize(d->stream));
   d->timer.drain();
   d->timer.reset();
@@ -788,7 +833,7 @@ int rmd_hip_denoiser_timing(const rmd_hip_denoiser_t* d, double* total_ms, long*
 int rmd_hip_reduce_sum_f32(const rmd_hip_image_t* img, float* sum) {
   if (!img || !sum) return fail(RMD_HIP_ERR_INVALID_ARG, "reduce_sum: null argument");
   if (img->kind != RMD_HIP_KIND_F32) return fail(RMD_HIP_ERR_INVALID_ARG, "reduce_sum: image is not f32");
-  if (img->owner_stream) HIP_TRY(hipStreamSynchronize(img->owner_stream));
+  TRY(image_settle(img));
   const dim3 block(256), grid((img->width + 255) / 256 < 8 ? (img->width + 255) / 256 : 8, img->height < 64 ? img->height : 64);
   const int nparts = grid.x * grid.y;
   double* d_parts = nullptr;
@@ -811,7 +856,7 @@ int rmd_hip_reduce_sum_f32(const rmd_hip_image_t* img, float* sum) {
 int rmd_hip_reduce_count_eq_i32(const rmd_hip_image_t* img, int value, size_t* count) {
   if (!img || !count) return fail(RMD_HIP_ERR_INVALID_ARG, "reduce_count_eq: null argument");
   if (img->kind != RMD_HIP_KIND_I32) return fail(RMD_HIP_ERR_INVALID_ARG, "reduce_count_eq: image is not i32");
-  if (img->owner_stream) HIP_TRY(hipStreamSynchronize(img->owner_stream));
+  TRY(image_settle(img));
   unsigned long long* d_out = nullptr;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), sizeof(unsigned long long)));
   (void)hipMemset(d_out, 0, sizeof(unsigned long long));

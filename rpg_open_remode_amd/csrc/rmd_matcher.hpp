@@ -19,8 +19,10 @@
 //                         ((SIDE+1)^2 LDS reads feed SIDE*(SIDE+1) + SIDE^2 lerps instead of 4*SIDE^2
 //                         texel fetches), segmented wave max, one 64-bit atomic max per seed run on
 //                         {orderable(ncc), ~step} (ties -> lowest step, as the reference's strict '>').
-//   seed_finalize_kernel  one lane per seed: decode the arg-max, match coordinates, triangulation,
-//                         posterior update.
+//   seed_finalize         one lane per seed: decode the arg-max, match coordinates, triangulation, posterior update.
+//                         Deferred: when the next update() arrives before anybody looked at the state, it runs
+//                         fused into that frame's seed_setup_kernel (same lane owns the same seed); otherwise as the
+//                         stand-alone seed_finalize_kernel.
 //
 // Why not one lane per pixel (the reference's shape, kept in rmd_kernels.hpp as the A/B baseline):
 // the per-seed trip count varies from 0 (converged / diverged / border) to 143, so a wave64 idles at
@@ -225,9 +227,45 @@ RMDK_D float ncc_at(const SeedParams& P, F2 px, const float* __restrict__ win, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// per-seed finalisation (epipolar_match.cu:131-139 + seed_update.cu:39-121), used by seed_finalize_kernel and by the
+// fused prologue of seed_setup_kernel
+// Decodes the arg-max of one seed whose state is UPDATE, writes the match, runs the Bayesian fusion.  Returns the
+// seed's final state of that frame.
+RMDK_D int finalize_seed(const SeedParams& P, const MatcherArgs& M, int x, int y, int gi) {
+  const unsigned long long key = M.best[gi];
+  F2 best_px = F2{0.0f, 0.0f};
+  float best_ncc = -1.0f;
+  if (key != 0ull) {
+    best_ncc = from_orderable_f32(static_cast<unsigned int>(key >> 32));
+    const int step = static_cast<int>(0xffffffffu - static_cast<unsigned int>(key & 0xffffffffu));
+    const int i_first = static_cast<int>(M.packed[gi] >> 16);
+    float l = M.lfirst[gi];
+    for (int q = i_first; q < step; ++q) l += 0.7f;
+    const float2 m = M.mean[gi], d = M.dir[gi];
+    best_px = F2{m.x + l * d.x, m.y + l * d.y};
+  }
+  int state = ST_UPDATE;
+  if (best_ncc < 0.5f) state = ST_NO_MATCH;
+  else P.match[y * P.stride2 + x] = make_float2(best_px.x, best_px.y);
+  seed_fuse(P, x, y, gi, state, P.mu[gi], P.sigma_sq[gi], P.a[gi], P.b[gi], best_px);
+  return state;
+}
+
+// Housekeeping once per frame: feedback for the host's next launch (unit count, window sizes) from the counter bank of
+// the frame being finalised, and a clean bank for the frame after next.
+RMDK_D void finalize_housekeeping(const unsigned int* bank_done, unsigned int* bank_to_clear, unsigned int* feedback) {
+  feedback[0] = bank_done[0]; feedback[1] = bank_done[2]; feedback[2] = bank_done[3]; feedback[3] = bank_done[4];
+  for (int k = 0; k < 8; ++k) bank_to_clear[k] = 0u;
+}
+
+// ------------------------------------------------------------------------------------------------
 // stage 1: per-tile setup
-template <int SIDE, int WS, int WROWS>
-__global__ __launch_bounds__(TILE_PIX) void seed_setup_kernel(SeedParams P, MatcherArgs M) {
+// FUSE_PREV: the previous frame's seed_finalize has been deferred (nobody looked at the state in between): run it here,
+// in the lane that owns the same seed, right before that seed's check for the new frame.  Saves one launch per frame
+// in streaming use.  Its intermediate convergence value (UPDATE / NO_MATCH of the previous frame) is never observable
+// -- any observer forces the stand-alone seed_finalize_kernel first -- and is overwritten below, so it is not stored.
+template <int SIDE, int WS, int WROWS, bool FUSE_PREV>
+__global__ __launch_bounds__(TILE_PIX) void seed_setup_kernel(SeedParams P, MatcherArgs M, Pose T_ref_curr_prev) {
   constexpr int HALF = SIDE / 2;
   __shared__ float red_f[4][8];
   __shared__ int red_i[4];
@@ -238,6 +276,14 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_kernel(SeedParams P, Matc
   const bool in_image = x < P.w && y < P.h;
   const int gi = y * P.stride + x;
 
+  if (FUSE_PREV) {
+    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) finalize_housekeeping(M.queue_next, M.queue_next, M.feedback);
+    if (in_image && P.conv[gi] == ST_UPDATE) {
+      SeedParams Pprev = P;
+      Pprev.T_ref_curr = T_ref_curr_prev;
+      (void)finalize_seed(Pprev, M, x, y, gi);
+    }
+  }
   int state = ST_BORDER;
   float mu = 0.0f, sigma_sq = 0.0f;
   if (in_image) {
@@ -421,6 +467,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void seed_plan_kernel(MatcherArgs M, 
     M.queue[3] = static_cast<unsigned int>(m_h);
     M.queue[4] = static_cast<unsigned int>(n_off);
     M.queue[5] = static_cast<unsigned int>(rounds * TILE_PIX);
+    M.queue[1] = 0u;  // hand-out counter of this frame's search
   }
   __syncthreads();
   const int unit_items = unit_items_s;
@@ -621,56 +668,45 @@ __global__ __launch_bounds__(TILE_PIX) void seed_search_kernel(SeedParams P, Mat
 }
 
 // ------------------------------------------------------------------------------------------------
-// stage 3: per-seed finalisation (epipolar_match.cu:131-139 + seed_update.cu:39-121)
+// stage 3: the stand-alone finalisation kernel (the per-seed code is finalize_seed above)
 __global__ __launch_bounds__(256) void seed_finalize_kernel(SeedParams P, MatcherArgs M) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x == 0 && y == 0) {  // housekeeping: feedback for the host's next launch, and a clean counter bank for it
-    M.feedback[0] = M.queue[0]; M.feedback[1] = M.queue[2]; M.feedback[2] = M.queue[3]; M.feedback[3] = M.queue[4];
-    for (int k = 0; k < 8; ++k) M.queue_next[k] = 0u;
-  }
+  if (x == 0 && y == 0) finalize_housekeeping(M.queue, M.queue_next, M.feedback);
   if (x >= P.w || y >= P.h) return;
   const int gi = y * P.stride + x;
-  int state = P.conv[gi];
-  if (state != ST_UPDATE) return;  // BORDER / CONVERGED / DIVERGED were settled by seed_setup
-  const unsigned long long key = M.best[gi];
-  F2 best_px = F2{0.0f, 0.0f};
-  float best_ncc = -1.0f;
-  if (key != 0ull) {
-    best_ncc = from_orderable_f32(static_cast<unsigned int>(key >> 32));
-    const int step = static_cast<int>(0xffffffffu - static_cast<unsigned int>(key & 0xffffffffu));
-    const int i_first = static_cast<int>(M.packed[gi] >> 16);
-    float l = M.lfirst[gi];
-    for (int q = i_first; q < step; ++q) l += 0.7f;
-    const float2 m = M.mean[gi], d = M.dir[gi];
-    best_px = F2{m.x + l * d.x, m.y + l * d.y};
-  }
-  if (best_ncc < 0.5f) {
-    state = ST_NO_MATCH;
-    P.conv[gi] = state;
-  } else {
-    P.match[y * P.stride2 + x] = make_float2(best_px.x, best_px.y);
-  }
-  seed_fuse(P, x, y, gi, state, P.mu[gi], P.sigma_sq[gi], P.a[gi], P.b[gi], best_px);
+  if (P.conv[gi] != ST_UPDATE) return;  // BORDER / CONVERGED / DIVERGED were settled by seed_setup
+  const int state = finalize_seed(P, M, x, y, gi);
+  if (state != ST_UPDATE) P.conv[gi] = state;
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int SIDE, int WS, int WROWS>
-inline hipError_t launch_seed_pipeline(const SeedParams& P, MatcherWorkspace& ws, hipStream_t stream, int num_cus, bool& attr_set) {
-  using Smem = SearchSmem<SIDE, WS, WROWS>;
+inline MatcherArgs matcher_args(const MatcherWorkspace& ws, int parity) {
   MatcherArgs M;
   M.mean = ws.d_mean; M.dir = ws.d_dir; M.lfirst = ws.d_lfirst; M.packed = ws.d_packed; M.best = ws.d_best;
   M.tiles = ws.d_tiles; M.units = ws.d_units; M.tiles_x = ws.tiles_x;
-  M.queue = ws.d_queue + 8 * ws.parity;
-  M.queue_next = ws.d_queue + 8 * (ws.parity ^ 1);
+  M.queue = ws.d_queue + 8 * parity;
+  M.queue_next = ws.d_queue + 8 * (parity ^ 1);
   M.feedback = ws.h_feedback;
+  return M;
+}
+
+// setup (+ the deferred finalisation of the previous frame when fuse_prev) -> plan -> search.  The frame's own
+// finalisation is NOT launched: the caller either fuses it into the next frame's setup or runs launch_seed_finalize.
+template <int SIDE, int WS, int WROWS>
+inline hipError_t launch_seed_pipeline(const SeedParams& P, MatcherWorkspace& ws, hipStream_t stream, int num_cus, bool& attr_set,
+                                       bool fuse_prev, const Pose& T_ref_curr_prev) {
+  using Smem = SearchSmem<SIDE, WS, WROWS>;
   ws.parity ^= 1;
+  const MatcherArgs M = matcher_args(ws, ws.parity);
   // Persistent grid: as many workgroups as fit the chip, but no more than the work of the previous frame suggests
   // (the unit count is read back through pinned memory, one or two frames late; any grid size is correct).
   const int by_lds = static_cast<int>((160 * 1024) / sizeof(Smem));
   const int wg_per_cu = by_lds < 4 ? (by_lds > 0 ? by_lds : 1) : 4;  // >4 x 256 threads gain nothing at this register count
   const int resident = num_cus * wg_per_cu;
-  hipLaunchKernelGGL((seed_setup_kernel<SIDE, WS, WROWS>), dim3(ws.tiles_x, ws.tiles_y), dim3(TILE_PIX), 0, stream, P, M);
+  const dim3 tiles(ws.tiles_x, ws.tiles_y);
+  if (fuse_prev) hipLaunchKernelGGL((seed_setup_kernel<SIDE, WS, WROWS, true>), tiles, dim3(TILE_PIX), 0, stream, P, M, T_ref_curr_prev);
+  else hipLaunchKernelGGL((seed_setup_kernel<SIDE, WS, WROWS, false>), tiles, dim3(TILE_PIX), 0, stream, P, M, T_ref_curr_prev);
   hipLaunchKernelGGL(seed_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, stream, M, ws.tiles_x * ws.tiles_y, resident);
   auto search = seed_search_kernel<SIDE, WS, WROWS>;
   if (!attr_set) {
@@ -686,7 +722,6 @@ inline hipError_t launch_seed_pipeline(const SeedParams& P, MatcherWorkspace& ws
     grid = want < resident ? static_cast<int>(want) : resident;
   }
   hipLaunchKernelGGL(search, dim3(grid), dim3(TILE_PIX), sizeof(Smem), stream, P, M);
-  hipLaunchKernelGGL(seed_finalize_kernel, dim3((P.w + 63) / 64, (P.h + 3) / 4), dim3(64, 4), 0, stream, P, M);
   return hipGetLastError();
 }
 
@@ -697,13 +732,20 @@ inline hipError_t launch_seed_pipeline(const SeedParams& P, MatcherWorkspace& ws
 // sends the overflowing samples to the global-memory path.
 template <int SIDE>
 inline hipError_t launch_seed_update_tile(const SeedParams& P, MatcherWorkspace& ws, hipStream_t stream, int num_cus,
-                                          int force_window) {
+                                          int force_window, bool fuse_prev, const Pose& T_ref_curr_prev) {
   const unsigned int need_w = ws.h_feedback[1], need_h = ws.h_feedback[2];
   bool small = ws.h_feedback[0] != 0xffffffffu && need_w + 6 <= 69 && need_h + 6 <= 64;
   if (force_window == 1) small = true;
   if (force_window == 2) small = false;
-  if (small) return launch_seed_pipeline<SIDE, 69, 64>(P, ws, stream, num_cus, ws.attr_set_small);
-  return launch_seed_pipeline<SIDE, 133, 104>(P, ws, stream, num_cus, ws.attr_set_large);
+  if (small) return launch_seed_pipeline<SIDE, 69, 64>(P, ws, stream, num_cus, ws.attr_set_small, fuse_prev, T_ref_curr_prev);
+  return launch_seed_pipeline<SIDE, 133, 104>(P, ws, stream, num_cus, ws.attr_set_large, fuse_prev, T_ref_curr_prev);
+}
+
+// the stand-alone finalisation of the frame whose pipeline was launched last (P must carry that frame's poses)
+inline hipError_t launch_seed_finalize(const SeedParams& P, MatcherWorkspace& ws, hipStream_t stream) {
+  const MatcherArgs M = matcher_args(ws, ws.parity);
+  hipLaunchKernelGGL(seed_finalize_kernel, dim3((P.w + 63) / 64, (P.h + 3) / 4), dim3(64, 4), 0, stream, P, M);
+  return hipGetLastError();
 }
 
 }  // namespace rmdk

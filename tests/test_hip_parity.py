@@ -173,6 +173,38 @@ def test_two_instances_are_independent():
     assert_states_equal(ob.state(), hb.state(), "instance B")
 
 
+def test_deferred_finalisation_is_unobservable():
+    """the last kernel of an update is deferred and fused into the next one unless somebody looks at the state first:
+    every interleaving of updates and observers must give the same bits as the eager path"""
+    seq = sequence(160, 120, 14)
+    lazy, eager = _hip_seeds(seq, 5, 1), _hip_seeds(seq, 5, 1)
+    eager.setOption(api.OPT_LAZY_FINALIZE, 0)
+    d = api.DepthmapDenoiser(seq.width, seq.height)
+    d.setLargeSigmaSq(seq.max_depth - seq.min_depth)
+    for s in (lazy, eager):
+        s.setReferenceImage(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    observers = {3: lambda s: s.getConvergedCount(), 5: lambda s: s.downloadConvergence().sum(), 6: lambda s: s.sync(),
+                 8: lambda s: float(d.denoise(s.getMu(), s.getSigmaSq(), s.getA(), s.getB(), 0.5, 3).sum()),
+                 9: lambda s: api.ImageReducer().countEqual(s.getConvergence(), 0), 11: lambda s: s.downloadEpipolarMatches().sum()}
+    for k in range(1, 14):
+        for s in (lazy, eager):
+            s.update(seq.images[k], seq.T_curr_world[k])
+        if k in observers:
+            a, b = observers[k](lazy), observers[k](eager)
+            assert a == b or (a != a and b != b), f"observer after update {k}"
+        if k == 7:  # re-reference in the middle of a stream, with a finalisation pending
+            for s in (lazy, eager):
+                s.setReferenceImage(seq.images[7], seq.T_curr_world[7], seq.min_depth, seq.max_depth)
+    assert_states_equal(eager.state(), lazy.state(), "lazy vs eager")
+    orc = _oracle_seeds("port", seq, 5)
+    orc.set_reference(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    for k in range(1, 14):
+        orc.update(seq.images[k], seq.T_curr_world[k])
+        if k == 7:
+            orc.set_reference(seq.images[7], seq.T_curr_world[7], seq.min_depth, seq.max_depth)
+    assert_states_equal(orc.state(), lazy.state(), "lazy vs oracle")
+
+
 def test_device_resident_frames_equal_host_frames():
     seq = sequence(160, 120, 6)
     h1, h2 = _hip_seeds(seq, 5, 1), _hip_seeds(seq, 5, 1)
