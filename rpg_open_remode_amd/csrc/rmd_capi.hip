@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <new>
+#include <tuple>
 #include <vector>
 
 #include "rmd_kernels.hpp"
@@ -322,7 +323,7 @@ struct rmd_hip_denoiser {
   float large_sigma_sq = -1.0f;
   hipStream_t stream = nullptr;
   int result_index = 0;
-  int opt_timing = 0, opt_iters_per_launch = 1;
+  int opt_timing = 0, opt_iters_per_launch = 4;
   StageTimer timer;
 };
 
@@ -743,7 +744,7 @@ int rmd_hip_denoiser_set_option(rmd_hip_denoiser_t* d, int option, int value) {
   switch (option) {
     case RMD_HIP_DENOISE_OPT_TIMING: d->opt_timing = value != 0; return RMD_HIP_OK;
     case RMD_HIP_DENOISE_OPT_ITERS_PER_LAUNCH:
-      if (value < 1 || value > 8) return fail(RMD_HIP_ERR_INVALID_ARG, "iters_per_launch %d outside 1..8", value);
+      if (value < 1 || value > 4) return fail(RMD_HIP_ERR_INVALID_ARG, "iters_per_launch %d outside 1..4", value);
       d->opt_iters_per_launch = value;
       return RMD_HIP_OK;
     default: return fail(RMD_HIP_ERR_INVALID_ARG, "denoiser_set_option: unknown option %d", option);
@@ -791,20 +792,44 @@ int rmd_hip_denoiser_denoise(rmd_hip_denoiser_t* d, const rmd_hip_image_t* mu, c
     HIP_TRY(hipGetLastError());
   }
   int cur_buf = 0;
-  {
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (d->opt_timing) {  // one event pair around the whole iteration loop (per-launch markers would serialise it)
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    HIP_TRY(hipEventRecord(ev0, d->stream));
+  }
+  long n_launches = 0;
+  auto bufs = [&](int b) {
+    return std::make_tuple(static_cast<float*>(d->u[b].data), static_cast<float*>(d->u_head[b].data), static_cast<float2*>(d->p[b].data));
+  };
+  if (d->opt_iters_per_launch <= 1) {
     const dim3 block(rmdk::TV_TX, rmdk::TV_TY);
     const dim3 grid((d->width + rmdk::TV_TX - 1) / rmdk::TV_TX, (d->height + rmdk::TV_TY - 1) / rmdk::TV_TY);
     for (int it = 0; it < iterations; ++it) {
       const int nxt = cur_buf ^ 1;
-      ScopedStage st(d->opt_timing ? &d->timer : nullptr, d->stream);
-      hipLaunchKernelGGL(rmdk::tv_iterate_kernel, grid, block, 0, d->stream, P,
-                         static_cast<const float*>(d->u[cur_buf].data), static_cast<const float*>(d->u_head[cur_buf].data),
-                         static_cast<const float2*>(d->p[cur_buf].data), static_cast<float*>(d->u[nxt].data),
-                         static_cast<float*>(d->u_head[nxt].data), static_cast<float2*>(d->p[nxt].data));
+      auto [ui, uhi, pi] = bufs(cur_buf);
+      auto [uo, uho, po] = bufs(nxt);
+      hipLaunchKernelGGL(rmdk::tv_iterate_kernel, grid, block, 0, d->stream, P, ui, uhi, pi, uo, uho, po);
       cur_buf = nxt;
+      ++n_launches;
     }
-    HIP_TRY(hipGetLastError());
+  } else {
+    constexpr int KMAX = 4;
+    using G = rmdk::TvBlocked<KMAX>;
+    const int k = d->opt_iters_per_launch < KMAX ? d->opt_iters_per_launch : KMAX;
+    const dim3 block(G::THREADS), grid((d->width + G::BX - 1) / G::BX, (d->height + G::BY - 1) / G::BY);
+    for (int done = 0; done < iterations; done += k) {
+      const int now = iterations - done < k ? iterations - done : k;
+      const int nxt = cur_buf ^ 1;
+      auto [ui, uhi, pi] = bufs(cur_buf);
+      auto [uo, uho, po] = bufs(nxt);
+      hipLaunchKernelGGL((rmdk::tv_iterate_blocked_kernel<KMAX>), grid, block, 0, d->stream, P, ui, uhi, pi, uo, uho, po, now);
+      cur_buf = nxt;
+      ++n_launches;
+    }
   }
+  HIP_TRY(hipGetLastError());
+  if (d->opt_timing) HIP_TRY(hipEventRecord(ev1, d->stream));
   d->result_index = cur_buf;
   if (host_denoised) {
     const rmd_hip_image& r = d->u[cur_buf];
@@ -812,7 +837,12 @@ int rmd_hip_denoiser_denoise(rmd_hip_denoiser_t* d, const rmd_hip_image_t* mu, c
     HIP_TRY(hipMemcpy2DAsync(host_denoised, row, r.data, r.pitch, row, r.height, hipMemcpyDeviceToHost, d->stream));
   }
   HIP_TRY(hipStreamSynchronize(d->stream));
-  d->timer.drain();
+  if (d->opt_timing) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) { d->timer.total_ms = ms; d->timer.launches = n_launches; }
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+  }
   return RMD_HIP_OK;
 }
 

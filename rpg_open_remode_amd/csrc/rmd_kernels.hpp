@@ -356,6 +356,118 @@ __global__ __launch_bounds__(TV_TX* TV_TY) void tv_iterate_kernel(TvParams P, co
 }
 
 // ------------------------------------------------------------------------------------------
+// Temporally blocked TV-L1: `iters` (<= KMAX) primal-dual iterations per launch.  A workgroup loads its BX x BY output
+// tile plus a halo of `iters` pixels (clipped to the image) of (u, u_head, p, g, mu) into LDS and iterates there; the
+// region in which the LDS copy equals the true iterate shrinks by one pixel per iteration on every side that is not an
+// image border (the dual looks east/south, the primal west/north), so after `iters` iterations exactly the output tile
+// is valid.  Per pixel the arithmetic is that of tv_iterate_kernel, hence the same bits; HBM traffic per iteration
+// drops from 40 B/pixel to (24*(BX+2K)(BY+2K) + 16*BX*BY)/(K*BX*BY) ~= 14 B/pixel at K = 4.
+template <int KMAX>
+struct TvBlocked {
+  static constexpr int BX = 64, BY = 16, THREADS = 256;
+  static constexpr int EW = BX + 2 * KMAX, EH = BY + 2 * KMAX, EN = EW * EH;
+  static constexpr int SLOTS = (EN + THREADS - 1) / THREADS;
+};
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void tv_iterate_blocked_kernel(TvParams P, const float* __restrict__ u_in,
+                                                                 const float* __restrict__ uh_in, const float2* __restrict__ p_in,
+                                                                 float* __restrict__ u_out, float* __restrict__ uh_out,
+                                                                 float2* __restrict__ p_out, int iters) {
+  using G = TvBlocked<KMAX>;
+  __shared__ float su[G::EN], suh[G::EN], spx[G::EN], spy[G::EN], sg[G::EN], smu[G::EN];
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * G::BX, y0 = blockIdx.y * G::BY;
+  const int ex0 = max(x0 - iters, 0), ey0 = max(y0 - iters, 0);
+  const int ex1 = min(x0 + G::BX + iters, P.w), ey1 = min(y0 + G::BY + iters, P.h);  // exclusive
+  const int ew = ex1 - ex0, eh = ey1 - ey0, en = ew * eh;
+  // this lane's pixels of the extended region: local index (row * EW + col) and whether the slot is used
+  int lidx[G::SLOTS];
+  short lxs[G::SLOTS], lys[G::SLOTS];
+  const float inv_ew = 1.0f / static_cast<float>(ew);
+#pragma unroll
+  for (int q = 0; q < G::SLOTS; ++q) {
+    const int e = tid + q * G::THREADS;
+    int ly = static_cast<int>(static_cast<float>(e) * inv_ew);
+    int lx = e - ly * ew;
+    if (lx < 0) { --ly; lx += ew; } else if (lx >= ew) { ++ly; lx -= ew; }
+    lxs[q] = static_cast<short>(lx); lys[q] = static_cast<short>(ly);
+    lidx[q] = e < en ? ly * G::EW + lx : -1;
+  }
+#pragma unroll
+  for (int q = 0; q < G::SLOTS; ++q) {
+    if (lidx[q] < 0) continue;
+    const int gx = ex0 + lxs[q], gy = ey0 + lys[q];
+    const int gi = gy * P.stride + gx;
+    su[lidx[q]] = u_in[gi];
+    suh[lidx[q]] = uh_in[gi];
+    const float2 pv = p_in[gy * P.stride2 + gx];
+    spx[lidx[q]] = pv.x; spy[lidx[q]] = pv.y;
+    sg[lidx[q]] = P.g[gi];
+    smu[lidx[q]] = P.mu[gy * P.in_stride + gx];
+  }
+  __syncthreads();
+  for (int it = 0; it < iters; ++it) {
+    // dual (depthmap_denoiser.cu:73-83); neighbour indices clamp to the region, which is the image clamp wherever the
+    // region ends at the image border and only touches the (discarded) rim elsewhere
+#pragma unroll
+    for (int q = 0; q < G::SLOTS; ++q) {
+      if (lidx[q] < 0) continue;
+      const int lx = lxs[q], ly = lys[q], i = lidx[q];
+      const float g = sg[i], cu = su[i];
+      const int xe = lx + 1 < ew - 1 ? lx + 1 : ew - 1;
+      const int ys = ly + 1 < eh - 1 ? ly + 1 : eh - 1;
+      const float gxv = suh[ly * G::EW + xe] - cu;
+      const float gyv = suh[ys * G::EW + lx] - cu;
+      const float tx = g * gxv * P.sigma + spx[i];
+      const float ty = g * gyv * P.sigma + spy[i];
+      const float mag = sqrtf(tx * tx + ty * ty);
+      const float den = 1.0f > mag ? 1.0f : mag;
+      spx[i] = tx / den;
+      spy[i] = ty / den;
+    }
+    __syncthreads();
+    // primal (depthmap_denoiser.cu:87-115); the boundary rules use image coordinates
+#pragma unroll
+    for (int q = 0; q < G::SLOTS; ++q) {
+      if (lidx[q] < 0) continue;
+      const int lx = lxs[q], ly = lys[q], i = lidx[q];
+      const int gx = ex0 + lx, gy = ey0 + ly;
+      const float noisy = smu[i], old_u = su[i], g = sg[i];
+      float cpx = spx[i], cpy = spy[i];
+      float wpx = spx[ly * G::EW + (lx - 1 > 0 ? lx - 1 : 0)];
+      float npy = spy[(ly - 1 > 0 ? ly - 1 : 0) * G::EW + lx];
+      if (gx == 0) wpx = 0.0f;
+      else if (gx >= P.w - 1) cpx = 0.0f;
+      if (gy == 0) npy = 0.0f;
+      else if (gy >= P.h - 1) cpy = 0.0f;
+      const float divergence = cpx - wpx + cpy - npy;
+      const float temp_u = old_u + P.tau * g * divergence;
+      float nu;
+      if ((temp_u - noisy) > (P.tau * P.lambda)) nu = temp_u - P.tau * P.lambda;
+      else if ((temp_u - noisy) < (-P.tau * P.lambda)) nu = temp_u + P.tau * P.lambda;
+      else nu = noisy;
+      su[i] = nu;
+      suh[i] = nu + P.theta * (nu - old_u);
+    }
+    __syncthreads();
+  }
+  // store the output tile
+#pragma unroll
+  for (int q = 0; q < (G::BX * G::BY) / G::THREADS; ++q) {
+    const int t = tid + q * G::THREADS;
+    const int ty = t / G::BX, tx = t - ty * G::BX;
+    const int gx = x0 + tx, gy = y0 + ty;
+    if (gx >= P.w || gy >= P.h) continue;
+    const int i = (gy - ey0) * G::EW + (gx - ex0);
+    const int gi = gy * P.stride + gx;
+    u_out[gi] = su[i];
+    uh_out[gi] = suh[i];
+    p_out[gy * P.stride2 + gx] = make_float2(spx[i], spy[i]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // device side of the arithmetic contract, for the self test
 __global__ void math_eval_kernel(int op, const float* x, const float* y, const float* z, float* out, size_t n) {
   const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;

@@ -58,6 +58,7 @@ struct MatcherWorkspace {
   unsigned int* d_packed = nullptr;      // per seed: first in-image step << 16 | number of in-image steps
   unsigned long long* d_best = nullptr;  // per seed: arg-max key
   TileInfo* d_tiles = nullptr;
+  uint2* d_tile_plan = nullptr;     // per tile, for seed_plan: (work items, need_w | need_h << 12 | off_window << 24)
   uint2* d_units = nullptr;         // (tile, first item)
   // two banks of 8 counters, used alternately frame by frame so that nobody has to memset between frames (the
   // finalize kernel of frame k clears the bank of frame k+1):
@@ -80,6 +81,7 @@ struct MatcherWorkspace {
     if (hipMalloc(reinterpret_cast<void**>(&d_packed), n * sizeof(unsigned int)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_best), n * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_tiles), static_cast<size_t>(tiles_x) * tiles_y * sizeof(TileInfo)) != hipSuccess) return -1;
+    if (hipMalloc(reinterpret_cast<void**>(&d_tile_plan), static_cast<size_t>(tiles_x) * tiles_y * sizeof(uint2)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_units), static_cast<size_t>(max_units) * sizeof(uint2)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_queue), 16 * sizeof(unsigned int)) != hipSuccess) return -1;
     if (hipHostMalloc(reinterpret_cast<void**>(&h_feedback), 4 * sizeof(unsigned int)) != hipSuccess) return -1;
@@ -91,13 +93,13 @@ struct MatcherWorkspace {
     return 0;
   }
   void release() {
-    void* all[] = {d_mean, d_dir, d_lfirst, d_packed, d_best, d_tiles, d_units, d_queue};
+    void* all[] = {d_mean, d_dir, d_lfirst, d_packed, d_best, d_tiles, d_tile_plan, d_units, d_queue};
     for (void* p : all)
       if (p) (void)hipFree(p);
     if (h_feedback) (void)hipHostFree(h_feedback);
     h_feedback = nullptr;
     d_mean = d_dir = nullptr; d_lfirst = nullptr; d_packed = nullptr; d_best = nullptr;
-    d_tiles = nullptr; d_units = nullptr; d_queue = nullptr;
+    d_tiles = nullptr; d_tile_plan = nullptr; d_units = nullptr; d_queue = nullptr;
   }
 };
 
@@ -109,6 +111,7 @@ struct MatcherArgs {
   unsigned int* packed;
   unsigned long long* best;
   TileInfo* tiles;
+  uint2* tile_plan;
   uint2* units;
   unsigned int* queue;       // this frame's counter bank
   unsigned int* queue_next;  // next frame's bank, cleared by seed_finalize
@@ -429,22 +432,40 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_kernel(SeedParams P, Matc
     }
   }
   M.tiles[tile] = ti;  // no atomics here: seed_plan turns the per-tile totals into the unit queue
+  M.tile_plan[tile] = make_uint2(static_cast<unsigned int>(total), static_cast<unsigned int>(ti.need_w) |
+                                                                        (static_cast<unsigned int>(ti.need_h) << 12) |
+                                                                        (static_cast<unsigned int>(ti.off_window) << 24));
 }
 
 // ------------------------------------------------------------------------------------------------
 // stage 1b: one workgroup turns the per-tile totals into the work-unit list (exclusive scan) and the feedback maxima
 constexpr int PLAN_THREADS = 1024;
+constexpr int PLAN_TILES_PER_THREAD = 8;  // up to 8192 tiles (e.g. 1920x1080 -> 8160) held in registers; more run a slow loop
 __global__ __launch_bounds__(PLAN_THREADS) void seed_plan_kernel(MatcherArgs M, int n_tiles, int target_units) {
   __shared__ int wave_tot[PLAN_THREADS / 64];
-  __shared__ int carry_s;
   __shared__ int red_s[4][PLAN_THREADS / 64];
   __shared__ int unit_items_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // pass 1: total work and the feedback maxima
+  // each thread owns a contiguous run of tiles; one load per tile, kept in registers for both passes
+  const int per_thread = (n_tiles + PLAN_THREADS - 1) / PLAN_THREADS;
+  const int t0 = tid * per_thread;
+  unsigned int tot[PLAN_TILES_PER_THREAD];
   int m_w = 0, m_h = 0, n_off = 0, items = 0;
-  for (int t = tid; t < n_tiles; t += PLAN_THREADS) {
-    const TileInfo ti = M.tiles[t];
-    m_w = max(m_w, ti.need_w); m_h = max(m_h, ti.need_h); n_off += ti.off_window; items += ti.total;
+#pragma unroll
+  for (int q = 0; q < PLAN_TILES_PER_THREAD; ++q) {
+    tot[q] = 0u;
+    const int t = t0 + q;
+    if (q < per_thread && t < n_tiles) {
+      const uint2 tp = M.tile_plan[t];
+      tot[q] = tp.x;
+      items += static_cast<int>(tp.x);
+      m_w = max(m_w, static_cast<int>(tp.y & 0xfffu)); m_h = max(m_h, static_cast<int>((tp.y >> 12) & 0xfffu));
+      n_off += static_cast<int>(tp.y >> 24);
+    }
+  }
+  for (int q = PLAN_TILES_PER_THREAD; q < per_thread; ++q) {  // images beyond 8192 tiles
+    const int t = t0 + q;
+    if (t < n_tiles) items += static_cast<int>(M.tile_plan[t].x);
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -462,40 +483,51 @@ __global__ __launch_bounds__(PLAN_THREADS) void seed_plan_kernel(MatcherArgs M, 
     int rounds = (items + target_units * TILE_PIX - 1) / (target_units * TILE_PIX);
     rounds = min(max(rounds, 1), MAX_UNIT_ROUNDS);
     unit_items_s = rounds * TILE_PIX;
-    carry_s = 0;
+    M.queue[1] = 0u;  // hand-out counter of this frame's search
     M.queue[2] = static_cast<unsigned int>(m_w);
     M.queue[3] = static_cast<unsigned int>(m_h);
     M.queue[4] = static_cast<unsigned int>(n_off);
     M.queue[5] = static_cast<unsigned int>(rounds * TILE_PIX);
-    M.queue[1] = 0u;  // hand-out counter of this frame's search
   }
   __syncthreads();
   const int unit_items = unit_items_s;
-  // pass 2: exclusive scan of the tiles' unit counts -> compact unit list
-  for (int chunk = 0; chunk < n_tiles; chunk += PLAN_THREADS) {
-    const int t = chunk + tid;
-    const int n_u = t < n_tiles ? (M.tiles[t].total + unit_items - 1) / unit_items : 0;
-    int incl = n_u;
+  // exclusive scan of the unit counts over threads (each thread's tiles are contiguous), then the unit list
+  int mine = 0;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int v = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += v;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    int wave_off = 0, block_tot = 0;
-    for (int wv = 0; wv < PLAN_THREADS / 64; ++wv) {
-      const int v = wave_tot[wv];
-      wave_off += wv < wave ? v : 0;
-      block_tot += v;
-    }
-    const int base = carry_s + wave_off + incl - n_u;
-    for (int u = 0; u < n_u; ++u) M.units[base + u] = make_uint2(static_cast<unsigned int>(t), static_cast<unsigned int>(u * unit_items));
-    __syncthreads();
-    if (tid == 0) carry_s += block_tot;
-    __syncthreads();
+  for (int q = 0; q < PLAN_TILES_PER_THREAD; ++q) mine += (static_cast<int>(tot[q]) + unit_items - 1) / unit_items;
+  for (int q = PLAN_TILES_PER_THREAD; q < per_thread; ++q) {
+    const int t = t0 + q;
+    if (t < n_tiles) mine += (static_cast<int>(M.tile_plan[t].x) + unit_items - 1) / unit_items;
   }
-  if (tid == 0) M.queue[0] = static_cast<unsigned int>(carry_s);
+  int incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  int wave_off = 0, block_tot = 0;
+  for (int wv = 0; wv < PLAN_THREADS / 64; ++wv) {
+    const int v = wave_tot[wv];
+    wave_off += wv < wave ? v : 0;
+    block_tot += v;
+  }
+  int base = wave_off + incl - mine;
+#pragma unroll
+  for (int q = 0; q < PLAN_TILES_PER_THREAD; ++q) {
+    const int n_u = (static_cast<int>(tot[q]) + unit_items - 1) / unit_items;  // 0 for tiles beyond this thread's run
+    for (int u = 0; u < n_u; ++u) M.units[base + u] = make_uint2(static_cast<unsigned int>(t0 + q), static_cast<unsigned int>(u * unit_items));
+    base += n_u;
+  }
+  for (int q = PLAN_TILES_PER_THREAD; q < per_thread; ++q) {
+    const int t = t0 + q;
+    if (t >= n_tiles) break;
+    const int n_u = (static_cast<int>(M.tile_plan[t].x) + unit_items - 1) / unit_items;
+    for (int u = 0; u < n_u; ++u) M.units[base + u] = make_uint2(static_cast<unsigned int>(t), static_cast<unsigned int>(u * unit_items));
+    base += n_u;
+  }
+  if (tid == 0) M.queue[0] = static_cast<unsigned int>(block_tot);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -684,7 +716,7 @@ __global__ __launch_bounds__(256) void seed_finalize_kernel(SeedParams P, Matche
 inline MatcherArgs matcher_args(const MatcherWorkspace& ws, int parity) {
   MatcherArgs M;
   M.mean = ws.d_mean; M.dir = ws.d_dir; M.lfirst = ws.d_lfirst; M.packed = ws.d_packed; M.best = ws.d_best;
-  M.tiles = ws.d_tiles; M.units = ws.d_units; M.tiles_x = ws.tiles_x;
+  M.tiles = ws.d_tiles; M.tile_plan = ws.d_tile_plan; M.units = ws.d_units; M.tiles_x = ws.tiles_x;
   M.queue = ws.d_queue + 8 * parity;
   M.queue_next = ws.d_queue + 8 * (parity ^ 1);
   M.feedback = ws.h_feedback;
