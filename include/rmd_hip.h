@@ -163,7 +163,7 @@ int rmd_hip_denoiser_result(const rmd_hip_denoiser_t* d, const rmd_hip_image_t**
 /* L, tau, sigma, theta of denoise::DeviceData (depthmap_denoiser.cu:124-141) */
 int rmd_hip_denoiser_constants(const rmd_hip_denoiser_t* d, float* out4);
 #define RMD_HIP_DENOISE_OPT_TIMING 1
-#define RMD_HIP_DENOISE_OPT_ITERS_PER_LAUNCH 2 /* temporal blocking depth, 1..4 (default 4; 1 = one launch per iteration) */
+#define RMD_HIP_DENOISE_OPT_ITERS_PER_LAUNCH 2 /* TV iterations per launch: 0 = chosen from the image size (default), 1 = one launch per iteration, 2..4 = temporal blocking depth */
 int rmd_hip_denoiser_set_option(rmd_hip_denoiser_t* d, int option, int value);
 /* accumulated device time / launches of the TV iteration kernel since the last denoise() started */
 int rmd_hip_denoiser_timing(const rmd_hip_denoiser_t* d, double* total_ms, long* launches);

@@ -323,7 +323,8 @@ struct rmd_hip_denoiser {
   float large_sigma_sq = -1.0f;
   hipStream_t stream = nullptr;
   int result_index = 0;
-  int opt_timing = 0, opt_iters_per_launch = 4;
+  float* h_staging = nullptr;  // pinned, W x H: device -> pinned (async DMA) -> caller's pageable buffer
+  int opt_timing = 0, opt_iters_per_launch = 0;
   StageTimer timer;
 };
 
@@ -685,6 +686,7 @@ int rmd_hip_denoiser_destroy(rmd_hip_denoiser_t* d) {
   (void)hipSetDevice(d->device);
   if (d->stream) (void)hipStreamSynchronize(d->stream);
   d->timer.destroy();
+  if (d->h_staging) (void)hipHostFree(d->h_staging);
   rmd_hip_image* all[] = {&d->u[0], &d->u[1], &d->u_head[0], &d->u_head[1], &d->p[0], &d->p[1], &d->g};
   for (auto* im : all)
     if (im->owns && im->data) (void)hipFree(im->data);
@@ -744,7 +746,7 @@ int rmd_hip_denoiser_set_option(rmd_hip_denoiser_t* d, int option, int value) {
   switch (option) {
     case RMD_HIP_DENOISE_OPT_TIMING: d->opt_timing = value != 0; return RMD_HIP_OK;
     case RMD_HIP_DENOISE_OPT_ITERS_PER_LAUNCH:
-      if (value < 1 || value > 4) return fail(RMD_HIP_ERR_INVALID_ARG, "iters_per_launch %d outside 1..4", value);
+      if (value < 0 || value > 4) return fail(RMD_HIP_ERR_INVALID_ARG, "iters_per_launch %d outside 0..4", value);
       d->opt_iters_per_launch = value;
       return RMD_HIP_OK;
     default: return fail(RMD_HIP_ERR_INVALID_ARG, "denoiser_set_option: unknown option %d", option);
@@ -802,7 +804,7 @@ int rmd_hip_denoiser_denoise(rmd_hip_denoiser_t* d, const rmd_hip_image_t* mu, c
   auto bufs = [&](int b) {
     return std::make_tuple(static_cast<float*>(d->u[b].data), static_cast<float*>(d->u_head[b].data), static_cast<float2*>(d->p[b].data));
   };
-  if (d->opt_iters_per_launch <= 1) {
+  if (d->opt_iters_per_launch == 1) {
     const dim3 block(rmdk::TV_TX, rmdk::TV_TY);
     const dim3 grid((d->width + rmdk::TV_TX - 1) / rmdk::TV_TX, (d->height + rmdk::TV_TY - 1) / rmdk::TV_TY);
     for (int it = 0; it < iterations; ++it) {
@@ -814,29 +816,39 @@ int rmd_hip_denoiser_denoise(rmd_hip_denoiser_t* d, const rmd_hip_image_t* mu, c
       ++n_launches;
     }
   } else {
-    constexpr int KMAX = 4;
-    using G = rmdk::TvBlocked<KMAX>;
-    const int k = d->opt_iters_per_launch < KMAX ? d->opt_iters_per_launch : KMAX;
-    const dim3 block(G::THREADS), grid((d->width + G::BX - 1) / G::BX, (d->height + G::BY - 1) / G::BY);
-    for (int done = 0; done < iterations; done += k) {
-      const int now = iterations - done < k ? iterations - done : k;
-      const int nxt = cur_buf ^ 1;
-      auto [ui, uhi, pi] = bufs(cur_buf);
-      auto [uo, uho, po] = bufs(nxt);
-      hipLaunchKernelGGL((rmdk::tv_iterate_blocked_kernel<KMAX>), grid, block, 0, d->stream, P, ui, uhi, pi, uo, uho, po, now);
-      cur_buf = nxt;
-      ++n_launches;
-    }
+    // two geometries: small images need many small workgroups to fill 256 CUs (32x8 tile, 2 iterations per launch);
+    // from ~1 Mpixel on, 64x16 tiles with 4 iterations per launch cut the traffic further
+    const bool big = static_cast<long long>(d->width) * d->height >= (1 << 20) && d->opt_iters_per_launch != 2;
+    auto run = [&](auto geom, int kmax) {
+      using G = decltype(geom);
+      const int k = d->opt_iters_per_launch == 0 ? kmax : (d->opt_iters_per_launch < kmax ? d->opt_iters_per_launch : kmax);
+      const dim3 block(G::THREADS), grid((d->width + G::BX - 1) / G::BX, (d->height + G::BY - 1) / G::BY);
+      for (int done = 0; done < iterations; done += k) {
+        const int now = iterations - done < k ? iterations - done : k;
+        const int nxt = cur_buf ^ 1;
+        auto [ui, uhi, pi] = bufs(cur_buf);
+        auto [uo, uho, po] = bufs(nxt);
+        if (big) hipLaunchKernelGGL((rmdk::tv_iterate_blocked_kernel<64, 16, 4>), grid, block, 0, d->stream, P, ui, uhi, pi, uo, uho, po, now);
+        else hipLaunchKernelGGL((rmdk::tv_iterate_blocked_kernel<32, 8, 2>), grid, block, 0, d->stream, P, ui, uhi, pi, uo, uho, po, now);
+        cur_buf = nxt;
+        ++n_launches;
+      }
+    };
+    if (big) run(rmdk::TvBlocked<64, 16, 4>(), 4);
+    else run(rmdk::TvBlocked<32, 8, 2>(), 2);
   }
   HIP_TRY(hipGetLastError());
   if (d->opt_timing) HIP_TRY(hipEventRecord(ev1, d->stream));
   d->result_index = cur_buf;
+  const size_t out_bytes = static_cast<size_t>(d->width) * d->height * 4;
   if (host_denoised) {
     const rmd_hip_image& r = d->u[cur_buf];
     const size_t row = static_cast<size_t>(r.width) * 4;
-    HIP_TRY(hipMemcpy2DAsync(host_denoised, row, r.data, r.pitch, row, r.height, hipMemcpyDeviceToHost, d->stream));
+    if (!d->h_staging) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&d->h_staging), out_bytes));
+    HIP_TRY(hipMemcpy2DAsync(d->h_staging, row, r.data, r.pitch, row, r.height, hipMemcpyDeviceToHost, d->stream));
   }
   HIP_TRY(hipStreamSynchronize(d->stream));
+  if (host_denoised) memcpy(host_denoised, d->h_staging, out_bytes);
   if (d->opt_timing) {
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) { d->timer.total_ms = ms; d->timer.launches = n_launches; }

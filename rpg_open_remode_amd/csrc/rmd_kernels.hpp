@@ -362,19 +362,19 @@ __global__ __launch_bounds__(TV_TX* TV_TY) void tv_iterate_kernel(TvParams P, co
 // image border (the dual looks east/south, the primal west/north), so after `iters` iterations exactly the output tile
 // is valid.  Per pixel the arithmetic is that of tv_iterate_kernel, hence the same bits; HBM traffic per iteration
 // drops from 40 B/pixel to (24*(BX+2K)(BY+2K) + 16*BX*BY)/(K*BX*BY) ~= 14 B/pixel at K = 4.
-template <int KMAX>
+template <int BX_, int BY_, int KMAX>
 struct TvBlocked {
-  static constexpr int BX = 64, BY = 16, THREADS = 256;
+  static constexpr int BX = BX_, BY = BY_, THREADS = 256;
   static constexpr int EW = BX + 2 * KMAX, EH = BY + 2 * KMAX, EN = EW * EH;
   static constexpr int SLOTS = (EN + THREADS - 1) / THREADS;
 };
 
-template <int KMAX>
+template <int BX_, int BY_, int KMAX>
 __global__ __launch_bounds__(256) void tv_iterate_blocked_kernel(TvParams P, const float* __restrict__ u_in,
                                                                  const float* __restrict__ uh_in, const float2* __restrict__ p_in,
                                                                  float* __restrict__ u_out, float* __restrict__ uh_out,
                                                                  float2* __restrict__ p_out, int iters) {
-  using G = TvBlocked<KMAX>;
+  using G = TvBlocked<BX_, BY_, KMAX>;
   __shared__ float su[G::EN], suh[G::EN], spx[G::EN], spy[G::EN], sg[G::EN], smu[G::EN];
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x * G::BX, y0 = blockIdx.y * G::BY;

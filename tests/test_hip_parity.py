@@ -238,7 +238,7 @@ def test_error_paths():
 
 # ---------------------------------------------------------------------------------------------- denoiser
 @pytest.mark.parametrize("wh", [(160, 120), (101, 67), (64, 5), (3, 70)])
-@pytest.mark.parametrize("iters_per_launch", [1, 4])
+@pytest.mark.parametrize("iters_per_launch", [0, 1, 2, 4])
 def test_denoiser_bit_exact(wh, iters_per_launch):
     w, h = wh
     seq = sequence(max(w, 24), max(h, 24), 8)
@@ -267,6 +267,34 @@ def test_denoiser_bit_exact(wh, iters_per_launch):
                                                 exp.ctypes.data, lam, iters)
         assert rc == 0
         assert O.planes_equal(exp, got), f"{w}x{h} lambda {lam} iters {iters}: {O.count_mismatch(exp, got)} pixels differ"
+
+
+@pytest.mark.parametrize("iters_per_launch", [0, 3])
+def test_denoiser_bit_exact_large_image_geometry(iters_per_launch):
+    """>= 1 Mpixel selects the 64x16 / 4-iterations-per-launch geometry"""
+    w, h = 1290, 821
+    rng = np.random.default_rng(77)
+    mu = rng.uniform(1.0, 2.0, (h, w)).astype(np.float32)
+    sig = (10.0 ** rng.uniform(-6, -1, (h, w))).astype(np.float32)
+    a = rng.uniform(1, 30, (h, w)).astype(np.float32)
+    b = rng.uniform(1, 30, (h, w)).astype(np.float32)
+    imgs = []
+    for arr in (mu, sig, a, b):
+        im = api.DeviceImage(w, h, np.float32)
+        im.setDevData(arr)
+        imgs.append(im)
+    d = api.DepthmapDenoiser(w, h)
+    d.setOption(api.DENOISE_OPT_ITERS_PER_LAUNCH, iters_per_launch)
+    d.setLargeSigmaSq(1.0)
+    ol = O.OracleLib("port", 5)
+    od = O.Denoiser(ol, w, h)
+    od.set_large_sigma_sq(1.0)
+    for lam, iters in ((0.5, 1), (0.5, 7), (0.3, 26)):
+        got = d.denoise(*imgs, lam, iters)
+        exp = np.empty((h, w), np.float32)
+        assert ol.lib.orc_denoiser_denoise_planes(od.ptr, mu.ctypes.data, sig.ctypes.data, a.ctypes.data, b.ctypes.data,
+                                                  exp.ctypes.data, lam, iters) == 0
+        assert O.planes_equal(exp, got), f"lambda {lam} iters {iters}: {O.count_mismatch(exp, got)} pixels differ"
 
 
 def test_denoiser_after_sequence_matches_oracle_and_reference_kernel():
