@@ -724,6 +724,8 @@ int rmd_hip_denoiser_create(int width, int height, rmd_hip_denoiser_t** out) {
     if (rc != RMD_HIP_OK) return bail(rc);
     d->p[k].owner_stream = d->stream;
   }
+  if (hipHostMalloc(reinterpret_cast<void**>(&d->h_staging), static_cast<size_t>(width) * height * 4) != hipSuccess)
+    return bail(fail(RMD_HIP_ERR_RUNTIME, "denoiser_create: pinned staging buffer"));
   if (hipDeviceSynchronize() != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "denoiser_create: device synchronisation failed"));
   *out = d;
   return RMD_HIP_OK;
@@ -844,7 +846,6 @@ int rmd_hip_denoiser_denoise(rmd_hip_denoiser_t* d, const rmd_hip_image_t* mu, c
   if (host_denoised) {
     const rmd_hip_image& r = d->u[cur_buf];
     const size_t row = static_cast<size_t>(r.width) * 4;
-    if (!d->h_staging) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&d->h_staging), out_bytes));
     HIP_TRY(hipMemcpy2DAsync(d->h_staging, row, r.data, r.pitch, row, r.height, hipMemcpyDeviceToHost, d->stream));
   }
   HIP_TRY(hipStreamSynchronize(d->stream));
