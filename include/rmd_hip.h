@@ -112,6 +112,13 @@ int rmd_hip_seeds_set_reference_device(rmd_hip_seeds_t* s, const float* dev_img,
                                        const float* T_curr_world, float min_depth, float max_depth);
 int rmd_hip_seeds_update_device(rmd_hip_seeds_t* s, const float* dev_img, size_t stride_elems,
                                 const float* T_curr_world);
+/* same two calls for an 8-bit gray frame (contiguous W x H bytes): what rmd::Depthmap::inputImage does on the host
+ * (src/depthmap.cpp:95-106, cv::Mat::convertTo(CV_32F, 1.0f/255.0f)) happens on the device, bit for bit; the frame goes
+ * through pinned double buffers, so update_u8 returns as soon as the bytes are staged and the host copy of the next frame
+ * overlaps the device work of this one */
+int rmd_hip_seeds_set_reference_u8(rmd_hip_seeds_t* s, const unsigned char* host_gray, const float* T_curr_world,
+                                   float min_depth, float max_depth);
+int rmd_hip_seeds_update_u8(rmd_hip_seeds_t* s, const unsigned char* host_gray, const float* T_curr_world);
 /* downloadDepthmap/downloadConvergence :160-168 and the RMD_BUILD_TESTS downloads :205-230 */
 int rmd_hip_seeds_download(const rmd_hip_seeds_t* s, int plane, void* host_dst);
 /* test hook: overwrite mu / sigma_sq / a / b (planes 0..3) */

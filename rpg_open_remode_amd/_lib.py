@@ -46,6 +46,8 @@ SIGNATURES = {
     "rmd_hip_seeds_update": (_i, [_p, _p, _p]),
     "rmd_hip_seeds_set_reference_device": (_i, [_p, _p, _sz, _p, _f, _f]),
     "rmd_hip_seeds_update_device": (_i, [_p, _p, _sz, _p]),
+    "rmd_hip_seeds_set_reference_u8": (_i, [_p, _p, _p, _f, _f]),
+    "rmd_hip_seeds_update_u8": (_i, [_p, _p, _p]),
     "rmd_hip_seeds_download": (_i, [_p, _i, _p]),
     "rmd_hip_seeds_upload": (_i, [_p, _i, _p]),
     "rmd_hip_seeds_plane": (_i, [_p, _i, _pp]),

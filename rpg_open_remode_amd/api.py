@@ -223,6 +223,20 @@ class SeedMatrix:
         check(_lib.lib().rmd_hip_seeds_update(self.ptr, img.ctypes.data, T.ctypes.data))
         return True
 
+    def setReferenceImageU8(self, gray_u8, T_curr_world, min_depth, max_depth):
+        img = np.ascontiguousarray(gray_u8, np.uint8)
+        assert img.shape == (self.height, self.width)
+        T = _as_pose(T_curr_world)
+        check(_lib.lib().rmd_hip_seeds_set_reference_u8(self.ptr, img.ctypes.data, T.ctypes.data, float(min_depth), float(max_depth)))
+        return True
+
+    def updateU8(self, gray_u8, T_curr_world):
+        img = np.ascontiguousarray(gray_u8, np.uint8)
+        assert img.shape == (self.height, self.width)
+        T = _as_pose(T_curr_world)
+        check(_lib.lib().rmd_hip_seeds_update_u8(self.ptr, img.ctypes.data, T.ctypes.data))
+        return True
+
     def setReferenceImageDevice(self, dev_ptr, stride_elems, T_curr_world, min_depth, max_depth):
         T = _as_pose(T_curr_world)
         check(_lib.lib().rmd_hip_seeds_set_reference_device(self.ptr, dev_ptr, int(stride_elems), T.ctypes.data,
@@ -377,21 +391,21 @@ class Depthmap:
         self.T_world_ref_ = SE3()
 
     @staticmethod
-    def _input_image(img_8uc1):  # depthmap.cpp:95-106 (undistortion is outside this path)
+    def _check_u8(img_8uc1):  # depthmap.cpp:95-106: the x(1/255) conversion runs on the device (undistortion is outside this path)
         img = np.asarray(img_8uc1)
         if img.dtype != np.uint8:
             raise TypeError("Depthmap expects 8-bit gray images (CV_8UC1)")
-        return (img.astype(np.float32) * np.float32(1.0 / 255.0)).astype(np.float32)
+        return img
 
     def setReferenceImage(self, img_curr, T_curr_world, min_depth, max_depth):  # depthmap.cpp:63-83
         self.denoiser_.setLargeSigmaSq(max_depth - min_depth)
-        ret = self.seeds_.setReferenceImage(self._input_image(img_curr), T_curr_world, min_depth, max_depth)
+        ret = self.seeds_.setReferenceImageU8(self._check_u8(img_curr), T_curr_world, min_depth, max_depth)
         self.ref_img_8uc1_ = np.array(img_curr, copy=True)
         self.T_world_ref_ = (T_curr_world if isinstance(T_curr_world, SE3) else SE3(T_curr_world)).inv()
         return ret
 
     def update(self, img_curr, T_curr_world):  # depthmap.cpp:85-93
-        self.seeds_.update(self._input_image(img_curr), T_curr_world)
+        self.seeds_.updateU8(self._check_u8(img_curr), T_curr_world)
 
     def downloadDepthmap(self):
         self.output_depth_32fc1_ = self.seeds_.downloadDepthmap()

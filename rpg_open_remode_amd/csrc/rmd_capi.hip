@@ -183,6 +183,12 @@ struct rmd_hip_seeds {
   bool finalize_pending = false;
   rmdk::SeedParams P_pending;
   int opt_lazy = 1;
+  // 8-bit ingest: two pinned staging buffers + two device byte planes, used alternately so that the host-side copy of
+  // frame k+1 overlaps the device work of frame k; an event per slot says when its H2D copy has been consumed
+  unsigned char* h_u8[2] = {nullptr, nullptr};
+  unsigned char* d_u8[2] = {nullptr, nullptr};
+  hipEvent_t u8_free[2] = {nullptr, nullptr};
+  int u8_pitch = 0, u8_slot = 0;
   StageTimer timers[RMD_HIP_NUM_SEED_STAGES];
   long long last_stats[16] = {0};
   bool stats_pending = false;
@@ -430,6 +436,11 @@ int rmd_hip_seeds_destroy(rmd_hip_seeds_t* s) {
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   for (auto& t : s->timers) t.destroy();
+  for (int k = 0; k < 2; ++k) {
+    if (s->h_u8[k]) (void)hipHostFree(s->h_u8[k]);
+    if (s->d_u8[k]) (void)hipFree(s->d_u8[k]);
+    if (s->u8_free[k]) (void)hipEventDestroy(s->u8_free[k]);
+  }
   if (s->region_start) (void)hipEventDestroy(s->region_start);
   if (s->region_stop) (void)hipEventDestroy(s->region_stop);
   for (auto& pl : s->planes)
@@ -544,6 +555,55 @@ int rmd_hip_seeds_update_device(rmd_hip_seeds_t* s, const float* dev_img, size_t
   // zero copy: the kernels read the caller's buffer in place (see the header for the lifetime rule)
   s->P.cur = dev_img;
   s->P.cur_stride = static_cast<int>(stride_elems);
+  return seeds_after_frame(s, T_curr_world);
+}
+
+// 8-bit frame -> pinned staging -> device bytes -> f32 plane `dst_plane` (async on the handle's stream)
+static int seeds_ingest_u8(rmd_hip_seeds* s, const unsigned char* host_gray, int dst_plane) {
+  if (!s->h_u8[0]) {
+    s->u8_pitch = (s->width + 255) / 256 * 256;
+    const size_t bytes = static_cast<size_t>(s->u8_pitch) * s->height;
+    for (int k = 0; k < 2; ++k) {
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_u8[k]), bytes));
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_u8[k]), bytes));
+      HIP_TRY(hipEventCreateWithFlags(&s->u8_free[k], hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(s->u8_free[k], s->stream));
+    }
+  }
+  const int k = s->u8_slot;
+  s->u8_slot ^= 1;
+  HIP_TRY(hipEventSynchronize(s->u8_free[k]));  // the copy that last used this staging buffer has drained
+  for (int y = 0; y < s->height; ++y)
+    memcpy(s->h_u8[k] + static_cast<size_t>(y) * s->u8_pitch, host_gray + static_cast<size_t>(y) * s->width, s->width);
+  const size_t bytes = static_cast<size_t>(s->u8_pitch) * s->height;
+  HIP_TRY(hipMemcpyAsync(s->d_u8[k], s->h_u8[k], bytes, hipMemcpyHostToDevice, s->stream));
+  HIP_TRY(hipEventRecord(s->u8_free[k], s->stream));
+  const rmd_hip_image& im = s->planes[dst_plane];
+  const dim3 block(64, 4), grid((s->width + 255) / 256, (s->height + 3) / 4);
+  hipLaunchKernelGGL(rmdk::ingest_u8_kernel, grid, block, 0, s->stream, s->d_u8[k], s->u8_pitch, static_cast<float*>(im.data),
+                     static_cast<int>(im.stride), s->width, s->height);
+  HIP_TRY(hipGetLastError());
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_seeds_set_reference_u8(rmd_hip_seeds_t* s, const unsigned char* host_gray, const float* T_curr_world, float min_depth,
+                                   float max_depth) {
+  if (!s || !host_gray || !T_curr_world) return fail(RMD_HIP_ERR_INVALID_ARG, "set_reference_u8: null argument");
+  TRY(seeds_bind_device(s));
+  TRY(seeds_flush(s));
+  TRY(seeds_ingest_u8(s, host_gray, RMD_HIP_PLANE_REF_IMG));
+  return seeds_after_reference(s, T_curr_world, min_depth, max_depth);
+}
+
+int rmd_hip_seeds_update_u8(rmd_hip_seeds_t* s, const unsigned char* host_gray, const float* T_curr_world) {
+  if (!s || !host_gray || !T_curr_world) return fail(RMD_HIP_ERR_INVALID_ARG, "update_u8: null argument");
+  if (!s->has_reference) return fail(RMD_HIP_ERR_NOT_READY, "update_u8: setReferenceImage has not been called");
+  TRY(seeds_bind_device(s));
+  // the previous update's search may still be reading planes[CURR_IMG]; everything is ordered by the stream
+  TRY(seeds_ingest_u8(s, host_gray, RMD_HIP_PLANE_CURR_IMG));
+  const rmd_hip_image& im = s->planes[RMD_HIP_PLANE_CURR_IMG];
+  s->P.cur = static_cast<const float*>(im.data);
+  s->P.cur_stride = s->P.stride;
   return seeds_after_frame(s, T_curr_world);
 }
 

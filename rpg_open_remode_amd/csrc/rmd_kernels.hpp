@@ -78,6 +78,30 @@ __global__ __launch_bounds__(256) void seed_init_kernel(SeedParams P) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Frame ingest (reference: Depthmap::inputImage, src/depthmap.cpp:95-106 -- cv::Mat::convertTo(CV_32F, 1.0f/255.0f) on the
+// host): 8-bit gray -> f32 plane on the device.  One fp32 multiply per pixel, identical bits to the host conversion.
+// 4 pixels per lane: one 32-bit load, one 128-bit store.
+__global__ __launch_bounds__(256) void ingest_u8_kernel(const unsigned char* __restrict__ src, int src_pitch, float* __restrict__ dst,
+                                                        int dst_stride, int w, int h) {
+  const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x4 >= w || y >= h) return;
+  const unsigned char* row = src + static_cast<size_t>(y) * src_pitch;
+  float* out = dst + static_cast<size_t>(y) * dst_stride;
+  if (x4 + 3 < w) {
+    const unsigned int v = *reinterpret_cast<const unsigned int*>(row + x4);  // src_pitch and x4 are multiples of 4
+    float4 f;
+    f.x = static_cast<float>(v & 0xffu) * (1.0f / 255.0f);
+    f.y = static_cast<float>((v >> 8) & 0xffu) * (1.0f / 255.0f);
+    f.z = static_cast<float>((v >> 16) & 0xffu) * (1.0f / 255.0f);
+    f.w = static_cast<float>(v >> 24) * (1.0f / 255.0f);
+    *reinterpret_cast<float4*>(out + x4) = f;
+  } else {
+    for (int x = x4; x < w; ++x) out[x] = static_cast<float>(row[x]) * (1.0f / 255.0f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // seed_check.cu:28-67 as a function of one pixel's state
 RMDK_D int seed_check(const SeedParams& P, int x, int y, float sigma_sq, float a, float b, int side) {
   // the reference compares in size_t: width - SIDE - 1 wraps for tiny images

@@ -75,6 +75,7 @@ class Sequence:
         self.width, self.height, self.n_frames, self.seed = width, height, n_frames, seed
         self.K = intrinsics(width, height)
         self.images = []
+        self.gray = []
         self.T_curr_world = []
         self.T_world_cam = []
         self.range0 = None
@@ -83,6 +84,7 @@ class Sequence:
             gray, rng = render(width, height, T, seed, want_range=(k == 0), K=self.K)
             if k == 0:
                 self.range0 = rng
+            self.gray.append(gray)
             self.images.append(to_float_image(gray))
             self.T_world_cam.append(T)
             self.T_curr_world.append(np.ascontiguousarray(invert_pose(T).astype(np.float32).reshape(12)))

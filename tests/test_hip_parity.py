@@ -221,6 +221,33 @@ def test_device_resident_frames_equal_host_frames():
     assert_states_equal(h1.state(), h2.state(), "device-resident input")
 
 
+def test_u8_ingest_and_depthmap_facade_equal_float_path():
+    """8-bit frames through pinned double buffers + device conversion (Depthmap::inputImage on the GPU) == float frames"""
+    seq = sequence(101, 67, 9)
+    hf, hu = _hip_seeds(seq, 5, 1), _hip_seeds(seq, 5, 1)
+    hf.setReferenceImage(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    hu.setReferenceImageU8(seq.gray[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    assert np.array_equal(hu.download(api.PLANE_REF_IMG), seq.images[0])
+    for k in range(1, 9):
+        hf.update(seq.images[k], seq.T_curr_world[k])
+        hu.updateU8(seq.gray[k], seq.T_curr_world[k])  # returns while the frame is still in flight; buffers alternate
+    assert np.array_equal(hu.download(api.PLANE_CURR_IMG), seq.images[8])
+    assert_states_equal(hf.state(), hu.state(), "u8 ingest")
+    # rmd::Depthmap mirror (constructor order fx, cx, fy, cy as depthmap.h:37-43)
+    fx, fy, cx, cy = seq.K
+    dm = api.Depthmap(seq.width, seq.height, fx, cx, fy, cy)
+    dm.setReferenceImage(seq.gray[0], api.SE3(seq.T_curr_world[0]), seq.min_depth, seq.max_depth)
+    for k in range(1, 9):
+        dm.update(seq.gray[k], api.SE3(seq.T_curr_world[k]))
+    dm.downloadDepthmap()
+    assert O.planes_equal(dm.getDepthmap(), hf.downloadDepthmap())
+    dm.downloadConvergenceMap()
+    assert np.array_equal(dm.getConvergenceMap(), hf.downloadConvergence())
+    assert dm.getConvergedCount() == hf.getConvergedCount()
+    dm.downloadDenoisedDepthmap(0.5, 10)
+    assert dm.getDepthmap().shape == (seq.height, seq.width) and np.isfinite(dm.getDepthmap()).all()
+
+
 def test_error_paths():
     seq = sequence(64, 48, 2)
     s = _hip_seeds(seq, 5, 1)
