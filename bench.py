@@ -47,6 +47,7 @@ def cpu_baseline(seq, budget_s, gpu_sample_fn):
     """The reference's own kernels (oracle/_ref, built from /root/reference for the host) over the first frames
     of the same sequence, all host cores, until `budget_s` is used up."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # idle OpenMP workers must not spin while the GPU sample is timed
     import oracles as O
     kind = "reference" if O.available("ref", SIDE) else "port"
     olib = O.OracleLib("ref" if kind == "reference" else "port", SIDE)
@@ -62,6 +63,7 @@ def cpu_baseline(seq, budget_s, gpu_sample_fn):
     mpix = seq.width * seq.height * n / dt / 1e6
     out = {"value": round(mpix, 4), "unit": "Mpix/s", "cores": int(cores), "kind": kind,
            "sample": f"updates 1..{n} of the same {seq.width}x{seq.height} sequence (patch side {SIDE}), {dt:.1f} s"}
+    time.sleep(0.3)
     gpu_same = gpu_sample_fn(n)
     if gpu_same:
         out["gpu_same_sample"] = round(gpu_same, 2)
