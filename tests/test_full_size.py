@@ -1,0 +1,134 @@
+"""GPU parity at BASELINE.json's full sizes (configs[1], [2], [3], [4]).
+
+The oracle (Oracle B, oracle/remode_oracle.cpp) is fast enough to follow the GPU frame by frame even at these sizes, so
+the bar stays BIT-EXACT on every plane; on top of that the two independent device implementations (per-pixel baseline
+kernel, matcher 0, and the load-balanced pipeline, matcher 1) are compared with each other over longer runs, and the
+denoiser's temporally blocked kernel against its one-iteration-per-launch form.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracles as O
+from common import assert_states_equal, sequence
+from rpg_open_remode_amd import api
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _more_oracle_threads():
+    """Large images: let the OpenMP oracle use more host cores than the small-image default of conftest.py."""
+    lib = O.OracleLib("port", 9)
+    before = lib.fn("max_threads")()
+    lib.fn("set_num_threads")(max(1, min(48, os.cpu_count() or 1)))
+    yield
+    lib.fn("set_num_threads")(before)
+
+
+def _hip(seq, side, matcher):
+    s = api.SeedMatrix(seq.width, seq.height, api.PinholeCamera(*seq.K), patch_side=side)
+    s.setOption(api.OPT_MATCHER, matcher)
+    s.setReferenceImage(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    return s
+
+
+def _oracle(seq, side):
+    o = O.Seeds(O.OracleLib("port", side), seq.width, seq.height, seq.K)
+    o.set_reference(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    return o
+
+
+def _denoise_oracle(seq, side, planes, lam, iters):
+    """Oracle TV-L1 on the given (mu, sigma_sq, a, b) planes."""
+    olib = O.OracleLib("port", side)
+    o = O.Seeds(olib, seq.width, seq.height, seq.K)
+    o.set_reference(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    for p in range(4):
+        o.upload(p, planes[p])
+    d = O.Denoiser(olib, seq.width, seq.height)
+    d.set_large_sigma_sq(seq.max_depth - seq.min_depth)
+    return d.denoise(o, lam, iters)
+
+
+def test_config1_vga_200_frames_side9_then_tvl1_200():
+    """configs[1]: 640x480, 1 reference + 199 updates, patch side 9, denoise(0.5, 200) -- every frame against the oracle."""
+    seq = sequence(640, 480, 200)
+    hip, orc = _hip(seq, 9, 1), _oracle(seq, 9)
+    for k in range(1, 200):
+        hip.update(seq.images[k], seq.T_curr_world[k])
+        orc.update(seq.images[k], seq.T_curr_world[k])
+        if k in (1, 2, 5, 10) or k % 33 == 0 or k == 199:
+            assert_states_equal(orc.state(), hip.state(), f"VGA side 9 update {k}")
+    n_conv = hip.getConvergedCount()
+    assert n_conv == orc.converged_count()
+    assert n_conv > 0.5 * 640 * 480, "the benchmark sequence is expected to converge for most seeds"
+    den = api.DepthmapDenoiser(640, 480)
+    den.setLargeSigmaSq(seq.max_depth - seq.min_depth)
+    got = den.denoise(hip.getMu(), hip.getSigmaSq(), hip.getA(), hip.getB(), 0.5, 200)
+    want = _denoise_oracle(seq, 9, hip.state(), 0.5, 200)
+    assert O.count_mismatch(want, got) == 0
+    # the converged depths are right, not merely equal: compare with the analytic range image of the generator
+    conv = hip.downloadConvergence() == api.ConvergenceStates.CONVERGED
+    err = np.abs(hip.downloadDepthmap()[conv] - seq.range0[conv])
+    assert np.median(err) < 2e-3 and np.mean(err < 0.02) > 0.97
+
+
+@pytest.mark.parametrize("scene", [1, 2, 3, 4, 5, 6, 7])
+def test_config4_other_scenes(scene):
+    """configs[3]: eight independent 640x480 sequences (scene seeds 0..7; seed 0 is the test above)."""
+    seq = sequence(640, 480, 9, scene)
+    hip, base, orc = _hip(seq, 9, 1), _hip(seq, 9, 0), _oracle(seq, 9)
+    for k in range(1, 9):
+        hip.update(seq.images[k], seq.T_curr_world[k])
+        base.update(seq.images[k], seq.T_curr_world[k])
+        if k <= 3:
+            orc.update(seq.images[k], seq.T_curr_world[k])
+            assert_states_equal(orc.state(), hip.state(), f"scene {scene} update {k}")
+    assert_states_equal(base.state(), hip.state(), f"scene {scene}: pipeline vs per-pixel kernel after 8 updates")
+
+
+def test_config2_1280x960_search_hits_the_extent_cap():
+    """configs[2]: 1280x960, side 9; the early searches are capped at RMD_MAX_EXTENT_EPIPOLAR_SEARCH (143 steps)."""
+    seq = sequence(1280, 960, 31)
+    hip, base, orc = _hip(seq, 9, 1), _hip(seq, 9, 0), _oracle(seq, 9)
+    hip.setOption(api.OPT_COLLECT_STATS, 1)
+    max_steps_per_seed = 0.0
+    for k in range(1, 31):
+        hip.update(seq.images[k], seq.T_curr_world[k])
+        base.update(seq.images[k], seq.T_curr_world[k])
+        if k <= 8:
+            orc.update(seq.images[k], seq.T_curr_world[k])
+            assert_states_equal(orc.state(), hip.state(), f"1280x960 update {k}")
+            st, ost = hip.lastStats(), orc.last_stats()
+            assert (st["live_seeds"], st["steps"], st["ncc_evals"]) == (ost["live_seeds"], ost["steps"], ost["ncc_evals"])
+            max_steps_per_seed = max(max_steps_per_seed, st["steps"] / max(st["live_seeds"], 1))
+        if k == 8:
+            hip.setOption(api.OPT_COLLECT_STATS, 0)
+    assert max_steps_per_seed > 30.0, max_steps_per_seed
+    assert_states_equal(base.state(), hip.state(), "1280x960: pipeline vs per-pixel kernel after 30 updates")
+    assert hip.getConvergedCount() == base.getConvergedCount()
+
+
+def test_config5_1080p_updates_and_tvl1_500():
+    """configs[4]: 1920x1080, side 9, denoise(0.5, 500): updates against the oracle, the blocked TV-L1 kernel against the
+    one-iteration-per-launch kernel over all 500 iterations and against the oracle."""
+    seq = sequence(1920, 1080, 13)
+    hip, base, orc = _hip(seq, 9, 1), _hip(seq, 9, 0), _oracle(seq, 9)
+    for k in range(1, 13):
+        hip.update(seq.images[k], seq.T_curr_world[k])
+        base.update(seq.images[k], seq.T_curr_world[k])
+        if k <= 4:
+            orc.update(seq.images[k], seq.T_curr_world[k])
+            assert_states_equal(orc.state(), hip.state(), f"1080p update {k}")
+    assert_states_equal(base.state(), hip.state(), "1080p: pipeline vs per-pixel kernel after 12 updates")
+    outs = []
+    for ipl in (0, 1):
+        den = api.DepthmapDenoiser(1920, 1080)
+        den.setOption(api.DENOISE_OPT_ITERS_PER_LAUNCH, ipl)
+        den.setLargeSigmaSq(seq.max_depth - seq.min_depth)
+        outs.append(den.denoise(hip.getMu(), hip.getSigmaSq(), hip.getA(), hip.getB(), 0.5, 500))
+    assert O.count_mismatch(outs[0], outs[1]) == 0
+    want = _denoise_oracle(seq, 9, hip.state(), 0.5, 500)
+    assert O.count_mismatch(want, outs[0]) == 0
