@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample (0 disables)")
     ap.add_argument("--matcher", type=int, default=1, help="0 per-pixel kernel, 1 tile kernel")
     ap.add_argument("--window", type=int, default=0, help="search LDS window: 0 auto, 1 small, 2 large")
+    ap.add_argument("--size", default=f"{WIDTH}x{HEIGHT}", help="frame size WxH; anything but the default 640x480 is one of "
+                    "BASELINE's other configs (1280x960, 1920x1080) and is labelled as such, not the headline metric")
+    ap.add_argument("--tv-iters", type=int, default=TV_ITERS)
     return ap.parse_args()
 
 
@@ -71,7 +74,11 @@ def cpu_baseline(seq, budget_s, gpu_sample_fn):
 
 
 def main():
+    global WIDTH, HEIGHT, TV_ITERS
     args = parse()
+    WIDTH, HEIGHT = (int(v) for v in args.size.lower().split("x"))
+    TV_ITERS = args.tv_iters
+    headline = (WIDTH, HEIGHT) == (640, 480)
     rank = int(os.environ.get("RANK", "0"))
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world_env == 1:
@@ -79,7 +86,8 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"), os.path.abspath(__file__),
                "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
-               "--cpu-seconds", str(args.cpu_seconds), "--matcher", str(args.matcher), "--window", str(args.window)]
+               "--cpu-seconds", str(args.cpu_seconds), "--matcher", str(args.matcher), "--window", str(args.window),
+               "--size", args.size, "--tv-iters", str(args.tv_iters)]
         sys.exit(subprocess.call(cmd))
 
     import torch
@@ -164,7 +172,7 @@ def main():
         achieved = FUSED_BYTES_PER_PIXEL * WIDTH * HEIGHT / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if headline and os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("seed_update_bytes_per_launch")
             except Exception:
@@ -234,11 +242,11 @@ def main():
 
         value = total_units / max_elapsed / 1e6
         result = {
-            "metric": "Mpix/s depth-filter updates (640x480, 200 frames)", "value": round(value, 2), "unit": "Mpix/s",
+            "metric": f"Mpix/s depth-filter updates ({WIDTH}x{HEIGHT}, 200 frames)", "value": round(value, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(max_elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: {WIDTH}x{HEIGHT} synthetic over-table sequence, 1 reference + {FRAMES - 1} "
+            "config": {"workload": f"{'configs[1]' if headline else 'non-headline size'}: {WIDTH}x{HEIGHT} synthetic over-table sequence, 1 reference + {FRAMES - 1} "
                                    f"updates per pass, NCC patch side {SIDE} (half-patch 4), max epipolar extent 100 px; "
                                    f"one independent sequence per GPU",
                        "frames_resident_in_hbm": True, "matcher": "tile" if args.matcher else "pixel",

@@ -136,7 +136,8 @@ int rmd_hip_seeds_sync(const rmd_hip_seeds_t* s);
 #define RMD_HIP_OPT_MATCHER 0      /* 0 = per-pixel kernel, 1 = tile-cooperative kernel (default) */
 #define RMD_HIP_OPT_TIMING 1       /* 1 = bracket every update with HIP events on the handle's stream; 2 = one event pair
                                       around everything between timing_reset and the timing query (no markers in between) */
-#define RMD_HIP_OPT_COLLECT_STATS 2 /* 1 = count live seeds / search steps / NCC evaluations per update */
+#define RMD_HIP_OPT_COLLECT_STATS 2 /* 1 = count live seeds / search steps / NCC evaluations per update;
+                                      2 = in-kernel timeline probes instead (see rmd_hip_seeds_trace_download) */
 #define RMD_HIP_OPT_WINDOW 3       /* search-kernel LDS window: 0 = chosen per frame from feedback, 1 = small, 2 = large */
 #define RMD_HIP_OPT_LAZY_FINALIZE 4 /* 1 (default) = defer an update's last kernel and fuse it into the next update */
 int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value);
@@ -155,6 +156,10 @@ int rmd_hip_seeds_last_stats(const rmd_hip_seeds_t* s, long long* out3);
  * cycles in setup / staging / search, [11] max workgroup cycles, [12] tiles with work, [13] search rounds,
  * [14] max setup cycles, [15] max search cycles */
 int rmd_hip_seeds_last_diagnostics(const rmd_hip_seeds_t* s, long long* out16);
+/* timeline of update number `frame` (0 = first update after COLLECT_STATS was set to 2; the last 256 are kept): pairs
+ * (start, end) in 10 ns ticks of the device wall clock, one pair per seed_setup workgroup (16x16 tile, row-major), then
+ * seed_plan, then up to 1024 seed_search workgroups; zero pairs = not launched.  Needs 2*(tiles + 1025) words. */
+int rmd_hip_seeds_trace_download(rmd_hip_seeds_t* s, int frame, unsigned long long* out, size_t capacity, size_t* written);
 
 /* ---- rmd::DepthmapDenoiser (depthmap_denoiser.cu) --------------------------------------- */
 int rmd_hip_denoiser_create(int width, int height, rmd_hip_denoiser_t** out); /* ctor :143-169 */

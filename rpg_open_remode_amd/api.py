@@ -321,6 +321,18 @@ class SeedMatrix:
         return {"live_seeds": int(out[0]), "steps": int(out[1]), "ncc_evals": int(out[2])}
 
 
+    def traceDownload(self, frame):
+        """Timeline of update `frame` since setOption(OPT_COLLECT_STATS, 2): dict of (n, 2) uint64 arrays of workgroup
+        (start, end) ticks (10 ns) for 'setup', 'plan', 'search' (only the workgroups that ran)."""
+        tiles = ((self.width + 15) // 16) * ((self.height + 15) // 16)
+        n = 2 * (tiles + 1025)
+        out = np.zeros(n, np.uint64)
+        written = ctypes.c_size_t()
+        check(_lib.lib().rmd_hip_seeds_trace_download(self.ptr, int(frame), out.ctypes.data, n, ctypes.byref(written)))
+        rec = out.reshape(-1, 2)
+        search = rec[tiles + 1:]
+        return {"setup": rec[:tiles], "plan": rec[tiles:tiles + 1], "search": search[search[:, 1] != 0]}
+
     def lastDiagnosticsRaw(self):
         out = np.zeros(16, np.int64)
         check(_lib.lib().rmd_hip_seeds_last_diagnostics(self.ptr, out.ctypes.data))

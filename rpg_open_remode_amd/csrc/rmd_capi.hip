@@ -192,6 +192,7 @@ struct rmd_hip_seeds {
   StageTimer timers[RMD_HIP_NUM_SEED_STAGES];
   long long last_stats[16] = {0};
   bool stats_pending = false;
+  long long trace_frame = 0;  // updates launched since timeline tracing was switched on
   rmdk::MatcherWorkspace matcher_ws;
 };
 
@@ -250,11 +251,14 @@ int seeds_launch_init(rmd_hip_seeds* s) {
 
 int seeds_launch_update(rmd_hip_seeds* s) {
   rmdk::SeedParams P = s->P;
-  if (s->opt_stats) {
+  P.stats = nullptr;
+  P.trace = nullptr;
+  if (s->opt_stats == 1) {
     HIP_TRY(hipMemsetAsync(s->d_scalars + 1, 0, 16 * sizeof(unsigned long long), s->stream));
     P.stats = s->d_scalars + 1;
-  } else {
-    P.stats = nullptr;
+  } else if (s->opt_stats == 2 && s->matcher_ws.d_trace) {  // timeline probes only: the pipeline runs as in production
+    P.trace = s->matcher_ws.d_trace + static_cast<size_t>(s->trace_frame % rmdk::TRACE_FRAMES) * s->matcher_ws.trace_slice_u64();
+    ++s->trace_frame;
   }
   int rc;
   if (s->opt_timing == 2) ++s->region_updates;
@@ -272,15 +276,16 @@ int seeds_launch_update(rmd_hip_seeds* s) {
         HIP_TRY(rmdk::launch_seed_update_tile<SIDE>(P, s->matcher_ws, s->stream, s->num_cus, s->opt_window, fuse, T_prev));
         s->P_pending = P;
         s->P_pending.stats = nullptr;
+        s->P_pending.trace = nullptr;
         s->finalize_pending = true;
-        if (!s->opt_lazy || s->opt_stats) TRY(seeds_flush(s));
+        if (!s->opt_lazy || s->opt_stats == 1) TRY(seeds_flush(s));
       }
       HIP_TRY(hipGetLastError());
       return RMD_HIP_OK;
     });
   }
   TRY(rc);
-  if (s->opt_stats) {
+  if (s->opt_stats == 1) {
     HIP_TRY(hipMemcpyAsync(s->h_scalars + 1, s->d_scalars + 1, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                            s->stream));
     s->stats_pending = true;
@@ -686,7 +691,19 @@ int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value) {
       if (value < 0 || value > 2) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: window %d", value);
       s->opt_window = value;
       return RMD_HIP_OK;
-    case RMD_HIP_OPT_COLLECT_STATS: s->opt_stats = value != 0; return RMD_HIP_OK;
+    case RMD_HIP_OPT_COLLECT_STATS:
+      s->opt_stats = value == 2 ? 2 : (value != 0);
+      if (s->opt_stats == 2) {  // (re)start a timeline: zeroed buffer, frame counter 0
+        TRY(seeds_bind_device(s));
+        rmdk::MatcherWorkspace& ws = s->matcher_ws;
+        const size_t bytes = ws.trace_slice_u64() * rmdk::TRACE_FRAMES * sizeof(unsigned long long);
+        if (!ws.d_trace) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ws.d_trace), bytes));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        HIP_TRY(hipMemset(ws.d_trace, 0, bytes));
+        HIP_TRY(hipDeviceSynchronize());
+        s->trace_frame = 0;
+      }
+      return RMD_HIP_OK;
     default: return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: unknown option %d", option);
   }
 }
@@ -737,6 +754,22 @@ int rmd_hip_seeds_last_diagnostics(const rmd_hip_seeds_t* s, long long* out16) {
   TRY(seeds_bind_device(s));
   TRY(seeds_sync(s));
   for (int k = 0; k < 16; ++k) out16[k] = s->last_stats[k];
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_seeds_trace_download(rmd_hip_seeds_t* s, int frame, unsigned long long* out, size_t capacity, size_t* written) {
+  if (!s || !out || !written) return fail(RMD_HIP_ERR_INVALID_ARG, "trace_download: null argument");
+  const rmdk::MatcherWorkspace& ws = s->matcher_ws;
+  if (!ws.d_trace) return fail(RMD_HIP_ERR_NOT_READY, "trace_download: set RMD_HIP_OPT_COLLECT_STATS to 2 first");
+  if (frame < 0 || frame >= s->trace_frame || frame < s->trace_frame - rmdk::TRACE_FRAMES)
+    return fail(RMD_HIP_ERR_INVALID_ARG, "trace_download: frame not in the buffer");
+  const size_t n = ws.trace_slice_u64();
+  if (capacity < n) return fail(RMD_HIP_ERR_INVALID_ARG, "trace_download: buffer too small");
+  TRY(seeds_bind_device(s));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  HIP_TRY(hipMemcpy(out, ws.d_trace + static_cast<size_t>(frame % rmdk::TRACE_FRAMES) * n, n * sizeof(unsigned long long),
+                    hipMemcpyDeviceToHost));
+  *written = n;
   return RMD_HIP_OK;
 }
 

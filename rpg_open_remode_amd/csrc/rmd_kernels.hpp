@@ -46,6 +46,7 @@ struct SeedParams {
   Pose T_curr_ref;
   Pose T_ref_curr;
   unsigned long long* stats;  // [0] live seeds, [1] steps visited, [2] NCC evaluations; may be null
+  unsigned long long* trace;  // diagnostics: in-kernel timeline probes (100 MHz wall clock) of the update pipeline; may be null
 };
 
 // ------------------------------------------------------------------------------------------

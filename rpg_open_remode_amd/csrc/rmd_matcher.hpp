@@ -35,12 +35,25 @@
 
 #include "rmd_kernels.hpp"
 
+#ifndef RMD_EXP_WPE
+#define RMD_EXP_WPE 0
+#endif
+#ifndef RMD_EXP_PREFETCH
+#define RMD_EXP_PREFETCH 0
+#endif
+#ifndef RMD_EXP_STAGE_BATCH
+#define RMD_EXP_STAGE_BATCH 8
+#endif
+#ifndef RMD_EXP_REGS
+#define RMD_EXP_REGS 0
+#endif
 namespace rmdk {
 
 constexpr int TILE_W = 16, TILE_H = 16, TILE_PIX = TILE_W * TILE_H;
 constexpr int MAX_UNIT_ROUNDS = 4;  // a work unit is 1..4 rounds of the 256 lanes (chosen per frame by seed_plan)
 constexpr int MIN_UNIT_ITEMS = TILE_PIX;
 constexpr int MAX_ITEMS_PER_TILE = TILE_PIX * 144;
+constexpr int TRACE_FRAMES = 256, TRACE_MAX_SEARCH_WGS = 1024;  // diagnostics (trace_record)
 
 // per-tile record written by seed_setup, read by seed_search
 struct TileInfo {
@@ -65,6 +78,7 @@ struct MatcherWorkspace {
   //   [0] units appended, [1] units handed out beyond the static first round, [2] widest / [3] tallest window needed,
   //   [4] tiles whose samples did not fit the window, [5] items per unit of this frame
   unsigned int* d_queue = nullptr;
+  unsigned long long* d_trace = nullptr;  // diagnostics, allocated on demand: TRACE_FRAMES slices of trace_slice_u64() words
   unsigned int* h_feedback = nullptr;  // pinned, written by the finalize kernel: [0] units of the last frame, [1..3] as [2..4] above
   int max_units = 0;
   int parity = 0;
@@ -92,14 +106,15 @@ struct MatcherWorkspace {
     h_feedback[1] = h_feedback[2] = h_feedback[3] = 0;
     return 0;
   }
+  size_t trace_slice_u64() const { return 2 * (static_cast<size_t>(tiles_x) * tiles_y + 1 + TRACE_MAX_SEARCH_WGS); }
   void release() {
-    void* all[] = {d_mean, d_dir, d_lfirst, d_packed, d_best, d_tiles, d_tile_plan, d_units, d_queue};
+    void* all[] = {d_mean, d_dir, d_lfirst, d_packed, d_best, d_tiles, d_tile_plan, d_units, d_queue, d_trace};
     for (void* p : all)
       if (p) (void)hipFree(p);
     if (h_feedback) (void)hipHostFree(h_feedback);
     h_feedback = nullptr;
     d_mean = d_dir = nullptr; d_lfirst = nullptr; d_packed = nullptr; d_best = nullptr;
-    d_tiles = nullptr; d_tile_plan = nullptr; d_units = nullptr; d_queue = nullptr;
+    d_tiles = nullptr; d_tile_plan = nullptr; d_units = nullptr; d_queue = nullptr; d_trace = nullptr;
   }
 };
 
@@ -117,7 +132,15 @@ struct MatcherArgs {
   unsigned int* queue_next;  // next frame's bank, cleared by seed_finalize
   unsigned int* feedback;    // pinned host memory
   int tiles_x;
+  unsigned long long* trace;  // this frame's slice of the timeline buffer, may be null (see trace_record)
 };
+
+// Timeline probe of one workgroup (diagnostics): record `slot` of the frame's trace slice gets the workgroup's start and
+// end in 10 ns ticks of the device-wide wall clock.  Slots: one per setup tile, then seed_plan, then the search workgroups.
+RMDK_D void trace_record(unsigned long long* trace, int slot, unsigned long long t0, unsigned long long t1) {
+  trace[2 * slot] = t0;
+  trace[2 * slot + 1] = t1;
+}
 
 RMDK_D unsigned int orderable_f32(float f) {
   const unsigned int u = __float_as_uint(f);
@@ -125,6 +148,32 @@ RMDK_D unsigned int orderable_f32(float f) {
 }
 RMDK_D float from_orderable_f32(unsigned int o) {
   return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+// The reference accumulates the search position, l += 0.7f once per step (epipolar_match.cu:88), and the float sequence has
+// no closed form, so whoever needs l at step n replays n additions.  The replays are dependent chains inside divergent
+// loops; running them in blocks of 8 additions per loop-control round makes them ~4x cheaper (same additions, same order).
+RMDK_D float replay_l(float l, int n) {
+  int q = 0;
+  for (; q + 8 <= n; q += 8) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) l += 0.7f;
+  }
+  for (; q < n; ++q) l += 0.7f;
+  return l;
+}
+// for (; i < i_target && l <= half; ++i) l += 0.7f;   -- l grows monotonically, so a block of 8 iterations runs to its end
+// exactly when the value before its last addition still passes the test
+RMDK_D void replay_until(int& i, float& l, int i_target, float half) {
+  while (i + 8 <= i_target) {
+    float t = l;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) t += 0.7f;
+    if (!(t <= half)) break;
+    l = t + 0.7f;
+    i += 8;
+  }
+  for (; i < i_target && l <= half; ++i) l += 0.7f;
 }
 
 RMDK_D bool px_outside(const SeedParams& P, F2 px, int side) {  // the guard at epipolar_match.cu:91-97
@@ -152,6 +201,17 @@ RMDK_D bool axis_params(float p, int (&idx)[SIDE], float (&wgt)[SIDE]) {
   return regular;
 }
 
+// The common case of axis_params: when p - HALF .. p + HALF + 0.5 all lie in p's own binade [2^e, 2^(e+1)), every one of
+// the additions above is exact (all operands are multiples of ulp(p) <= 0.5 and no result leaves the binade), so
+// b_k = p + (OFFSET + k) exactly, idx[k] = floor(p) + OFFSET + k and every weight equals p - floor(p).  Away from
+// powers of two (about 80 % of all positions of a VGA frame) that replaces the replay by three instructions.
+template <int SIDE>
+RMDK_D bool axis_is_uniform(float p) {
+  constexpr float H = static_cast<float>(SIDE / 2);
+  const float lo = __uint_as_float(__float_as_uint(p) & 0x7f800000u);  // 2^e
+  return p >= 1.0f && p - H >= lo && p + (H + 0.5f) < lo + lo;
+}
+
 // Sums of one NCC evaluation over a REGULAR footprint: texel rows j0 .. j0+SIDE, columns i0 .. i0+SIDE,
 // read from `base` (pointing at texel (i0, j0)) with row stride CT_STRIDE (compile time, LDS window)
 // or rt_stride (run time, global memory).  Separable filter: SIDE+1 horizontal lerps per texel row are
@@ -160,6 +220,46 @@ template <int SIDE, int CT_STRIDE>
 RMDK_D void ncc_sums_regular(const float* __restrict__ base, int rt_stride, const float (&ax)[SIDE], const float (&ay)[SIDE],
                              const float* __restrict__ ref_patch, int ref_stride, float& sum_img, float& sum_img_sq,
                              float& sum_img_templ) {
+#if RMD_EXP_REGS
+  constexpr int N = SIDE + 1;
+  // The whole footprint and the template patch go to registers first, all loads in flight together: the search kernel
+  // runs two waves per SIMD (LDS-limited), so a wave may use up to 256 VGPRs, and one exposed LDS latency per
+  // evaluation beats one per texel row.
+  float t[N * N], tp[SIDE * SIDE];
+#pragma unroll
+  for (int r = 0; r < N; ++r) {
+    const float* row = CT_STRIDE > 0 ? base + r * CT_STRIDE : base + r * rt_stride;
+#pragma unroll
+    for (int c = 0; c < N; ++c) t[r * N + c] = row[c];
+  }
+#pragma unroll
+  for (int m = 0; m < SIDE; ++m) {
+#pragma unroll
+    for (int k = 0; k < SIDE; ++k) tp[m * SIDE + k] = ref_patch[m * ref_stride + k];
+  }
+#if RMD_EXP_PREFETCH
+  asm volatile("" ::: "memory");  // keeps the loads above the arithmetic
+#endif
+  float hprev[SIDE], hcur[SIDE];
+#pragma unroll
+  for (int r = 0; r < N; ++r) {
+#pragma unroll
+    for (int k = 0; k < SIDE; ++k) hcur[k] = rmd_lerp(ax[k], t[r * N + k], t[r * N + k + 1]);
+    if (r > 0) {
+      const float by = ay[r - 1];
+#pragma unroll
+      for (int k = 0; k < SIDE; ++k) {
+        const float img = rmd_lerp(by, hprev[k], hcur[k]);
+        const float templ = tp[(r - 1) * SIDE + k];
+        sum_img += img;
+        sum_img_sq += img * img;
+        sum_img_templ += img * templ;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < SIDE; ++k) hprev[k] = hcur[k];
+  }
+#else
   float hprev[SIDE], hcur[SIDE];
 #pragma unroll
   for (int r = 0; r <= SIDE; ++r) {
@@ -183,6 +283,7 @@ RMDK_D void ncc_sums_regular(const float* __restrict__ base, int rt_stride, cons
 #pragma unroll
     for (int k = 0; k < SIDE; ++k) hprev[k] = hcur[k];
   }
+#endif
 }
 
 // One NCC evaluation at px.  Three sources for the current-image samples, same arithmetic in all:
@@ -197,8 +298,17 @@ RMDK_D float ncc_at(const SeedParams& P, F2 px, const float* __restrict__ win, i
   float sum_img = 0.0f, sum_img_sq = 0.0f, sum_img_templ = 0.0f;
   int ix[SIDE], iy[SIDE];
   float ax[SIDE], ay[SIDE];
-  const bool reg_x = axis_params<SIDE>(px.x, ix, ax);
-  const bool reg_y = axis_params<SIDE>(px.y, iy, ay);
+  bool reg_x = true, reg_y = true;
+  if (__all(axis_is_uniform<SIDE>(px.x) && axis_is_uniform<SIDE>(px.y))) {  // wave-uniform branch
+    const float fx = floorf(px.x), fy = floorf(px.y);
+    const float wx = px.x - fx, wy = px.y - fy;
+    ix[0] = static_cast<int>(fx) + OFFSET; iy[0] = static_cast<int>(fy) + OFFSET;
+#pragma unroll
+    for (int k = 0; k < SIDE; ++k) { ax[k] = wx; ay[k] = wy; }
+  } else {
+    reg_x = axis_params<SIDE>(px.x, ix, ax);
+    reg_y = axis_params<SIDE>(px.y, iy, ay);
+  }
   if (reg_x && reg_y) {
     // the guard keeps px in [SIDE, dim-SIDE), so rows iy[0]..iy[0]+SIDE and columns ix[0]..ix[0]+SIDE are in the image
     const bool in_window = ix[0] >= wx0 && iy[0] >= wy0 && ix[0] + SIDE <= wx1 && iy[0] + SIDE <= wy1;
@@ -242,8 +352,7 @@ RMDK_D int finalize_seed(const SeedParams& P, const MatcherArgs& M, int x, int y
     best_ncc = from_orderable_f32(static_cast<unsigned int>(key >> 32));
     const int step = static_cast<int>(0xffffffffu - static_cast<unsigned int>(key & 0xffffffffu));
     const int i_first = static_cast<int>(M.packed[gi] >> 16);
-    float l = M.lfirst[gi];
-    for (int q = i_first; q < step; ++q) l += 0.7f;
+    const float l = replay_l(M.lfirst[gi], step - i_first);
     const float2 m = M.mean[gi], d = M.dir[gi];
     best_px = F2{m.x + l * d.x, m.y + l * d.y};
   }
@@ -278,6 +387,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_kernel(SeedParams P, Matc
   const int x = blockIdx.x * TILE_W + tx, y = blockIdx.y * TILE_H + ty;
   const bool in_image = x < P.w && y < P.h;
   const int gi = y * P.stride + x;
+  const unsigned long long trace_t0 = P.trace ? wall_clock64() : 0ull;
 
   if (FUSE_PREV) {
     if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) finalize_housekeeping(M.queue_next, M.queue_next, M.feedback);
@@ -325,7 +435,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_kernel(SeedParams P, Matc
         const int i_a = max(static_cast<int>(floorf((la + half) * (1.0f / 0.7f))) - 2, 0);
         int i = 0;
         float l = -half;
-        for (; i < i_a && l <= half; ++i) l += 0.7f;  // replay
+        replay_until(i, l, i_a, half);  // replay
         F2 px_first = F2{0.0f, 0.0f}, px_last = F2{0.0f, 0.0f};
         for (; l <= half && l <= lb + 1.5f; l += 0.7f, ++i) {  // exact scan for the first in-image step
           const F2 px = F2{seg.mean.x + l * seg.dir.x, seg.mean.y + l * seg.dir.y};
@@ -333,7 +443,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_kernel(SeedParams P, Matc
         }
         if (n_valid) {
           const int i_b = max(static_cast<int>(floorf((lb + half) * (1.0f / 0.7f))) - 2, i_first);
-          for (; i < i_b && l <= half; ++i) l += 0.7f;  // replay across the interior of the run (in-image by convexity)
+          replay_until(i, l, i_b, half);  // replay across the interior of the run (in-image by convexity)
           int i_last = i_first;
           if (l <= half && i > i_first) {  // the replayed position: still in the run unless the estimate overshot
             const F2 px = F2{seg.mean.x + l * seg.dir.x, seg.mean.y + l * seg.dir.y};
@@ -435,6 +545,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_kernel(SeedParams P, Matc
   M.tile_plan[tile] = make_uint2(static_cast<unsigned int>(total), static_cast<unsigned int>(ti.need_w) |
                                                                         (static_cast<unsigned int>(ti.need_h) << 12) |
                                                                         (static_cast<unsigned int>(ti.off_window) << 24));
+  if (P.trace) trace_record(P.trace, tile, trace_t0, wall_clock64());
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -446,6 +557,7 @@ __global__ __launch_bounds__(PLAN_THREADS) void seed_plan_kernel(MatcherArgs M, 
   __shared__ int red_s[4][PLAN_THREADS / 64];
   __shared__ int unit_items_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long trace_t0 = M.trace ? wall_clock64() : 0ull;
   // each thread owns a contiguous run of tiles; one load per tile, kept in registers for both passes
   const int per_thread = (n_tiles + PLAN_THREADS - 1) / PLAN_THREADS;
   const int t0 = tid * per_thread;
@@ -528,6 +640,10 @@ __global__ __launch_bounds__(PLAN_THREADS) void seed_plan_kernel(MatcherArgs M, 
     base += n_u;
   }
   if (tid == 0) M.queue[0] = static_cast<unsigned int>(block_tot);
+  if (M.trace) {
+    __syncthreads();
+    if (tid == 0) trace_record(M.trace, n_tiles, trace_t0, wall_clock64());
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -548,7 +664,12 @@ struct SearchSmem {
 };
 
 template <int SIDE, int WS, int WROWS>
-__global__ __launch_bounds__(TILE_PIX) void seed_search_kernel(SeedParams P, MatcherArgs M) {
+#if RMD_EXP_WPE
+#define RMD_SEARCH_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#else
+#define RMD_SEARCH_ATTR
+#endif
+__global__ __launch_bounds__(TILE_PIX) RMD_SEARCH_ATTR void seed_search_kernel(SeedParams P, MatcherArgs M) {
   using Smem = SearchSmem<SIDE, WS, WROWS>;
   constexpr int HALF = SIDE / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -561,6 +682,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_search_kernel(SeedParams P, Mat
   unsigned int n_path[3] = {0, 0, 0};
   unsigned long long t_stage = 0, t_search = 0;
   unsigned int my_units = 0;
+  const unsigned long long trace_t0 = P.trace ? wall_clock64() : 0ull;
 
   // unit blockIdx.x is ours for free; further units come from the shared counter (one returning atomic each)
   unsigned int u = blockIdx.x;
@@ -602,21 +724,36 @@ __global__ __launch_bounds__(TILE_PIX) void seed_search_kernel(SeedParams P, Mat
     {
       const int n_el = ww * wh;
       const float inv_ww = 1.0f / static_cast<float>(ww);
-      for (int e0 = tid; e0 < n_el; e0 += TILE_PIX * 8) {
-        float v[8];
-        int dst[8];
+      // all of a thread's loads are issued before its first LDS store (chunks of 8, skipped wave-uniformly beyond the
+      // window's end): one memory round trip per window, two for the largest, instead of one per 8 texels
+      constexpr int CAP = (WS * WROWS + TILE_PIX - 1) / TILE_PIX;
+      constexpr int BATCH = ((CAP < RMD_EXP_STAGE_BATCH ? CAP : RMD_EXP_STAGE_BATCH) + 7) / 8 * 8;
+      for (int e0 = tid; e0 < n_el; e0 += TILE_PIX * BATCH) {
+        float v[BATCH];
+        int dst[BATCH];
+        const int e_wg = e0 - tid;  // same for the whole workgroup
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int e = e0 + q * TILE_PIX;
-          int r = static_cast<int>(static_cast<float>(e) * inv_ww);  // e / ww, fixed up below (e < 2^14)
-          int c = e - r * ww;
-          if (c < 0) { --r; c += ww; } else if (c >= ww) { ++r; c -= ww; }
-          dst[q] = r * WS + c;
-          v[q] = e < n_el ? P.cur[(wy0 + r) * P.cur_stride + wx0 + c] : 0.0f;
+        for (int c = 0; c < BATCH; c += 8) {
+          if (e_wg + c * TILE_PIX < n_el) {
+#pragma unroll
+            for (int q = c; q < c + 8; ++q) {
+              const int e = e0 + q * TILE_PIX;
+              int r = static_cast<int>(static_cast<float>(e) * inv_ww);  // e / ww, fixed up below (e < 2^14)
+              int cc = e - r * ww;
+              if (cc < 0) { --r; cc += ww; } else if (cc >= ww) { ++r; cc -= ww; }
+              dst[q] = r * WS + cc;
+              v[q] = e < n_el ? P.cur[(wy0 + r) * P.cur_stride + wx0 + cc] : 0.0f;
+            }
+          }
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
-          if (e0 + q * TILE_PIX < n_el) S.win[dst[q]] = v[q];
+        for (int c = 0; c < BATCH; c += 8) {
+          if (e_wg + c * TILE_PIX < n_el) {
+#pragma unroll
+            for (int q = c; q < c + 8; ++q)
+              if (e0 + q * TILE_PIX < n_el) S.win[dst[q]] = v[q];
+          }
+        }
       }
       for (int i = tid; i < Smem::REF_H * Smem::REF_W; i += TILE_PIX) {
         const int ry = i / Smem::REF_W, rx = i - ry * Smem::REF_W;
@@ -647,8 +784,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_search_kernel(SeedParams P, Mat
         }
         p = lo;
         const int j = k - S.prefix[p];
-        float l = S.l_first[p];
-        for (int q = 0; q < j; ++q) l += 0.7f;  // the reference accumulates l; replay it
+        const float l = replay_l(S.l_first[p], j);  // the reference accumulates l; replay it
         const F2 px = F2{S.mean_x[p] + l * S.dir_x[p], S.mean_y[p] + l * S.dir_y[p]};
         const int ptx = p & (TILE_W - 1), pty = p >> 4;
         int path = 0;
@@ -697,6 +833,10 @@ __global__ __launch_bounds__(TILE_PIX) void seed_search_kernel(SeedParams P, Mat
       atomicAdd(&P.stats[13], static_cast<unsigned long long>(my_units));
     }
   }
+  if (P.trace && tid == 0) {
+    if (blockIdx.x < TRACE_MAX_SEARCH_WGS)
+      trace_record(P.trace, M.tiles_x * ((P.h + TILE_H - 1) / TILE_H) + 1 + static_cast<int>(blockIdx.x), trace_t0, wall_clock64());
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -720,6 +860,7 @@ inline MatcherArgs matcher_args(const MatcherWorkspace& ws, int parity) {
   M.queue = ws.d_queue + 8 * parity;
   M.queue_next = ws.d_queue + 8 * (parity ^ 1);
   M.feedback = ws.h_feedback;
+  M.trace = nullptr;
   return M;
 }
 
@@ -730,7 +871,8 @@ inline hipError_t launch_seed_pipeline(const SeedParams& P, MatcherWorkspace& ws
                                        bool fuse_prev, const Pose& T_ref_curr_prev) {
   using Smem = SearchSmem<SIDE, WS, WROWS>;
   ws.parity ^= 1;
-  const MatcherArgs M = matcher_args(ws, ws.parity);
+  MatcherArgs M = matcher_args(ws, ws.parity);
+  M.trace = P.trace;
   // Persistent grid: as many workgroups as fit the chip, but no more than the work of the previous frame suggests
   // (the unit count is read back through pinned memory, one or two frames late; any grid size is correct).
   const int by_lds = static_cast<int>((160 * 1024) / sizeof(Smem));
