@@ -35,18 +35,6 @@
 
 #include "rmd_kernels.hpp"
 
-#ifndef RMD_EXP_WPE
-#define RMD_EXP_WPE 0
-#endif
-#ifndef RMD_EXP_PREFETCH
-#define RMD_EXP_PREFETCH 0
-#endif
-#ifndef RMD_EXP_STAGE_BATCH
-#define RMD_EXP_STAGE_BATCH 8
-#endif
-#ifndef RMD_EXP_REGS
-#define RMD_EXP_REGS 0
-#endif
 namespace rmdk {
 
 constexpr int TILE_W = 16, TILE_H = 16, TILE_PIX = TILE_W * TILE_H;
@@ -59,8 +47,6 @@ constexpr int TRACE_FRAMES = 256, TRACE_MAX_SEARCH_WGS = 1024;  // diagnostics (
 struct TileInfo {
   int total;               // NCC evaluations of the tile
   int wx0, wy0, wx1, wy1;  // inclusive texel box of the current image staged for the tile
-  int need_w, need_h;      // size of the box that would hold every sample of the tile
-  int off_window;          // 1 if that box did not fit and the window was centred on the bulk of the samples
 };
 
 struct MatcherWorkspace {
@@ -71,17 +57,13 @@ struct MatcherWorkspace {
   unsigned int* d_packed = nullptr;      // per seed: first in-image step << 16 | number of in-image steps
   unsigned long long* d_best = nullptr;  // per seed: arg-max key
   TileInfo* d_tiles = nullptr;
-  uint2* d_tile_plan = nullptr;     // per tile, for seed_plan: (work items, need_w | need_h << 12 | off_window << 24)
+  unsigned int* d_tile_plan = nullptr;  // per tile, for seed_plan: work items
   uint2* d_units = nullptr;         // (tile, first item)
-  // two banks of 8 counters, used alternately frame by frame so that nobody has to memset between frames (the
-  // finalize kernel of frame k clears the bank of frame k+1):
-  //   [0] units appended, [1] units handed out beyond the static first round, [2] widest / [3] tallest window needed,
-  //   [4] tiles whose samples did not fit the window, [5] items per unit of this frame
+  // counters of the current frame, rewritten by seed_plan every frame: [0] work units, [1] units handed out beyond the
+  // static first round, [5] items per unit
   unsigned int* d_queue = nullptr;
   unsigned long long* d_trace = nullptr;  // diagnostics, allocated on demand: TRACE_FRAMES slices of trace_slice_u64() words
-  unsigned int* h_feedback = nullptr;  // pinned, written by the finalize kernel: [0] units of the last frame, [1..3] as [2..4] above
   int max_units = 0;
-  int parity = 0;
   bool attr_set_small = false, attr_set_large = false;
   int allocate(int w, int h, int stride_elems) {
     tiles_x = (w + TILE_W - 1) / TILE_W;
@@ -95,15 +77,12 @@ struct MatcherWorkspace {
     if (hipMalloc(reinterpret_cast<void**>(&d_packed), n * sizeof(unsigned int)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_best), n * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_tiles), static_cast<size_t>(tiles_x) * tiles_y * sizeof(TileInfo)) != hipSuccess) return -1;
-    if (hipMalloc(reinterpret_cast<void**>(&d_tile_plan), static_cast<size_t>(tiles_x) * tiles_y * sizeof(uint2)) != hipSuccess) return -1;
+    if (hipMalloc(reinterpret_cast<void**>(&d_tile_plan), static_cast<size_t>(tiles_x) * tiles_y * sizeof(unsigned int)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_units), static_cast<size_t>(max_units) * sizeof(uint2)) != hipSuccess) return -1;
-    if (hipMalloc(reinterpret_cast<void**>(&d_queue), 16 * sizeof(unsigned int)) != hipSuccess) return -1;
-    if (hipHostMalloc(reinterpret_cast<void**>(&h_feedback), 4 * sizeof(unsigned int)) != hipSuccess) return -1;
+    if (hipMalloc(reinterpret_cast<void**>(&d_queue), 8 * sizeof(unsigned int)) != hipSuccess) return -1;
     (void)hipMemset(d_packed, 0, n * sizeof(unsigned int));
     (void)hipMemset(d_best, 0, n * sizeof(unsigned long long));
-    (void)hipMemset(d_queue, 0, 16 * sizeof(unsigned int));
-    h_feedback[0] = 0xffffffffu;  // unknown
-    h_feedback[1] = h_feedback[2] = h_feedback[3] = 0;
+    (void)hipMemset(d_queue, 0, 8 * sizeof(unsigned int));
     return 0;
   }
   size_t trace_slice_u64() const { return 2 * (static_cast<size_t>(tiles_x) * tiles_y + 1 + TRACE_MAX_SEARCH_WGS); }
@@ -111,8 +90,6 @@ struct MatcherWorkspace {
     void* all[] = {d_mean, d_dir, d_lfirst, d_packed, d_best, d_tiles, d_tile_plan, d_units, d_queue, d_trace};
     for (void* p : all)
       if (p) (void)hipFree(p);
-    if (h_feedback) (void)hipHostFree(h_feedback);
-    h_feedback = nullptr;
     d_mean = d_dir = nullptr; d_lfirst = nullptr; d_packed = nullptr; d_best = nullptr;
     d_tiles = nullptr; d_tile_plan = nullptr; d_units = nullptr; d_queue = nullptr; d_trace = nullptr;
   }
@@ -126,11 +103,9 @@ struct MatcherArgs {
   unsigned int* packed;
   unsigned long long* best;
   TileInfo* tiles;
-  uint2* tile_plan;
+  unsigned int* tile_plan;
   uint2* units;
-  unsigned int* queue;       // this frame's counter bank
-  unsigned int* queue_next;  // next frame's bank, cleared by seed_finalize
-  unsigned int* feedback;    // pinned host memory
+  unsigned int* queue;       // this frame's counters (see MatcherWorkspace)
   int tiles_x;
   unsigned long long* trace;  // this frame's slice of the timeline buffer, may be null (see trace_record)
 };
@@ -174,6 +149,17 @@ RMDK_D void replay_until(int& i, float& l, int i_target, float half) {
     i += 8;
   }
   for (; i < i_target && l <= half; ++i) l += 0.7f;
+}
+
+// number of work units of a tile with `items` work items; a unit is `rounds` (1..MAX_UNIT_ROUNDS) rounds of TILE_PIX items
+RMDK_D int units_of(int items, int rounds) {
+  const int r = (items + TILE_PIX - 1) / TILE_PIX;  // rounds of work, a shift
+  switch (rounds) {
+    case 1: return r;
+    case 2: return (r + 1) / 2;
+    case 3: return (r + 2) / 3;
+    default: return (r + 3) / 4;
+  }
 }
 
 RMDK_D bool px_outside(const SeedParams& P, F2 px, int side) {  // the guard at epipolar_match.cu:91-97
@@ -220,46 +206,6 @@ template <int SIDE, int CT_STRIDE>
 RMDK_D void ncc_sums_regular(const float* __restrict__ base, int rt_stride, const float (&ax)[SIDE], const float (&ay)[SIDE],
                              const float* __restrict__ ref_patch, int ref_stride, float& sum_img, float& sum_img_sq,
                              float& sum_img_templ) {
-#if RMD_EXP_REGS
-  constexpr int N = SIDE + 1;
-  // The whole footprint and the template patch go to registers first, all loads in flight together: the search kernel
-  // runs two waves per SIMD (LDS-limited), so a wave may use up to 256 VGPRs, and one exposed LDS latency per
-  // evaluation beats one per texel row.
-  float t[N * N], tp[SIDE * SIDE];
-#pragma unroll
-  for (int r = 0; r < N; ++r) {
-    const float* row = CT_STRIDE > 0 ? base + r * CT_STRIDE : base + r * rt_stride;
-#pragma unroll
-    for (int c = 0; c < N; ++c) t[r * N + c] = row[c];
-  }
-#pragma unroll
-  for (int m = 0; m < SIDE; ++m) {
-#pragma unroll
-    for (int k = 0; k < SIDE; ++k) tp[m * SIDE + k] = ref_patch[m * ref_stride + k];
-  }
-#if RMD_EXP_PREFETCH
-  asm volatile("" ::: "memory");  // keeps the loads above the arithmetic
-#endif
-  float hprev[SIDE], hcur[SIDE];
-#pragma unroll
-  for (int r = 0; r < N; ++r) {
-#pragma unroll
-    for (int k = 0; k < SIDE; ++k) hcur[k] = rmd_lerp(ax[k], t[r * N + k], t[r * N + k + 1]);
-    if (r > 0) {
-      const float by = ay[r - 1];
-#pragma unroll
-      for (int k = 0; k < SIDE; ++k) {
-        const float img = rmd_lerp(by, hprev[k], hcur[k]);
-        const float templ = tp[(r - 1) * SIDE + k];
-        sum_img += img;
-        sum_img_sq += img * img;
-        sum_img_templ += img * templ;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < SIDE; ++k) hprev[k] = hcur[k];
-  }
-#else
   float hprev[SIDE], hcur[SIDE];
 #pragma unroll
   for (int r = 0; r <= SIDE; ++r) {
@@ -283,7 +229,6 @@ RMDK_D void ncc_sums_regular(const float* __restrict__ base, int rt_stride, cons
 #pragma unroll
     for (int k = 0; k < SIDE; ++k) hprev[k] = hcur[k];
   }
-#endif
 }
 
 // One NCC evaluation at px.  Three sources for the current-image samples, same arithmetic in all:
@@ -363,13 +308,6 @@ RMDK_D int finalize_seed(const SeedParams& P, const MatcherArgs& M, int x, int y
   return state;
 }
 
-// Housekeeping once per frame: feedback for the host's next launch (unit count, window sizes) from the counter bank of
-// the frame being finalised, and a clean bank for the frame after next.
-RMDK_D void finalize_housekeeping(const unsigned int* bank_done, unsigned int* bank_to_clear, unsigned int* feedback) {
-  feedback[0] = bank_done[0]; feedback[1] = bank_done[2]; feedback[2] = bank_done[3]; feedback[3] = bank_done[4];
-  for (int k = 0; k < 8; ++k) bank_to_clear[k] = 0u;
-}
-
 // ------------------------------------------------------------------------------------------------
 // stage 1: per-tile setup
 // FUSE_PREV: the previous frame's seed_finalize has been deferred (nobody looked at the state in between): run it here,
@@ -390,7 +328,6 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_kernel(SeedParams P, Matc
   const unsigned long long trace_t0 = P.trace ? wall_clock64() : 0ull;
 
   if (FUSE_PREV) {
-    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) finalize_housekeeping(M.queue_next, M.queue_next, M.feedback);
     if (in_image && P.conv[gi] == ST_UPDATE) {
       SeedParams Pprev = P;
       Pprev.T_ref_curr = T_ref_curr_prev;
@@ -511,7 +448,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_kernel(SeedParams P, Matc
   if (tid != 0) return;
   const int total = red_i[0] + red_i[1] + red_i[2] + red_i[3];
   TileInfo ti;
-  ti.total = total; ti.wx0 = 0; ti.wy0 = 0; ti.wx1 = -1; ti.wy1 = -1; ti.need_w = 0; ti.need_h = 0; ti.off_window = 0;
+  ti.total = total; ti.wx0 = 0; ti.wy0 = 0; ti.wx1 = -1; ti.wy1 = -1;
   const int tile = blockIdx.y * M.tiles_x + blockIdx.x;
   if (total > 0) {
     const float fx0 = fminf(fminf(red_f[0][0], red_f[1][0]), fminf(red_f[2][0], red_f[3][0]));
@@ -523,93 +460,71 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_kernel(SeedParams P, Matc
     ti.wy0 = max(static_cast<int>(floorf(fy0)) - HALF - 1, 0);
     ti.wx1 = min(static_cast<int>(floorf(fx1)) + HALF + 2, P.w - 1);
     ti.wy1 = min(static_cast<int>(floorf(fy1)) + HALF + 2, P.h - 1);
-    ti.need_w = ti.wx1 - ti.wx0 + 1;
-    ti.need_h = ti.wy1 - ti.wy0 + 1;
-    if (ti.need_w > WS || ti.need_h > WROWS) {
+    const int need_w = ti.wx1 - ti.wx0 + 1, need_h = ti.wy1 - ti.wy0 + 1;
+    if (need_w > WS || need_h > WROWS) {
       // a few seeds wandered off: centre the window on where most samples are; the rest read global memory
       const float w_sum = red_f[0][4] + red_f[1][4] + red_f[2][4] + red_f[3][4];
       const float cx = (red_f[0][5] + red_f[1][5] + red_f[2][5] + red_f[3][5]) / w_sum;
       const float cy = (red_f[0][6] + red_f[1][6] + red_f[2][6] + red_f[3][6]) / w_sum;
-      if (ti.need_w > WS) {
+      if (need_w > WS) {
         ti.wx0 = min(max(static_cast<int>(cx) - WS / 2, 0), max(P.w - WS, 0));
         ti.wx1 = min(ti.wx0 + WS - 1, P.w - 1);
       }
-      if (ti.need_h > WROWS) {
+      if (need_h > WROWS) {
         ti.wy0 = min(max(static_cast<int>(cy) - WROWS / 2, 0), max(P.h - WROWS, 0));
         ti.wy1 = min(ti.wy0 + WROWS - 1, P.h - 1);
       }
-      ti.off_window = 1;
     }
   }
   M.tiles[tile] = ti;  // no atomics here: seed_plan turns the per-tile totals into the unit queue
-  M.tile_plan[tile] = make_uint2(static_cast<unsigned int>(total), static_cast<unsigned int>(ti.need_w) |
-                                                                        (static_cast<unsigned int>(ti.need_h) << 12) |
-                                                                        (static_cast<unsigned int>(ti.off_window) << 24));
+  M.tile_plan[tile] = static_cast<unsigned int>(total);
   if (P.trace) trace_record(P.trace, tile, trace_t0, wall_clock64());
 }
 
 // ------------------------------------------------------------------------------------------------
-// stage 1b: one workgroup turns the per-tile totals into the work-unit list (exclusive scan) and the feedback maxima
-constexpr int PLAN_THREADS = 1024;
-constexpr int PLAN_TILES_PER_THREAD = 8;  // up to 8192 tiles (e.g. 1920x1080 -> 8160) held in registers; more run a slow loop
+// stage 1b: one workgroup turns the per-tile totals into the work-unit list (exclusive scan)
+constexpr int PLAN_THREADS = 256;
+constexpr int PLAN_TILES_IN_REGS = 8;  // per thread: 2048 tiles (e.g. 640x480 -> 1200) stay in registers; larger images re-read L2
 __global__ __launch_bounds__(PLAN_THREADS) void seed_plan_kernel(MatcherArgs M, int n_tiles, int target_units) {
   __shared__ int wave_tot[PLAN_THREADS / 64];
-  __shared__ int red_s[4][PLAN_THREADS / 64];
-  __shared__ int unit_items_s;
+  __shared__ int red_s[PLAN_THREADS / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long trace_t0 = M.trace ? wall_clock64() : 0ull;
-  // each thread owns a contiguous run of tiles; one load per tile, kept in registers for both passes
-  const int per_thread = (n_tiles + PLAN_THREADS - 1) / PLAN_THREADS;
-  const int t0 = tid * per_thread;
-  unsigned int tot[PLAN_TILES_PER_THREAD];
-  int m_w = 0, m_h = 0, n_off = 0, items = 0;
+  // thread t owns the contiguous run of tiles [t*c, (t+1)*c): one batch of independent loads, then two block-wide
+  // reductions (total work -> unit size; exclusive scan of the unit counts -> unit list)
+  const int c_tiles = (n_tiles + PLAN_THREADS - 1) / PLAN_THREADS;
+  const int t_first = tid * c_tiles;
+  int tot[PLAN_TILES_IN_REGS];
+  int items = 0;
 #pragma unroll
-  for (int q = 0; q < PLAN_TILES_PER_THREAD; ++q) {
-    tot[q] = 0u;
-    const int t = t0 + q;
-    if (q < per_thread && t < n_tiles) {
-      const uint2 tp = M.tile_plan[t];
-      tot[q] = tp.x;
-      items += static_cast<int>(tp.x);
-      m_w = max(m_w, static_cast<int>(tp.y & 0xfffu)); m_h = max(m_h, static_cast<int>((tp.y >> 12) & 0xfffu));
-      n_off += static_cast<int>(tp.y >> 24);
-    }
+  for (int q = 0; q < PLAN_TILES_IN_REGS; ++q) {
+    const int t = t_first + q;
+    tot[q] = (q < c_tiles && t < n_tiles) ? static_cast<int>(M.tile_plan[t]) : 0;
+    items += tot[q];
   }
-  for (int q = PLAN_TILES_PER_THREAD; q < per_thread; ++q) {  // images beyond 8192 tiles
-    const int t = t0 + q;
-    if (t < n_tiles) items += static_cast<int>(M.tile_plan[t].x);
+  for (int q = PLAN_TILES_IN_REGS; q < c_tiles; ++q) {
+    const int t = t_first + q;
+    if (t >= n_tiles) break;
+    items += static_cast<int>(M.tile_plan[t]);
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    m_w = max(m_w, __shfl_xor(m_w, off, 64)); m_h = max(m_h, __shfl_xor(m_h, off, 64));
-    n_off += __shfl_xor(n_off, off, 64); items += __shfl_xor(items, off, 64);
-  }
-  if (lane == 0) { red_s[0][wave] = m_w; red_s[1][wave] = m_h; red_s[2][wave] = n_off; red_s[3][wave] = items; }
+  for (int off = 32; off > 0; off >>= 1) items += __shfl_xor(items, off, 64);
+  if (lane == 0) red_s[wave] = items;
   __syncthreads();
-  if (tid == 0) {
-    for (int wv = 1; wv < PLAN_THREADS / 64; ++wv) {
-      m_w = max(m_w, red_s[0][wv]); m_h = max(m_h, red_s[1][wv]); n_off += red_s[2][wv]; items += red_s[3][wv];
-    }
-    // unit size: small when there is little work (latency: more workgroups, fewer rounds each), up to
-    // MAX_UNIT_ROUNDS rounds when there is plenty (amortises the per-unit staging)
-    int rounds = (items + target_units * TILE_PIX - 1) / (target_units * TILE_PIX);
-    rounds = min(max(rounds, 1), MAX_UNIT_ROUNDS);
-    unit_items_s = rounds * TILE_PIX;
-    M.queue[1] = 0u;  // hand-out counter of this frame's search
-    M.queue[2] = static_cast<unsigned int>(m_w);
-    M.queue[3] = static_cast<unsigned int>(m_h);
-    M.queue[4] = static_cast<unsigned int>(n_off);
-    M.queue[5] = static_cast<unsigned int>(rounds * TILE_PIX);
-  }
-  __syncthreads();
-  const int unit_items = unit_items_s;
-  // exclusive scan of the unit counts over threads (each thread's tiles are contiguous), then the unit list
+  items = red_s[0] + red_s[1] + red_s[2] + red_s[3];
+  // unit size: one round of the 256 lanes when there is little work (latency: more workgroups, each short), up to
+  // MAX_UNIT_ROUNDS rounds when there is plenty (amortises the per-unit staging).  Decided here, on the device, from this
+  // frame's own total: a host that enqueues frames in bursts runs many frames ahead of anything it could read back.
+  int unit_rounds = (items + target_units * TILE_PIX - 1) / (target_units * TILE_PIX);
+  unit_rounds = min(max(unit_rounds, 1), MAX_UNIT_ROUNDS);
+  const int unit_items = unit_rounds * TILE_PIX;
   int mine = 0;
 #pragma unroll
-  for (int q = 0; q < PLAN_TILES_PER_THREAD; ++q) mine += (static_cast<int>(tot[q]) + unit_items - 1) / unit_items;
-  for (int q = PLAN_TILES_PER_THREAD; q < per_thread; ++q) {
-    const int t = t0 + q;
-    if (t < n_tiles) mine += (static_cast<int>(M.tile_plan[t].x) + unit_items - 1) / unit_items;
+  for (int q = 0; q < PLAN_TILES_IN_REGS; ++q) mine += units_of(tot[q], unit_rounds);
+  for (int q = PLAN_TILES_IN_REGS; q < c_tiles; ++q) {
+    const int t = t_first + q;
+    if (t >= n_tiles) break;
+    mine += units_of(static_cast<int>(M.tile_plan[t]), unit_rounds);
   }
   int incl = mine;
 #pragma unroll
@@ -620,30 +535,33 @@ __global__ __launch_bounds__(PLAN_THREADS) void seed_plan_kernel(MatcherArgs M, 
   if (lane == 63) wave_tot[wave] = incl;
   __syncthreads();
   int wave_off = 0, block_tot = 0;
+#pragma unroll
   for (int wv = 0; wv < PLAN_THREADS / 64; ++wv) {
     const int v = wave_tot[wv];
     wave_off += wv < wave ? v : 0;
     block_tot += v;
   }
+  if (tid == 0) {
+    M.queue[0] = static_cast<unsigned int>(block_tot);
+    M.queue[1] = 0u;  // hand-out counter of this frame's search
+    M.queue[5] = static_cast<unsigned int>(unit_items);
+  }
   int base = wave_off + incl - mine;
 #pragma unroll
-  for (int q = 0; q < PLAN_TILES_PER_THREAD; ++q) {
-    const int n_u = (static_cast<int>(tot[q]) + unit_items - 1) / unit_items;  // 0 for tiles beyond this thread's run
-    for (int u = 0; u < n_u; ++u) M.units[base + u] = make_uint2(static_cast<unsigned int>(t0 + q), static_cast<unsigned int>(u * unit_items));
+  for (int q = 0; q < PLAN_TILES_IN_REGS; ++q) {
+    const int n_u = units_of(tot[q], unit_rounds);  // 0 for tiles beyond this thread's run
+    for (int u = 0; u < n_u; ++u) M.units[base + u] = make_uint2(static_cast<unsigned int>(t_first + q), static_cast<unsigned int>(u * unit_items));
     base += n_u;
   }
-  for (int q = PLAN_TILES_PER_THREAD; q < per_thread; ++q) {
-    const int t = t0 + q;
+  for (int q = PLAN_TILES_IN_REGS; q < c_tiles; ++q) {
+    const int t = t_first + q;
     if (t >= n_tiles) break;
-    const int n_u = (static_cast<int>(M.tile_plan[t].x) + unit_items - 1) / unit_items;
+    const int n_u = units_of(static_cast<int>(M.tile_plan[t]), unit_rounds);
     for (int u = 0; u < n_u; ++u) M.units[base + u] = make_uint2(static_cast<unsigned int>(t), static_cast<unsigned int>(u * unit_items));
     base += n_u;
   }
-  if (tid == 0) M.queue[0] = static_cast<unsigned int>(block_tot);
-  if (M.trace) {
-    __syncthreads();
-    if (tid == 0) trace_record(M.trace, n_tiles, trace_t0, wall_clock64());
-  }
+  if (M.trace && tid == 0)  // the unit size rides in the top byte of the end time stamp
+    trace_record(M.trace, n_tiles, trace_t0, wall_clock64() | (static_cast<unsigned long long>(unit_rounds) << 56));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -664,12 +582,7 @@ struct SearchSmem {
 };
 
 template <int SIDE, int WS, int WROWS>
-#if RMD_EXP_WPE
-#define RMD_SEARCH_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
-#else
-#define RMD_SEARCH_ATTR
-#endif
-__global__ __launch_bounds__(TILE_PIX) RMD_SEARCH_ATTR void seed_search_kernel(SeedParams P, MatcherArgs M) {
+__global__ __launch_bounds__(TILE_PIX) void seed_search_kernel(SeedParams P, MatcherArgs M) {
   using Smem = SearchSmem<SIDE, WS, WROWS>;
   constexpr int HALF = SIDE / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -726,8 +639,7 @@ __global__ __launch_bounds__(TILE_PIX) RMD_SEARCH_ATTR void seed_search_kernel(S
       const float inv_ww = 1.0f / static_cast<float>(ww);
       // all of a thread's loads are issued before its first LDS store (chunks of 8, skipped wave-uniformly beyond the
       // window's end): one memory round trip per window, two for the largest, instead of one per 8 texels
-      constexpr int CAP = (WS * WROWS + TILE_PIX - 1) / TILE_PIX;
-      constexpr int BATCH = ((CAP < RMD_EXP_STAGE_BATCH ? CAP : RMD_EXP_STAGE_BATCH) + 7) / 8 * 8;
+      constexpr int BATCH = 8;  // 16 or 32 in flight per thread measured slower (register pressure)
       for (int e0 = tid; e0 < n_el; e0 += TILE_PIX * BATCH) {
         float v[BATCH];
         int dst[BATCH];
@@ -814,6 +726,7 @@ __global__ __launch_bounds__(TILE_PIX) RMD_SEARCH_ATTR void seed_search_kernel(S
       t_stage += static_cast<unsigned long long>(t1 - t0);
       t_search += static_cast<unsigned long long>(t2 - t1);
     }
+    if (n_units <= gridDim.x) break;  // light frame: every unit had its own workgroup, nothing to hand out
     __syncthreads();  // this unit's LDS is no longer read
     if (tid == 0) S.unit[0] = gridDim.x + atomicAdd(&M.queue[1], 1u);
     __syncthreads();
@@ -844,7 +757,6 @@ __global__ __launch_bounds__(TILE_PIX) RMD_SEARCH_ATTR void seed_search_kernel(S
 __global__ __launch_bounds__(256) void seed_finalize_kernel(SeedParams P, MatcherArgs M) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x == 0 && y == 0) finalize_housekeeping(M.queue, M.queue_next, M.feedback);
   if (x >= P.w || y >= P.h) return;
   const int gi = y * P.stride + x;
   if (P.conv[gi] != ST_UPDATE) return;  // BORDER / CONVERGED / DIVERGED were settled by seed_setup
@@ -853,13 +765,11 @@ __global__ __launch_bounds__(256) void seed_finalize_kernel(SeedParams P, Matche
 }
 
 // ------------------------------------------------------------------------------------------------
-inline MatcherArgs matcher_args(const MatcherWorkspace& ws, int parity) {
+inline MatcherArgs matcher_args(const MatcherWorkspace& ws) {
   MatcherArgs M;
   M.mean = ws.d_mean; M.dir = ws.d_dir; M.lfirst = ws.d_lfirst; M.packed = ws.d_packed; M.best = ws.d_best;
   M.tiles = ws.d_tiles; M.tile_plan = ws.d_tile_plan; M.units = ws.d_units; M.tiles_x = ws.tiles_x;
-  M.queue = ws.d_queue + 8 * parity;
-  M.queue_next = ws.d_queue + 8 * (parity ^ 1);
-  M.feedback = ws.h_feedback;
+  M.queue = ws.d_queue;
   M.trace = nullptr;
   return M;
 }
@@ -870,11 +780,9 @@ template <int SIDE, int WS, int WROWS>
 inline hipError_t launch_seed_pipeline(const SeedParams& P, MatcherWorkspace& ws, hipStream_t stream, int num_cus, bool& attr_set,
                                        bool fuse_prev, const Pose& T_ref_curr_prev) {
   using Smem = SearchSmem<SIDE, WS, WROWS>;
-  ws.parity ^= 1;
-  MatcherArgs M = matcher_args(ws, ws.parity);
+  MatcherArgs M = matcher_args(ws);
   M.trace = P.trace;
-  // Persistent grid: as many workgroups as fit the chip, but no more than the work of the previous frame suggests
-  // (the unit count is read back through pinned memory, one or two frames late; any grid size is correct).
+  // Persistent grid: as many workgroups as fit the chip; those without a unit leave within a microsecond.
   const int by_lds = static_cast<int>((160 * 1024) / sizeof(Smem));
   const int wg_per_cu = by_lds < 4 ? (by_lds > 0 ? by_lds : 1) : 4;  // >4 x 256 threads gain nothing at this register count
   const int resident = num_cus * wg_per_cu;
@@ -889,35 +797,27 @@ inline hipError_t launch_seed_pipeline(const SeedParams& P, MatcherWorkspace& ws
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const unsigned int prev_units = ws.h_feedback[0];
-  int grid = resident;
-  if (prev_units != 0xffffffffu) {
-    const long long want = static_cast<long long>(prev_units) + prev_units / 4 + 16;
-    grid = want < resident ? static_cast<int>(want) : resident;
-  }
+  const int grid = resident;
   hipLaunchKernelGGL(search, dim3(grid), dim3(TILE_PIX), sizeof(Smem), stream, P, M);
   return hipGetLastError();
 }
 
 // Two LDS window geometries for the search kernel (odd row strides spread the LDS banks):
-//   small  69 x 64 texels: searches up to ~40 px; 4 workgroups per CU
-//   large 133 x 104 texels: holds a 16x16 tile's worst case (100 px search, any direction); 2 workgroups per CU
-// The host picks per frame from the previous frame's widest / tallest tile window (pinned feedback); a wrong guess only
-// sends the overflowing samples to the global-memory path.
+//   large 133 x 104 texels (default): holds a 16x16 tile's worst case (100 px search, any direction)
+//   small  69 x 64 texels: searches up to ~40 px; selectable for experiments (RMD_HIP_OPT_WINDOW = 1)
+// Samples outside a tile's window are read from global memory.  Picking the geometry per frame from a read-back of the
+// previous frames' window sizes was tried and removed: a host that submits frames in bursts decides from stale numbers,
+// and at the search kernel's register count the small window does not buy more resident waves.
 template <int SIDE>
 inline hipError_t launch_seed_update_tile(const SeedParams& P, MatcherWorkspace& ws, hipStream_t stream, int num_cus,
                                           int force_window, bool fuse_prev, const Pose& T_ref_curr_prev) {
-  const unsigned int need_w = ws.h_feedback[1], need_h = ws.h_feedback[2];
-  bool small = ws.h_feedback[0] != 0xffffffffu && need_w + 6 <= 69 && need_h + 6 <= 64;
-  if (force_window == 1) small = true;
-  if (force_window == 2) small = false;
-  if (small) return launch_seed_pipeline<SIDE, 69, 64>(P, ws, stream, num_cus, ws.attr_set_small, fuse_prev, T_ref_curr_prev);
+  if (force_window == 1) return launch_seed_pipeline<SIDE, 69, 64>(P, ws, stream, num_cus, ws.attr_set_small, fuse_prev, T_ref_curr_prev);
   return launch_seed_pipeline<SIDE, 133, 104>(P, ws, stream, num_cus, ws.attr_set_large, fuse_prev, T_ref_curr_prev);
 }
 
 // the stand-alone finalisation of the frame whose pipeline was launched last (P must carry that frame's poses)
 inline hipError_t launch_seed_finalize(const SeedParams& P, MatcherWorkspace& ws, hipStream_t stream) {
-  const MatcherArgs M = matcher_args(ws, ws.parity);
+  const MatcherArgs M = matcher_args(ws);
   hipLaunchKernelGGL(seed_finalize_kernel, dim3((P.w + 63) / 64, (P.h + 3) / 4), dim3(64, 4), 0, stream, P, M);
   return hipGetLastError();
 }

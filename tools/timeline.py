@@ -34,6 +34,7 @@ prev_end = None
 for k in range(a.frames - 1):
     t = s.traceDownload(k)
     S, P, Q = t["setup"].astype(np.int64), t["plan"].astype(np.int64), t["search"].astype(np.int64)
+    unit_rounds = int(P[0, 1] >> 56); P[0, 1] &= (1 << 56) - 1
     t0 = S[:, 0].min()
     L = S[:, 1] - S[:, 0]
     row = [us(prev_end - t0) if prev_end is not None else 0.0, us(S[:, 0].max() - t0), us(S[:, 1].max() - t0), us(L.mean()), us(np.percentile(L, 99)),
@@ -53,7 +54,7 @@ for k in range(a.frames - 1):
               f"p90 {us(np.percentile(L, 90)):.1f} p99 {us(np.percentile(L, 99)):.1f}; setup ends: p50 {us(np.percentile(S[:, 1] - t0, 50)):.1f} p90 {us(np.percentile(S[:, 1] - t0, 90)):.1f}")
     if k + 1 in (1, 2, 5, 10, 20, 40, 60, 100, 150, a.frames - 1):
         print(f"{k + 1:5d} {row[0]:6.1f} | {row[1]:16.1f} {row[2]:6.1f} {row[3]:5.1f} {row[4]:5.1f} {row[5]:5.1f} | {row[6]:12.1f} {row[7]:6.1f} | "
-              f"{row[8]:12d} {row[9]:6.1f} {row[10]:6.1f} {row[11]:6.1f} {row[12]:6.1f} {row[13]:6.1f}")
+              f"r{unit_rounds} {row[8]:9d} {row[9]:6.1f} {row[10]:6.1f} {row[11]:6.1f} {row[12]:6.1f} {row[13]:6.1f}")
 A = np.array(rows)[1:]
 m = A.mean(0)
 print(f" mean {m[0]:6.1f} | {m[1]:16.1f} {m[2]:6.1f} {m[3]:5.1f} {m[4]:5.1f} {m[5]:5.1f} | {m[6]:12.1f} {m[7]:6.1f} | {m[8]:12.0f} {m[9]:6.1f} {m[10]:6.1f} {m[11]:6.1f} {m[12]:6.1f} {m[13]:6.1f}")
