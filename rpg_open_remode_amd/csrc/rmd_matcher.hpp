@@ -6,10 +6,10 @@
 //                         State check; epipolar segment; ONE walk of the search loop to find the
 //                         contiguous run of steps whose patch lies inside the image.  Writes the
 //                         per-seed search descriptor, the tile's total work and the image window its
-//                         samples fall into, and appends fixed-size WORK UNITS (tile, item range) to
-//                         a device queue.
-//   seed_plan_kernel      one workgroup: exclusive scan of the tiles' unit counts -> compact unit list (keeps every
-//                         atomic out of seed_setup: 1200 tiles x 3 atomics on shared words cost 40 us per frame).
+//                         samples fall into.
+//   seed_plan_kernel      one workgroup: unit size from the frame's total work, exclusive scan of the tiles' unit counts ->
+//                         compact unit list (keeps every atomic out of seed_setup: 1200 tiles x 3 atomics on shared words
+//                         cost 40 us per frame).  All scheduling decisions are taken on the device.
 //   seed_search_kernel    persistent workgroups pull units from the queue (one returning atomic per
 //                         unit), so a tile whose seeds all search 143 steps is spread over many CUs
 //                         while converged tiles cost nothing.  Per unit: stage the tile's window of

@@ -15,9 +15,6 @@ echo "== kernel trace + stats: bench.py $BENCH_ARGS"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python "$ROOT/bench.py" $BENCH_ARGS > "$SUM/bench_under_trace.json" 2> "$OUT/trace.err"
 PMC_ARGS="--steps 30 --warmup 2 --cpu-seconds 0"
 if [ "${PMC:-1}" = "1" ]; then
-# NB: the set {SQ_ACTIVE_INST_VALU, SQ_ACTIVE_INST_LDS, SQ_LDS_BANK_CONFLICT, SQ_BUSY_CYCLES} makes rocprofv3 abort with a GPU memory
-# fault on this pipeline (the same binary runs clean unprofiled, with AMD_SERIALIZE_KERNEL=3, under --kernel-trace and under the
-# sets below), so it is not collected.
 echo "== PMC pass 1 (instruction counts)"
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d "$OUT/pmc_insts" -- python "$ROOT/bench.py" $PMC_ARGS > /dev/null 2> "$OUT/pmc_insts.err"
 echo "== PMC pass 2 (FETCH_SIZE)"
