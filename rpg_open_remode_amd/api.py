@@ -110,6 +110,9 @@ class SE3:
     def getTranslation(self):
         return self.data[[3, 7, 11]].copy()
 
+    def __str__(self):  # matrix.cuh:56-67: setprecision(9), a space after every element, one line per row
+        return "".join("".join(f"{float(v):.9g} " for v in self.data[4 * r:4 * r + 4]) + "\n" for r in range(3))
+
 
 def _as_pose(T):
     return np.ascontiguousarray(T.data if isinstance(T, SE3) else T, np.float32).reshape(12)
