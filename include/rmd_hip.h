@@ -128,6 +128,12 @@ int rmd_hip_seeds_plane(const rmd_hip_seeds_t* s, int plane, const rmd_hip_image
 /* getConvergedCount :195-198 (count of CONVERGED in the convergence plane) */
 int rmd_hip_seeds_converged_count(const rmd_hip_seeds_t* s, size_t* count);
 /* getDistFromRef :200-203 */
+/* CONVERGED-masked back-projection to world-frame XYZI points, the loop of Publisher::publishPointCloud (publisher.cpp:54-104)
+ * on the device: for every pixel (x, y) in row-major order whose state is CONVERGED,
+ *   f = normalize(((x - cx) / fx, (y - cy) / fy, 1));  (X, Y, Z) = T_world_ref * (f * depth(x, y));  I = 8-bit reference image.
+ * depth: an f32 W x H device image (e.g. rmd_hip_denoiser_result) or NULL for the seeds' own mu.  out_xyzi: `capacity` points
+ * of 4 floats.  *n_points = number of converged seeds; if it exceeds `capacity` only the first `capacity` points are written. */
+int rmd_hip_seeds_point_cloud(rmd_hip_seeds_t* s, const rmd_hip_image_t* depth, float* out_xyzi, size_t capacity, size_t* n_points);
 int rmd_hip_seeds_dist_from_ref(const rmd_hip_seeds_t* s, float* dist);
 /* blocks until all work queued by this handle has finished */
 int rmd_hip_seeds_sync(const rmd_hip_seeds_t* s);

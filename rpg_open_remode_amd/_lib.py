@@ -60,6 +60,7 @@ SIGNATURES = {
     "rmd_hip_seeds_last_stats": (_i, [_p, _p]),
     "rmd_hip_seeds_last_diagnostics": (_i, [_p, _p]),
     "rmd_hip_seeds_trace_download": (_i, [_p, _i, _p, _sz, _c.POINTER(_sz)]),
+    "rmd_hip_seeds_point_cloud": (_i, [_p, _p, _p, _sz, _c.POINTER(_sz)]),
     "rmd_hip_denoiser_create": (_i, [_i, _i, _pp]),
     "rmd_hip_denoiser_destroy": (_i, [_p]),
     "rmd_hip_denoiser_set_large_sigma_sq": (_i, [_p, _f]),

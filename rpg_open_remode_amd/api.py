@@ -298,6 +298,16 @@ class SeedMatrix:
         check(_lib.lib().rmd_hip_seeds_converged_count(self.ptr, ctypes.byref(out)))
         return int(out.value)
 
+    def pointCloud(self, depth=None):
+        """World-frame XYZI points of the CONVERGED seeds, row-major pixel order (Publisher::publishPointCloud,
+        publisher.cpp:54-104, computed on the device).  depth: a DeviceImage (e.g. DepthmapDenoiser.result()) or None for mu.
+        Returns an (N, 4) float32 array."""
+        cap = self.width * self.height
+        out = np.empty((cap, 4), np.float32)
+        n = ctypes.c_size_t()
+        check(_lib.lib().rmd_hip_seeds_point_cloud(self.ptr, depth.ptr if depth is not None else None, out.ctypes.data, cap, ctypes.byref(n)))
+        return out[:int(n.value)].copy()
+
     def getDistFromRef(self):
         out = ctypes.c_float()
         check(_lib.lib().rmd_hip_seeds_dist_from_ref(self.ptr, ctypes.byref(out)))
@@ -377,6 +387,14 @@ class DepthmapDenoiser:
                                                   out.ctypes.data if download else None, float(lam), int(iterations)))
         return out
 
+    def result(self):
+        """Device-resident output of the last denoise() (a view; valid until the next denoise() of this object)."""
+        v = ctypes.c_void_p()
+        check(_lib.lib().rmd_hip_denoiser_result(self.ptr, ctypes.byref(v)))
+        img = DeviceImage(0, 0, _view=v.value)
+        img._keepalive = self
+        return img
+
     def constants(self):
         out = np.zeros(4, np.float32)
         check(_lib.lib().rmd_hip_denoiser_constants(self.ptr, out.ctypes.data))
@@ -435,6 +453,11 @@ class Depthmap:
         self.output_convergence_int_ = self.seeds_.downloadConvergence()
 
     def getConvergenceMap(self): return self.output_convergence_int_
+
+    def downloadPointCloud(self, denoised=True):
+        """(N, 4) XYZI points of the converged seeds from the depth map of the last downloadDenoisedDepthmap() (or from
+        the raw depth estimate): what rmd::Publisher builds on the host from two downloaded images."""
+        return self.seeds_.pointCloud(self.denoiser_.result() if denoised else None)
     def getReferenceImage(self): return self.ref_img_8uc1_
     def getConvergedCount(self): return self.seeds_.getConvergedCount()
 

@@ -193,6 +193,8 @@ struct rmd_hip_seeds {
   long long last_stats[16] = {0};
   bool stats_pending = false;
   long long trace_frame = 0;  // updates launched since timeline tracing was switched on
+  unsigned int* d_pc_counts = nullptr;  // point cloud (allocated at the first request): per-block counts / offsets, [n_blocks] = total
+  float4* d_pc_points = nullptr;        // W x H points
   rmdk::MatcherWorkspace matcher_ws;
 };
 
@@ -451,6 +453,8 @@ int rmd_hip_seeds_destroy(rmd_hip_seeds_t* s) {
   for (auto& pl : s->planes)
     if (pl.owns && pl.data) (void)hipFree(pl.data);
   s->matcher_ws.release();
+  if (s->d_pc_counts) (void)hipFree(s->d_pc_counts);
+  if (s->d_pc_points) (void)hipFree(s->d_pc_points);
   if (s->d_scalars) (void)hipFree(s->d_scalars);
   if (s->h_scalars) (void)hipHostFree(s->h_scalars);
   if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -658,6 +662,44 @@ int rmd_hip_seeds_converged_count(const rmd_hip_seeds_t* s, size_t* count) {
   HIP_TRY(hipMemcpyAsync(m->h_scalars, m->d_scalars, sizeof(unsigned long long), hipMemcpyDeviceToHost, m->stream));
   TRY(seeds_sync(s));
   *count = static_cast<size_t>(m->h_scalars[0]);
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_seeds_point_cloud(rmd_hip_seeds_t* s, const rmd_hip_image_t* depth, float* out_xyzi, size_t capacity, size_t* n_points) {
+  if (!s || !n_points || (!out_xyzi && capacity)) return fail(RMD_HIP_ERR_INVALID_ARG, "point_cloud: null argument");
+  if (!s->has_reference) return fail(RMD_HIP_ERR_NOT_READY, "point_cloud: no reference image set");
+  if (depth && (depth->kind != RMD_HIP_KIND_F32 || depth->width != s->width || depth->height != s->height))
+    return fail(RMD_HIP_ERR_INVALID_ARG, "point_cloud: depth must be an f32 %dx%d image", s->width, s->height);
+  TRY(seeds_bind_device(s));
+  TRY(seeds_flush(s));
+  if (depth && !(depth->owner_seeds == s) && (depth->owner_seeds || (depth->owner_stream && depth->owner_stream != s->stream)))
+    TRY(image_settle(depth));
+  const int n_pix = s->width * s->height;
+  const int n_blocks = (n_pix + rmdk::PC_BLOCK - 1) / rmdk::PC_BLOCK;
+  if (!s->d_pc_counts) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_pc_counts), (static_cast<size_t>(n_blocks) + 1) * sizeof(unsigned int)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_pc_points), static_cast<size_t>(n_pix) * sizeof(float4)));
+  }
+  rmdk::PointCloudParams P;
+  P.w = s->width; P.h = s->height;
+  P.stride = s->P.stride;
+  P.depth = depth ? static_cast<const float*>(depth->data) : s->P.mu;
+  P.depth_stride = depth ? static_cast<int>(depth->stride) : s->P.stride;
+  P.conv = s->P.conv;
+  P.ref = s->P.ref;
+  P.cam = s->P.cam;
+  P.T_world_ref = s->T_world_ref;
+  hipLaunchKernelGGL(rmdk::pc_count_kernel, dim3(n_blocks), dim3(rmdk::PC_BLOCK), 0, s->stream, P, s->d_pc_counts);
+  hipLaunchKernelGGL(rmdk::pc_scan_kernel, dim3(1), dim3(1024), 0, s->stream, s->d_pc_counts, n_blocks, s->d_pc_counts + n_blocks);
+  hipLaunchKernelGGL(rmdk::pc_write_kernel, dim3(n_blocks), dim3(rmdk::PC_BLOCK), 0, s->stream, P, s->d_pc_counts, s->d_pc_points,
+                     static_cast<unsigned int>(n_pix));
+  HIP_TRY(hipGetLastError());
+  unsigned int total = 0;
+  HIP_TRY(hipMemcpyAsync(&total, s->d_pc_counts + n_blocks, sizeof(total), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  *n_points = total;
+  const size_t n_copy = total < capacity ? total : capacity;
+  if (n_copy) HIP_TRY(hipMemcpy(out_xyzi, s->d_pc_points, n_copy * sizeof(float4), hipMemcpyDeviceToHost));
   return RMD_HIP_OK;
 }
 

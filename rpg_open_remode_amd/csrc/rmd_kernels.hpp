@@ -285,6 +285,95 @@ __global__ __launch_bounds__(64) void sum_final_kernel(const double* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// CONVERGED-masked back-projection to a world-frame XYZI point cloud: src/publisher.cpp:54-104 (a host loop over two
+// downloaded images in the reference).  Per pixel (x, y), row-major:  f = normalize(((x-cx)/fx, (y-cy)/fy, 1));
+// xyz = T_world_ref * (f * depth(x, y));  kept iff convergence(x, y) == CONVERGED;  intensity = 8-bit reference image.
+// Three launches keep the reference's point order (order-preserving compaction): per-block counts, one-block exclusive
+// scan, write at block offset + rank.  Only the points cross the bus afterwards, not two W x H images.
+struct PointCloudParams {
+  int w, h;
+  int stride;        // conv, ref planes
+  int depth_stride;  // depth plane (the SeedMatrix's mu or a denoiser's output)
+  const float* depth;
+  const int* conv;
+  const float* ref;  // reference image as uploaded: u8 * (1/255)
+  Cam cam;
+  Pose T_world_ref;
+};
+constexpr int PC_BLOCK = 256;
+
+RMDK_D bool pc_pixel(const PointCloudParams& P, int i, int& x, int& y) {
+  if (i >= P.w * P.h) return false;
+  y = i / P.w;
+  x = i - y * P.w;
+  return P.conv[static_cast<size_t>(y) * P.stride + x] == ST_CONVERGED;
+}
+
+__global__ __launch_bounds__(PC_BLOCK) void pc_count_kernel(PointCloudParams P, unsigned int* __restrict__ block_counts) {
+  __shared__ unsigned int wave_part[PC_BLOCK / 64];
+  int x, y;
+  const bool keep = pc_pixel(P, blockIdx.x * PC_BLOCK + threadIdx.x, x, y);
+  const unsigned int n = static_cast<unsigned int>(__popcll(__ballot(keep)));
+  if ((threadIdx.x & 63) == 0) wave_part[threadIdx.x >> 6] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_part[0] + wave_part[1] + wave_part[2] + wave_part[3];
+}
+
+// in place: counts -> exclusive offsets; total to *total
+__global__ __launch_bounds__(1024) void pc_scan_kernel(unsigned int* __restrict__ counts, int n, unsigned int* __restrict__ total) {
+  __shared__ unsigned int wave_tot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (n + 1023) / 1024;
+  const int first = tid * per;
+  unsigned int mine = 0;
+  for (int q = 0; q < per; ++q)
+    if (first + q < n) mine += counts[first + q];
+  unsigned int incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned int v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  unsigned int base = 0, all = 0;
+  for (int wv = 0; wv < 16; ++wv) {
+    base += wv < wave ? wave_tot[wv] : 0u;
+    all += wave_tot[wv];
+  }
+  base += incl - mine;
+  for (int q = 0; q < per; ++q) {
+    if (first + q < n) {
+      const unsigned int c = counts[first + q];
+      counts[first + q] = base;
+      base += c;
+    }
+  }
+  if (tid == 0) *total = all;
+}
+
+__global__ __launch_bounds__(PC_BLOCK) void pc_write_kernel(PointCloudParams P, const unsigned int* __restrict__ block_offsets,
+                                                            float4* __restrict__ out, unsigned int capacity) {
+  __shared__ unsigned int wave_part[PC_BLOCK / 64];
+  int x = 0, y = 0;
+  const bool keep = pc_pixel(P, blockIdx.x * PC_BLOCK + threadIdx.x, x, y);
+  const unsigned long long mask = __ballot(keep);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_part[wave] = static_cast<unsigned int>(__popcll(mask));
+  __syncthreads();
+  if (!keep) return;
+  unsigned int rank = static_cast<unsigned int>(__popcll(mask & ((1ull << lane) - 1ull)));
+  for (int wv = 0; wv < wave; ++wv) rank += wave_part[wv];
+  const unsigned int idx = block_offsets[blockIdx.x] + rank;
+  if (idx >= capacity) return;
+  const F3 f = normalize3(cam2world(P.cam, static_cast<float>(x), static_cast<float>(y)));
+  const F3 xyz = pose_apply(P.T_world_ref, scale3(f, P.depth[static_cast<size_t>(y) * P.depth_stride + x]));
+  // the 8-bit intensity back from the float image the path works on: rint(v * 255) is exact for v = k * (1/255)f
+  const float intensity = rintf(P.ref[static_cast<size_t>(y) * P.stride + x] * 255.0f);
+  out[idx] = make_float4(xyz.x, xyz.y, xyz.z, intensity);
+}
+
+// ------------------------------------------------------------------------------------------
 // TV-L1 denoiser.
 struct TvParams {
   int w, h;

@@ -208,3 +208,27 @@ def count_mismatch(a, b):
     if a.dtype.kind == "f":
         return int(np.count_nonzero(~((a == b) | (np.isnan(a) & np.isnan(b)))))
     return int(np.count_nonzero(a != b))
+
+
+def point_cloud(depth, convergence, ref_img_u8, K, T_world_ref):
+    """CPU restatement of Publisher::publishPointCloud (src/publisher.cpp:54-104) in numpy float32, one rounding per
+    operation in the reference's order: f = normalize(((x-cx)/fx, (y-cy)/fy, 1)) with normalize = v * (1/sqrt(v.v))
+    (helper_math.h:1248-1251,1309-1313, rsqrtf as 1/sqrtf off-device), xyz = T_world_ref.translate(rotate(f * depth))
+    (se3.cuh:111-124,165-168); CONVERGED pixels only, row-major; intensity = the 8-bit reference image.
+    Test infrastructure only."""
+    f32 = np.float32
+    fx, fy, cx, cy = (f32(v) for v in K)
+    depth = np.asarray(depth, f32)
+    h, w = depth.shape
+    xs = np.broadcast_to(np.arange(w, dtype=f32)[None, :], (h, w))
+    ys = np.broadcast_to(np.arange(h, dtype=f32)[:, None], (h, w))
+    vx, vy, vz = (xs - cx) / fx, (ys - cy) / fy, np.ones((h, w), f32)
+    dot = vx * vx + vy * vy + vz * vz
+    inv = f32(1.0) / np.sqrt(dot)
+    px, py, pz = (vx * inv) * depth, (vy * inv) * depth, (vz * inv) * depth
+    T = np.asarray(T_world_ref, f32).reshape(12)
+    X = (T[0] * px + T[1] * py + T[2] * pz) + T[3]
+    Y = (T[4] * px + T[5] * py + T[6] * pz) + T[7]
+    Z = (T[8] * px + T[9] * py + T[10] * pz) + T[11]
+    keep = np.asarray(convergence) == 1
+    return np.stack([X[keep], Y[keep], Z[keep], np.asarray(ref_img_u8)[keep].astype(f32)], axis=1).astype(f32)

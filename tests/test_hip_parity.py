@@ -432,3 +432,62 @@ def test_device_math_equals_host_math_bit_for_bit():
     t = rng.random(60000).astype(np.float32)
     a, b = rng.random(60000).astype(np.float32), rng.random(60000).astype(np.float32)
     assert O.planes_equal(dev(6, t, a, b), host(6, t, a, b))
+
+
+# ---------------------------------------------------------------------------------------------- point cloud
+def test_point_cloud_equals_the_publisher_loop():
+    seq = sequence(160, 120, 41)
+    dm = api.Depthmap(160, 120, seq.K[0], seq.K[2], seq.K[1], seq.K[3], patch_side=5)
+    with pytest.raises(api.RmdHipError):
+        dm.seeds_.pointCloud()  # no reference yet
+    dm.setReferenceImage(seq.gray[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    assert dm.seeds_.pointCloud().shape == (0, 4)  # nothing has converged yet
+    for k in range(1, 41):
+        dm.update(seq.gray[k], seq.T_curr_world[k])
+    T_world_ref = dm.getT_world_ref().data
+    dm.downloadConvergenceMap()
+    conv = dm.getConvergenceMap()
+    assert (conv == 1).sum() > 2000
+    # raw depth estimate
+    dm.downloadDepthmap()
+    want = O.point_cloud(dm.getDepthmap(), conv, seq.gray[0], seq.K, T_world_ref)
+    got = dm.downloadPointCloud(denoised=False)
+    assert got.shape == want.shape and O.count_mismatch(want, got) == 0
+    # denoised depth, straight from the denoiser's device buffer
+    dm.downloadDenoisedDepthmap(0.5, 30)
+    want = O.point_cloud(dm.getDepthmap(), conv, seq.gray[0], seq.K, T_world_ref)
+    got = dm.downloadPointCloud()
+    assert O.count_mismatch(want, got) == 0
+    # every point lies on the scene: back-projected depth along the ray reproduces the analytic range within the filter's accuracy
+    centre = np.asarray(seq.T_world_cam[0], np.float64)[:, 3]
+    rng = np.linalg.norm(got[:, :3].astype(np.float64) - centre, axis=1)
+    assert np.median(np.abs(rng - seq.range0[conv == 1])) < 5e-3
+    # a caller buffer smaller than the cloud: the count is still reported, the first points are written
+    import ctypes
+    from rpg_open_remode_amd import _lib
+    small = np.zeros((100, 4), np.float32)
+    n = ctypes.c_size_t()
+    _lib.check(_lib.lib().rmd_hip_seeds_point_cloud(dm.seeds_.ptr, None, small.ctypes.data, 100, ctypes.byref(n)))
+    assert n.value == (conv == 1).sum()
+    dm.downloadDepthmap()
+    assert O.count_mismatch(O.point_cloud(dm.getDepthmap(), conv, seq.gray[0], seq.K, T_world_ref)[:100], small) == 0
+
+
+def test_point_cloud_ragged_size_and_intensity_round_trip():
+    seq = sequence(101, 67, 30)
+    s = api.SeedMatrix(101, 67, api.PinholeCamera(*seq.K), patch_side=3)
+    ramp = (np.arange(101 * 67) % 256).astype(np.uint8).reshape(67, 101)  # every 8-bit value as reference intensity
+    s.setReferenceImageU8(ramp, seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    rngs = np.random.default_rng(5).uniform(0.5, 3.0, (67, 101)).astype(np.float32)
+    s.upload(api.PLANE_MU, rngs)
+    s.upload(api.PLANE_SIGMA_SQ, np.full((67, 101), 1e-9, np.float32))
+    s.upload(api.PLANE_A, np.full((67, 101), 50.0, np.float32))
+    s.upload(api.PLANE_B, np.full((67, 101), 1.0, np.float32))
+    s.update(seq.images[1], seq.T_curr_world[1])  # seed_check marks all interior seeds CONVERGED, they keep their depth
+    conv = s.downloadConvergence()
+    assert (conv == 1).sum() == (101 - 6) * (67 - 6)
+    T_world_ref = api.SE3(seq.T_curr_world[0]).inv().data
+    want = O.point_cloud(s.downloadDepthmap(), conv, ramp, seq.K, T_world_ref)
+    got = s.pointCloud()
+    assert O.count_mismatch(want, got) == 0
+    assert set(np.unique(got[:, 3]).astype(int)) == set(range(256))
