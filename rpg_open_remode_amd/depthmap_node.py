@@ -1,0 +1,116 @@
+"""The live system's control flow around the depth filter, without ROS: rmd::DepthmapNode (src/depthmap_node.cpp:30-182) and
+rmd::Publisher (src/publisher.cpp:28-147) as a library, so that a batch job can cycle reference frames exactly like the
+node does and its throughput includes the periodic seed_init, TV-L1 and point-cloud steps.
+
+What the reference hands to ROS topics is handed to callbacks here:
+    on_depthmap(depth float32 HxW)                      remode/depth        (publisher.cpp:40-52)
+    on_pointcloud(points float32 Nx4: x, y, z, I)        remode/pointcloud   (:54-104), the cloud ACCUMULATES over publications
+    on_convergence(bgr uint8 HxWx3)                      remode/convergence  (:112-147)
+The point cloud is computed on the device from the denoiser's output and the convergence plane
+(rmd_hip_seeds_point_cloud); the reference downloads both images and loops on the host.
+"""
+import numpy as np
+
+from . import api
+
+
+class State:  # depthmap_node.h:32-36
+    TAKE_REFERENCE_FRAME = 0
+    UPDATE = 1
+
+
+class Publisher:
+    def __init__(self, depthmap, on_depthmap=None, on_pointcloud=None, on_convergence=None, verbose=False):
+        self.depthmap_ = depthmap
+        self.on_depthmap, self.on_pointcloud, self.on_convergence = on_depthmap, on_pointcloud, on_convergence
+        self.verbose = verbose
+        self.pc_ = np.zeros((0, 4), np.float32)  # the reference never clears its cloud: every publication appends (publisher.cpp:83)
+
+    def publishDepthmap(self):
+        if self.on_depthmap:
+            self.on_depthmap(self.depthmap_.getDepthmap())
+        if self.verbose:
+            print("INFO: publishing depth map")
+
+    def publishPointCloud(self):
+        pts = self.depthmap_.downloadPointCloud(denoised=True)
+        if len(pts):
+            self.pc_ = np.concatenate([self.pc_, pts], axis=0)
+        if len(self.pc_):
+            if self.on_pointcloud:
+                self.on_pointcloud(self.pc_)
+            if self.verbose:
+                print(f"INFO: publishing pointcloud, {len(self.pc_)} points")
+
+    def publishDepthmapAndPointCloud(self):
+        self.publishDepthmap()
+        self.publishPointCloud()
+
+    def publishConvergenceMap(self):
+        conv = self.depthmap_.getConvergenceMap()
+        colored = np.repeat(self.depthmap_.getReferenceImage()[:, :, None], 3, axis=2)  # CV_GRAY2BGR
+        colored[..., 0][conv == api.ConvergenceStates.CONVERGED] = 255
+        colored[..., 2][conv == api.ConvergenceStates.DIVERGED] = 255
+        if self.on_convergence:
+            self.on_convergence(colored)
+        if self.verbose:
+            print("INFO: publishing convergence map")
+        return colored
+
+
+class DepthmapNode:
+    """denseInput() is DepthmapNode::denseInputCallback (depthmap_node.cpp:88-163); the parameters are the node's ROS
+    parameters with their defaults (:76-78)."""
+
+    def __init__(self, cam_width, cam_height, cam_fx, cam_fy, cam_cx, cam_cy, ref_compl_perc=10.0, max_dist_from_ref=0.5,
+                 publish_conv_every_n=10, patch_side=5, max_extent=100, denoise_lambda=0.5, denoise_iterations=200,
+                 on_depthmap=None, on_pointcloud=None, on_convergence=None, verbose=False):
+        self.depthmap_ = api.Depthmap(cam_width, cam_height, cam_fx, cam_cx, cam_fy, cam_cy, patch_side=patch_side, max_extent=max_extent)
+        self.state_ = State.TAKE_REFERENCE_FRAME
+        self.ref_compl_perc_ = np.float32(ref_compl_perc)
+        self.max_dist_from_ref_ = np.float32(max_dist_from_ref)
+        self.publish_conv_every_n_ = publish_conv_every_n
+        self.num_msgs_ = 0
+        self.lambda_, self.iterations_ = denoise_lambda, denoise_iterations  # 0.5f, 200 at depthmap_node.cpp:167
+        self.publisher_ = Publisher(self.depthmap_, on_depthmap, on_pointcloud, on_convergence, verbose)
+        self.verbose = verbose
+        self.references_taken = 0
+        self.updates_done = 0
+
+    def denseInput(self, img_8uC1, T_world_curr, min_depth, max_depth):
+        """One svo_msgs::DenseInput message: 8-bit image, camera pose in the world frame (an api.SE3, 12 floats, or
+        (qw, qx, qy, qz, tx, ty, tz)), scene depth range.  Returns the state the node is in afterwards."""
+        self.num_msgs_ += 1
+        if not isinstance(T_world_curr, api.SE3):
+            T_world_curr = api.SE3(*T_world_curr) if len(T_world_curr) == 7 else api.SE3(T_world_curr)
+        if self.verbose:
+            print(f"DEPTHMAP NODE: received image {img_8uC1.shape[1]}x{img_8uC1.shape[0]}")
+            print("T_world_curr:")
+            print(T_world_curr)
+        if self.state_ == State.TAKE_REFERENCE_FRAME:
+            if self.depthmap_.setReferenceImage(img_8uC1, T_world_curr.inv(), min_depth, max_depth):
+                self.state_ = State.UPDATE
+                self.references_taken += 1
+        elif self.state_ == State.UPDATE:
+            self.depthmap_.update(img_8uC1, T_world_curr.inv())
+            self.updates_done += 1
+            perc_conv = np.float32(self.depthmap_.getConvergedPercentage())
+            dist_from_ref = np.float32(self.depthmap_.getDistFromRef())
+            if self.verbose:
+                print(f"INFO: percentage of converged measurements: {perc_conv}%")
+            if perc_conv > self.ref_compl_perc_ or dist_from_ref > self.max_dist_from_ref_:
+                self.state_ = State.TAKE_REFERENCE_FRAME
+                self.denoiseAndPublishResults()
+        if self.publish_conv_every_n_ < self.num_msgs_:
+            self.publishConvergenceMap()
+            self.num_msgs_ = 0
+        return self.state_
+
+    def denoiseAndPublishResults(self):  # depthmap_node.cpp:165-173
+        self.depthmap_.downloadDenoisedDepthmap(self.lambda_, self.iterations_)
+        self.depthmap_.downloadConvergenceMap()
+        self.publisher_.publishDepthmapAndPointCloud()
+
+    def publishConvergenceMap(self):  # :175-182
+        self.depthmap_.downloadConvergenceMap()
+        self.publisher_.publishConvergenceMap()
