@@ -25,14 +25,16 @@ class OracleNode:
 
     def dense_input(self, k):
         seq = self.seq
+        # the node receives T_world_curr and inverts it (depthmap_node.cpp:130,144): the same fp32 round trip here
+        T_curr_world = api.SE3(seq.T_curr_world[k]).inv().inv().data
         if self.taking_reference:
-            self.seeds.set_reference(seq.images[k], seq.T_curr_world[k], seq.min_depth, seq.max_depth)
+            self.seeds.set_reference(seq.images[k], T_curr_world, seq.min_depth, seq.max_depth)
             self.den.set_large_sigma_sq(seq.max_depth - seq.min_depth)
-            self.ref_gray, self.T_world_ref = seq.gray[k], api.SE3(seq.T_curr_world[k]).inv().data
+            self.ref_gray, self.T_world_ref = seq.gray[k], api.SE3(T_curr_world).inv().data
             self.taking_reference = False
             self.reference_frames.append(k)
             return
-        self.seeds.update(seq.images[k], seq.T_curr_world[k])
+        self.seeds.update(seq.images[k], T_curr_world)
         perc = np.float32(self.seeds.converged_count()) / np.float32(seq.width * seq.height) * np.float32(100.0)
         if perc > self.perc or np.float32(self.seeds.dist_from_ref()) > self.dist:
             self.taking_reference = True
