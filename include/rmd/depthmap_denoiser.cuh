@@ -27,6 +27,12 @@ class DepthmapDenoiser {
   void setLargeSigmaSq(float depth_range) {
     detail::throw_on_error(rmd_hip_denoiser_set_large_sigma_sq(handle_, depth_range), "DepthmapDenoiser: setLargeSigmaSq failed");
   }
+  // Extension: the device-resident output of the last denoise() (valid until the next one), for SeedMatrix::downloadPointCloud.
+  const rmd_hip_image_t* resultHandle() const {
+    const rmd_hip_image_t* v = NULL;
+    detail::throw_on_error(rmd_hip_denoiser_result(handle_, &v), "DepthmapDenoiser: result failed");
+    return v;
+  }
 
  private:
   DepthmapDenoiser(const DepthmapDenoiser&);

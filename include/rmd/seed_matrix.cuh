@@ -73,6 +73,18 @@ class SeedMatrix {
     return d;
   }
 
+  // Extension (not in the reference class): the loop of Publisher::publishPointCloud (publisher.cpp:54-104) on the device.
+  // World-frame (x, y, z, intensity) of every CONVERGED seed, row-major pixel order; `depth` = NULL uses the seeds' own mu,
+  // otherwise e.g. DepthmapDenoiser::resultHandle().  Returns the number of converged seeds; at most `capacity` points are written.
+  size_t downloadPointCloud(const rmd_hip_image_t* depth, float* host_xyzi, size_t capacity) const {
+    size_t n = 0;
+    detail::throw_on_error(rmd_hip_seeds_point_cloud(handle_, depth, host_xyzi, capacity, &n), "SeedMatrix: downloadPointCloud failed");
+    return n;
+  }
+  size_t downloadPointCloud(const DeviceImage<float>& depth, float* host_xyzi, size_t capacity) const {
+    return downloadPointCloud(depth.handle(), host_xyzi, capacity);
+  }
+
 #if RMD_BUILD_TESTS
   void downloadSigmaSq(float* host_align_row_maj) const { download(RMD_HIP_PLANE_SIGMA_SQ, host_align_row_maj); }
   void downloadA(float* host_align_row_maj) const { download(RMD_HIP_PLANE_A, host_align_row_maj); }

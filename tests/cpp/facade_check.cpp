@@ -69,6 +69,11 @@ int main(int argc, char** argv) {
   fwrite(mu.data(), 4, px, out); fwrite(sig.data(), 4, px, out); fwrite(a.data(), 4, px, out); fwrite(b.data(), 4, px, out);
   fwrite(conv.data(), 4, px, out); fwrite(den.data(), 4, px, out);
   fwrite(&n_conv, 8, 1, out); fwrite(&n_conv2, 8, 1, out); fwrite(&mu_sum, 4, 1, out); fwrite(&dist, 4, 1, out);
+  // extension: the publisher's point cloud, from the denoised depth still resident on the device
+  std::vector<float> cloud(static_cast<size_t>(px) * 4);
+  const unsigned long long n_points = seeds.downloadPointCloud(denoiser.resultHandle(), cloud.data(), px);
+  fwrite(&n_points, 8, 1, out);
+  fwrite(cloud.data(), 16, n_points, out);
   fclose(out);
   printf("facade_check OK: %dx%d, %d frames, converged %llu\n", w, h, n, n_conv);
   return 0;

@@ -36,7 +36,7 @@ def test_facade_headers_compile_with_plain_gxx_and_probe(tmp_path):
 @pytest.mark.parametrize("side", [5, 9])
 def test_reference_style_cpp_flow_equals_oracle(tmp_path, side):
     exe = _build(tmp_path, side)
-    seq = sequence(160, 120, 10)
+    seq = sequence(160, 120, 36)
     inp, outp = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
     with open(inp, "wb") as f:
         f.write(struct.pack("3i", seq.width, seq.height, seq.n_frames))
@@ -65,3 +65,8 @@ def test_reference_style_cpp_flow_equals_oracle(tmp_path, side):
     assert dist == np.float32(orc.dist_from_ref())
     expect = np.float32(orc.download(O.PLANE_MU).astype(np.float64).sum())
     assert abs(mu_sum - expect) <= 4 * np.spacing(expect)
+    (n_points,) = struct.unpack_from("Q", raw, 6 * px * 4 + 24)
+    cloud = np.frombuffer(raw, np.float32, n_points * 4, 6 * px * 4 + 32).reshape(-1, 4)
+    from rpg_open_remode_amd import api
+    want = O.point_cloud(planes[5], planes[4], seq.gray[0], seq.K, api.SE3(seq.T_curr_world[0]).inv().data)
+    assert n_points == n_conv > 100 and O.count_mismatch(want, cloud) == 0
