@@ -75,8 +75,19 @@ def build_oracles(force=False, verbose=False):
         _run(["make", "-C", odir, "ref"], verbose=verbose)
 
 
+def build_apps(force=False, verbose=False):
+    """apps/dataset_main: the reference's test/dataset_main.cpp on the drop-in headers (needs librmd_hip.so)."""
+    out = os.path.join(ROOT, "apps", "dataset_main")
+    srcs = [os.path.join(ROOT, "apps", "dataset_main.cpp"), os.path.join(ROOT, "apps", "dataset.h")]
+    if force or _newer(out, srcs):
+        _run(["g++", "-std=c++11", "-O2", "-Wall", "-DRMD_CORR_PATCH_SIDE=5", "-I" + os.path.join(ROOT, "include"), srcs[0],
+              "-L" + HERE, "-lrmd_hip", "-lz", "-Wl,-rpath," + HERE, "-o", out], verbose=verbose)
+    return out
+
+
 def build_all(force=False, verbose=False):
     build_hip(force, verbose)
+    build_apps(force, verbose)
     build_synth(force, verbose)
     build_oracles(force, verbose)
 
