@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample (0 disables)")
     ap.add_argument("--matcher", type=int, default=1, help="0 per-pixel kernel, 1 tile kernel")
-    ap.add_argument("--window", type=int, default=0, help="search LDS window: 0 auto, 1 small, 2 large")
+    ap.add_argument("--window", type=int, default=0, help="search LDS window: 0 / 2 large (default), 1 small")
     ap.add_argument("--size", default=f"{WIDTH}x{HEIGHT}", help="frame size WxH; anything but the default 640x480 is one of "
                     "BASELINE's other configs (1280x960, 1920x1080) and is labelled as such, not the headline metric")
     ap.add_argument("--tv-iters", type=int, default=TV_ITERS)

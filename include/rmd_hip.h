@@ -144,7 +144,7 @@ int rmd_hip_seeds_sync(const rmd_hip_seeds_t* s);
                                       around everything between timing_reset and the timing query (no markers in between) */
 #define RMD_HIP_OPT_COLLECT_STATS 2 /* 1 = count live seeds / search steps / NCC evaluations per update;
                                       2 = in-kernel timeline probes instead (see rmd_hip_seeds_trace_download) */
-#define RMD_HIP_OPT_WINDOW 3       /* search-kernel LDS window: 0 = chosen per frame from feedback, 1 = small, 2 = large */
+#define RMD_HIP_OPT_WINDOW 3       /* search-kernel LDS window: 0 or 2 = large (133 x 104 texels, default), 1 = small (69 x 64), for experiments */
 #define RMD_HIP_OPT_LAZY_FINALIZE 4 /* 1 (default) = defer an update's last kernel and fuse it into the next update */
 int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value);
 /* kernels of the seed path, for rmd_hip_seeds_timing */
