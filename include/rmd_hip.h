@@ -128,6 +128,17 @@ int rmd_hip_seeds_plane(const rmd_hip_seeds_t* s, int plane, const rmd_hip_image
 /* getConvergedCount :195-198 (count of CONVERGED in the convergence plane) */
 int rmd_hip_seeds_converged_count(const rmd_hip_seeds_t* s, size_t* count);
 /* getDistFromRef :200-203 */
+/* Lens undistortion of the 8-bit frames handed to set_reference_u8 / update_u8, in front of the x(1/255) conversion:
+ * Depthmap::initUndistortionMap + inputImage (depthmap.cpp:45-61,95-106), i.e. cv::initUndistortRectifyMap(K, (k1, k2, r1, r2),
+ * I, K, size, CV_16SC2) once (host, double precision) and cv::remap(INTER_LINEAR, BORDER_CONSTANT 0) per frame (device, integer
+ * arithmetic).  OpenCV itself is not linked; its published algorithm is restated (parity with a particular OpenCV build is not
+ * pinned). */
+int rmd_hip_seeds_init_undistortion_map(rmd_hip_seeds_t* s, float k1, float k2, float r1, float r2);
+/* the map computation alone (host only, no device needed): what cv::initUndistortRectifyMap(..., CV_16SC2, map1, map2) returns */
+int rmd_hip_compute_undistortion_map(int width, int height, float fx, float fy, float cx, float cy, float k1, float k2, float r1, float r2,
+                                     short* map1_xy, unsigned short* map2);
+/* the maps as computed: map1_xy = W*H (x, y) int16 pairs, map2 = W*H uint16 (fy * 32 + fx) */
+int rmd_hip_seeds_undistortion_map(const rmd_hip_seeds_t* s, short* map1_xy, unsigned short* map2);
 /* CONVERGED-masked back-projection to world-frame XYZI points, the loop of Publisher::publishPointCloud (publisher.cpp:54-104)
  * on the device: for every pixel (x, y) in row-major order whose state is CONVERGED,
  *   f = normalize(((x - cx) / fx, (y - cy) / fy, 1));  (X, Y, Z) = T_world_ref * (f * depth(x, y));  I = 8-bit reference image.

@@ -61,6 +61,9 @@ SIGNATURES = {
     "rmd_hip_seeds_last_diagnostics": (_i, [_p, _p]),
     "rmd_hip_seeds_trace_download": (_i, [_p, _i, _p, _sz, _c.POINTER(_sz)]),
     "rmd_hip_seeds_point_cloud": (_i, [_p, _p, _p, _sz, _c.POINTER(_sz)]),
+    "rmd_hip_seeds_init_undistortion_map": (_i, [_p, _f, _f, _f, _f]),
+    "rmd_hip_seeds_undistortion_map": (_i, [_p, _p, _p]),
+    "rmd_hip_compute_undistortion_map": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _p, _p]),
     "rmd_hip_denoiser_create": (_i, [_i, _i, _pp]),
     "rmd_hip_denoiser_destroy": (_i, [_p]),
     "rmd_hip_denoiser_set_large_sigma_sq": (_i, [_p, _f]),

@@ -121,6 +121,16 @@ def _as_pose(T):
 _KIND_OF = {np.dtype(np.float32): KIND_F32, np.dtype(np.int32): KIND_I32}
 
 
+def computeUndistortionMap(width, height, fx, fy, cx, cy, k1, k2, r1, r2):
+    """cv::initUndistortRectifyMap(K, (k1, k2, r1, r2), I, K, (width, height), CV_16SC2) as restated in the library (host code):
+    (map1 int16 HxWx2 (x, y), map2 uint16 HxW)."""
+    m1 = np.zeros((height, width, 2), np.int16)
+    m2 = np.zeros((height, width), np.uint16)
+    check(_lib.lib().rmd_hip_compute_undistortion_map(int(width), int(height), float(fx), float(fy), float(cx), float(cy), float(k1),
+                                                      float(k2), float(r1), float(r2), m1.ctypes.data, m2.ctypes.data))
+    return m1, m2
+
+
 class DeviceImage:
     """rmd::DeviceImage<T>: a pitched 2-D device buffer.  dtype float32, int32, or 'float2'."""
 
@@ -298,6 +308,18 @@ class SeedMatrix:
         check(_lib.lib().rmd_hip_seeds_converged_count(self.ptr, ctypes.byref(out)))
         return int(out.value)
 
+    def initUndistortionMap(self, k1, k2, r1, r2):
+        """Lens undistortion of the 8-bit frames of setReferenceImageU8 / updateU8 (Depthmap::initUndistortionMap,
+        depthmap.cpp:45-61: cv::initUndistortRectifyMap + cv::remap, restated)."""
+        check(_lib.lib().rmd_hip_seeds_init_undistortion_map(self.ptr, float(k1), float(k2), float(r1), float(r2)))
+
+    def undistortionMap(self):
+        """(map1 int16 HxWx2 (x, y), map2 uint16 HxW) as computed by initUndistortionMap."""
+        m1 = np.zeros((self.height, self.width, 2), np.int16)
+        m2 = np.zeros((self.height, self.width), np.uint16)
+        check(_lib.lib().rmd_hip_seeds_undistortion_map(self.ptr, m1.ctypes.data, m2.ctypes.data))
+        return m1, m2
+
     def pointCloud(self, depth=None):
         """World-frame XYZI points of the CONVERGED seeds, row-major pixel order (Publisher::publishPointCloud,
         publisher.cpp:54-104, computed on the device).  depth: a DeviceImage (e.g. DepthmapDenoiser.result()) or None for mu.
@@ -430,10 +452,17 @@ class Depthmap:
             raise TypeError("Depthmap expects 8-bit gray images (CV_8UC1)")
         return img
 
+    def initUndistortionMap(self, k1, k2, r1, r2):  # depthmap.cpp:45-61
+        self.seeds_.initUndistortionMap(k1, k2, r1, r2)
+        self.is_distorted_ = True
+
     def setReferenceImage(self, img_curr, T_curr_world, min_depth, max_depth):  # depthmap.cpp:63-83
         self.denoiser_.setLargeSigmaSq(max_depth - min_depth)
         ret = self.seeds_.setReferenceImageU8(self._check_u8(img_curr), T_curr_world, min_depth, max_depth)
-        self.ref_img_8uc1_ = np.array(img_curr, copy=True)
+        if getattr(self, "is_distorted_", False):  # ref_img_undistorted_8uc1_ (depthmap.cpp:74-79): the undistorted frame, back in 8 bits
+            self.ref_img_8uc1_ = np.rint(self.seeds_.download(PLANE_REF_IMG) * np.float32(255.0)).astype(np.uint8)
+        else:
+            self.ref_img_8uc1_ = np.array(img_curr, copy=True)
         self.T_world_ref_ = (T_curr_world if isinstance(T_curr_world, SE3) else SE3(T_curr_world)).inv()
         return ret
 

@@ -193,6 +193,10 @@ struct rmd_hip_seeds {
   long long last_stats[16] = {0};
   bool stats_pending = false;
   long long trace_frame = 0;  // updates launched since timeline tracing was switched on
+  short2* d_undist_map1 = nullptr;          // lens undistortion (initUndistortionMap): source pixel per destination pixel
+  unsigned short* d_undist_map2 = nullptr;  // ... and its 5-bit fractions; null = frames are used as they come
+  std::vector<short> h_undist_map1;
+  std::vector<unsigned short> h_undist_map2;
   unsigned int* d_pc_counts = nullptr;  // point cloud (allocated at the first request): per-block counts / offsets, [n_blocks] = total
   float4* d_pc_points = nullptr;        // W x H points
   rmdk::MatcherWorkspace matcher_ws;
@@ -453,6 +457,8 @@ int rmd_hip_seeds_destroy(rmd_hip_seeds_t* s) {
   for (auto& pl : s->planes)
     if (pl.owns && pl.data) (void)hipFree(pl.data);
   s->matcher_ws.release();
+  if (s->d_undist_map1) (void)hipFree(s->d_undist_map1);
+  if (s->d_undist_map2) (void)hipFree(s->d_undist_map2);
   if (s->d_pc_counts) (void)hipFree(s->d_pc_counts);
   if (s->d_pc_points) (void)hipFree(s->d_pc_points);
   if (s->d_scalars) (void)hipFree(s->d_scalars);
@@ -588,9 +594,15 @@ static int seeds_ingest_u8(rmd_hip_seeds* s, const unsigned char* host_gray, int
   HIP_TRY(hipMemcpyAsync(s->d_u8[k], s->h_u8[k], bytes, hipMemcpyHostToDevice, s->stream));
   HIP_TRY(hipEventRecord(s->u8_free[k], s->stream));
   const rmd_hip_image& im = s->planes[dst_plane];
-  const dim3 block(64, 4), grid((s->width + 255) / 256, (s->height + 3) / 4);
-  hipLaunchKernelGGL(rmdk::ingest_u8_kernel, grid, block, 0, s->stream, s->d_u8[k], s->u8_pitch, static_cast<float*>(im.data),
-                     static_cast<int>(im.stride), s->width, s->height);
+  if (s->d_undist_map1) {
+    const dim3 block(64, 4), grid((s->width + 63) / 64, (s->height + 3) / 4);
+    hipLaunchKernelGGL(rmdk::ingest_u8_remap_kernel, grid, block, 0, s->stream, s->d_u8[k], s->u8_pitch, s->d_undist_map1, s->d_undist_map2,
+                       static_cast<float*>(im.data), static_cast<int>(im.stride), s->width, s->height);
+  } else {
+    const dim3 block(64, 4), grid((s->width + 255) / 256, (s->height + 3) / 4);
+    hipLaunchKernelGGL(rmdk::ingest_u8_kernel, grid, block, 0, s->stream, s->d_u8[k], s->u8_pitch, static_cast<float*>(im.data),
+                       static_cast<int>(im.stride), s->width, s->height);
+  }
   HIP_TRY(hipGetLastError());
   return RMD_HIP_OK;
 }
@@ -614,6 +626,73 @@ int rmd_hip_seeds_update_u8(rmd_hip_seeds_t* s, const unsigned char* host_gray, 
   s->P.cur = static_cast<const float*>(im.data);
   s->P.cur_stride = s->P.stride;
   return seeds_after_frame(s, T_curr_world);
+}
+
+// Depthmap::initUndistortionMap (depthmap.cpp:45-61) = cv::initUndistortRectifyMap(K, (k1, k2, r1, r2), I, K, size, CV_16SC2).
+// OpenCV is not part of this build (and the reference does not pin its version); the map is computed here the way OpenCV's
+// scalar code does (imgproc/undistort.cpp, core cv::invert): K and the coefficients are float values widened to double;
+// ir = K^-1 by the closed-form 3x3 inverse cv::invert uses for n <= 3 (cofactors times 1/det, every product written out, zeros
+// included); the normalised coordinates are ACCUMULATED along a row (_x += ir[0] per column); u, v are rounded to 1/32 pixel
+// (cvRound: ties to even) and split into the integer position (map1) and the two 5-bit fractions (map2 = fy * 32 + fx).
+// Host code, IEEE double, no contraction.  tests/oracles.py restates the same in numpy; neither can be pinned against OpenCV
+// here ("parity unpinned" for this step).
+int rmd_hip_compute_undistortion_map(int w, int h, float cam_fx, float cam_fy, float cam_cx, float cam_cy, float k1, float k2, float r1,
+                                     float r2, short* map1_xy, unsigned short* map2) {
+  if (w <= 0 || h <= 0 || !map1_xy || !map2) return fail(RMD_HIP_ERR_INVALID_ARG, "compute_undistortion_map: bad argument");
+  const double fx = cam_fx, fy = cam_fy, u0 = cam_cx, v0 = cam_cy;
+  const double dk1 = k1, dk2 = k2, p1 = r1, p2 = r2, k3 = 0.0, k4 = 0.0, k5 = 0.0, k6 = 0.0;
+  const double S[3][3] = {{fx, 0.0, u0}, {0.0, fy, v0}, {0.0, 0.0, 1.0}};
+  double d = S[0][0] * (S[1][1] * S[2][2] - S[1][2] * S[2][1]) - S[0][1] * (S[1][0] * S[2][2] - S[1][2] * S[2][0]) +
+             S[0][2] * (S[1][0] * S[2][1] - S[1][1] * S[2][0]);
+  d = 1.0 / d;
+  const double ir[9] = {(S[1][1] * S[2][2] - S[1][2] * S[2][1]) * d, (S[0][2] * S[2][1] - S[0][1] * S[2][2]) * d,
+                        (S[0][1] * S[1][2] - S[0][2] * S[1][1]) * d, (S[1][2] * S[2][0] - S[1][0] * S[2][2]) * d,
+                        (S[0][0] * S[2][2] - S[0][2] * S[2][0]) * d, (S[0][2] * S[1][0] - S[0][0] * S[1][2]) * d,
+                        (S[1][0] * S[2][1] - S[1][1] * S[2][0]) * d, (S[0][1] * S[2][0] - S[0][0] * S[2][1]) * d,
+                        (S[0][0] * S[1][1] - S[0][1] * S[1][0]) * d};
+  for (int i = 0; i < h; ++i) {
+    double _x = i * ir[1] + ir[2], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
+    for (int j = 0; j < w; ++j, _x += ir[0], _y += ir[3], _w += ir[6]) {
+      const double wi = 1. / _w, x = _x * wi, y = _y * wi;
+      const double x2 = x * x, y2 = y * y;
+      const double r2_ = x2 + y2, _2xy = 2 * x * y;
+      const double kr = (1 + ((k3 * r2_ + dk2) * r2_ + dk1) * r2_) / (1 + ((k6 * r2_ + k5) * r2_ + k4) * r2_);
+      const double u = fx * (x * kr + p1 * _2xy + p2 * (r2_ + 2 * x2)) + u0;
+      const double v = fy * (y * kr + p1 * (r2_ + 2 * y2) + p2 * _2xy) + v0;
+      const int iu = static_cast<int>(lrint(u * 32)), iv = static_cast<int>(lrint(v * 32));  // saturate_cast<int>(double) = cvRound
+      const size_t k = static_cast<size_t>(i) * w + j;
+      map1_xy[2 * k] = static_cast<short>(iu >> 5);
+      map1_xy[2 * k + 1] = static_cast<short>(iv >> 5);
+      map2[k] = static_cast<unsigned short>((iv & 31) * 32 + (iu & 31));
+    }
+  }
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_seeds_init_undistortion_map(rmd_hip_seeds_t* s, float k1, float k2, float r1, float r2) {
+  if (!s) return fail(RMD_HIP_ERR_INVALID_ARG, "init_undistortion_map: null handle");
+  TRY(seeds_bind_device(s));
+  const int w = s->width, h = s->height;
+  s->h_undist_map1.assign(static_cast<size_t>(w) * h * 2, 0);
+  s->h_undist_map2.assign(static_cast<size_t>(w) * h, 0);
+  TRY(rmd_hip_compute_undistortion_map(w, h, s->P.cam.fx, s->P.cam.fy, s->P.cam.cx, s->P.cam.cy, k1, k2, r1, r2, s->h_undist_map1.data(),
+                                       s->h_undist_map2.data()));
+  TRY(seeds_sync(s));
+  if (!s->d_undist_map1) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_undist_map1), static_cast<size_t>(w) * h * sizeof(short2)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_undist_map2), static_cast<size_t>(w) * h * sizeof(unsigned short)));
+  }
+  HIP_TRY(hipMemcpy(s->d_undist_map1, s->h_undist_map1.data(), static_cast<size_t>(w) * h * sizeof(short2), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(s->d_undist_map2, s->h_undist_map2.data(), static_cast<size_t>(w) * h * sizeof(unsigned short), hipMemcpyHostToDevice));
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_seeds_undistortion_map(const rmd_hip_seeds_t* s, short* map1_xy, unsigned short* map2) {
+  if (!s || !map1_xy || !map2) return fail(RMD_HIP_ERR_INVALID_ARG, "undistortion_map: null argument");
+  if (s->h_undist_map1.empty()) return fail(RMD_HIP_ERR_NOT_READY, "undistortion_map: initUndistortionMap has not been called");
+  memcpy(map1_xy, s->h_undist_map1.data(), s->h_undist_map1.size() * sizeof(short));
+  memcpy(map2, s->h_undist_map2.data(), s->h_undist_map2.size() * sizeof(unsigned short));
+  return RMD_HIP_OK;
 }
 
 int rmd_hip_seeds_download(const rmd_hip_seeds_t* s, int plane, void* host_dst) {
