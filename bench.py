@@ -234,7 +234,7 @@ def main():
         pcie = {"float_frames_update_mpix_s": round(host_path(False), 1), "u8_frames_update_u8_mpix_s": round(host_path(True), 1)}
 
         cpu = None
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and world == 1:  # the CPU baseline is an N = 1 figure; at N > 1 the other ranks would spin beside it
             try:
                 cpu = cpu_baseline(seq, args.cpu_seconds, gpu_sample)
             except Exception as e:  # the bench line must survive a missing oracle
