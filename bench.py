@@ -46,6 +46,23 @@ def parse():
     return ap.parse_args()
 
 
+VALU_PEAK_GINST_S = 256 * 4 * 2.4 / 4.0  # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz = 614.4 G/s
+
+
+def valu_roofline(avg_launch_s, traffic_path):
+    """The roof that actually binds the seed update: VALU issue.  Instruction counts per update() come from the
+    committed PMC passes (profiles/traffic.json, SQ_INSTS_VALU over the whole job), the launch time from this run."""
+    try:
+        t = json.load(open(traffic_path))
+        n = float(sum(t["valu_wave_instructions_per_update"].values()))
+        achieved = n / avg_launch_s / 1e9
+        return {"bound": "valu", "kernel": "seed_update", "achieved": round(achieved, 1), "peak": round(VALU_PEAK_GINST_S, 1),
+                "unit": "G wave-instructions/s", "frac": round(achieved / VALU_PEAK_GINST_S, 4),
+                "wave_instructions_per_launch": int(n), "source": "profiles/traffic.json (rocprofv3 --pmc SQ_INSTS_VALU)"}
+    except Exception:
+        return None
+
+
 def cpu_baseline(seq, budget_s, gpu_sample_fn):
     """The reference's own kernels (oracle/_ref, built from /root/reference for the host) over the first frames
     of the same sequence, all host cores, until `budget_s` is used up."""
@@ -251,7 +268,8 @@ def main():
                                    f"one independent sequence per GPU",
                        "frames_resident_in_hbm": True, "matcher": "tile" if args.matcher else "pixel",
                        "converged_seeds_at_end": converged, "mean_per_update": search_stats},
-            "roofline": roofline, "roofline_denoiser": roofline_tv, "cpu_baseline": cpu, "pcie_inclusive": pcie,
+            "roofline": roofline, "roofline_valu": valu_roofline(avg_kernel_s, tpath) if headline and avg_kernel_s > 0 else None,
+            "roofline_denoiser": roofline_tv, "cpu_baseline": cpu, "pcie_inclusive": pcie,
             "per_rank": [{"elapsed_s": round(e, 6), "mpix": u / 1e6} for e, u in per_rank],
         }
     batch.barrier(device)
