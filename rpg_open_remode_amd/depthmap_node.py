@@ -64,8 +64,10 @@ class DepthmapNode:
 
     def __init__(self, cam_width, cam_height, cam_fx, cam_fy, cam_cx, cam_cy, ref_compl_perc=10.0, max_dist_from_ref=0.5,
                  publish_conv_every_n=10, patch_side=5, max_extent=100, denoise_lambda=0.5, denoise_iterations=200,
-                 on_depthmap=None, on_pointcloud=None, on_convergence=None, verbose=False, distortion=None):
-        self.depthmap_ = api.Depthmap(cam_width, cam_height, cam_fx, cam_cx, cam_fy, cam_cy, patch_side=patch_side, max_extent=max_extent)
+                 on_depthmap=None, on_pointcloud=None, on_convergence=None, verbose=False, distortion=None, depthmap=None):
+        # `depthmap`: an object with rmd::Depthmap's interface to drive instead of the library's (the CPU tests use one)
+        self.depthmap_ = depthmap if depthmap is not None else api.Depthmap(cam_width, cam_height, cam_fx, cam_cx, cam_fy, cam_cy,
+                                                                            patch_side=patch_side, max_extent=max_extent)
         if distortion is not None:  # remode/cam_k1, cam_k2, cam_r1, cam_r2 (depthmap_node.cpp:66-74)
             self.depthmap_.initUndistortionMap(*distortion)
         self.state_ = State.TAKE_REFERENCE_FRAME
