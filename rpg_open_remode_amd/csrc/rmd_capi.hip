@@ -634,7 +634,7 @@ int rmd_hip_seeds_update_u8(rmd_hip_seeds_t* s, const unsigned char* host_gray, 
 // ir = K^-1 by the closed-form 3x3 inverse cv::invert uses for n <= 3 (cofactors times 1/det, every product written out, zeros
 // included); the normalised coordinates are ACCUMULATED along a row (_x += ir[0] per column); u, v are rounded to 1/32 pixel
 // (cvRound: ties to even) and split into the integer position (map1) and the two 5-bit fractions (map2 = fy * 32 + fx).
-// Host code, IEEE double, no contraction.  tests/oracles.py restates the same in numpy; neither can be pinned against OpenCV
+// Host code, IEEE double, no contraction.  oracle/host_steps.py restates the same in numpy; neither can be pinned against OpenCV
 // here ("parity unpinned" for this step).
 int rmd_hip_compute_undistortion_map(int w, int h, float cam_fx, float cam_fy, float cam_cx, float cam_cy, float k1, float k2, float r1,
                                      float r2, short* map1_xy, unsigned short* map2) {
