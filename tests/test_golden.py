@@ -74,3 +74,31 @@ def test_hip_reproduces_the_reference_golden_vectors(side, matcher):
     d.setLargeSigmaSq(dmax - dmin)
     den = d.denoise(s.getMu(), s.getSigmaSq(), s.getA(), s.getB(), float(g["tv_lambda"]), int(g["tv_iterations"]))
     _check(g, "refrmd", state, np.stack(convs), den, s.getConvergedCount(), s.getDistFromRef())
+
+
+# ---- host-side steps (point cloud, undistortion): vectors frozen from oracle/host_steps.py (make_golden_host_steps.py)
+def _host_golden():
+    return np.load(os.path.join(HERE, "golden", "host_steps_golden.npz"))
+
+
+def test_host_steps_oracle_and_library_map_equal_golden():
+    from rpg_open_remode_amd import api
+    g = _host_golden()
+    w, h = int(g["width"]), int(g["height"])
+    m1, m2 = O.undistort_maps(w, h, g["K"], g["D"])
+    assert np.array_equal(m1, g["map1"]) and np.array_equal(m2, g["map2"])
+    l1, l2 = api.computeUndistortionMap(w, h, *g["K"], *g["D"])  # the library's host code
+    assert np.array_equal(l1, g["map1"]) and np.array_equal(l2, g["map2"])
+    assert np.array_equal(O.remap_u8(g["gray"], g["map1"], g["map2"]), g["remapped"])
+    assert O.count_mismatch(O.point_cloud(g["depth"], g["convergence"], g["gray"], g["K"], g["T_world_ref"]), g["cloud"]) == 0
+
+
+@pytest.mark.gpu
+def test_hip_remap_equals_golden():
+    from rpg_open_remode_amd import api
+    g = _host_golden()
+    w, h = int(g["width"]), int(g["height"])
+    s = api.SeedMatrix(w, h, api.PinholeCamera(*g["K"]), patch_side=3)
+    s.initUndistortionMap(*g["D"])
+    s.setReferenceImageU8(g["gray"], np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32), 1.0, 2.0)
+    assert O.count_mismatch(s.download(api.PLANE_REF_IMG), g["remapped"].astype(np.float32) * np.float32(1.0 / 255.0)) == 0
