@@ -47,7 +47,7 @@ def _worker(rank, world, port, n_sequences, out_dir):
     batch.barrier()
     elapsed = time.perf_counter() - t0 + 0.01 * (r + 1)  # distinct per rank so MAX is observable
     units = float(W * H * (frames - 1) * len(mine))
-    max_e, total_u, per_rank = batch.gather_throughput(elapsed, units, torch.device("cpu"))
+    max_e, total_u, per_rank = batch.gather_throughput(elapsed, units, torch.device("cpu"), extra=(float(len(mine) * (frames - 1)), float(r + 7)))
     json.dump({"rank": r, "mine": mine, "elapsed": elapsed, "max_e": max_e, "total_u": total_u, "per_rank": per_rank, "checks": checks},
               open(os.path.join(out_dir, f"rank{r}.json"), "w"))
     import torch.distributed as dist
@@ -75,7 +75,9 @@ def test_two_rank_gloo_sharding_and_gather(tmp_path, n_sequences):
     for r in res:
         assert r["max_e"] == pytest.approx(max(res[0]["elapsed"], res[1]["elapsed"]))
         assert r["total_u"] == 64 * 48 * 3 * n_sequences
-        assert [u for _, u in r["per_rank"]] == [64 * 48 * 3 * len(res[0]["mine"]), 64 * 48 * 3 * len(res[1]["mine"])]
+        assert [rec[1] for rec in r["per_rank"]] == [64 * 48 * 3 * len(res[0]["mine"]), 64 * 48 * 3 * len(res[1]["mine"])]
+        # the 4 x f64 record of SURVEY.md 8e: seconds, pixels, update() calls, converged seeds (here: a per-rank marker)
+        assert [rec[2:] for rec in r["per_rank"]] == [[3.0 * len(res[0]["mine"]), 7.0], [3.0 * len(res[1]["mine"]), 8.0]]
     # different seeds really are different workloads
     allc = {**res[0]["checks"], **res[1]["checks"]}
     assert len(set(round(v, 3) for v in allc.values())) == n_sequences

@@ -1,4 +1,4 @@
-"""bench.py pieces that do not need a GPU: argument plumbing, the JSON helpers, the committed traffic figures."""
+"""bench.py pieces that do not need a GPU: argument plumbing, workload resolution, the JSON helpers, the committed counters."""
 import importlib.util
 import json
 import os
@@ -21,22 +21,41 @@ def _bench(argv):
 
 def test_defaults_are_the_headline_workload():
     b, a = _bench([])
-    assert (a.gpus, a.steps, a.size, a.tv_iters, a.matcher) == (1, 199, "640x480", 200, 1)
-    assert (b.WIDTH, b.HEIGHT, b.FRAMES, b.SIDE) == (640, 480, 200, 9)  # BASELINE.json configs[1]
+    assert (a.gpus, a.size, a.matcher) == (1, "640x480", 1)
+    assert b.resolve_workload(a) == (640, 480, 200, 200)  # BASELINE.json configs[1]: 200 frames, TV-L1 200 iterations
+    assert b.KNOWN_CONFIGS[(640, 480, 200)] == "configs[1]"
+    assert (b.WIDTH, b.HEIGHT, b.FRAMES, b.SIDE) == (640, 480, 200, 9)
     assert b.FUSED_BYTES_PER_PIXEL == 52 and b.TV_BYTES_PER_PIXEL_ITER == 40
 
 
-def test_contract_flags_parse():
-    _, a = _bench(["--gpus", "8", "--steps", "50", "--warmup", "5", "--size", "1920x1080", "--tv-iters", "500", "--cpu-seconds", "0"])
-    assert (a.gpus, a.steps, a.warmup, a.size, a.tv_iters, a.cpu_seconds) == (8, 50, 5, "1920x1080", 500, 0.0)
+def test_steps_do_not_change_the_workload():
+    """Whatever --steps / --warmup the driver passes, a step is a complete pass over the configured sequence."""
+    b, a = _bench(["--steps", "20", "--warmup", "5"])
+    assert (a.steps, a.warmup) == (20, 5)
+    assert b.resolve_workload(a) == (640, 480, 200, 200)
 
 
-def test_committed_traffic_file_feeds_both_rooflines():
+def test_other_baseline_configs_run_at_their_configured_length():
+    b, a = _bench(["--size", "1280x960"])
+    assert b.resolve_workload(a) == (1280, 960, 500, 200) and b.KNOWN_CONFIGS[(1280, 960, 500)] == "configs[2]"
+    b, a = _bench(["--size", "1920x1080"])
+    assert b.resolve_workload(a) == (1920, 1080, 1000, 500) and b.KNOWN_CONFIGS[(1920, 1080, 1000)] == "configs[4]"
+    b, a = _bench(["--gpus", "8", "--steps", "50", "--warmup", "5", "--size", "1920x1080", "--frames", "30", "--tv-iters", "20", "--cpu-seconds", "0"])
+    assert (a.gpus, a.steps, a.warmup, a.cpu_seconds) == (8, 50, 5, 0.0)
+    assert b.resolve_workload(a) == (1920, 1080, 30, 20)
+
+
+def test_rooflines():
     b, _ = _bench([])
+    assert b.VALU_PEAK_GINST_S == 1228.8  # wave64 VALU = 2 cycles on a SIMD-32 (MI355X_MICROARCH.md), 1024 SIMDs, 2.4 GHz
     path = os.path.join(ROOT, "profiles", "traffic.json")
     t = json.load(open(path))
     assert t["algorithmic_bytes_per_update"] == 52 * 640 * 480
     assert t["seed_update_bytes_per_launch"] >= t["algorithmic_bytes_per_update"]  # measured traffic cannot be below the compulsory bytes
     r = b.valu_roofline(60e-6, path)
-    assert r["bound"] == "valu" and 0.0 < r["frac"] < 1.0 and r["peak"] == 614.4
+    assert r["bound"] == "valu" and 0.0 < r["frac"] < 1.0 and r["peak"] == 1228.8
     assert b.valu_roofline(60e-6, os.path.join(ROOT, "no_such_file.json")) is None
+    f = b.flops_roofline(60e-6, 489000.0, 9)
+    assert f["flop_per_launch"] == 14 * 81 * 489000 and f["peak"] == 157.3
+    assert abs(f["achieved"] - 14 * 81 * 489000 / 60e-6 / 1e12) < 0.01
+    assert b.flops_roofline(60e-6, None, 9) is None
