@@ -150,13 +150,17 @@ int rmd_hip_seeds_dist_from_ref(const rmd_hip_seeds_t* s, float* dist);
 int rmd_hip_seeds_sync(const rmd_hip_seeds_t* s);
 
 /* knobs (not in the reference) */
-#define RMD_HIP_OPT_MATCHER 0      /* 0 = per-pixel kernel, 1 = tile-cooperative kernel (default) */
+#define RMD_HIP_OPT_MATCHER 0      /* 0 = per-pixel kernel (the reference's shape), 1 = round-1 tile pipeline (66 KB search window), 2 = one-launch frame
+                                      kernel (experimental), 3 = tile pipeline with the compact search kernel (default) */
 #define RMD_HIP_OPT_TIMING 1       /* 1 = bracket every update with HIP events on the handle's stream; 2 = one event pair
                                       around everything between timing_reset and the timing query (no markers in between) */
 #define RMD_HIP_OPT_COLLECT_STATS 2 /* 1 = count live seeds / search steps / NCC evaluations per update;
                                       2 = in-kernel timeline probes instead (see rmd_hip_seeds_trace_download) */
 #define RMD_HIP_OPT_WINDOW 3       /* search-kernel LDS window: 0 or 2 = large (133 x 104 texels, default), 1 = small (69 x 64), for experiments */
 #define RMD_HIP_OPT_LAZY_FINALIZE 4 /* 1 (default) = defer an update's last kernel and fuse it into the next update */
+#define RMD_HIP_OPT_LOCAL_MAX 5     /* frame kernel: work items a tile keeps to itself before it hands its search out through the
+                                      queue; 0 (default) = from the previous frame's load */
+#define RMD_HIP_OPT_UNIT_ROUNDS 6   /* frame kernel: rounds of 256 NCC evaluations per handed-out unit, 1..4; 0 (default) = from the load */
 int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value);
 /* kernels of the seed path, for rmd_hip_seeds_timing */
 #define RMD_HIP_STAGE_SEED_INIT 0

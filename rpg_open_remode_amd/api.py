@@ -28,7 +28,8 @@ __all__ = ["PinholeCamera", "SE3", "DeviceImage", "SeedMatrix", "DepthmapDenoise
 PLANE_MU, PLANE_SIGMA_SQ, PLANE_A, PLANE_B, PLANE_CONVERGENCE = 0, 1, 2, 3, 4
 PLANE_SUM_TEMPL, PLANE_CONST_TEMPL_DENOM, PLANE_EPIPOLAR_MATCHES, PLANE_REF_IMG, PLANE_CURR_IMG = 5, 6, 7, 8, 9
 KIND_F32, KIND_I32, KIND_F32X2 = 0, 1, 2
-OPT_MATCHER, OPT_TIMING, OPT_COLLECT_STATS, OPT_WINDOW, OPT_LAZY_FINALIZE = 0, 1, 2, 3, 4
+OPT_MATCHER, OPT_TIMING, OPT_COLLECT_STATS, OPT_WINDOW, OPT_LAZY_FINALIZE, OPT_LOCAL_MAX, OPT_UNIT_ROUNDS = 0, 1, 2, 3, 4, 5, 6
+MATCHER_PIXEL, MATCHER_PIPELINE_R01, MATCHER_FRAME, MATCHER_PIPELINE = 0, 1, 2, 3
 STAGE_SEED_INIT, STAGE_UPDATE, STAGE_COUNT = 0, 1, 2
 DENOISE_OPT_TIMING, DENOISE_OPT_ITERS_PER_LAUNCH = 1, 2
 
@@ -367,6 +368,18 @@ class SeedMatrix:
         rec = out.reshape(-1, 2)
         search = rec[tiles + 1:]
         return {"setup": rec[:tiles], "plan": rec[tiles:tiles + 1], "search": search[search[:, 1] != 0]}
+
+    def frameTraceDownload(self, frame):
+        """Timeline of update `frame` of the one-launch frame kernel (OPT_MATCHER 2) since setOption(OPT_COLLECT_STATS, 2): an
+        (n_workgroups, 8) uint64 array -- start, first tile set up, no tiles left to claim, exit (10 ns ticks of the device
+        wall clock), work items of the tiles set up here (bits 32..: tiles handed out), units searched, tiles set up.  Rows
+        beyond the (persistent) grid are zero."""
+        tiles = ((self.width + 15) // 16) * ((self.height + 15) // 16)
+        n = tiles * 8
+        out = np.zeros(n, np.uint64)
+        written = ctypes.c_size_t()
+        check(_lib.lib().rmd_hip_seeds_trace_download(self.ptr, int(frame), out.ctypes.data, n, ctypes.byref(written)))
+        return out.reshape(-1, 8)
 
     def lastDiagnosticsRaw(self):
         out = np.zeros(16, np.int64)

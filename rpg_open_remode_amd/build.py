@@ -20,6 +20,10 @@ HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     # arithmetic contract (csrc/rmd_math.h): no contraction, IEEE fp32 divide / sqrt
     "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
+    # gfx950 issues v_pk_{add,mul,fma}_f32 at half the rate of the scalar forms (tools/ubench/valu_rate.hip: 4.6 vs 2.4 cycles
+    # per wave64 instruction with >= 2 waves per SIMD), so SLP-packing two fp32 operations into one gains nothing and costs the
+    # v_mov's that assemble the register pairs: -22 % issue slots in the NCC inner block without it
+    "-fno-slp-vectorize",
 ]
 
 

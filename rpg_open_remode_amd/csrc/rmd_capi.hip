@@ -17,6 +17,7 @@
 
 #include "rmd_kernels.hpp"
 #include "rmd_matcher.hpp"
+#include "rmd_frame.hpp"
 
 #define RMD_HIP_VERSION_NUMBER 100
 
@@ -175,7 +176,7 @@ struct rmd_hip_seeds {
   hipStream_t stream = nullptr;
   unsigned long long* d_scalars = nullptr;  // [0] count result, [1..16] diagnostics
   unsigned long long* h_scalars = nullptr;  // pinned mirror
-  int opt_matcher = 1, opt_timing = 0, opt_stats = 0, opt_window = 0;
+  int opt_matcher = 3, opt_timing = 0, opt_stats = 0, opt_window = 0, opt_local_max = 0, opt_unit_rounds = 0;
   hipEvent_t region_start = nullptr, region_stop = nullptr;
   long region_updates = 0;
   // deferred finalisation of the last tile-pipeline update (see rmd_matcher.hpp): pending until the next update()
@@ -200,6 +201,7 @@ struct rmd_hip_seeds {
   unsigned int* d_pc_counts = nullptr;  // point cloud (allocated at the first request): per-block counts / offsets, [n_blocks] = total
   float4* d_pc_points = nullptr;        // W x H points
   rmdk::MatcherWorkspace matcher_ws;
+  rmdk::FrameWorkspace frame_ws;
 };
 
 namespace {
@@ -229,7 +231,11 @@ int seeds_flush(rmd_hip_seeds* s) {
 int seeds_sync(const rmd_hip_seeds* s) {
   rmd_hip_seeds* m = const_cast<rmd_hip_seeds*>(s);
   TRY(seeds_flush(m));
+  if (m->frame_ws.frame > 0) HIP_TRY(hipMemcpyAsync(m->frame_ws.h_error, m->frame_ws.d_error, sizeof(unsigned int), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  if (m->frame_ws.h_error && m->frame_ws.h_error[0] != 0u)
+    return fail(RMD_HIP_ERR_RUNTIME, "seed update: a bounded wait inside the frame kernel ran out (error bits 0x%x); results are invalid",
+                m->frame_ws.h_error[0]);
   for (auto& t : m->timers) t.drain();
   if (m->stats_pending) {
     for (int k = 0; k < 16; ++k) m->last_stats[k] = static_cast<long long>(m->h_scalars[1 + k]);
@@ -262,7 +268,7 @@ int seeds_launch_update(rmd_hip_seeds* s) {
   if (s->opt_stats == 1) {
     HIP_TRY(hipMemsetAsync(s->d_scalars + 1, 0, 16 * sizeof(unsigned long long), s->stream));
     P.stats = s->d_scalars + 1;
-  } else if (s->opt_stats == 2 && s->matcher_ws.d_trace) {  // timeline probes only: the pipeline runs as in production
+  } else if (s->opt_stats == 2 && s->opt_matcher == 1 && s->matcher_ws.d_trace) {  // timeline probes only: the pipeline runs as in production
     P.trace = s->matcher_ws.d_trace + static_cast<size_t>(s->trace_frame % rmdk::TRACE_FRAMES) * s->matcher_ws.trace_slice_u64();
     ++s->trace_frame;
   }
@@ -276,10 +282,19 @@ int seeds_launch_update(rmd_hip_seeds* s) {
         TRY(seeds_flush(s));
         const dim3 block(64, 4), grid((s->width + 63) / 64, (s->height + 3) / 4);
         hipLaunchKernelGGL((rmdk::seed_update_pixel_kernel<SIDE>), grid, block, 0, s->stream, P);
+      } else if (s->opt_matcher == 2) {
+        TRY(seeds_flush(s));
+        unsigned long long* slice = nullptr;
+        if (s->opt_stats == 2 && s->frame_ws.d_trace) {
+          slice = s->frame_ws.d_trace + static_cast<size_t>(s->trace_frame % rmdk::FR_TRACE_FRAMES) * s->frame_ws.trace_slice_u64();
+          ++s->trace_frame;
+        }
+        HIP_TRY(rmdk::launch_seed_frame<SIDE>(P, s->frame_ws, s->stream, s->num_cus, s->opt_local_max, s->opt_unit_rounds, slice));
       } else {
         const bool fuse = s->finalize_pending;
         const rmdk::Pose T_prev = fuse ? s->P_pending.T_ref_curr : P.T_ref_curr;
-        HIP_TRY(rmdk::launch_seed_update_tile<SIDE>(P, s->matcher_ws, s->stream, s->num_cus, s->opt_window, fuse, T_prev));
+        if (s->opt_matcher == 3) HIP_TRY(rmdk::launch_seed_pipeline_compact<SIDE>(P, s->matcher_ws, s->frame_ws, s->stream, s->num_cus, fuse, T_prev));
+        else HIP_TRY(rmdk::launch_seed_update_tile<SIDE>(P, s->matcher_ws, s->stream, s->num_cus, s->opt_window, fuse, T_prev));
         s->P_pending = P;
         s->P_pending.stats = nullptr;
         s->P_pending.trace = nullptr;
@@ -313,6 +328,9 @@ int seeds_after_reference(rmd_hip_seeds* s, const float* T_curr_world, float min
   memcpy(T.d, T_curr_world, sizeof(T.d));
   s->T_world_ref = pose_inverse(T);
   TRY(seeds_launch_init(s));
+  // the frame kernel's load statistics belong to the old sequence
+  s->frame_ws.frame = 0;
+  HIP_TRY(hipMemsetAsync(s->frame_ws.d_ctl, 0, 3 * rmdk::FR_CTL_WORDS * sizeof(unsigned int), s->stream));
   s->has_reference = true;
   // the reference synchronises here (seed_matrix.cu:113); so do we: the host image is borrowed
   return seeds_sync(s);
@@ -457,6 +475,7 @@ int rmd_hip_seeds_destroy(rmd_hip_seeds_t* s) {
   for (auto& pl : s->planes)
     if (pl.owns && pl.data) (void)hipFree(pl.data);
   s->matcher_ws.release();
+  s->frame_ws.release();
   if (s->d_undist_map1) (void)hipFree(s->d_undist_map1);
   if (s->d_undist_map2) (void)hipFree(s->d_undist_map2);
   if (s->d_pc_counts) (void)hipFree(s->d_pc_counts);
@@ -520,6 +539,7 @@ int rmd_hip_seeds_create(int width, int height, float fx, float fy, float cx, fl
   P.max_extent = static_cast<float>(max_extent);
   const int rcw = s->matcher_ws.allocate(width, height, P.stride);
   if (rcw != 0) return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: matcher workspace"));
+  if (s->frame_ws.allocate(width, height, P.stride) != 0) return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: frame workspace"));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) s->num_cus = prop.multiProcessorCount;
   if (hipDeviceSynchronize() != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: device synchronisation failed"));  // all fills done
@@ -798,8 +818,22 @@ int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value) {
   if (!s) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: null handle");
   switch (option) {
     case RMD_HIP_OPT_MATCHER:
-      if (value != 0 && value != 1) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: matcher %d", value);
+      if (value < 0 || value > 3) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: matcher %d", value);
+      if (value != s->opt_matcher) {  // each matcher keeps its own per-frame state: settle the old one first
+        TRY(seeds_bind_device(s));
+        TRY(seeds_sync(s));
+        s->frame_ws.frame = 0;
+        HIP_TRY(hipMemsetAsync(s->frame_ws.d_ctl, 0, 3 * rmdk::FR_CTL_WORDS * sizeof(unsigned int), s->stream));
+      }
       s->opt_matcher = value;
+      return RMD_HIP_OK;
+    case RMD_HIP_OPT_LOCAL_MAX:
+      if (value < 0) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: local_max %d", value);
+      s->opt_local_max = value;
+      return RMD_HIP_OK;
+    case RMD_HIP_OPT_UNIT_ROUNDS:
+      if (value < 0 || value > 4) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: unit_rounds %d", value);
+      s->opt_unit_rounds = value;
       return RMD_HIP_OK;
     case RMD_HIP_OPT_TIMING:
       if (value < 0 || value > 2) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: timing mode %d", value);
@@ -819,8 +853,12 @@ int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value) {
         rmdk::MatcherWorkspace& ws = s->matcher_ws;
         const size_t bytes = ws.trace_slice_u64() * rmdk::TRACE_FRAMES * sizeof(unsigned long long);
         if (!ws.d_trace) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ws.d_trace), bytes));
+        rmdk::FrameWorkspace& fw = s->frame_ws;
+        const size_t fbytes = fw.trace_slice_u64() * rmdk::FR_TRACE_FRAMES * sizeof(unsigned long long);
+        if (!fw.d_trace) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&fw.d_trace), fbytes));
         HIP_TRY(hipStreamSynchronize(s->stream));
         HIP_TRY(hipMemset(ws.d_trace, 0, bytes));
+        HIP_TRY(hipMemset(fw.d_trace, 0, fbytes));
         HIP_TRY(hipDeviceSynchronize());
         s->trace_frame = 0;
       }
@@ -884,6 +922,16 @@ int rmd_hip_seeds_trace_download(rmd_hip_seeds_t* s, int frame, unsigned long lo
   if (!ws.d_trace) return fail(RMD_HIP_ERR_NOT_READY, "trace_download: set RMD_HIP_OPT_COLLECT_STATS to 2 first");
   if (frame < 0 || frame >= s->trace_frame || frame < s->trace_frame - rmdk::TRACE_FRAMES)
     return fail(RMD_HIP_ERR_INVALID_ARG, "trace_download: frame not in the buffer");
+  if (s->opt_matcher == 2) {  // frame kernel: FR_TRACE_WORDS words per workgroup (256 front slots, then the tile grid)
+    const rmdk::FrameWorkspace& fw = s->frame_ws;
+    const size_t fn = fw.trace_slice_u64();
+    if (capacity < fn) return fail(RMD_HIP_ERR_INVALID_ARG, "trace_download: buffer too small (%zu words needed)", fn);
+    TRY(seeds_bind_device(s));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipMemcpy(out, fw.d_trace + static_cast<size_t>(frame % rmdk::FR_TRACE_FRAMES) * fn, fn * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    *written = fn;
+    return RMD_HIP_OK;
+  }
   const size_t n = ws.trace_slice_u64();
   if (capacity < n) return fail(RMD_HIP_ERR_INVALID_ARG, "trace_download: buffer too small");
   TRY(seeds_bind_device(s));

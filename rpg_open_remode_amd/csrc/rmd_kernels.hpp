@@ -161,14 +161,14 @@ RMDK_D Segment epipolar_segment(const SeedParams& P, int x, int y, float mu, flo
   return s;
 }
 
-// seed_update.cu:58-119 for one pixel whose state (after matching) is `state`
-RMDK_D void seed_fuse(const SeedParams& P, int x, int y, int i, int state, float mu, float sigma_sq, float a, float b,
-                      F2 match) {
+// seed_update.cu:58-119 for one pixel whose state (after matching) is `state`, on values in registers.
+// Returns 0: nothing changes, 1: (mu, sigma_sq, a, b) have been replaced by the posterior, 2: only b has changed (NO_MATCH).
+RMDK_D int seed_fuse_values(const SeedParams& P, int x, int y, int state, float& mu, float& sigma_sq, float& a, float& b, F2 match) {
   if (state == ST_UPDATE) {
     const F3 f_ref = normalize3(cam2world(P.cam, static_cast<float>(x), static_cast<float>(y)));
     const F3 f_epi = normalize3(cam2world(P.cam, match.x, match.y));
     const F3 pt = triangulate(f_ref, f_epi, P.T_ref_curr);
-    if (pt.z < 0.0f) return;
+    if (pt.z < 0.0f) return 0;
     const float depth = norm3(pt);
     const float tau = triangulation_uncertainty(depth, f_ref, pose_translation(P.T_ref_curr), P.one_pix_angle);
     const float tau_sq = tau * tau;
@@ -182,15 +182,34 @@ RMDK_D void seed_fuse(const SeedParams& P, int x, int y, int i, int state, float
     const float f = c1 * ((a + 1.0f) / (a + b + 1.0f)) + c2 * (a / (a + b + 1.0f));
     const float e = c1 * (((a + 1.0f) * (a + 2.0f)) / ((a + b + 1.0f) * (a + b + 2.0f))) +
                     c2 * (a * (a + 1.0f) / ((a + b + 1.0f) * (a + b + 2.0f)));
-    if (isnan(c1 * m)) return;
+    if (isnan(c1 * m)) return 0;
     const float mu_prime = c1 * m + c2 * mu;
-    P.sigma_sq[i] = c1 * (s_sq + m * m) + c2 * (sigma_sq + mu * mu) - mu_prime * mu_prime;
-    P.mu[i] = mu_prime;
+    const float sigma_sq_prime = c1 * (s_sq + m * m) + c2 * (sigma_sq + mu * mu) - mu_prime * mu_prime;
     const float a_prime = (e - f) / (f - e / f);
-    P.a[i] = a_prime;
-    P.b[i] = a_prime * (1.0f - f) / f;
-  } else if (state == ST_NO_MATCH) {
-    P.b[i] = b + 1.0f;
+    sigma_sq = sigma_sq_prime;
+    mu = mu_prime;
+    a = a_prime;
+    b = a_prime * (1.0f - f) / f;
+    return 1;
+  }
+  if (state == ST_NO_MATCH) {
+    b = b + 1.0f;
+    return 2;
+  }
+  return 0;
+}
+
+// ... and on the planes of the SeedMatrix
+RMDK_D void seed_fuse(const SeedParams& P, int x, int y, int i, int state, float mu, float sigma_sq, float a, float b,
+                      F2 match) {
+  const int what = seed_fuse_values(P, x, y, state, mu, sigma_sq, a, b, match);
+  if (what == 1) {
+    P.sigma_sq[i] = sigma_sq;
+    P.mu[i] = mu;
+    P.a[i] = a;
+    P.b[i] = b;
+  } else if (what == 2) {
+    P.b[i] = b;
   }
 }
 

@@ -58,6 +58,7 @@ struct MatcherWorkspace {
   unsigned long long* d_best = nullptr;  // per seed: arg-max key
   TileInfo* d_tiles = nullptr;
   unsigned int* d_tile_plan = nullptr;  // per tile, for seed_plan: work items
+  unsigned int* d_tile_pending = nullptr;  // per tile (two-launch pipeline): work units not yet searched
   uint2* d_units = nullptr;         // (tile, first item)
   // counters of the current frame, rewritten by seed_plan every frame: [0] work units, [1] units handed out beyond the
   // static first round, [5] items per unit
@@ -78,6 +79,8 @@ struct MatcherWorkspace {
     if (hipMalloc(reinterpret_cast<void**>(&d_best), n * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_tiles), static_cast<size_t>(tiles_x) * tiles_y * sizeof(TileInfo)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_tile_plan), static_cast<size_t>(tiles_x) * tiles_y * sizeof(unsigned int)) != hipSuccess) return -1;
+    if (hipMalloc(reinterpret_cast<void**>(&d_tile_pending), static_cast<size_t>(tiles_x) * tiles_y * sizeof(unsigned int)) != hipSuccess) return -1;
+    (void)hipMemset(d_tile_pending, 0, static_cast<size_t>(tiles_x) * tiles_y * sizeof(unsigned int));
     if (hipMalloc(reinterpret_cast<void**>(&d_units), static_cast<size_t>(max_units) * sizeof(uint2)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_queue), 8 * sizeof(unsigned int)) != hipSuccess) return -1;
     (void)hipMemset(d_packed, 0, n * sizeof(unsigned int));
@@ -87,11 +90,11 @@ struct MatcherWorkspace {
   }
   size_t trace_slice_u64() const { return 2 * (static_cast<size_t>(tiles_x) * tiles_y + 1 + TRACE_MAX_SEARCH_WGS); }
   void release() {
-    void* all[] = {d_mean, d_dir, d_lfirst, d_packed, d_best, d_tiles, d_tile_plan, d_units, d_queue, d_trace};
+    void* all[] = {d_mean, d_dir, d_lfirst, d_packed, d_best, d_tiles, d_tile_plan, d_tile_pending, d_units, d_queue, d_trace};
     for (void* p : all)
       if (p) (void)hipFree(p);
     d_mean = d_dir = nullptr; d_lfirst = nullptr; d_packed = nullptr; d_best = nullptr;
-    d_tiles = nullptr; d_tile_plan = nullptr; d_units = nullptr; d_queue = nullptr; d_trace = nullptr;
+    d_tiles = nullptr; d_tile_plan = nullptr; d_tile_pending = nullptr; d_units = nullptr; d_queue = nullptr; d_trace = nullptr;
   }
 };
 
@@ -104,6 +107,7 @@ struct MatcherArgs {
   unsigned long long* best;
   TileInfo* tiles;
   unsigned int* tile_plan;
+  unsigned int* tile_pending;
   uint2* units;
   unsigned int* queue;       // this frame's counters (see MatcherWorkspace)
   int tiles_x;
@@ -165,6 +169,70 @@ RMDK_D int units_of(int items, int rounds) {
 RMDK_D bool px_outside(const SeedParams& P, F2 px, int side) {  // the guard at epipolar_match.cu:91-97
   return px.x >= static_cast<float>(P.w - side) || px.y >= static_cast<float>(P.h - side) ||
          px.x < static_cast<float>(side) || px.y < static_cast<float>(side);
+}
+
+// Which steps of the search loop (epipolar_match.cu:88: l = -half; l <= half; l += 0.7f) pass the in-image guard (:91-97)?
+// px(l) = fl(mean + fl(l * dir)) is monotone per axis (rounding is monotone) and the guard region is a box, so they form ONE
+// contiguous run.  Real-arithmetic bounds [la, lb] of that run tell where to look; the float sequence l_i itself has no
+// closed form, so it is replayed (one add per step), and the exact guard is evaluated only around the two ends.
+// A non-finite position yields NaN sums in the reference and never becomes a candidate: no work.
+struct ValidRun {
+  int n_valid, i_first;  // number of in-image steps, index of the first one
+  float l_first;         // accumulated l at the first one
+  F2 px_first, px_last;  // sample positions of the first and the last one
+};
+RMDK_D ValidRun find_valid_run(const SeedParams& P, const Segment& seg, int side) {
+  ValidRun r;
+  r.n_valid = 0; r.i_first = 0; r.l_first = 0.0f;
+  r.px_first = F2{0.0f, 0.0f}; r.px_last = F2{0.0f, 0.0f};
+  const float half = seg.half_length;
+  const bool finite = isfinite(seg.mean.x) && isfinite(seg.mean.y) && isfinite(seg.dir.x) && isfinite(seg.dir.y);
+  if (!finite) return r;
+  float la = -half, lb = half;
+  bool empty = false;
+  const float lo_x = static_cast<float>(side), hi_x = static_cast<float>(P.w - side);
+  const float lo_y = static_cast<float>(side), hi_y = static_cast<float>(P.h - side);
+  // An axis along which the segment barely moves (|dir| * step below the spacing of floats near the image coordinates)
+  // gives no usable estimate: the rounding of mean + l * dir decides on which side of a bound the sample falls, and
+  // (bound - mean) / dir is off by 0.5 ulp(mean) / |dir| steps.  Along such an axis the whole segment stays within
+  // half * TINY_DIR <= 0.1 px of mean: if mean is further than that (and a margin) outside the bounds no step is inside, if
+  // it is further inside the axis never matters, and only in the narrow band around a bound the exact guard decides alone.
+  constexpr float TINY_DIR = 2e-3f;  // 0.7 * 2e-3 = 12 ulp of 8192.0f: the estimate is good to a fraction of a step above it
+  const float band = half * TINY_DIR + 0.125f;
+  if (seg.dir.x > TINY_DIR) { la = fmaxf(la, (lo_x - seg.mean.x) / seg.dir.x); lb = fminf(lb, (hi_x - seg.mean.x) / seg.dir.x); }
+  else if (seg.dir.x < -TINY_DIR) { la = fmaxf(la, (hi_x - seg.mean.x) / seg.dir.x); lb = fminf(lb, (lo_x - seg.mean.x) / seg.dir.x); }
+  else if (seg.dir.x == 0.0f) empty = empty || !(seg.mean.x >= lo_x && seg.mean.x < hi_x);
+  else empty = empty || !(seg.mean.x >= lo_x - band && seg.mean.x < hi_x + band);
+  if (seg.dir.y > TINY_DIR) { la = fmaxf(la, (lo_y - seg.mean.y) / seg.dir.y); lb = fminf(lb, (hi_y - seg.mean.y) / seg.dir.y); }
+  else if (seg.dir.y < -TINY_DIR) { la = fmaxf(la, (hi_y - seg.mean.y) / seg.dir.y); lb = fminf(lb, (lo_y - seg.mean.y) / seg.dir.y); }
+  else if (seg.dir.y == 0.0f) empty = empty || !(seg.mean.y >= lo_y && seg.mean.y < hi_y);
+  else empty = empty || !(seg.mean.y >= lo_y - band && seg.mean.y < hi_y + band);
+  // the estimates are good to ~1e-3 of a step; everything within 2 steps of them is checked exactly
+  if (empty || !(la <= lb + 1.5f)) return r;
+  const int i_a = max(static_cast<int>(floorf((la + half) * (1.0f / 0.7f))) - 2, 0);
+  int i = 0;
+  float l = -half;
+  replay_until(i, l, i_a, half);  // replay
+  for (; l <= half && l <= lb + 1.5f; l += 0.7f, ++i) {  // exact scan for the first in-image step
+    const F2 px = F2{seg.mean.x + l * seg.dir.x, seg.mean.y + l * seg.dir.y};
+    if (!px_outside(P, px, side)) { r.n_valid = 1; r.i_first = i; r.l_first = l; r.px_first = px; r.px_last = px; break; }
+  }
+  if (!r.n_valid) return r;
+  const int i_b = max(static_cast<int>(floorf((lb + half) * (1.0f / 0.7f))) - 2, r.i_first);
+  replay_until(i, l, i_b, half);  // replay across the interior of the run (in-image by convexity)
+  int i_last = r.i_first;
+  if (l <= half && i > r.i_first) {  // the replayed position: still in the run unless the estimate overshot
+    const F2 px = F2{seg.mean.x + l * seg.dir.x, seg.mean.y + l * seg.dir.y};
+    if (!px_outside(P, px, side)) { i_last = i; r.px_last = px; }
+    else { i = r.i_first; l = r.l_first; }  // overshoot (an axis left to the exact guard): rescan from the first step
+  } else if (i > r.i_first) { i = r.i_first; l = r.l_first; }
+  for (l += 0.7f, ++i; l <= half; l += 0.7f, ++i) {  // exact scan for the last in-image step
+    const F2 px = F2{seg.mean.x + l * seg.dir.x, seg.mean.y + l * seg.dir.y};
+    if (px_outside(P, px, side)) break;
+    i_last = i; r.px_last = px;
+  }
+  r.n_valid = i_last - r.i_first + 1;
+  return r;
 }
 
 // Per-axis sample parameters of one step: for patch column/row k the reference evaluates
@@ -231,6 +299,48 @@ RMDK_D void ncc_sums_regular(const float* __restrict__ base, int rt_stride, cons
   }
 }
 
+// Sums of one NCC evaluation over a regular footprint in the LDS window (the hot block of the whole path): the arithmetic of
+// ncc_sums_regular, software-pipelined by hand.  The texel row r + 1 and the template row r are requested from the LDS BEFORE
+// the filter / accumulate work on row r, and scheduling barriers keep the compiler from sinking the reads back to their first
+// use (left alone it issues every read a few instructions before an s_waitcnt: ~60 exposed LDS latencies per evaluation, which
+// is most of a round's time when a wave has its SIMD to itself, i.e. on every frame but the first twenty).
+template <int SIDE>
+RMDK_D void ncc_sums_lds_pipelined(const float* __restrict__ base, int stride, const float (&ax)[SIDE], const float (&ay)[SIDE],
+                                   const float* __restrict__ ref_patch, int ref_stride, float& sum_img, float& sum_img_sq,
+                                   float& sum_img_templ) {
+  float t[2][SIDE + 1], tm[2][SIDE], hprev[SIDE], hcur[SIDE];
+#pragma unroll
+  for (int c = 0; c <= SIDE; ++c) t[0][c] = base[c];
+#pragma unroll
+  for (int r = 0; r <= SIDE; ++r) {
+    const int cur = r & 1, nxt = cur ^ 1;
+    if (r < SIDE) {
+      const float* row = base + (r + 1) * stride;
+#pragma unroll
+      for (int c = 0; c <= SIDE; ++c) t[nxt][c] = row[c];
+#pragma unroll
+      for (int k = 0; k < SIDE; ++k) tm[nxt][k] = ref_patch[r * ref_stride + k];  // template row r, used with texel rows r, r + 1
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < SIDE; ++k) hcur[k] = rmd_lerp(ax[k], t[cur][k], t[cur][k + 1]);
+    if (r > 0) {
+      const float by = ay[r - 1];
+#pragma unroll
+      for (int k = 0; k < SIDE; ++k) {
+        const float img = rmd_lerp(by, hprev[k], hcur[k]);
+        const float templ = tm[cur][k];
+        sum_img += img;
+        sum_img_sq += img * img;
+        sum_img_templ += img * templ;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < SIDE; ++k) hprev[k] = hcur[k];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // One NCC evaluation at px.  Three sources for the current-image samples, same arithmetic in all:
 //   0. the LDS window staged for this tile, when the footprint lies inside it;
 //   1. global memory (L1/L2) with the same regular footprint, for seeds that wandered off the window;
@@ -259,8 +369,8 @@ RMDK_D float ncc_at(const SeedParams& P, F2 px, const float* __restrict__ win, i
     const bool in_window = ix[0] >= wx0 && iy[0] >= wy0 && ix[0] + SIDE <= wx1 && iy[0] + SIDE <= wy1;
     path = in_window ? 0 : 1;
     if (in_window) {
-      ncc_sums_regular<SIDE, WS>(win + (iy[0] - wy0) * WS + (ix[0] - wx0), 0, ax, ay, ref_patch, ref_stride, sum_img,
-                                 sum_img_sq, sum_img_templ);
+      ncc_sums_lds_pipelined<SIDE>(win + (iy[0] - wy0) * WS + (ix[0] - wx0), WS, ax, ay, ref_patch, ref_stride, sum_img,
+                                   sum_img_sq, sum_img_templ);
     } else {
       ncc_sums_regular<SIDE, 0>(P.cur + iy[0] * P.cur_stride + ix[0], P.cur_stride, ax, ay, ref_patch, ref_stride, sum_img,
                                 sum_img_sq, sum_img_templ);
@@ -350,55 +460,11 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_kernel(SeedParams P, Matc
   if (live) {
     const Segment seg = epipolar_segment(P, x, y, mu, sigma_sq);
     const float half = seg.half_length;
-    const bool finite = isfinite(seg.mean.x) && isfinite(seg.mean.y) && isfinite(seg.dir.x) && isfinite(seg.dir.y);
-    // Which steps of the search loop (epipolar_match.cu:88: l = -half; l <= half; l += 0.7f) pass the in-image guard?
-    // px(l) = mean + l*dir is monotone per axis and the guard region is a box, so they form ONE contiguous run.
-    // Real-arithmetic bounds [la, lb] of that run tell where to look; the float sequence l_i itself has no closed
-    // form, so it is replayed (one add per step), and the exact guard is evaluated only around the two ends.
-    // A non-finite position yields NaN sums in the reference and never becomes a candidate: no work.
-    if (finite) {
-      float la = -half, lb = half;
-      bool empty = false;
-      const float lo_x = static_cast<float>(SIDE), hi_x = static_cast<float>(P.w - SIDE);
-      const float lo_y = static_cast<float>(SIDE), hi_y = static_cast<float>(P.h - SIDE);
-      if (seg.dir.x > 0.0f) { la = fmaxf(la, (lo_x - seg.mean.x) / seg.dir.x); lb = fminf(lb, (hi_x - seg.mean.x) / seg.dir.x); }
-      else if (seg.dir.x < 0.0f) { la = fmaxf(la, (hi_x - seg.mean.x) / seg.dir.x); lb = fminf(lb, (lo_x - seg.mean.x) / seg.dir.x); }
-      else empty = empty || !(seg.mean.x >= lo_x && seg.mean.x < hi_x);
-      if (seg.dir.y > 0.0f) { la = fmaxf(la, (lo_y - seg.mean.y) / seg.dir.y); lb = fminf(lb, (hi_y - seg.mean.y) / seg.dir.y); }
-      else if (seg.dir.y < 0.0f) { la = fmaxf(la, (hi_y - seg.mean.y) / seg.dir.y); lb = fminf(lb, (lo_y - seg.mean.y) / seg.dir.y); }
-      else empty = empty || !(seg.mean.y >= lo_y && seg.mean.y < hi_y);
-      // the estimates are good to ~1e-3 of a step; everything within 2 steps of them is checked exactly
-      if (!empty && la <= lb + 1.5f) {
-        const int i_a = max(static_cast<int>(floorf((la + half) * (1.0f / 0.7f))) - 2, 0);
-        int i = 0;
-        float l = -half;
-        replay_until(i, l, i_a, half);  // replay
-        F2 px_first = F2{0.0f, 0.0f}, px_last = F2{0.0f, 0.0f};
-        for (; l <= half && l <= lb + 1.5f; l += 0.7f, ++i) {  // exact scan for the first in-image step
-          const F2 px = F2{seg.mean.x + l * seg.dir.x, seg.mean.y + l * seg.dir.y};
-          if (!px_outside(P, px, SIDE)) { n_valid = 1; i_first = i; l_first = l; px_first = px; px_last = px; break; }
-        }
-        if (n_valid) {
-          const int i_b = max(static_cast<int>(floorf((lb + half) * (1.0f / 0.7f))) - 2, i_first);
-          replay_until(i, l, i_b, half);  // replay across the interior of the run (in-image by convexity)
-          int i_last = i_first;
-          if (l <= half && i > i_first) {  // the replayed position: still in the run unless the estimate overshot
-            const F2 px = F2{seg.mean.x + l * seg.dir.x, seg.mean.y + l * seg.dir.y};
-            if (!px_outside(P, px, SIDE)) { i_last = i; px_last = px; }
-            else {  // overshoot (cannot happen within the error bounds, kept for safety): rescan from the first step
-              i = i_first; l = l_first;
-            }
-          } else if (i > i_first) { i = i_first; l = l_first; }
-          for (l += 0.7f, ++i; l <= half; l += 0.7f, ++i) {  // exact scan for the last in-image step
-            const F2 px = F2{seg.mean.x + l * seg.dir.x, seg.mean.y + l * seg.dir.y};
-            if (px_outside(P, px, SIDE)) break;
-            i_last = i; px_last = px;
-          }
-          n_valid = i_last - i_first + 1;
-          bb_x0 = fminf(px_first.x, px_last.x); bb_x1 = fmaxf(px_first.x, px_last.x);
-          bb_y0 = fminf(px_first.y, px_last.y); bb_y1 = fmaxf(px_first.y, px_last.y);
-        }
-      }
+    const ValidRun run = find_valid_run(P, seg, SIDE);
+    n_valid = run.n_valid; i_first = run.i_first; l_first = run.l_first;
+    if (n_valid) {
+      bb_x0 = fminf(run.px_first.x, run.px_last.x); bb_x1 = fmaxf(run.px_first.x, run.px_last.x);
+      bb_y0 = fminf(run.px_first.y, run.px_last.y); bb_y1 = fmaxf(run.px_first.y, run.px_last.y);
     }
     if (P.stats) {  // diagnostics only: the full walk, counting what the reference would visit / evaluate
       int i = 0;
@@ -768,7 +834,7 @@ __global__ __launch_bounds__(256) void seed_finalize_kernel(SeedParams P, Matche
 inline MatcherArgs matcher_args(const MatcherWorkspace& ws) {
   MatcherArgs M;
   M.mean = ws.d_mean; M.dir = ws.d_dir; M.lfirst = ws.d_lfirst; M.packed = ws.d_packed; M.best = ws.d_best;
-  M.tiles = ws.d_tiles; M.tile_plan = ws.d_tile_plan; M.units = ws.d_units; M.tiles_x = ws.tiles_x;
+  M.tiles = ws.d_tiles; M.tile_plan = ws.d_tile_plan; M.tile_pending = ws.d_tile_pending; M.units = ws.d_units; M.tiles_x = ws.tiles_x;
   M.queue = ws.d_queue;
   M.trace = nullptr;
   return M;

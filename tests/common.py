@@ -62,3 +62,20 @@ def ulp_distance(a, b):
     ia = np.where(ia < 0, np.int64(-2**31) - ia, ia)
     ib = np.where(ib < 0, np.int64(-2**31) - ib, ib)
     return np.abs(ia - ib)
+
+
+# Matcher variants every parity test runs: 0 = per-pixel kernel (the reference's shape), 3 = the tile pipeline with the compact
+# search kernel (the default), 1 = the round-1 pipeline (66 KB search window), 2 = the one-launch frame kernel (experimental),
+# 21 = the frame kernel with every tile of more than one round of work handed out between workgroups.
+MATCHERS = [0, 3, 1, 2, 21]
+
+
+def apply_matcher(seeds, matcher):
+    from rpg_open_remode_amd import api
+    if matcher == 21:
+        seeds.setOption(api.OPT_MATCHER, api.MATCHER_FRAME)
+        seeds.setOption(api.OPT_LOCAL_MAX, 256)
+        seeds.setOption(api.OPT_UNIT_ROUNDS, 1)
+    else:
+        seeds.setOption(api.OPT_MATCHER, matcher)
+    return seeds

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import oracles as O
-from common import assert_states_equal, sequence
+from common import apply_matcher, assert_states_equal, sequence
 from rpg_open_remode_amd import api
 
 pytestmark = pytest.mark.gpu
@@ -29,7 +29,7 @@ def _more_oracle_threads():
 
 def _hip(seq, side, matcher):
     s = api.SeedMatrix(seq.width, seq.height, api.PinholeCamera(*seq.K), patch_side=side)
-    s.setOption(api.OPT_MATCHER, matcher)
+    apply_matcher(s, matcher)
     s.setReferenceImage(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
     return s
 
@@ -55,7 +55,7 @@ def _denoise_oracle(seq, side, planes, lam, iters):
 def test_config1_vga_200_frames_side9_then_tvl1_200():
     """configs[1]: 640x480, 1 reference + 199 updates, patch side 9, denoise(0.5, 200) -- every frame against the oracle."""
     seq = sequence(640, 480, 200)
-    hip, orc = _hip(seq, 9, 1), _oracle(seq, 9)
+    hip, orc = _hip(seq, 9, 3), _oracle(seq, 9)
     for k in range(1, 200):
         hip.update(seq.images[k], seq.T_curr_world[k])
         orc.update(seq.images[k], seq.T_curr_world[k])
@@ -79,7 +79,7 @@ def test_config1_vga_200_frames_side9_then_tvl1_200():
 def test_config4_other_scenes(scene):
     """configs[3]: eight independent 640x480 sequences (scene seeds 0..7; seed 0 is the test above)."""
     seq = sequence(640, 480, 9, scene)
-    hip, base, orc = _hip(seq, 9, 1), _hip(seq, 9, 0), _oracle(seq, 9)
+    hip, base, orc = _hip(seq, 9, 3), _hip(seq, 9, 0), _oracle(seq, 9)
     for k in range(1, 9):
         hip.update(seq.images[k], seq.T_curr_world[k])
         base.update(seq.images[k], seq.T_curr_world[k])
@@ -92,7 +92,7 @@ def test_config4_other_scenes(scene):
 def test_config2_1280x960_search_hits_the_extent_cap():
     """configs[2]: 1280x960, side 9; the early searches are capped at RMD_MAX_EXTENT_EPIPOLAR_SEARCH (143 steps)."""
     seq = sequence(1280, 960, 31)
-    hip, base, orc = _hip(seq, 9, 1), _hip(seq, 9, 0), _oracle(seq, 9)
+    hip, base, orc = _hip(seq, 9, 3), _hip(seq, 9, 0), _oracle(seq, 9)
     hip.setOption(api.OPT_COLLECT_STATS, 1)
     max_steps_per_seed = 0.0
     for k in range(1, 31):
@@ -115,7 +115,7 @@ def test_config5_1080p_updates_and_tvl1_500():
     """configs[4]: 1920x1080, side 9, denoise(0.5, 500): updates against the oracle, the blocked TV-L1 kernel against the
     one-iteration-per-launch kernel over all 500 iterations and against the oracle."""
     seq = sequence(1920, 1080, 13)
-    hip, base, orc = _hip(seq, 9, 1), _hip(seq, 9, 0), _oracle(seq, 9)
+    hip, base, orc = _hip(seq, 9, 3), _hip(seq, 9, 0), _oracle(seq, 9)
     for k in range(1, 13):
         hip.update(seq.images[k], seq.T_curr_world[k])
         base.update(seq.images[k], seq.T_curr_world[k])

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import oracles as O
+from common import MATCHERS, apply_matcher
 from rpg_open_remode_amd import synth
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -53,7 +54,7 @@ def test_oracle_reproduces_the_reference_golden_vectors(side):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("matcher", [0, 1])
+@pytest.mark.parametrize("matcher", MATCHERS)
 @pytest.mark.parametrize("side", [5, 9])
 def test_hip_reproduces_the_reference_golden_vectors(side, matcher):
     from rpg_open_remode_amd import api
@@ -61,7 +62,7 @@ def test_hip_reproduces_the_reference_golden_vectors(side, matcher):
     w, h = int(g["width"]), int(g["height"])
     dmin, dmax = g["depth_range"]
     s = api.SeedMatrix(w, h, api.PinholeCamera(*g["K"]), patch_side=side)
-    s.setOption(api.OPT_MATCHER, matcher)
+    apply_matcher(s, matcher)
     s.setReferenceImage(images[0], g["T_curr_world"][0], dmin, dmax)
     init = {"sum_templ": s.downloadSumTempl(), "denom": s.downloadConstTemplDenom()}
     convs = []

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import oracles as O
-from common import PLANE_NAMES, assert_states_equal, random_state, rmse, sequence
+from common import MATCHERS, PLANE_NAMES, apply_matcher, assert_states_equal, random_state, rmse, sequence
 from rpg_open_remode_amd import api
 
 pytestmark = pytest.mark.gpu
@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 def _hip_seeds(seq, side, matcher):
     s = api.SeedMatrix(seq.width, seq.height, api.PinholeCamera(*seq.K), patch_side=side)
-    s.setOption(api.OPT_MATCHER, matcher)
+    apply_matcher(s, matcher)
     return s
 
 
@@ -55,13 +55,13 @@ def test_device_is_gfx950():
     assert b"gfx950" in buf.value, buf.value
 
 
-@pytest.mark.parametrize("matcher", [0, 1])
+@pytest.mark.parametrize("matcher", MATCHERS)
 @pytest.mark.parametrize("side", [3, 5, 7, 9])
 def test_sequence_bit_exact_vs_port(side, matcher):
     _compare_run(sequence(320, 240, 13), side, matcher, 12)
 
 
-@pytest.mark.parametrize("matcher", [0, 1])
+@pytest.mark.parametrize("matcher", MATCHERS)
 def test_sequence_bit_exact_vs_reference_sources(matcher):
     if not O.available("ref_rmd", 5):
         pytest.skip("oracle/_ref not present")
@@ -69,14 +69,14 @@ def test_sequence_bit_exact_vs_reference_sources(matcher):
     _compare_run(sequence(160, 120, 9), 9, matcher, 8, oracle_kind="ref_rmd")
 
 
-@pytest.mark.parametrize("matcher", [0, 1])
+@pytest.mark.parametrize("matcher", MATCHERS)
 @pytest.mark.parametrize("side", [5, 9])
 def test_long_sequence_through_convergence(side, matcher):
     hip, orc = _compare_run(sequence(160, 120, 45), side, matcher, 44, check_every=11)
     assert hip.getConvergedCount() > 0.3 * 160 * 120
 
 
-@pytest.mark.parametrize("matcher", [0, 1])
+@pytest.mark.parametrize("matcher", MATCHERS)
 @pytest.mark.parametrize("side", [5, 9])
 def test_adversarial_seed_states(side, matcher):
     """NaN / Inf / negative / huge state planes, searches at the 100 px cap, depths behind the camera"""
@@ -89,7 +89,7 @@ def test_adversarial_seed_states(side, matcher):
         assert (conv == st).any(), f"state {st} never produced"
 
 
-@pytest.mark.parametrize("matcher", [0, 1])
+@pytest.mark.parametrize("matcher", MATCHERS)
 @pytest.mark.parametrize("wh", [(101, 67), (64, 48), (257, 33), (40, 200)])
 def test_ragged_sizes(wh, matcher):
     """widths/heights that are not multiples of any tile, pitched rows (stride != width)"""
@@ -97,7 +97,7 @@ def test_ragged_sizes(wh, matcher):
     _compare_run(sequence(w, h, 5), 5, matcher, 4)
 
 
-@pytest.mark.parametrize("matcher", [0, 1])
+@pytest.mark.parametrize("matcher", MATCHERS)
 def test_tiny_images_are_all_border(matcher):
     for (w, h) in ((10, 10), (11, 30), (18, 18)):
         seq = sequence(w, h, 3)
@@ -107,7 +107,7 @@ def test_tiny_images_are_all_border(matcher):
             assert np.all(conv == api.ConvergenceStates.BORDER)
 
 
-@pytest.mark.parametrize("matcher", [0, 1])
+@pytest.mark.parametrize("matcher", MATCHERS)
 def test_identity_pose_reference_kat(matcher):
     """test/epipolar_test.cpp:206-220 on the GPU: zero-length segments -> NO_MATCH, the rest match themselves"""
     seq = sequence(320, 240, 2)
@@ -126,7 +126,7 @@ def test_identity_pose_reference_kat(matcher):
     assert np.max(np.abs(match[..., 0][upd] - xx[upd])) < 0.01 and np.max(np.abs(match[..., 1][upd] - yy[upd])) < 0.01
 
 
-@pytest.mark.parametrize("matcher", [0, 1])
+@pytest.mark.parametrize("matcher", MATCHERS)
 def test_search_statistics_equal_the_oracle(matcher):
     """live seeds, search-loop iterations and NCC evaluations per update: same work as the reference does"""
     seq = sequence(192, 144, 8)
@@ -143,7 +143,7 @@ def test_search_statistics_equal_the_oracle(matcher):
 def test_reference_kat_seed_matrix_init_and_check_on_gpu():
     """test/seed_matrix_test.cpp:99-110 and :219-241"""
     seq = sequence(320, 240, 21)
-    s = _hip_seeds(seq, 5, 1)
+    s = _hip_seeds(seq, 5, 3)
     s.setReferenceImage(seq.images[0], seq.T_curr_world[0], 0.4, 1.8)
     avg = np.float32((np.float32(0.4) + np.float32(1.8)) / np.float32(2.0))
     assert np.all(s.downloadDepthmap() == avg) and np.all(s.downloadA() == 10.0) and np.all(s.downloadB() == 10.0)
@@ -159,7 +159,7 @@ def test_reference_kat_seed_matrix_init_and_check_on_gpu():
 def test_two_instances_are_independent():
     """the reference's global texture references allow ONE live SeedMatrix per process (texture_memory.cuh:27-42)"""
     sa, sb = sequence(160, 120, 5, seed=0), sequence(128, 96, 5, seed=3)
-    ha, hb = _hip_seeds(sa, 5, 1), _hip_seeds(sb, 9, 1)
+    ha, hb = _hip_seeds(sa, 5, 3), _hip_seeds(sb, 9, 3)
     oa, ob = _oracle_seeds("port", sa, 5), _oracle_seeds("port", sb, 9)
     for h, o, s in ((ha, oa, sa), (hb, ob, sb)):
         h.setReferenceImage(s.images[0], s.T_curr_world[0], s.min_depth, s.max_depth)
@@ -177,7 +177,7 @@ def test_deferred_finalisation_is_unobservable():
     """the last kernel of an update is deferred and fused into the next one unless somebody looks at the state first:
     every interleaving of updates and observers must give the same bits as the eager path"""
     seq = sequence(160, 120, 14)
-    lazy, eager = _hip_seeds(seq, 5, 1), _hip_seeds(seq, 5, 1)
+    lazy, eager = _hip_seeds(seq, 5, 3), _hip_seeds(seq, 5, 3)
     eager.setOption(api.OPT_LAZY_FINALIZE, 0)
     d = api.DepthmapDenoiser(seq.width, seq.height)
     d.setLargeSigmaSq(seq.max_depth - seq.min_depth)
@@ -207,7 +207,7 @@ def test_deferred_finalisation_is_unobservable():
 
 def test_device_resident_frames_equal_host_frames():
     seq = sequence(160, 120, 6)
-    h1, h2 = _hip_seeds(seq, 5, 1), _hip_seeds(seq, 5, 1)
+    h1, h2 = _hip_seeds(seq, 5, 3), _hip_seeds(seq, 5, 3)
     frames = []
     for im in seq.images:
         d = api.DeviceImage(seq.width, seq.height, np.float32)
@@ -224,7 +224,7 @@ def test_device_resident_frames_equal_host_frames():
 def test_u8_ingest_and_depthmap_facade_equal_float_path():
     """8-bit frames through pinned double buffers + device conversion (Depthmap::inputImage on the GPU) == float frames"""
     seq = sequence(101, 67, 9)
-    hf, hu = _hip_seeds(seq, 5, 1), _hip_seeds(seq, 5, 1)
+    hf, hu = _hip_seeds(seq, 5, 3), _hip_seeds(seq, 5, 3)
     hf.setReferenceImage(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
     hu.setReferenceImageU8(seq.gray[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
     assert np.array_equal(hu.download(api.PLANE_REF_IMG), seq.images[0])
@@ -250,7 +250,7 @@ def test_u8_ingest_and_depthmap_facade_equal_float_path():
 
 def test_error_paths():
     seq = sequence(64, 48, 2)
-    s = _hip_seeds(seq, 5, 1)
+    s = _hip_seeds(seq, 5, 3)
     with pytest.raises(api.RmdHipError) as e:
         s.update(seq.images[1], seq.T_curr_world[1])  # no reference yet
     assert e.value.code == -3
