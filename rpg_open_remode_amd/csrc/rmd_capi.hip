@@ -285,7 +285,7 @@ int seeds_launch_update(rmd_hip_seeds* s) {
       } else if (s->opt_matcher == 2) {
         TRY(seeds_flush(s));
         unsigned long long* slice = nullptr;
-        if (s->opt_stats == 2 && s->frame_ws.d_trace) {
+        if (s->opt_stats == 2 && s->frame_ws.d_trace) {  // timeline probes
           slice = s->frame_ws.d_trace + static_cast<size_t>(s->trace_frame % rmdk::FR_TRACE_FRAMES) * s->frame_ws.trace_slice_u64();
           ++s->trace_frame;
         }
@@ -293,7 +293,14 @@ int seeds_launch_update(rmd_hip_seeds* s) {
       } else {
         const bool fuse = s->finalize_pending;
         const rmdk::Pose T_prev = fuse ? s->P_pending.T_ref_curr : P.T_ref_curr;
-        if (s->opt_matcher == 3) HIP_TRY(rmdk::launch_seed_pipeline_compact<SIDE>(P, s->matcher_ws, s->frame_ws, s->stream, s->num_cus, fuse, T_prev));
+        if (s->opt_matcher == 3) {
+          rmdk::SeedParams Pt = P;
+          if (s->opt_stats == 2 && s->frame_ws.d_trace) {  // timeline probes of the search workgroups (same slices as the frame kernel's)
+            Pt.trace = s->frame_ws.d_trace + static_cast<size_t>(s->trace_frame % rmdk::FR_TRACE_FRAMES) * s->frame_ws.trace_slice_u64();
+            ++s->trace_frame;
+          }
+          HIP_TRY(rmdk::launch_seed_pipeline_compact<SIDE>(Pt, s->matcher_ws, s->frame_ws, s->stream, s->num_cus, fuse, T_prev, 1 + s->opt_window));
+        }
         else HIP_TRY(rmdk::launch_seed_update_tile<SIDE>(P, s->matcher_ws, s->stream, s->num_cus, s->opt_window, fuse, T_prev));
         s->P_pending = P;
         s->P_pending.stats = nullptr;
@@ -922,7 +929,7 @@ int rmd_hip_seeds_trace_download(rmd_hip_seeds_t* s, int frame, unsigned long lo
   if (!ws.d_trace) return fail(RMD_HIP_ERR_NOT_READY, "trace_download: set RMD_HIP_OPT_COLLECT_STATS to 2 first");
   if (frame < 0 || frame >= s->trace_frame || frame < s->trace_frame - rmdk::TRACE_FRAMES)
     return fail(RMD_HIP_ERR_INVALID_ARG, "trace_download: frame not in the buffer");
-  if (s->opt_matcher == 2) {  // frame kernel: FR_TRACE_WORDS words per workgroup (256 front slots, then the tile grid)
+  if (s->opt_matcher == 2 || s->opt_matcher == 3) {  // frame kernel / compact search: FR_TRACE_WORDS words per workgroup (256 front slots, then the tile grid)
     const rmdk::FrameWorkspace& fw = s->frame_ws;
     const size_t fn = fw.trace_slice_u64();
     if (capacity < fn) return fail(RMD_HIP_ERR_INVALID_ARG, "trace_download: buffer too small (%zu words needed)", fn);

@@ -1028,8 +1028,10 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
   const int tx = tid & (TILE_W - 1), ty = tid >> 4;
   const unsigned int n_units = M.queue[0];
   const int unit_items = static_cast<int>(M.queue[5]);
-  unsigned int n_fallback = 0, n_windows = 0;
+  unsigned int n_fallback = 0, n_windows = 0, n_done = 0, n_items = 0;
   int lds_tile = -1, x0 = 0, y0 = 0, total = 0;
+  unsigned long long* const tr = P.trace && static_cast<int>(blockIdx.x) < M.tiles_x * ((P.h + TILE_H - 1) / TILE_H) ? P.trace + static_cast<size_t>(blockIdx.x) * FR_TRACE_WORDS : nullptr;
+  if (tr && tid == 0) tr[0] = wall_clock64();
   FrameWindow W;
   W.valid = false; W.x0 = W.y0 = 0; W.x1 = W.y1 = -1; W.ws = 1;
   unsigned int u = blockIdx.x;  // unit blockIdx.x is ours for free; further units come from the shared counter
@@ -1063,8 +1065,10 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
       }
       total = frame_prefix_and_window<SIDE>(P, S, tid, W);  // barriers inside
       lds_tile = tile;
+      if (tr && tid == 0 && n_done == 0) tr[1] = wall_clock64();
     }
     frame_search<SIDE>(P, S, tid, first, min(first + unit_items, total), W, n_fallback, n_windows);  // ends with a barrier
+    ++n_done; n_items += static_cast<unsigned int>(min(first + unit_items, total) - first);
     if (n_units <= gridDim.x) break;  // light frame: every unit had its own workgroup, nothing to hand out
     if (tid == 0) S.bcast[0] = gridDim.x + atomicAdd(&M.queue[1], 1u);
     __syncthreads();
@@ -1075,12 +1079,20 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
     const unsigned long long key = S.best[tid];
     if (key != 0ull) atomicMax(&M.best[static_cast<size_t>(y0 + ty) * P.stride + x0 + tx], key);
   }
+  if (tr && tid < 64) {
+    const unsigned long long fb = wave_sum_u64(n_fallback);  // the first wave's lanes only: a hint, not a count
+    if (tid == 0) {
+      tr[3] = wall_clock64();
+      tr[4] = n_items; tr[5] = n_done; tr[6] = static_cast<unsigned long long>(lds_tile >= 0 ? lds_tile : 0);
+      tr[7] = fb | (static_cast<unsigned long long>(n_windows) << 32);
+    }
+  }
 }
 
 // setup (+ the deferred finalisation of the previous frame when fuse_prev) -> plan -> compact search
 template <int SIDE>
 inline hipError_t launch_seed_pipeline_compact(const SeedParams& P, MatcherWorkspace& ws, FrameWorkspace& fws, hipStream_t stream, int num_cus,
-                                               bool fuse_prev, const Pose& T_ref_curr_prev) {
+                                               bool fuse_prev, const Pose& T_ref_curr_prev, int target_mult = 1) {
   using Smem = FrameSmem<SIDE>;
   MatcherArgs M = matcher_args(ws);
   M.trace = nullptr;
@@ -1099,7 +1111,7 @@ inline hipError_t launch_seed_pipeline_compact(const SeedParams& P, MatcherWorks
   const dim3 tiles(ws.tiles_x, ws.tiles_y);
   if (fuse_prev) hipLaunchKernelGGL((seed_setup_compact_kernel<SIDE, true>), tiles, dim3(TILE_PIX), 0, stream, P, M, T_ref_curr_prev);
   else hipLaunchKernelGGL((seed_setup_compact_kernel<SIDE, false>), tiles, dim3(TILE_PIX), 0, stream, P, M, T_ref_curr_prev);
-  hipLaunchKernelGGL(seed_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, stream, M, ws.tiles_x * ws.tiles_y, resident);
+  hipLaunchKernelGGL(seed_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, stream, M, ws.tiles_x * ws.tiles_y, resident * target_mult);
   hipLaunchKernelGGL(search, dim3(resident), dim3(TILE_PIX), sizeof(Smem), stream, P, M);
   return hipGetLastError();
 }

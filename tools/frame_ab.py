@@ -51,6 +51,8 @@ def main():
                 s.setOption(api.OPT_LOCAL_MAX, 256); s.setOption(api.OPT_UNIT_ROUNDS, 1)
             else:
                 s.setOption(api.OPT_LOCAL_MAX, ((v // 10) % 100) * 256); s.setOption(api.OPT_UNIT_ROUNDS, v % 10)
+        elif v in (31, 32):  # tile pipeline with 2x / 3x as many (smaller) work units
+            s.setOption(api.OPT_MATCHER, 3); s.setOption(api.OPT_WINDOW, v - 30)
         else:
             s.setOption(api.OPT_MATCHER, v)
         return s
