@@ -196,7 +196,9 @@ int rmd_hip_denoiser_result(const rmd_hip_denoiser_t* d, const rmd_hip_image_t**
 /* L, tau, sigma, theta of denoise::DeviceData (depthmap_denoiser.cu:124-141) */
 int rmd_hip_denoiser_constants(const rmd_hip_denoiser_t* d, float* out4);
 #define RMD_HIP_DENOISE_OPT_TIMING 1
-#define RMD_HIP_DENOISE_OPT_ITERS_PER_LAUNCH 2 /* TV iterations per launch: 0 = chosen from the image size (default), 1 = one launch per iteration, 2..4 = temporal blocking depth */
+#define RMD_HIP_DENOISE_OPT_ITERS_PER_LAUNCH 2 /* TV iterations per launch: 0 = chosen from the image size (default), 1 = one launch per iteration, 2..8 = temporal blocking depth (capped by the geometry's) */
+#define RMD_HIP_DENOISE_OPT_GEOMETRY 3 /* tile geometry of the blocked kernel: 0 = default (16x16 tiles, 4 iterations per launch), 1 = 32x8 K2, 2 = 64x16 K4,
+                                          3 = 32x16 K4, 4 = 16x16 K4, 5 = 16x16 K8 (experiments, tools/denoise_sweep.py) */
 int rmd_hip_denoiser_set_option(rmd_hip_denoiser_t* d, int option, int value);
 /* accumulated device time / launches of the TV iteration kernel since the last denoise() started */
 int rmd_hip_denoiser_timing(const rmd_hip_denoiser_t* d, double* total_ms, long* launches);

@@ -31,7 +31,7 @@ KIND_F32, KIND_I32, KIND_F32X2 = 0, 1, 2
 OPT_MATCHER, OPT_TIMING, OPT_COLLECT_STATS, OPT_WINDOW, OPT_LAZY_FINALIZE, OPT_LOCAL_MAX, OPT_UNIT_ROUNDS = 0, 1, 2, 3, 4, 5, 6
 MATCHER_PIXEL, MATCHER_PIPELINE_R01, MATCHER_FRAME, MATCHER_PIPELINE = 0, 1, 2, 3
 STAGE_SEED_INIT, STAGE_UPDATE, STAGE_COUNT = 0, 1, 2
-DENOISE_OPT_TIMING, DENOISE_OPT_ITERS_PER_LAUNCH = 1, 2
+DENOISE_OPT_TIMING, DENOISE_OPT_ITERS_PER_LAUNCH, DENOISE_OPT_GEOMETRY = 1, 2, 3
 
 
 class ConvergenceStates:  # seed_matrix.cuh:33-41

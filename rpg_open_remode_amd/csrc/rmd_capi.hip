@@ -9,17 +9,21 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <new>
 #include <tuple>
+#include <utility>
 #include <vector>
 
 #include "rmd_kernels.hpp"
 #include "rmd_matcher.hpp"
 #include "rmd_frame.hpp"
 
-#define RMD_HIP_VERSION_NUMBER 100
+#define RMD_HIP_VERSION_NUMBER 200
+
 
 namespace {
 
@@ -186,10 +190,17 @@ struct rmd_hip_seeds {
   int opt_lazy = 1;
   // 8-bit ingest: two pinned staging buffers + two device byte planes, used alternately so that the host-side copy of
   // frame k+1 overlaps the device work of frame k; an event per slot says when its H2D copy has been consumed
-  unsigned char* h_u8[2] = {nullptr, nullptr};
-  unsigned char* d_u8[2] = {nullptr, nullptr};
-  hipEvent_t u8_free[2] = {nullptr, nullptr};
-  int u8_pitch = 0, u8_slot = 0;
+  static constexpr int SLOTS = 3;           // frames in flight between the host and the update kernels
+  unsigned char* h_u8[SLOTS] = {};
+  unsigned char* d_u8[SLOTS] = {};
+  float* h_f32[SLOTS] = {};                 // pinned staging of float frames (update / set_reference with host pointers)
+  hipEvent_t staged[SLOTS] = {};            // copy stream: the slot's frame is in its f32 plane
+  hipEvent_t frame_done[SLOTS] = {};        // compute stream: the update that read the slot's plane has run
+  hipStream_t copy_stream = nullptr;        // frame uploads and conversions run here, beside the previous frames' kernels
+  void* cur_planes[SLOTS] = {};             // current-image planes (pitch of planes[CURR_IMG]), used in rotation; [0] is the handle's own
+  int u8_pitch = 0, ingest_slot = 0;
+  double ingest_us[4] = {0, 0, 0, 0};  // diagnostics (RMD_HIP_INGEST_PROFILE): host time waiting for a slot, copying, submitting; frames
+  bool ingest_profile = false, ingest_host_wait = false;
   StageTimer timers[RMD_HIP_NUM_SEED_STAGES];
   long long last_stats[16] = {0};
   bool stats_pending = false;
@@ -366,7 +377,7 @@ struct rmd_hip_denoiser {
   hipStream_t stream = nullptr;
   int result_index = 0;
   float* h_staging = nullptr;  // pinned, W x H: device -> pinned (async DMA) -> caller's pageable buffer
-  int opt_timing = 0, opt_iters_per_launch = 0;
+  int opt_timing = 0, opt_iters_per_launch = 0, opt_geometry = 0;
   StageTimer timer;
 };
 
@@ -472,11 +483,20 @@ int rmd_hip_seeds_destroy(rmd_hip_seeds_t* s) {
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   for (auto& t : s->timers) t.destroy();
-  for (int k = 0; k < 2; ++k) {
+  if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);
+  if (s->ingest_profile && s->ingest_us[3] > 0)
+    fprintf(stderr, "[rmd_hip ingest] %.0f frames: wait for slot %.2f us, host copy %.2f us, submit %.2f us per frame\n", s->ingest_us[3],
+            s->ingest_us[0] / s->ingest_us[3], s->ingest_us[1] / s->ingest_us[3], s->ingest_us[2] / s->ingest_us[3]);
+  for (int k = 0; k < rmd_hip_seeds::SLOTS; ++k) {
     if (s->h_u8[k]) (void)hipHostFree(s->h_u8[k]);
+    if (s->h_f32[k]) (void)hipHostFree(s->h_f32[k]);
     if (s->d_u8[k]) (void)hipFree(s->d_u8[k]);
-    if (s->u8_free[k]) (void)hipEventDestroy(s->u8_free[k]);
+    if (s->staged[k]) (void)hipEventDestroy(s->staged[k]);
+    if (s->frame_done[k]) (void)hipEventDestroy(s->frame_done[k]);
+    if (k > 0 && s->cur_planes[k]) (void)hipFree(s->cur_planes[k]);  // [0] belongs to planes[]
   }
+  if (s->cur_planes[0]) s->planes[RMD_HIP_PLANE_CURR_IMG].data = s->cur_planes[0];
+  if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
   if (s->region_start) (void)hipEventDestroy(s->region_start);
   if (s->region_stop) (void)hipEventDestroy(s->region_stop);
   for (auto& pl : s->planes)
@@ -554,14 +574,15 @@ int rmd_hip_seeds_create(int width, int height, float fx, float fy, float cx, fl
   return RMD_HIP_OK;
 }
 
+static int ingest_current(rmd_hip_seeds* s, const unsigned char* host_gray, const float* host_f32, const float* T_curr_world);
+static int ingest_reference(rmd_hip_seeds* s, const unsigned char* host_gray, const float* host_f32, const float* T_curr_world, float min_depth,
+                            float max_depth);
+
 int rmd_hip_seeds_set_reference(rmd_hip_seeds_t* s, const float* host_img, const float* T_curr_world, float min_depth,
                                 float max_depth) {
   if (!s || !host_img || !T_curr_world) return fail(RMD_HIP_ERR_INVALID_ARG, "set_reference: null argument");
   TRY(seeds_bind_device(s));
-  const rmd_hip_image& im = s->planes[RMD_HIP_PLANE_REF_IMG];
-  const size_t row = static_cast<size_t>(s->width) * 4;
-  HIP_TRY(hipMemcpy2DAsync(im.data, im.pitch, host_img, row, row, s->height, hipMemcpyHostToDevice, s->stream));
-  return seeds_after_reference(s, T_curr_world, min_depth, max_depth);
+  return ingest_reference(s, nullptr, host_img, T_curr_world, min_depth, max_depth);
 }
 
 int rmd_hip_seeds_set_reference_device(rmd_hip_seeds_t* s, const float* dev_img, size_t stride_elems,
@@ -579,14 +600,9 @@ int rmd_hip_seeds_update(rmd_hip_seeds_t* s, const float* host_img, const float*
   if (!s || !host_img || !T_curr_world) return fail(RMD_HIP_ERR_INVALID_ARG, "update: null argument");
   if (!s->has_reference) return fail(RMD_HIP_ERR_NOT_READY, "update: setReferenceImage has not been called");
   TRY(seeds_bind_device(s));
-  const rmd_hip_image& im = s->planes[RMD_HIP_PLANE_CURR_IMG];
-  const size_t row = static_cast<size_t>(s->width) * 4;
-  // pageable source: the runtime stages it and returns once the host buffer may be reused
-  HIP_TRY(hipMemcpy2DAsync(im.data, im.pitch, host_img, row, row, s->height, hipMemcpyHostToDevice, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
-  s->P.cur = static_cast<const float*>(im.data);
-  s->P.cur_stride = s->P.stride;
-  return seeds_after_frame(s, T_curr_world);
+  // the frame is copied into pinned memory here (the caller's buffer is free on return, as after the reference's blocking
+  // cudaMemcpy, seed_matrix.cu:128) and uploaded beside the previous frame's kernels; nothing waits for the device
+  return ingest_current(s, nullptr, host_img, T_curr_world);
 }
 
 int rmd_hip_seeds_update_device(rmd_hip_seeds_t* s, const float* dev_img, size_t stride_elems, const float* T_curr_world) {
@@ -600,59 +616,138 @@ int rmd_hip_seeds_update_device(rmd_hip_seeds_t* s, const float* dev_img, size_t
   return seeds_after_frame(s, T_curr_world);
 }
 
-// 8-bit frame -> pinned staging -> device bytes -> f32 plane `dst_plane` (async on the handle's stream)
-static int seeds_ingest_u8(rmd_hip_seeds* s, const unsigned char* host_gray, int dst_plane) {
-  if (!s->h_u8[0]) {
-    s->u8_pitch = (s->width + 255) / 256 * 256;
+// Frames that arrive in host memory go through a two-slot pipeline on a stream of their own, so that the upload (and for
+// 8-bit frames the conversion / undistortion) of frame k + 1 runs beside the kernels of frame k instead of in front of them,
+// and no call waits for the device:
+//   host      wait until slot's staging buffer has been read (two frames ago), copy the caller's frame into it (the caller's
+//             buffer is free on return, as with the reference's synchronous cudaMemcpy, seed_matrix.cu:128)
+//   copy      wait until the update that read the slot's plane (two frames ago) has run -> H2D -> [u8: x(1/255) / remap kernel]
+//   compute   wait until the slot's plane is staged -> this frame's kernels -> mark the slot's plane free
+// The current image alternates between two planes; planes[CURR_IMG] always names the one of the latest frame.
+static int ingest_init(rmd_hip_seeds* s) {
+  if (s->copy_stream) return RMD_HIP_OK;
+  HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+  s->ingest_profile = getenv("RMD_HIP_INGEST_PROFILE") != nullptr;
+  if (const char* e = getenv("RMD_HIP_INGEST_HOST_WAIT")) s->ingest_host_wait = e[0] == '1';
+  const rmd_hip_image& im = s->planes[RMD_HIP_PLANE_CURR_IMG];
+  s->cur_planes[0] = im.data;
+  for (int k = 1; k < rmd_hip_seeds::SLOTS; ++k) {
+    HIP_TRY(hipMalloc(&s->cur_planes[k], im.pitch * im.height));
+    HIP_TRY(hipMemset(s->cur_planes[k], 0, im.pitch * im.height));
+  }
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  s->u8_pitch = (s->width + 3) / 4 * 4;  // rows start on a dword (the conversion kernel reads 4 pixels at a time)
+  // The events only order work of this device's two streams (and tell the host that a staging buffer has been read): a
+  // device-scope release is enough.  The default -- a system-scope fence with cache write-back and invalidation at every
+  // record -- cost more per frame than the upload it was ordering.
+  for (int k = 0; k < rmd_hip_seeds::SLOTS; ++k) {
+    HIP_TRY(hipEventCreateWithFlags(&s->staged[k], hipEventDisableTiming | hipEventReleaseToDevice));
+    HIP_TRY(hipEventCreateWithFlags(&s->frame_done[k], hipEventDisableTiming | hipEventReleaseToDevice));
+    HIP_TRY(hipEventRecord(s->staged[k], s->copy_stream));
+    HIP_TRY(hipEventRecord(s->frame_done[k], s->stream));
+  }
+  return RMD_HIP_OK;
+}
+
+// stage a host frame (8-bit gray if host_gray, else float) into `dst` (an f32 plane with the pitch of the SeedMatrix planes);
+// on return the compute stream is ordered behind the staging.  dst_is_ref: every earlier update reads that plane.
+static double host_now_us() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
+
+static int ingest_frame(rmd_hip_seeds* s, const unsigned char* host_gray, const float* host_f32, void* dst, size_t dst_pitch, bool dst_is_ref, int k) {
+  const double t_a = s->ingest_profile ? host_now_us() : 0.0;
+  HIP_TRY(hipEventSynchronize(s->staged[k]));  // the upload that last used this slot's staging buffers has run
+  const double t_b = s->ingest_profile ? host_now_us() : 0.0;
+  const size_t row_f32 = static_cast<size_t>(s->width) * 4;
+  if (host_gray) {
     const size_t bytes = static_cast<size_t>(s->u8_pitch) * s->height;
-    for (int k = 0; k < 2; ++k) {
+    if (!s->h_u8[k]) {
       HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_u8[k]), bytes));
       HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_u8[k]), bytes));
-      HIP_TRY(hipEventCreateWithFlags(&s->u8_free[k], hipEventDisableTiming));
-      HIP_TRY(hipEventRecord(s->u8_free[k], s->stream));
     }
-  }
-  const int k = s->u8_slot;
-  s->u8_slot ^= 1;
-  HIP_TRY(hipEventSynchronize(s->u8_free[k]));  // the copy that last used this staging buffer has drained
-  for (int y = 0; y < s->height; ++y)
-    memcpy(s->h_u8[k] + static_cast<size_t>(y) * s->u8_pitch, host_gray + static_cast<size_t>(y) * s->width, s->width);
-  const size_t bytes = static_cast<size_t>(s->u8_pitch) * s->height;
-  HIP_TRY(hipMemcpyAsync(s->d_u8[k], s->h_u8[k], bytes, hipMemcpyHostToDevice, s->stream));
-  HIP_TRY(hipEventRecord(s->u8_free[k], s->stream));
-  const rmd_hip_image& im = s->planes[dst_plane];
-  if (s->d_undist_map1) {
-    const dim3 block(64, 4), grid((s->width + 63) / 64, (s->height + 3) / 4);
-    hipLaunchKernelGGL(rmdk::ingest_u8_remap_kernel, grid, block, 0, s->stream, s->d_u8[k], s->u8_pitch, s->d_undist_map1, s->d_undist_map2,
-                       static_cast<float*>(im.data), static_cast<int>(im.stride), s->width, s->height);
+    if (s->u8_pitch == s->width) memcpy(s->h_u8[k], host_gray, bytes);
+    else
+      for (int y = 0; y < s->height; ++y)
+        memcpy(s->h_u8[k] + static_cast<size_t>(y) * s->u8_pitch, host_gray + static_cast<size_t>(y) * s->width, s->width);
   } else {
-    const dim3 block(64, 4), grid((s->width + 255) / 256, (s->height + 3) / 4);
-    hipLaunchKernelGGL(rmdk::ingest_u8_kernel, grid, block, 0, s->stream, s->d_u8[k], s->u8_pitch, static_cast<float*>(im.data),
-                       static_cast<int>(im.stride), s->width, s->height);
+    if (!s->h_f32[k]) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_f32[k]), row_f32 * s->height));
+    memcpy(s->h_f32[k], host_f32, row_f32 * s->height);
   }
-  HIP_TRY(hipGetLastError());
+  const double t_c = s->ingest_profile ? host_now_us() : 0.0;
+  if (dst_is_ref) {  // everything issued so far may read the reference plane
+    HIP_TRY(hipEventRecord(s->frame_done[k], s->stream));
+  }
+  HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->frame_done[k], 0));
+  if (host_gray) {
+    HIP_TRY(hipMemcpyAsync(s->d_u8[k], s->h_u8[k], static_cast<size_t>(s->u8_pitch) * s->height, hipMemcpyHostToDevice, s->copy_stream));
+    const int dst_stride = static_cast<int>(dst_pitch / 4);
+    if (s->d_undist_map1) {
+      const dim3 block(64, 4), grid((s->width + 63) / 64, (s->height + 3) / 4);
+      hipLaunchKernelGGL(rmdk::ingest_u8_remap_kernel, grid, block, 0, s->copy_stream, s->d_u8[k], s->u8_pitch, s->d_undist_map1, s->d_undist_map2,
+                         static_cast<float*>(dst), dst_stride, s->width, s->height);
+    } else {
+      const dim3 block(64, 4), grid((s->width + 255) / 256, (s->height + 3) / 4);
+      hipLaunchKernelGGL(rmdk::ingest_u8_kernel, grid, block, 0, s->copy_stream, s->d_u8[k], s->u8_pitch, static_cast<float*>(dst), dst_stride,
+                         s->width, s->height);
+    }
+    HIP_TRY(hipGetLastError());
+  } else {
+    HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch, s->h_f32[k], row_f32, row_f32, s->height, hipMemcpyHostToDevice, s->copy_stream));
+  }
+  HIP_TRY(hipEventRecord(s->staged[k], s->copy_stream));
+  // The compute stream has to run behind the staging.  A stream-side wait (barrier packet) costs the compute queue ~6 us per
+  // frame even when the event has long fired; the staging of a frame finishes while the PREVIOUS frame's kernels still run,
+  // so the host can simply wait for it before it queues this frame's kernels behind them (no bubble, no packet).
+  if (s->ingest_host_wait) HIP_TRY(hipEventSynchronize(s->staged[k]));
+  else HIP_TRY(hipStreamWaitEvent(s->stream, s->staged[k], 0));
+  if (s->ingest_profile) {
+    const double t_d = host_now_us();
+    s->ingest_us[0] += t_b - t_a; s->ingest_us[1] += t_c - t_b; s->ingest_us[2] += t_d - t_c; s->ingest_us[3] += 1.0;
+  }
   return RMD_HIP_OK;
+}
+
+// a host frame becomes the current image: stage it into the plane that is NOT being read by the update in flight
+static int ingest_current(rmd_hip_seeds* s, const unsigned char* host_gray, const float* host_f32, const float* T_curr_world) {
+  TRY(ingest_init(s));
+  const int k = s->ingest_slot;
+  s->ingest_slot = (k + 1) % rmd_hip_seeds::SLOTS;
+  rmd_hip_image& im = s->planes[RMD_HIP_PLANE_CURR_IMG];
+  im.data = s->cur_planes[k];  // the plane last used SLOTS frames ago (its frame_done event is this slot's)
+  TRY(ingest_frame(s, host_gray, host_f32, im.data, im.pitch, false, k));
+  s->P.cur = static_cast<const float*>(im.data);
+  s->P.cur_stride = s->P.stride;
+  const int rc = seeds_after_frame(s, T_curr_world);
+  HIP_TRY(hipEventRecord(s->frame_done[k], s->stream));
+  return rc;
+}
+
+static int ingest_reference(rmd_hip_seeds* s, const unsigned char* host_gray, const float* host_f32, const float* T_curr_world, float min_depth,
+                            float max_depth) {
+  TRY(ingest_init(s));
+  TRY(seeds_flush(s));
+  const int k = s->ingest_slot;
+  s->ingest_slot = (k + 1) % rmd_hip_seeds::SLOTS;
+  const rmd_hip_image& im = s->planes[RMD_HIP_PLANE_REF_IMG];
+  TRY(ingest_frame(s, host_gray, host_f32, im.data, im.pitch, true, k));
+  return seeds_after_reference(s, T_curr_world, min_depth, max_depth);
 }
 
 int rmd_hip_seeds_set_reference_u8(rmd_hip_seeds_t* s, const unsigned char* host_gray, const float* T_curr_world, float min_depth,
                                    float max_depth) {
   if (!s || !host_gray || !T_curr_world) return fail(RMD_HIP_ERR_INVALID_ARG, "set_reference_u8: null argument");
   TRY(seeds_bind_device(s));
-  TRY(seeds_flush(s));
-  TRY(seeds_ingest_u8(s, host_gray, RMD_HIP_PLANE_REF_IMG));
-  return seeds_after_reference(s, T_curr_world, min_depth, max_depth);
+  return ingest_reference(s, host_gray, nullptr, T_curr_world, min_depth, max_depth);
 }
 
 int rmd_hip_seeds_update_u8(rmd_hip_seeds_t* s, const unsigned char* host_gray, const float* T_curr_world) {
   if (!s || !host_gray || !T_curr_world) return fail(RMD_HIP_ERR_INVALID_ARG, "update_u8: null argument");
   if (!s->has_reference) return fail(RMD_HIP_ERR_NOT_READY, "update_u8: setReferenceImage has not been called");
   TRY(seeds_bind_device(s));
-  // the previous update's search may still be reading planes[CURR_IMG]; everything is ordered by the stream
-  TRY(seeds_ingest_u8(s, host_gray, RMD_HIP_PLANE_CURR_IMG));
-  const rmd_hip_image& im = s->planes[RMD_HIP_PLANE_CURR_IMG];
-  s->P.cur = static_cast<const float*>(im.data);
-  s->P.cur_stride = s->P.stride;
-  return seeds_after_frame(s, T_curr_world);
+  return ingest_current(s, host_gray, nullptr, T_curr_world);
 }
 
 // Depthmap::initUndistortionMap (depthmap.cpp:45-61) = cv::initUndistortRectifyMap(K, (k1, k2, r1, r2), I, K, size, CV_16SC2).
@@ -1017,8 +1112,12 @@ int rmd_hip_denoiser_set_option(rmd_hip_denoiser_t* d, int option, int value) {
   switch (option) {
     case RMD_HIP_DENOISE_OPT_TIMING: d->opt_timing = value != 0; return RMD_HIP_OK;
     case RMD_HIP_DENOISE_OPT_ITERS_PER_LAUNCH:
-      if (value < 0 || value > 4) return fail(RMD_HIP_ERR_INVALID_ARG, "iters_per_launch %d outside 0..4", value);
+      if (value < 0 || value > 8) return fail(RMD_HIP_ERR_INVALID_ARG, "iters_per_launch %d outside 0..8", value);
       d->opt_iters_per_launch = value;
+      return RMD_HIP_OK;
+    case RMD_HIP_DENOISE_OPT_GEOMETRY:
+      if (value < 0 || value > 5) return fail(RMD_HIP_ERR_INVALID_ARG, "geometry %d outside 0..5", value);
+      d->opt_geometry = value;
       return RMD_HIP_OK;
     default: return fail(RMD_HIP_ERR_INVALID_ARG, "denoiser_set_option: unknown option %d", option);
   }
@@ -1087,10 +1186,10 @@ int rmd_hip_denoiser_denoise(rmd_hip_denoiser_t* d, const rmd_hip_image_t* mu, c
       ++n_launches;
     }
   } else {
-    // two geometries: small images need many small workgroups to fill 256 CUs (32x8 tile, 2 iterations per launch);
-    // from ~1 Mpixel on, 64x16 tiles with 4 iterations per launch cut the traffic further
-    const bool big = static_cast<long long>(d->width) * d->height >= (1 << 20) && d->opt_iters_per_launch != 2;
-    auto run = [&](auto geom, int kmax) {
+    // Temporally blocked kernel: tile geometry and blocking depth K by image size (K iterations per launch; the halo
+    // grows with K, so small tiles pay more redundant work per iteration, but a VGA launch is latency-bound: fewer, fatter
+    // launches win there).  opt_geometry (experiments): 0 = by size, 1..n = a fixed entry of the table below.
+    auto run = [&](auto geom, int kmax, auto kernel) {
       using G = decltype(geom);
       const int k = d->opt_iters_per_launch == 0 ? kmax : (d->opt_iters_per_launch < kmax ? d->opt_iters_per_launch : kmax);
       const dim3 block(G::THREADS), grid((d->width + G::BX - 1) / G::BX, (d->height + G::BY - 1) / G::BY);
@@ -1099,14 +1198,24 @@ int rmd_hip_denoiser_denoise(rmd_hip_denoiser_t* d, const rmd_hip_image_t* mu, c
         const int nxt = cur_buf ^ 1;
         auto [ui, uhi, pi] = bufs(cur_buf);
         auto [uo, uho, po] = bufs(nxt);
-        if (big) hipLaunchKernelGGL((rmdk::tv_iterate_blocked_kernel<64, 16, 4>), grid, block, 0, d->stream, P, ui, uhi, pi, uo, uho, po, now);
-        else hipLaunchKernelGGL((rmdk::tv_iterate_blocked_kernel<32, 8, 2>), grid, block, 0, d->stream, P, ui, uhi, pi, uo, uho, po, now);
+        hipLaunchKernelGGL(kernel, grid, block, 0, d->stream, P, ui, uhi, pi, uo, uho, po, now);
         cur_buf = nxt;
         ++n_launches;
       }
     };
-    if (big) run(rmdk::TvBlocked<64, 16, 4>(), 4);
-    else run(rmdk::TvBlocked<32, 8, 2>(), 2);
+    // Measured (tools/denoise_sweep.py, MI355X): 16x16 tiles with K = 4 are the fastest at 640x480 (3.4 us per iteration, 50
+    // launches for 200 iterations, latency-bound) AND at 1920x1080 (11.5 us per iteration = 7.2 TB/s of algorithmic traffic);
+    // deeper blocking (K = 8) loses more to the redundant halo work than it saves in launches.
+    int geometry = d->opt_geometry;
+    if (geometry == 0) geometry = d->opt_iters_per_launch == 2 ? 1 : 4;
+    switch (geometry) {
+      case 1: run(rmdk::TvBlocked<32, 8, 2>(), 2, rmdk::tv_iterate_blocked_kernel<32, 8, 2>); break;
+      case 2: run(rmdk::TvBlocked<64, 16, 4>(), 4, rmdk::tv_iterate_blocked_kernel<64, 16, 4>); break;
+      case 3: run(rmdk::TvBlocked<32, 16, 4>(), 4, rmdk::tv_iterate_blocked_kernel<32, 16, 4>); break;
+      case 4: run(rmdk::TvBlocked<16, 16, 4>(), 4, rmdk::tv_iterate_blocked_kernel<16, 16, 4>); break;
+      case 5: run(rmdk::TvBlocked<16, 16, 8>(), 8, rmdk::tv_iterate_blocked_kernel<16, 16, 8>); break;
+      default: return fail(RMD_HIP_ERR_INVALID_ARG, "denoise: unknown geometry %d", geometry);
+    }
   }
   HIP_TRY(hipGetLastError());
   if (d->opt_timing) HIP_TRY(hipEventRecord(ev1, d->stream));

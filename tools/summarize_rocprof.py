@@ -14,13 +14,18 @@ def find(raw, sub, pattern):
 
 
 def short(name):
-    name = name.replace("void ", "")
-    for k in ("seed_update_tile_kernel", "seed_update_pixel_kernel", "seed_init_kernel", "tv_iterate", "tv_prepare", "count_eq",
-              "sum_partial", "sum_final", "math_eval"):
-        if k in name:
-            i = name.find("<")
-            return k + (name[i:name.find(">") + 1] if "<" in name and i < name.find("(") else "")
-    return name[:60]
+    """kernel name without return type, namespace and argument list; template arguments kept"""
+    name = name.replace("void ", "").replace("rmdk::", "")
+    depth, out = 0, []
+    for ch in name:
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            break
+        out.append(ch)
+    return "".join(out)[:60]
 
 
 def main():
@@ -77,7 +82,7 @@ def main():
                 counters[n]["_dispatches_" + sub] = len(cnt[n])
     if counters:
         lines.append("")
-        lines.append("# PMC counters, mean per dispatch (separate rocprofv3 --pmc passes; bench.py --steps 40)")
+        lines.append("# PMC counters, mean per dispatch (separate rocprofv3 --pmc passes)")
         for n, cs in counters.items():
             lines.append(f"[{n}]")
             for c, v in sorted(cs.items()):
