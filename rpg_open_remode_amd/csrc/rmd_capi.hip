@@ -514,6 +514,8 @@ int rmd_hip_seeds_destroy(rmd_hip_seeds_t* s) {
   return RMD_HIP_OK;
 }
 
+static int ingest_init(rmd_hip_seeds* s);
+
 int rmd_hip_seeds_create(int width, int height, float fx, float fy, float cx, float cy, int patch_side, int max_extent,
                          rmd_hip_seeds_t** out) {
   if (!out) return fail(RMD_HIP_ERR_INVALID_ARG, "seeds_create: null output");
@@ -570,6 +572,7 @@ int rmd_hip_seeds_create(int width, int height, float fx, float fy, float cx, fl
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) s->num_cus = prop.multiProcessorCount;
   if (hipDeviceSynchronize() != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: device synchronisation failed"));  // all fills done
+  if (ingest_init(s) != RMD_HIP_OK) return bail(RMD_HIP_ERR_RUNTIME);  // the copy stream is created right next to the compute stream
   *out = s;
   return RMD_HIP_OK;
 }

@@ -21,7 +21,7 @@ def _bench(argv):
 
 def test_defaults_are_the_headline_workload():
     b, a = _bench([])
-    assert (a.gpus, a.size, a.matcher) == (1, "640x480", 1)
+    assert (a.gpus, a.size, a.matcher) == (1, "640x480", -1)  # matcher: the library's default
     assert b.resolve_workload(a) == (640, 480, 200, 200)  # BASELINE.json configs[1]: 200 frames, TV-L1 200 iterations
     assert b.KNOWN_CONFIGS[(640, 480, 200)] == "configs[1]"
     assert (b.WIDTH, b.HEIGHT, b.FRAMES, b.SIDE) == (640, 480, 200, 9)
