@@ -349,6 +349,8 @@ int seeds_after_reference(rmd_hip_seeds* s, const float* T_curr_world, float min
   // the frame kernel's load statistics belong to the old sequence
   s->frame_ws.frame = 0;
   HIP_TRY(hipMemsetAsync(s->frame_ws.d_ctl, 0, 3 * rmdk::FR_CTL_WORDS * sizeof(unsigned int), s->stream));
+  s->matcher_ws.frame = 0;
+  HIP_TRY(hipMemsetAsync(s->matcher_ws.d_shards, 0, 3 * rmdk::UNIT_SHARDS * sizeof(unsigned long long), s->stream));
   s->has_reference = true;
   // the reference synchronises here (seed_matrix.cu:113); so do we: the host image is borrowed
   return seeds_sync(s);
@@ -929,6 +931,8 @@ int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value) {
         TRY(seeds_sync(s));
         s->frame_ws.frame = 0;
         HIP_TRY(hipMemsetAsync(s->frame_ws.d_ctl, 0, 3 * rmdk::FR_CTL_WORDS * sizeof(unsigned int), s->stream));
+        s->matcher_ws.frame = 0;
+        HIP_TRY(hipMemsetAsync(s->matcher_ws.d_shards, 0, 3 * rmdk::UNIT_SHARDS * sizeof(unsigned long long), s->stream));
       }
       s->opt_matcher = value;
       return RMD_HIP_OK;

@@ -943,9 +943,13 @@ RMDK_D void plan_units_in_kernel(const MatcherArgs& M, int n_tiles, int target_u
 // registers into the new frame's check.  Everything a lane needs from memory is requested in ONE batch up front (the
 // compiler does not hoist loads out of the branches that consume them, and five dependent round trips under a burst of a
 // million requests were two thirds of this kernel's time).
+// The unit list is built without a planning step: a tile reserves its units in the list of its shard (tile % 16) with one
+// returning atomic on the shard's counter; the unit size comes from the PREVIOUS frame's total work (the counters of three
+// consecutive frames rotate).  The search kernel reads the sixteen counts and walks the shards' lists as one list.
 template <int SIDE, bool FUSE_PREV>
-__global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(SeedParams P, MatcherArgs M, Pose T_ref_curr_prev) {
+__global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(SeedParams P, MatcherArgs M, Pose T_ref_curr_prev, int target_units) {
   __shared__ int red_i[4];
+  __shared__ unsigned int s_base;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int tx = tid & (TILE_W - 1), ty = tid >> 4;
@@ -1015,7 +1019,30 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(SeedParams
   for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
   if (lane == 0) red_i[wave] = tot;
   __syncthreads();
-  if (tid == 0) M.tile_plan[blockIdx.y * M.tiles_x + blockIdx.x] = static_cast<unsigned int>(red_i[0] + red_i[1] + red_i[2] + red_i[3]);
+  const int total = red_i[0] + red_i[1] + red_i[2] + red_i[3];
+  const int tile = blockIdx.y * M.tiles_x + blockIdx.x;
+  // unit size: 1..4 rounds of 256 evaluations, from the previous frame's work (a frame differs little from the one before)
+  int unit_rounds = MAX_UNIT_ROUNDS;
+  if (M.shards_prev) {
+    unsigned long long items = 0;
+#pragma unroll
+    for (int q = 0; q < UNIT_SHARDS; ++q) items += M.shards_prev[q] >> 32;
+    unit_rounds = static_cast<int>(min(max((items + static_cast<unsigned long long>(target_units) * TILE_PIX - 1) / (static_cast<unsigned long long>(target_units) * TILE_PIX), 1ull),
+                                       static_cast<unsigned long long>(MAX_UNIT_ROUNDS)));
+  }
+  const int unit_items = unit_rounds * TILE_PIX;
+  if (tile == 0 && tid < UNIT_SHARDS) M.shards_next[tid] = 0ull;  // the set the NEXT frame counts in (nobody reads it now)
+  if (tile == 0 && tid == 0) { M.queue[1] = 0u; M.queue[5] = static_cast<unsigned int>(unit_items); }
+  if (total == 0) return;
+  const int n_u = units_of(total, unit_rounds);
+  if (tid == 0) {
+    const unsigned long long old = atomicAdd(&M.shards_cur[tile % UNIT_SHARDS], (static_cast<unsigned long long>(total) << 32) | static_cast<unsigned long long>(n_u));
+    s_base = static_cast<unsigned int>(old);  // units reserved so far in this shard
+  }
+  __syncthreads();
+  if (tid < n_u) M.units[static_cast<size_t>(tile % UNIT_SHARDS) * M.shard_cap + s_base + tid] =
+      make_uint2(static_cast<unsigned int>(tile), static_cast<unsigned int>(tid * unit_items));
+  if (tid == 0) M.tile_plan[tile] = static_cast<unsigned int>(total);
 }
 
 template <int SIDE>
@@ -1026,7 +1053,12 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
   Smem& S = *reinterpret_cast<Smem*>(smem_raw);
   const int tid = threadIdx.x;
   const int tx = tid & (TILE_W - 1), ty = tid >> 4;
-  const unsigned int n_units = M.queue[0];
+  // the shards' unit lists as one list: unit g lives in shard s with first[s] <= g < first[s + 1]
+  unsigned int shard_first[UNIT_SHARDS + 1];
+  shard_first[0] = 0u;
+#pragma unroll
+  for (int q = 0; q < UNIT_SHARDS; ++q) shard_first[q + 1] = shard_first[q] + static_cast<unsigned int>(M.shards_cur[q]);
+  const unsigned int n_units = shard_first[UNIT_SHARDS];
   const int unit_items = static_cast<int>(M.queue[5]);
   unsigned int n_fallback = 0, n_windows = 0, n_done = 0, n_items = 0;
   int lds_tile = -1, x0 = 0, y0 = 0, total = 0;
@@ -1036,7 +1068,13 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
   W.valid = false; W.x0 = W.y0 = 0; W.x1 = W.y1 = -1; W.ws = 1;
   unsigned int u = blockIdx.x;  // unit blockIdx.x is ours for free; further units come from the shared counter
   while (u < n_units) {
-    const uint2 unit = M.units[u];
+    int sh = 0;
+#pragma unroll
+    for (int q = 1; q < UNIT_SHARDS; ++q) sh += u >= shard_first[q] ? 1 : 0;
+    unsigned int sh_first = 0u;
+#pragma unroll
+    for (int q = 1; q < UNIT_SHARDS; ++q) sh_first = u >= shard_first[q] ? shard_first[q] : sh_first;
+    const uint2 unit = M.units[static_cast<size_t>(sh) * M.shard_cap + (u - sh_first)];
     const int tile = static_cast<int>(unit.x), first = static_cast<int>(unit.y);
     if (tile != lds_tile) {
       if (lds_tile >= 0) {  // hand the previous tile's keys over
@@ -1089,7 +1127,8 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
   }
 }
 
-// setup (+ the deferred finalisation of the previous frame when fuse_prev) -> plan -> compact search
+// setup (+ the deferred finalisation of the previous frame when fuse_prev; builds the unit list) -> compact search.
+// The caller zeroes ws.d_shards and sets ws.frame = 0 whenever the sequence restarts.
 template <int SIDE>
 inline hipError_t launch_seed_pipeline_compact(const SeedParams& P, MatcherWorkspace& ws, FrameWorkspace& fws, hipStream_t stream, int num_cus,
                                                bool fuse_prev, const Pose& T_ref_curr_prev, int target_mult = 1) {
@@ -1109,10 +1148,10 @@ inline hipError_t launch_seed_pipeline_compact(const SeedParams& P, MatcherWorks
   }
   const int resident = num_cus * fws.compact_wg_per_cu[SIDE / 2 - 1];
   const dim3 tiles(ws.tiles_x, ws.tiles_y);
-  if (fuse_prev) hipLaunchKernelGGL((seed_setup_compact_kernel<SIDE, true>), tiles, dim3(TILE_PIX), 0, stream, P, M, T_ref_curr_prev);
-  else hipLaunchKernelGGL((seed_setup_compact_kernel<SIDE, false>), tiles, dim3(TILE_PIX), 0, stream, P, M, T_ref_curr_prev);
-  hipLaunchKernelGGL(seed_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, stream, M, ws.tiles_x * ws.tiles_y, resident * target_mult);
+  if (fuse_prev) hipLaunchKernelGGL((seed_setup_compact_kernel<SIDE, true>), tiles, dim3(TILE_PIX), 0, stream, P, M, T_ref_curr_prev, resident * target_mult);
+  else hipLaunchKernelGGL((seed_setup_compact_kernel<SIDE, false>), tiles, dim3(TILE_PIX), 0, stream, P, M, T_ref_curr_prev, resident * target_mult);
   hipLaunchKernelGGL(search, dim3(resident), dim3(TILE_PIX), sizeof(Smem), stream, P, M);
+  ++ws.frame;
   return hipGetLastError();
 }
 

@@ -41,6 +41,7 @@ constexpr int TILE_W = 16, TILE_H = 16, TILE_PIX = TILE_W * TILE_H;
 constexpr int MAX_UNIT_ROUNDS = 4;  // a work unit is 1..4 rounds of the 256 lanes (chosen per frame by seed_plan)
 constexpr int MIN_UNIT_ITEMS = TILE_PIX;
 constexpr int MAX_ITEMS_PER_TILE = TILE_PIX * 144;
+constexpr int UNIT_SHARDS = 16;  // plan-free pipeline: unit lists / counters, tile t -> shard t % UNIT_SHARDS
 constexpr int TRACE_FRAMES = 256, TRACE_MAX_SEARCH_WGS = 1024;  // diagnostics (trace_record)
 
 // per-tile record written by seed_setup, read by seed_search
@@ -63,6 +64,9 @@ struct MatcherWorkspace {
   // counters of the current frame, rewritten by seed_plan every frame: [0] work units, [1] units handed out beyond the
   // static first round, [5] items per unit
   unsigned int* d_queue = nullptr;
+  unsigned long long* d_shards = nullptr;  // plan-free pipeline: 3 sets (frame % 3) of UNIT_SHARDS counters {work items << 32 | units}
+  long long frame = 0;                     // updates since the last reference (plan-free pipeline: which set is current)
+  int shard_cap = 0;                       // unit-list entries per shard
   unsigned long long* d_trace = nullptr;  // diagnostics, allocated on demand: TRACE_FRAMES slices of trace_slice_u64() words
   int max_units = 0;
   bool attr_set_small = false, attr_set_large = false;
@@ -71,7 +75,7 @@ struct MatcherWorkspace {
     tiles_y = (h + TILE_H - 1) / TILE_H;
     stride = stride_elems;
     const size_t n = static_cast<size_t>(stride) * h;
-    max_units = tiles_x * tiles_y * ((MAX_ITEMS_PER_TILE + MIN_UNIT_ITEMS - 1) / MIN_UNIT_ITEMS);
+    max_units = (tiles_x * tiles_y + UNIT_SHARDS) * ((MAX_ITEMS_PER_TILE + MIN_UNIT_ITEMS - 1) / MIN_UNIT_ITEMS);
     if (hipMalloc(reinterpret_cast<void**>(&d_mean), n * sizeof(float2)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_dir), n * sizeof(float2)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_lfirst), n * sizeof(float)) != hipSuccess) return -1;
@@ -81,8 +85,12 @@ struct MatcherWorkspace {
     if (hipMalloc(reinterpret_cast<void**>(&d_tile_plan), static_cast<size_t>(tiles_x) * tiles_y * sizeof(unsigned int)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_tile_pending), static_cast<size_t>(tiles_x) * tiles_y * sizeof(unsigned int)) != hipSuccess) return -1;
     (void)hipMemset(d_tile_pending, 0, static_cast<size_t>(tiles_x) * tiles_y * sizeof(unsigned int));
+    shard_cap = ((tiles_x * tiles_y + UNIT_SHARDS - 1) / UNIT_SHARDS) * ((MAX_ITEMS_PER_TILE + MIN_UNIT_ITEMS - 1) / MIN_UNIT_ITEMS);  // tiles of a shard x units of a tile
+    if (max_units < UNIT_SHARDS * shard_cap) max_units = UNIT_SHARDS * shard_cap;
     if (hipMalloc(reinterpret_cast<void**>(&d_units), static_cast<size_t>(max_units) * sizeof(uint2)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_queue), 8 * sizeof(unsigned int)) != hipSuccess) return -1;
+    if (hipMalloc(reinterpret_cast<void**>(&d_shards), 3 * UNIT_SHARDS * sizeof(unsigned long long)) != hipSuccess) return -1;
+    (void)hipMemset(d_shards, 0, 3 * UNIT_SHARDS * sizeof(unsigned long long));
     (void)hipMemset(d_packed, 0, n * sizeof(unsigned int));
     (void)hipMemset(d_best, 0, n * sizeof(unsigned long long));
     (void)hipMemset(d_queue, 0, 8 * sizeof(unsigned int));
@@ -90,11 +98,11 @@ struct MatcherWorkspace {
   }
   size_t trace_slice_u64() const { return 2 * (static_cast<size_t>(tiles_x) * tiles_y + 1 + TRACE_MAX_SEARCH_WGS); }
   void release() {
-    void* all[] = {d_mean, d_dir, d_lfirst, d_packed, d_best, d_tiles, d_tile_plan, d_tile_pending, d_units, d_queue, d_trace};
+    void* all[] = {d_mean, d_dir, d_lfirst, d_packed, d_best, d_tiles, d_tile_plan, d_tile_pending, d_units, d_queue, d_shards, d_trace};
     for (void* p : all)
       if (p) (void)hipFree(p);
     d_mean = d_dir = nullptr; d_lfirst = nullptr; d_packed = nullptr; d_best = nullptr;
-    d_tiles = nullptr; d_tile_plan = nullptr; d_tile_pending = nullptr; d_units = nullptr; d_queue = nullptr; d_trace = nullptr;
+    d_tiles = nullptr; d_tile_plan = nullptr; d_tile_pending = nullptr; d_units = nullptr; d_queue = nullptr; d_shards = nullptr; d_trace = nullptr;
   }
 };
 
@@ -110,6 +118,10 @@ struct MatcherArgs {
   unsigned int* tile_pending;
   uint2* units;
   unsigned int* queue;       // this frame's counters (see MatcherWorkspace)
+  unsigned long long* shards_cur;         // plan-free pipeline: this frame's shard counters (zero at launch)
+  const unsigned long long* shards_prev;  // the previous frame's (null: no previous frame)
+  unsigned long long* shards_next;        // cleared by this frame's setup for the next one
+  int shard_cap;
   int tiles_x;
   unsigned long long* trace;  // this frame's slice of the timeline buffer, may be null (see trace_record)
 };
@@ -836,6 +848,10 @@ inline MatcherArgs matcher_args(const MatcherWorkspace& ws) {
   M.mean = ws.d_mean; M.dir = ws.d_dir; M.lfirst = ws.d_lfirst; M.packed = ws.d_packed; M.best = ws.d_best;
   M.tiles = ws.d_tiles; M.tile_plan = ws.d_tile_plan; M.tile_pending = ws.d_tile_pending; M.units = ws.d_units; M.tiles_x = ws.tiles_x;
   M.queue = ws.d_queue;
+  M.shards_cur = ws.d_shards + (ws.frame % 3) * UNIT_SHARDS;
+  M.shards_prev = ws.frame > 0 ? ws.d_shards + ((ws.frame + 2) % 3) * UNIT_SHARDS : nullptr;
+  M.shards_next = ws.d_shards + ((ws.frame + 1) % 3) * UNIT_SHARDS;
+  M.shard_cap = ws.shard_cap;
   M.trace = nullptr;
   return M;
 }
