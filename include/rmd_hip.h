@@ -204,8 +204,14 @@ int rmd_hip_denoiser_set_option(rmd_hip_denoiser_t* d, int option, int value);
 int rmd_hip_denoiser_timing(const rmd_hip_denoiser_t* d, double* total_ms, long* launches);
 
 /* ---- rmd::ImageReducer<T> (reduction.cu) ------------------------------------------------ */
-int rmd_hip_reduce_sum_f32(const rmd_hip_image_t* img, float* sum);                    /* sum :81-130 */
-int rmd_hip_reduce_count_eq_i32(const rmd_hip_image_t* img, int value, size_t* count); /* countEqual :133-183 */
+int rmd_hip_reduce_sum_f32(const rmd_hip_image_t* img, float* sum);                    /* ImageReducer<float>::sum(const DeviceImage&) :132-139 */
+int rmd_hip_reduce_sum_i32(const rmd_hip_image_t* img, int* sum);                      /* ImageReducer<int>::sum (explicit instantiation :186) */
+int rmd_hip_reduce_count_eq_i32(const rmd_hip_image_t* img, int value, size_t* count); /* countEqual(const DeviceImage<int>&, int) :175-183 */
+/* the raw-pointer overloads (reduction.cuh:33-36, 41-45; reduction.cu:81-130, 145-173): DEVICE pointers on the current device,
+ * row stride in elements */
+int rmd_hip_reduce_sum_f32_raw(const float* dev_data, size_t stride_elems, size_t width, size_t height, float* sum);
+int rmd_hip_reduce_sum_i32_raw(const int* dev_data, size_t stride_elems, size_t width, size_t height, int* sum);
+int rmd_hip_reduce_count_eq_i32_raw(const int* dev_data, size_t stride_elems, size_t width, size_t height, int value, size_t* count);
 
 /* ---- arithmetic-contract self test (device side of csrc/rmd_math.h) ---------------------- */
 /* op: 0 expf, 1 sinf, 2 acosf, 3 rsqrtf, 4 sqrtf, 5 x/y, 6 lerp(t=x, a=y, b=z); n host floats in, n out */

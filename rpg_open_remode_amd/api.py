@@ -192,14 +192,34 @@ class ImageReducer:
     def __init__(self, num_threads_per_block=None, num_blocks_per_grid=None):
         pass
 
-    def sum(self, img):  # reduction.cu:81-130
+    def sum(self, img, stride=None, width=None, height=None):
+        """sum(const DeviceImage<T>&) (reduction.cu:132-139), or -- with stride / width / height -- the raw-pointer form
+        sum(const T*, stride, width, height) (:81-130) on a device pointer (an int).  float or int images."""
+        L = _lib.lib()
+        if stride is not None:
+            out = ctypes.c_float()
+            check(L.rmd_hip_reduce_sum_f32_raw(int(img), int(stride), int(width), int(height), ctypes.byref(out)))
+            return float(out.value)
+        if img.kind == KIND_I32:
+            out = ctypes.c_int()
+            check(L.rmd_hip_reduce_sum_i32(img.ptr, ctypes.byref(out)))
+            return int(out.value)
         out = ctypes.c_float()
-        check(_lib.lib().rmd_hip_reduce_sum_f32(img.ptr, ctypes.byref(out)))
+        check(L.rmd_hip_reduce_sum_f32(img.ptr, ctypes.byref(out)))
         return float(out.value)
 
-    def countEqual(self, img, value):  # reduction.cu:133-183
+    def sumIntRaw(self, dev_ptr, stride, width, height):  # ImageReducer<int>::sum(const int*, ...)
+        out = ctypes.c_int()
+        check(_lib.lib().rmd_hip_reduce_sum_i32_raw(int(dev_ptr), int(stride), int(width), int(height), ctypes.byref(out)))
+        return int(out.value)
+
+    def countEqual(self, img, value, stride=None, width=None, height=None):
+        """countEqual(const DeviceImage<int>&, value) (reduction.cu:175-183) or the raw-pointer form (:145-173)"""
         out = ctypes.c_size_t()
-        check(_lib.lib().rmd_hip_reduce_count_eq_i32(img.ptr, int(value), ctypes.byref(out)))
+        if stride is not None:
+            check(_lib.lib().rmd_hip_reduce_count_eq_i32_raw(int(img), int(stride), int(width), int(height), int(value), ctypes.byref(out)))
+        else:
+            check(_lib.lib().rmd_hip_reduce_count_eq_i32(img.ptr, int(value), ctypes.byref(out)))
         return int(out.value)
 
 

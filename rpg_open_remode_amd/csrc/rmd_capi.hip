@@ -13,6 +13,7 @@
 #include <string.h>
 #include <time.h>
 
+#include <mutex>
 #include <new>
 #include <tuple>
 #include <utility>
@@ -50,6 +51,17 @@ int fail(int code, const char* fmt, ...) {
     const int rc_ = (expr);   \
     if (rc_ != RMD_HIP_OK) return rc_; \
   } while (0)
+
+struct ScopedDevice {  // run on `device`, restore the caller's current device afterwards
+  int prev = -1;
+  bool switched = false;
+  explicit ScopedDevice(int device) {
+    if (hipGetDevice(&prev) == hipSuccess && device >= 0 && prev != device) switched = hipSetDevice(device) == hipSuccess;
+  }
+  ~ScopedDevice() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
 
 size_t kind_size(int kind) { return kind == RMD_HIP_KIND_F32X2 ? 8 : 4; }
 
@@ -144,6 +156,7 @@ int seeds_sync(const rmd_hip_seeds* s);
 
 // wait until the owner of an image (if any) has settled it
 int image_settle(const rmd_hip_image* img) {
+  ScopedDevice dev(img->device);  // the owner's stream belongs to the image's device, whatever the caller's current one is
   if (img->owner_seeds) return seeds_sync(img->owner_seeds);
   if (img->owner_stream) HIP_TRY(hipStreamSynchronize(img->owner_stream));
   return RMD_HIP_OK;
@@ -1257,45 +1270,120 @@ int rmd_hip_denoiser_timing(const rmd_hip_denoiser_t* d, double* total_ms, long*
   return RMD_HIP_OK;
 }
 
+}  // extern "C"
+
 // ---- ImageReducer ---------------------------------------------------------------------------
+namespace {
+
+// scratch of the reducers: allocated once per device (the reference keeps dev_partial_ / dev_final_ in the object,
+// reduction.cu:29-73), used on the null stream under a lock
+struct ReduceScratch {
+  double* parts = nullptr;            // 8 x 64 fp64 partials
+  float* out_f32 = nullptr;
+  unsigned long long* out_u64 = nullptr;
+};
+constexpr int MAX_DEVICES = 64;
+ReduceScratch g_reduce_scratch[MAX_DEVICES];
+std::mutex g_reduce_mutex;
+
+int reduce_scratch(ReduceScratch** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= MAX_DEVICES) return fail(RMD_HIP_ERR_RUNTIME, "reduce: device index %d", dev);
+  ReduceScratch& r = g_reduce_scratch[dev];
+  if (!r.parts) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&r.parts), 8 * 64 * sizeof(double)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&r.out_f32), sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&r.out_u64), sizeof(unsigned long long)));
+  }
+  *out = &r;
+  return RMD_HIP_OK;
+}
+
+int reduce_sum_f32_dev(const float* data, size_t stride, size_t width, size_t height, float* sum) {
+  if (width == 0 || height == 0 || width > 0x7fffffff || height > 0x7fffffff || stride > 0x7fffffff) return fail(RMD_HIP_ERR_INVALID_ARG, "reduce_sum: bad shape");
+  std::lock_guard<std::mutex> lock(g_reduce_mutex);
+  ReduceScratch* r = nullptr;
+  TRY(reduce_scratch(&r));
+  const int w = static_cast<int>(width), h = static_cast<int>(height);
+  const dim3 block(256), grid((w + 255) / 256 < 8 ? (w + 255) / 256 : 8, h < 64 ? h : 64);
+  hipLaunchKernelGGL(rmdk::sum_partial_kernel, grid, block, 0, nullptr, data, w, h, static_cast<int>(stride), r->parts);
+  hipLaunchKernelGGL(rmdk::sum_final_kernel, dim3(1), dim3(64), 0, nullptr, r->parts, static_cast<int>(grid.x * grid.y), r->out_f32);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(sum, r->out_f32, sizeof(float), hipMemcpyDeviceToHost));
+  return RMD_HIP_OK;
+}
+
+int reduce_u64_dev(bool count_eq, const int* data, size_t stride, size_t width, size_t height, int value, unsigned long long* result) {
+  if (width == 0 || height == 0 || width > 0x7fffffff || height > 0x7fffffff || stride > 0x7fffffff) return fail(RMD_HIP_ERR_INVALID_ARG, "reduce: bad shape");
+  std::lock_guard<std::mutex> lock(g_reduce_mutex);
+  ReduceScratch* r = nullptr;
+  TRY(reduce_scratch(&r));
+  const int w = static_cast<int>(width), h = static_cast<int>(height);
+  HIP_TRY(hipMemsetAsync(r->out_u64, 0, sizeof(unsigned long long), nullptr));
+  const dim3 block(256), grid((w + 255) / 256, h < 64 ? h : 64);
+  if (count_eq) hipLaunchKernelGGL(rmdk::count_eq_kernel, grid, block, 0, nullptr, data, w, h, static_cast<int>(stride), value, r->out_u64);
+  else hipLaunchKernelGGL(rmdk::sum_i32_kernel, grid, block, 0, nullptr, data, w, h, static_cast<int>(stride), r->out_u64);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(result, r->out_u64, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return RMD_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int rmd_hip_reduce_sum_f32(const rmd_hip_image_t* img, float* sum) {
   if (!img || !sum) return fail(RMD_HIP_ERR_INVALID_ARG, "reduce_sum: null argument");
   if (img->kind != RMD_HIP_KIND_F32) return fail(RMD_HIP_ERR_INVALID_ARG, "reduce_sum: image is not f32");
+  ScopedDevice dev(img->device);
   TRY(image_settle(img));
-  const dim3 block(256), grid((img->width + 255) / 256 < 8 ? (img->width + 255) / 256 : 8, img->height < 64 ? img->height : 64);
-  const int nparts = grid.x * grid.y;
-  double* d_parts = nullptr;
-  float* d_out = nullptr;
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_parts), nparts * sizeof(double)));
-  if (hipMalloc(reinterpret_cast<void**>(&d_out), sizeof(float)) != hipSuccess) {
-    (void)hipFree(d_parts);
-    return fail(RMD_HIP_ERR_RUNTIME, "reduce_sum: hipMalloc failed");
-  }
-  hipLaunchKernelGGL(rmdk::sum_partial_kernel, grid, block, 0, nullptr, static_cast<const float*>(img->data), img->width,
-                     img->height, static_cast<int>(img->stride), d_parts);
-  hipLaunchKernelGGL(rmdk::sum_final_kernel, dim3(1), dim3(64), 0, nullptr, d_parts, nparts, d_out);
-  const hipError_t e = hipMemcpy(sum, d_out, sizeof(float), hipMemcpyDeviceToHost);
-  (void)hipFree(d_parts);
-  (void)hipFree(d_out);
-  if (e != hipSuccess) return fail(RMD_HIP_ERR_RUNTIME, "reduce_sum: %s", hipGetErrorString(e));
+  return reduce_sum_f32_dev(static_cast<const float*>(img->data), img->stride, img->width, img->height, sum);
+}
+
+int rmd_hip_reduce_sum_i32(const rmd_hip_image_t* img, int* sum) {
+  if (!img || !sum) return fail(RMD_HIP_ERR_INVALID_ARG, "reduce_sum_i32: null argument");
+  if (img->kind != RMD_HIP_KIND_I32) return fail(RMD_HIP_ERR_INVALID_ARG, "reduce_sum_i32: image is not i32");
+  ScopedDevice dev(img->device);
+  TRY(image_settle(img));
+  unsigned long long r = 0;
+  TRY(reduce_u64_dev(false, static_cast<const int*>(img->data), img->stride, img->width, img->height, 0, &r));
+  *sum = static_cast<int>(static_cast<unsigned int>(r));
   return RMD_HIP_OK;
 }
 
 int rmd_hip_reduce_count_eq_i32(const rmd_hip_image_t* img, int value, size_t* count) {
   if (!img || !count) return fail(RMD_HIP_ERR_INVALID_ARG, "reduce_count_eq: null argument");
   if (img->kind != RMD_HIP_KIND_I32) return fail(RMD_HIP_ERR_INVALID_ARG, "reduce_count_eq: image is not i32");
+  ScopedDevice dev(img->device);
   TRY(image_settle(img));
-  unsigned long long* d_out = nullptr;
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), sizeof(unsigned long long)));
-  (void)hipMemset(d_out, 0, sizeof(unsigned long long));
-  const dim3 block(256), grid((img->width + 255) / 256, img->height < 64 ? img->height : 64);
-  hipLaunchKernelGGL(rmdk::count_eq_kernel, grid, block, 0, nullptr, static_cast<const int*>(img->data), img->width,
-                     img->height, static_cast<int>(img->stride), value, d_out);
-  unsigned long long h = 0;
-  const hipError_t e = hipMemcpy(&h, d_out, sizeof(h), hipMemcpyDeviceToHost);
-  (void)hipFree(d_out);
-  if (e != hipSuccess) return fail(RMD_HIP_ERR_RUNTIME, "reduce_count_eq: %s", hipGetErrorString(e));
-  *count = static_cast<size_t>(h);
+  unsigned long long r = 0;
+  TRY(reduce_u64_dev(true, static_cast<const int*>(img->data), img->stride, img->width, img->height, value, &r));
+  *count = static_cast<size_t>(r);
+  return RMD_HIP_OK;
+}
+
+// the raw-pointer forms of the reference (reduction.cuh:33-47): device pointers on the current device; the caller is
+// responsible for the data being complete (as with the reference, which launches on the default stream)
+int rmd_hip_reduce_sum_f32_raw(const float* dev_data, size_t stride_elems, size_t width, size_t height, float* sum) {
+  if (!dev_data || !sum) return fail(RMD_HIP_ERR_INVALID_ARG, "reduce_sum_raw: null argument");
+  HIP_TRY(hipDeviceSynchronize());
+  return reduce_sum_f32_dev(dev_data, stride_elems, width, height, sum);
+}
+int rmd_hip_reduce_sum_i32_raw(const int* dev_data, size_t stride_elems, size_t width, size_t height, int* sum) {
+  if (!dev_data || !sum) return fail(RMD_HIP_ERR_INVALID_ARG, "reduce_sum_i32_raw: null argument");
+  HIP_TRY(hipDeviceSynchronize());
+  unsigned long long r = 0;
+  TRY(reduce_u64_dev(false, dev_data, stride_elems, width, height, 0, &r));
+  *sum = static_cast<int>(static_cast<unsigned int>(r));
+  return RMD_HIP_OK;
+}
+int rmd_hip_reduce_count_eq_i32_raw(const int* dev_data, size_t stride_elems, size_t width, size_t height, int value, size_t* count) {
+  if (!dev_data || !count) return fail(RMD_HIP_ERR_INVALID_ARG, "reduce_count_eq_raw: null argument");
+  HIP_TRY(hipDeviceSynchronize());
+  unsigned long long r = 0;
+  TRY(reduce_u64_dev(true, dev_data, stride_elems, width, height, value, &r));
+  *count = static_cast<size_t>(r);
   return RMD_HIP_OK;
 }
 
@@ -1309,9 +1397,16 @@ int rmd_hip_math_eval(int op, const float* x, const float* y, const float* z, fl
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dy), bytes));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dz), bytes));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dout), bytes));
-  (void)hipMemcpy(dx, x, bytes, hipMemcpyHostToDevice);
-  (void)hipMemcpy(dy, y ? y : x, bytes, hipMemcpyHostToDevice);
-  (void)hipMemcpy(dz, z ? z : x, bytes, hipMemcpyHostToDevice);
+  const hipError_t e_in = [&] {
+    hipError_t r = hipMemcpy(dx, x, bytes, hipMemcpyHostToDevice);
+    if (r == hipSuccess) r = hipMemcpy(dy, y ? y : x, bytes, hipMemcpyHostToDevice);
+    if (r == hipSuccess) r = hipMemcpy(dz, z ? z : x, bytes, hipMemcpyHostToDevice);
+    return r;
+  }();
+  if (e_in != hipSuccess) {
+    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dz); (void)hipFree(dout);
+    return fail(RMD_HIP_ERR_RUNTIME, "math_eval: upload failed: %s", hipGetErrorString(e_in));
+  }
   hipLaunchKernelGGL(rmdk::math_eval_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, nullptr, op, dx, dy,
                      dz, dout, n);
   const hipError_t e = hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);

@@ -323,6 +323,22 @@ __global__ __launch_bounds__(256) void sum_partial_kernel(const float* __restric
   if (threadIdx.x == 0)
     partials[blockIdx.y * gridDim.x + blockIdx.x] = ((wave_part[0] + wave_part[1]) + wave_part[2]) + wave_part[3];
 }
+// integer image sum (ImageReducer<int>::sum, reduction.cu:186): exact in 64 bits, the caller truncates to int like the
+// reference's int accumulation wraps
+__global__ __launch_bounds__(256) void sum_i32_kernel(const int* __restrict__ img, int w, int h, int stride, unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long wave_part[4];
+  unsigned long long acc = 0;
+  for (int y = blockIdx.y; y < h; y += gridDim.y) {
+    const int* row = img + static_cast<size_t>(y) * stride;
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < w; x += gridDim.x * blockDim.x) acc += static_cast<unsigned long long>(static_cast<long long>(row[x]));
+  }
+  acc = wave_sum_u64(acc);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, wave_part[0] + wave_part[1] + wave_part[2] + wave_part[3]);
+}
+
 __global__ __launch_bounds__(64) void sum_final_kernel(const double* __restrict__ partials, int n, float* __restrict__ out) {
   double acc = 0.0;
   for (int i = threadIdx.x; i < n; i += 64) acc += partials[i];

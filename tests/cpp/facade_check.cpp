@@ -63,6 +63,12 @@ int main(int argc, char** argv) {
   const unsigned long long n_conv2 = seeds.getConvergedCount();
   rmd::ImageReducer<float> summer(dim3(16, 16), dim3(4, 4));
   const float mu_sum = summer.sum(seeds.getMu());
+  // the raw-pointer overloads and the int sum of the reference's header (reduction.cuh:33-47)
+  const rmd::DeviceImage<int>& cv = seeds.getConvergence();
+  const rmd::DeviceImage<float>& mu_img = seeds.getMu();
+  if (counter.countEqual(cv.data, cv.stride, cv.width, cv.height, rmd::ConvergenceStates::CONVERGED) != n_conv) return 8;
+  if (summer.sum(mu_img.data, mu_img.stride, mu_img.width, mu_img.height) != mu_sum) return 9;
+  if (counter.sum(cv) != counter.sum(cv.data, cv.stride, cv.width, cv.height)) return 10;
   const float dist = seeds.getDistFromRef();
   FILE* out = fopen(argv[2], "wb");
   if (!out) return 7;

@@ -1,4 +1,4 @@
-"""GPU parity at BASELINE.json's full sizes (configs[1], [2], [3], [4]).
+"""GPU parity at BASELINE.json's full sizes and lengths (configs[1], [2], [3], [4]).
 
 The oracle (Oracle B, oracle/remode_oracle.cpp) is fast enough to follow the GPU frame by frame even at these sizes, so
 the bar stays BIT-EXACT on every plane; on top of that the two independent device implementations (per-pixel baseline
@@ -89,40 +89,74 @@ def test_config4_other_scenes(scene):
     assert_states_equal(base.state(), hip.state(), f"scene {scene}: pipeline vs per-pixel kernel after 8 updates")
 
 
-def test_config2_1280x960_search_hits_the_extent_cap():
-    """configs[2]: 1280x960, side 9; the early searches are capped at RMD_MAX_EXTENT_EPIPOLAR_SEARCH (143 steps)."""
-    seq = sequence(1280, 960, 31)
-    hip, base, orc = _hip(seq, 9, 3), _hip(seq, 9, 0), _oracle(seq, 9)
+class LazySequence:
+    """frames rendered on demand (a 1000-frame 1080p sequence does not fit comfortably in host memory as float images)"""
+
+    def __init__(self, width, height, n_frames, seed=0):
+        from rpg_open_remode_amd import synth
+        self.synth, self.width, self.height, self.n_frames, self.seed = synth, width, height, n_frames, seed
+        self.K = synth.intrinsics(width, height)
+        g, rng = self.synth.render(width, height, synth.pose(0, seed), seed, want_range=True, K=self.K)
+        self.min_depth, self.max_depth = float(rng.min()), float(rng.max())
+        self.range0 = rng
+
+    def frame(self, k):
+        T = self.synth.pose(k, self.seed)
+        g, _ = self.synth.render(self.width, self.height, T, self.seed, want_range=False, K=self.K)
+        return g, np.ascontiguousarray(self.synth.invert_pose(T).astype(np.float32).reshape(12))
+
+
+def _long_run(w, h, n_frames, oracle_updates, compare_every, what):
+    """Pipeline (default matcher, 8-bit frames through the ingest path) against the per-pixel kernel over the whole configured
+    length, against the oracle on the first updates (where every seed is live and the searches are longest)."""
+    seq = LazySequence(w, h, n_frames)
+    cam = api.PinholeCamera(*seq.K)
+    hip, base = api.SeedMatrix(w, h, cam, patch_side=9), api.SeedMatrix(w, h, cam, patch_side=9)
+    base.setOption(api.OPT_MATCHER, 0)
+    orc = O.Seeds(O.OracleLib("port", 9), w, h, seq.K)
+    g0, T0 = seq.frame(0)
+    img0 = synth_float(g0)
+    hip.setReferenceImageU8(g0, T0, seq.min_depth, seq.max_depth)
+    base.setReferenceImage(img0, T0, seq.min_depth, seq.max_depth)
+    orc.set_reference(img0, T0, seq.min_depth, seq.max_depth)
     hip.setOption(api.OPT_COLLECT_STATS, 1)
     max_steps_per_seed = 0.0
-    for k in range(1, 31):
-        hip.update(seq.images[k], seq.T_curr_world[k])
-        base.update(seq.images[k], seq.T_curr_world[k])
-        if k <= 8:
-            orc.update(seq.images[k], seq.T_curr_world[k])
-            assert_states_equal(orc.state(), hip.state(), f"1280x960 update {k}")
+    for k in range(1, n_frames):
+        g, T = seq.frame(k)
+        img = synth_float(g)
+        hip.updateU8(g, T)
+        base.update(img, T)
+        if k <= oracle_updates:
+            orc.update(img, T)
+            assert_states_equal(orc.state(), hip.state(), f"{what} update {k} vs the oracle")
             st, ost = hip.lastStats(), orc.last_stats()
             assert (st["live_seeds"], st["steps"], st["ncc_evals"]) == (ost["live_seeds"], ost["steps"], ost["ncc_evals"])
             max_steps_per_seed = max(max_steps_per_seed, st["steps"] / max(st["live_seeds"], 1))
-        if k == 8:
-            hip.setOption(api.OPT_COLLECT_STATS, 0)
-    assert max_steps_per_seed > 30.0, max_steps_per_seed
-    assert_states_equal(base.state(), hip.state(), "1280x960: pipeline vs per-pixel kernel after 30 updates")
+            if k == oracle_updates:
+                hip.setOption(api.OPT_COLLECT_STATS, 0)
+        elif k % compare_every == 0 or k == n_frames - 1:
+            assert_states_equal(base.state(), hip.state(), f"{what}: pipeline vs per-pixel kernel after {k} updates")
     assert hip.getConvergedCount() == base.getConvergedCount()
+    return seq, hip, max_steps_per_seed
 
 
-def test_config5_1080p_updates_and_tvl1_500():
-    """configs[4]: 1920x1080, side 9, denoise(0.5, 500): updates against the oracle, the blocked TV-L1 kernel against the
+def synth_float(gray):
+    from rpg_open_remode_amd import synth
+    return synth.to_float_image(gray)
+
+
+def test_config2_1280x960_500_frames():
+    """configs[2] as configured: 1280x960, 500 frames, side 9; the early searches are capped at
+    RMD_MAX_EXTENT_EPIPOLAR_SEARCH (143 steps): LDS window sizing."""
+    seq, hip, max_steps_per_seed = _long_run(1280, 960, 500, oracle_updates=6, compare_every=83, what="1280x960")
+    assert max_steps_per_seed > 30.0, max_steps_per_seed
+    assert hip.getConvergedCount() > 0.5 * 1280 * 960
+
+
+def test_config5_1080p_1000_frames_and_tvl1_500():
+    """configs[4] as configured: 1920x1080, 1000 frames, side 9, then denoise(0.5, 500): the blocked TV-L1 kernel against the
     one-iteration-per-launch kernel over all 500 iterations and against the oracle."""
-    seq = sequence(1920, 1080, 13)
-    hip, base, orc = _hip(seq, 9, 3), _hip(seq, 9, 0), _oracle(seq, 9)
-    for k in range(1, 13):
-        hip.update(seq.images[k], seq.T_curr_world[k])
-        base.update(seq.images[k], seq.T_curr_world[k])
-        if k <= 4:
-            orc.update(seq.images[k], seq.T_curr_world[k])
-            assert_states_equal(orc.state(), hip.state(), f"1080p update {k}")
-    assert_states_equal(base.state(), hip.state(), "1080p: pipeline vs per-pixel kernel after 12 updates")
+    seq, hip, _ = _long_run(1920, 1080, 1000, oracle_updates=4, compare_every=199, what="1080p")
     outs = []
     for ipl in (0, 1):
         den = api.DepthmapDenoiser(1920, 1080)
@@ -130,5 +164,13 @@ def test_config5_1080p_updates_and_tvl1_500():
         den.setLargeSigmaSq(seq.max_depth - seq.min_depth)
         outs.append(den.denoise(hip.getMu(), hip.getSigmaSq(), hip.getA(), hip.getB(), 0.5, 500))
     assert O.count_mismatch(outs[0], outs[1]) == 0
-    want = _denoise_oracle(seq, 9, hip.state(), 0.5, 500)
-    assert O.count_mismatch(want, outs[0]) == 0
+    olib = O.OracleLib("port", 9)
+    o = O.Seeds(olib, 1920, 1080, seq.K)
+    g0, T0 = seq.frame(0)
+    o.set_reference(synth_float(g0), T0, seq.min_depth, seq.max_depth)
+    st = hip.state()
+    for p in range(4):
+        o.upload(p, st[p])
+    d = O.Denoiser(olib, 1920, 1080)
+    d.set_large_sigma_sq(seq.max_depth - seq.min_depth)
+    assert O.count_mismatch(d.denoise(o, 0.5, 500), outs[0]) == 0

@@ -355,6 +355,30 @@ def test_denoiser_after_sequence_matches_oracle_and_reference_kernel():
 
 
 # ---------------------------------------------------------------------------------------------- reductions, images
+def test_reducer_raw_pointer_forms_and_int_sum():
+    """reduction.cuh:33-47: sum / countEqual on (device pointer, stride, width, height), and ImageReducer<int>::sum
+    (instantiated by the reference, reduction.cu:186): equal to the DeviceImage forms and to numpy, on a pitched image"""
+    rng = np.random.default_rng(5)
+    w, h = 333, 77  # pitched: stride != width
+    ints = rng.integers(-5, 6, (h, w)).astype(np.int32)
+    flts = rng.uniform(-1, 1, (h, w)).astype(np.float32)
+    ii, ff = api.DeviceImage(w, h, np.int32), api.DeviceImage(w, h, np.float32)
+    ii.setDevData(ints); ff.setDevData(flts)
+    assert ii.stride != w
+    red = api.ImageReducer()
+    assert red.sum(ii) == int(ints.sum()) == red.sumIntRaw(ii.data, ii.stride, w, h)
+    assert red.countEqual(ii.data, 3, ii.stride, w, h) == red.countEqual(ii, 3) == int((ints == 3).sum())
+    assert red.sum(ff.data, ff.stride, w, h) == red.sum(ff)
+    e = np.float32(flts.astype(np.float64).sum())
+    assert abs(red.sum(ff) - e) <= 4 * np.spacing(np.float32(np.abs(flts).astype(np.float64).sum()))
+    big = np.full((h, w), 2**30, np.int32)  # the int sum wraps like the reference's int accumulation
+    ii.setDevData(big)
+    assert red.sum(ii) == int(np.int32((int(big.astype(np.int64).sum()) + 2**31) % 2**32 - 2**31))
+    # a sub-rectangle through the raw form: rows 10.., columns 7..
+    ii.setDevData(ints)
+    assert red.countEqual(ii.data + 4 * (10 * ii.stride + 7), -2, ii.stride, 100, 40) == int((ints[10:50, 7:107] == -2).sum())
+
+
 def test_reductions_reference_kat():
     """test/reduction_test.cpp:24-122 at its own size (752x480)"""
     rng = np.random.default_rng(11)
