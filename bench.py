@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--tv-iters", type=int, default=0, help="TV-L1 iterations of the separately reported denoise (default 200; 500 at 1920x1080)")
     ap.add_argument("--dist", action="store_true", help="create the torch.distributed (RCCL) group even for a single rank")
     ap.add_argument("--no-extras", action="store_true", help="skip the H2D / statistics / CPU passes (profiling runs)")
+    ap.add_argument("--rendezvous-only", action="store_true", help="launch-path check, no measurement: join the process group (gloo when "
+                    "there is no GPU), run the barriers and the throughput gather with zero work, print {\"rendezvous\": ...} and exit")
     return ap.parse_args()
 
 
@@ -154,6 +156,19 @@ def main():
     from rpg_open_remode_amd import api, batch, synth
 
     rank, local_rank, world = batch.init("nccl", force=args.dist)
+    if args.rendezvous_only:
+        # the control plane of a --gpus N launch and nothing else (tests/test_bench_cpu.py runs it under torch.distributed.run
+        # with two ranks on the CPU): same barrier / gather / rank-0-prints sequence as the measurement below
+        batch.barrier()
+        max_e, total_u, per_rank = batch.gather_throughput(0.001 * (rank + 1), float(rank + 1), None, extra=(float(local_rank), 0.0))
+        batch.barrier()
+        if rank == 0:
+            print(json.dumps({"rendezvous": "ok", "n_gpus": world, "control_plane": batch.backend_name(), "max_elapsed_s": max_e,
+                              "total_units": total_u, "per_rank": [list(r) for r in per_rank]}), flush=True)
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
     n_dev = torch.cuda.device_count()

@@ -4,6 +4,7 @@
   rpg_open_remode_amd/librmd_synth.so   synthetic sequence generator (host only)
   oracle/libremode_oracle*_s{3,5,7,9}.so  CPU oracle B (test infrastructure)
   oracle/_ref/libremode_ref_s{3,5,7,9}.so CPU oracle A, only where /root/reference exists
+  oracle/_ref/{dataset_main,depthmap_check}_ref  the reference's host sources, unmodified, on include/rmd/ (test infrastructure)
 
 Run as `python -m rpg_open_remode_amd.build` or through __graft_entry__.build().
 """
@@ -79,21 +80,46 @@ def build_oracles(force=False, verbose=False):
         _run(["make", "-C", odir, "ref"], verbose=verbose)
 
 
-def build_apps(force=False, verbose=False):
-    """apps/dataset_main: the reference's test/dataset_main.cpp on the drop-in headers (needs librmd_hip.so)."""
-    out = os.path.join(ROOT, "apps", "dataset_main")
-    srcs = [os.path.join(ROOT, "apps", "dataset_main.cpp"), os.path.join(ROOT, "apps", "dataset.h")]
-    if force or _newer(out, srcs):
-        _run(["g++", "-std=c++11", "-O2", "-Wall", "-DRMD_CORR_PATCH_SIDE=5", "-I" + os.path.join(ROOT, "include"), srcs[0],
-              "-L" + HERE, "-lrmd_hip", "-lz", "-Wl,-rpath," + HERE, "-o", out], verbose=verbose)
-    return out
+REFERENCE = "/root/reference"
+
+
+def reference_host_program_cmds(out_dir):
+    """The reference's HOST sources for the path -- src/depthmap.cpp (rmd::Depthmap), test/dataset.cpp, test/dataset_main.cpp --
+    compiled UNMODIFIED, where they lie under /root/reference, against include/rmd/ (this repository's drop-in headers first,
+    the reference's include/ only for depthmap.h, which has no counterpart here) and the test-only Eigen / Boost / OpenCV stand-ins
+    of tests/cpp/stubs.  Test infrastructure: {program: command}."""
+    stubs = os.path.join(ROOT, "tests", "cpp", "stubs")
+    common = ["g++", "-std=c++11", "-O1", "-DRMD_CORR_PATCH_SIDE=5", "-DRMD_MAX_EXTENT_EPIPOLAR_SEARCH=100", "-I" + stubs,
+              "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(REFERENCE, "include")]
+    link = ["-L" + HERE, "-lrmd_hip", "-Wl,-rpath," + HERE, "-Wl,-rpath,$ORIGIN/../../rpg_open_remode_amd"]
+    ref = lambda *p: os.path.join(REFERENCE, *p)
+    return {
+        "dataset_main_ref": common + [ref("src", "depthmap.cpp"), ref("test", "dataset.cpp"), ref("test", "dataset_main.cpp")] + link +
+        ["-o", os.path.join(out_dir, "dataset_main_ref")],
+        "depthmap_check_ref": common + [ref("src", "depthmap.cpp"), os.path.join(ROOT, "tests", "cpp", "depthmap_check.cpp")] + link +
+        ["-o", os.path.join(out_dir, "depthmap_check_ref")],
+    }
+
+
+def build_reference_host_programs(force=False, verbose=False):
+    """oracle/_ref/{dataset_main_ref,depthmap_check_ref}; only where /root/reference exists (the GPU box uses the prebuilt files)."""
+    if not os.path.isdir(os.path.join(REFERENCE, "src")):
+        return
+    out_dir = os.path.join(ROOT, "oracle", "_ref")
+    os.makedirs(out_dir, exist_ok=True)
+    deps = [os.path.join(HERE, "librmd_hip.so"), os.path.join(ROOT, "tests", "cpp", "depthmap_check.cpp")]
+    for d in (os.path.join(ROOT, "include", "rmd"), os.path.join(ROOT, "tests", "cpp", "stubs", "opencv2")):
+        deps += [os.path.join(d, f) for f in os.listdir(d) if os.path.isfile(os.path.join(d, f))]
+    for name, cmd in reference_host_program_cmds(out_dir).items():
+        if force or _newer(os.path.join(out_dir, name), deps):
+            _run(cmd, verbose=verbose)
 
 
 def build_all(force=False, verbose=False):
     build_hip(force, verbose)
-    build_apps(force, verbose)
     build_synth(force, verbose)
     build_oracles(force, verbose)
+    build_reference_host_programs(force, verbose)
 
 
 if __name__ == "__main__":

@@ -444,6 +444,7 @@ int rmd_hip_image_create(int kind, int width, int height, rmd_hip_image_t** out)
 }
 int rmd_hip_image_destroy(rmd_hip_image_t* img) {
   if (!img) return RMD_HIP_OK;
+  ScopedDevice dev(img->device);
   if (img->owns && img->data) (void)hipFree(img->data);  // destructors must not throw (device_image.cuh:124-132 does)
   delete img;
   return RMD_HIP_OK;
@@ -451,6 +452,7 @@ int rmd_hip_image_destroy(rmd_hip_image_t* img) {
 int rmd_hip_image_upload(rmd_hip_image_t* img, const void* host) {
   if (!img || !host) return fail(RMD_HIP_ERR_INVALID_ARG, "image_upload: null argument");
   TRY(image_settle(img));
+  ScopedDevice dev(img->device);
   const size_t row = static_cast<size_t>(img->width) * kind_size(img->kind);
   HIP_TRY(hipMemcpy2D(img->data, img->pitch, host, row, row, img->height, hipMemcpyHostToDevice));
   return RMD_HIP_OK;
@@ -458,6 +460,7 @@ int rmd_hip_image_upload(rmd_hip_image_t* img, const void* host) {
 int rmd_hip_image_download(const rmd_hip_image_t* img, void* host) {
   if (!img || !host) return fail(RMD_HIP_ERR_INVALID_ARG, "image_download: null argument");
   TRY(image_settle(img));
+  ScopedDevice dev(img->device);
   const size_t row = static_cast<size_t>(img->width) * kind_size(img->kind);
   HIP_TRY(hipMemcpy2D(host, row, img->data, img->pitch, row, img->height, hipMemcpyDeviceToHost));
   return RMD_HIP_OK;
@@ -465,6 +468,7 @@ int rmd_hip_image_download(const rmd_hip_image_t* img, void* host) {
 int rmd_hip_image_zero(rmd_hip_image_t* img) {
   if (!img) return fail(RMD_HIP_ERR_INVALID_ARG, "image_zero: null image");
   TRY(image_settle(img));
+  ScopedDevice dev(img->device);  // the null stream that is waited on below is the image's device's
   HIP_TRY(hipMemset(img->data, 0, img->pitch * img->height));
   HIP_TRY(hipStreamSynchronize(nullptr));
   return RMD_HIP_OK;
@@ -476,6 +480,7 @@ int rmd_hip_image_copy(rmd_hip_image_t* dst, const rmd_hip_image_t* src) {
     return fail(RMD_HIP_ERR_INVALID_ARG, "image_copy: shape mismatch");
   TRY(image_settle(src));
   TRY(image_settle(dst));
+  ScopedDevice dev(dst->device);
   const size_t row = static_cast<size_t>(src->width) * kind_size(src->kind);
   HIP_TRY(hipMemcpy2D(dst->data, dst->pitch, src->data, src->pitch, row, src->height, hipMemcpyDeviceToDevice));
   return RMD_HIP_OK;
@@ -586,6 +591,8 @@ int rmd_hip_seeds_create(int width, int height, float fx, float fy, float cx, fl
   if (s->frame_ws.allocate(width, height, P.stride) != 0) return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: frame workspace"));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) s->num_cus = prop.multiProcessorCount;
+  int lds = 0;
+  if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, s->device) == hipSuccess && lds > 0) s->matcher_ws.lds_bytes = lds;
   if (hipDeviceSynchronize() != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: device synchronisation failed"));  // all fills done
   if (ingest_init(s) != RMD_HIP_OK) return bail(RMD_HIP_ERR_RUNTIME);  // the copy stream is created right next to the compute stream
   *out = s;

@@ -67,6 +67,7 @@ struct MatcherWorkspace {
   unsigned long long* d_shards = nullptr;  // plan-free pipeline: 3 sets (frame % 3) of UNIT_SHARDS counters {work items << 32 | units}
   long long frame = 0;                     // updates since the last reference (plan-free pipeline: which set is current)
   int shard_cap = 0;                       // unit-list entries per shard
+  int lds_bytes = 160 * 1024;              // LDS per CU of the handle's device (gfx950: 160 KB)
   unsigned long long* d_trace = nullptr;  // diagnostics, allocated on demand: TRACE_FRAMES slices of trace_slice_u64() words
   int max_units = 0;
   bool attr_set_small = false, attr_set_large = false;
@@ -865,8 +866,11 @@ inline hipError_t launch_seed_pipeline(const SeedParams& P, MatcherWorkspace& ws
   MatcherArgs M = matcher_args(ws);
   M.trace = P.trace;
   // Persistent grid: as many workgroups as fit the chip; those without a unit leave within a microsecond.
-  const int by_lds = static_cast<int>((160 * 1024) / sizeof(Smem));
-  const int wg_per_cu = by_lds < 4 ? (by_lds > 0 ? by_lds : 1) : 4;  // >4 x 256 threads gain nothing at this register count
+  // the LDS the device really has per CU (160 KB on gfx950; read at handle creation): a window that does not fit is an error the
+  // caller sees (the default matcher's 38 KB always fits), never a silent launch failure
+  if (sizeof(Smem) > static_cast<size_t>(ws.lds_bytes)) return hipErrorInvalidConfiguration;
+  const int by_lds = static_cast<int>(static_cast<size_t>(ws.lds_bytes) / sizeof(Smem));
+  const int wg_per_cu = by_lds < 4 ? by_lds : 4;  // >4 x 256 threads gain nothing at this register count
   const int resident = num_cus * wg_per_cu;
   const dim3 tiles(ws.tiles_x, ws.tiles_y);
   if (fuse_prev) hipLaunchKernelGGL((seed_setup_kernel<SIDE, WS, WROWS, true>), tiles, dim3(TILE_PIX), 0, stream, P, M, T_ref_curr_prev);

@@ -4,6 +4,8 @@ import json
 import os
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -59,3 +61,42 @@ def test_rooflines():
     assert f["flop_per_launch"] == 14 * 81 * 489000 and f["peak"] == 157.3
     assert abs(f["achieved"] - 14 * 81 * 489000 / 60e-6 / 1e12) < 0.01
     assert b.flops_roofline(60e-6, None, 9) is None
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("launcher", ["driver", "self"])
+def test_two_rank_launch_path_of_bench_py(launcher):
+    """The --gpus 2 launch exactly as the driver issues it (python -m torch.distributed.run ... bench.py --gpus 2 ...), and
+    bench.py's own re-launch from a plain `python bench.py --gpus 2`: rendezvous on 127.0.0.1, barrier, gather (MAX of elapsed,
+    SUM of units), rank 0 alone prints one JSON line, the group is torn down.  No GPU here: the control plane falls to gloo."""
+    import json
+    import subprocess
+    import sys
+    port = str(_free_port())
+    bench_py = os.path.join(ROOT, "bench.py")
+    tail = ["--gpus", "2", "--steps", "1", "--warmup", "0", "--rendezvous-only"]
+    if launcher == "driver":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", port, bench_py] + tail
+        env = dict(os.environ)
+    else:
+        cmd = [sys.executable, bench_py] + tail
+        env = dict(os.environ, MASTER_PORT=port)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["rendezvous"] == "ok" and out["n_gpus"] == 2 and out["control_plane"] == "gloo"
+    assert out["max_elapsed_s"] == pytest.approx(0.002) and out["total_units"] == 3.0
+    assert [r[2] for r in out["per_rank"]] == [0.0, 1.0]  # LOCAL_RANK of each rank, in rank order

@@ -151,47 +151,6 @@ def test_config0_first_30_frames_on_the_cpu_oracle(tmp_path):
     assert np.median(err) < 3e-3 and np.mean(err < 0.03) > 0.95
 
 
-def test_cpp_dataset_reader_equals_the_python_reader(tmp_path):
-    """apps/dataset.h (the C++ reader behind apps/dataset_main.cpp) against dataset.py on the same directory, with PGM,
-    gray PNG (all five filter types) and colour PNG frames."""
-    import subprocess
-    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "dataset_io_check")
-    res = subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-Werror", "-I" + os.path.join(root_dir, "include"),
-                          os.path.join(root_dir, "tests", "cpp", "dataset_io_check.cpp"), "-lz", "-o", exe],
-                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    assert res.returncode == 0, res.stdout
-    root = str(tmp_path / "seq")
-    D.export_synthetic(root, 64, 48, 4, seed=2, image_ext="pgm", depth_every=2)
-    rng = np.random.default_rng(7)
-    gray = rng.integers(0, 256, (48, 64, 1), dtype=np.uint8)
-    rgb = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
-    open(os.path.join(root, "images", "extra_0.png"), "wb").write(_png_bytes(gray, 0, [0, 1, 2, 3, 4]))
-    open(os.path.join(root, "images", "extra_1.png"), "wb").write(_png_bytes(rgb, 2, [4, 3, 2, 1]))
-    with open(os.path.join(root, D.DEFAULT_SEQUENCE_FILE), "a") as f:
-        f.write("extra_0.png 0.5 -1.25 2 0.1 0.2 0.3 0.927361850\nextra_1.png 1 2 3 0 0 0 1\nmissing.png 0 0 0 0 0 0 1\n")
-    res = subprocess.run([exe, root, D.DEFAULT_SEQUENCE_FILE, "64", "48"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    assert res.returncode == 0, res.stdout
-    lines = res.stdout.strip().splitlines()
-    ds = D.Dataset(root)
-    assert ds.readDataSequence() and lines[0] == f"entries {len(ds)}" and len(ds) == 7
-    for e, line in zip(ds, lines[1:]):
-        tok = line.split()
-        img = ds.readImage(e)
-        assert tok[0] == e.image_file_name and tok[1] == e.depthmap_file_name
-        assert int(tok[3]) == (img is not None)
-        if img is not None:
-            flat = img.reshape(-1).astype(np.uint64)
-            assert tok[4] == f"{img.shape[1]}x{img.shape[0]}" and int(tok[5]) == int(flat.sum())
-            assert int(tok[6]) == int((flat * (np.arange(flat.size, dtype=np.uint64) % 251 + 1)).sum())
-        dm = ds.readDepthmap(e, 64, 48)
-        assert int(tok[8]) == (dm is not None)
-        if dm is not None:
-            assert abs(float(tok[9]) - float(dm.astype(np.float64).sum())) < 1e-4  # printed with 9 significant digits
-        pose = np.array([float(v) for v in tok[11:23]], np.float32)
-        assert np.array_equal(pose, np.asarray(ds.readCameraPose(e).data, np.float32))  # the same fp32 quaternion constructor
-
-
 def test_scale_mat_is_the_reference_s():
     from rpg_open_remode_amd.dataset_main import parse, scale_mat
     d = np.array([[1.0, 1.5], [2.0, 1.25]], np.float32)
@@ -229,40 +188,3 @@ def test_dataset_main_end_to_end_equals_the_direct_api(tmp_path, capsys):
     assert O.count_mismatch(dm.getDepthmap(), den) == 0
     dm.downloadConvergenceMap()
     assert np.array_equal(dm.getConvergenceMap(), conv)
-
-
-@pytest.mark.gpu
-def test_cpp_dataset_main_equals_the_python_api(tmp_path):
-    """apps/dataset_main.cpp (the reference's experiment on the drop-in C++ headers) on an exported 640x480 sequence."""
-    import subprocess
-    from rpg_open_remode_amd import api
-    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    pkg = os.path.join(root_dir, "rpg_open_remode_amd")
-    exe = str(tmp_path / "dataset_main")
-    res = subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-Werror", "-DRMD_CORR_PATCH_SIDE=5", "-I" + os.path.join(root_dir, "include"),
-                          os.path.join(root_dir, "apps", "dataset_main.cpp"), "-L" + pkg, "-lrmd_hip", "-lz", "-Wl,-rpath," + pkg, "-o", exe],
-                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    assert res.returncode == 0, res.stdout
-    root = str(tmp_path / "over_table")
-    D.export_synthetic(root, 640, 480, 14)
-    env = dict(os.environ, RMD_TEST_DATA_PATH=root)
-    prefix = str(tmp_path / "out_")
-    res = subprocess.run([exe, "--end=14", "--out=" + prefix], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
-    assert res.returncode == 0, res.stdout[-2000:]
-    assert res.stdout.count("UPDATE execution time") == 13 and "MEAN update time" in res.stdout and "RUN EXPERIMENT: inputting image scene_000.png" in res.stdout
-    depth = np.fromfile(prefix + "depth.f32", np.float32).reshape(480, 640)
-    den = np.fromfile(prefix + "denoised.f32", np.float32).reshape(480, 640)
-    ds = D.Dataset(root)
-    assert ds.readDataSequence(0, 14)
-    dm = api.Depthmap(640, 480, 481.2, 319.5, -480.0, 239.5)
-    for k, e in enumerate(ds):
-        T = ds.readCameraPose(e).inv()
-        if k == 0:
-            gt = ds.readDepthmap(e, 640, 480)
-            dm.setReferenceImage(ds.readImage(e), T, float(gt.min()), float(gt.max()))
-        else:
-            dm.update(ds.readImage(e), T)
-    dm.downloadDepthmap()
-    assert O.count_mismatch(dm.getDepthmap(), depth) == 0
-    dm.downloadDenoisedDepthmap(0.5, 200)
-    assert O.count_mismatch(dm.getDepthmap(), den) == 0
