@@ -15,4 +15,22 @@ struct dim3 {
 };
 #endif
 
+// The float3 arithmetic the reference's HOST sources use (src/publisher.cpp:73-74 through cuda_toolkit/helper_math.h:
+// operator* :814-821, dot :1248-1251, length :1291-1294, normalize :1309-1313 with the off-device rsqrtf of :62-65,
+// i.e. v * (1.0f / sqrtf(dot(v, v)))).  One fp32 rounding per operation, in that order.
+#if !defined(__HIP_PLATFORM_AMD__) && !defined(RMD_HOST_FLOAT3_MATH)
+#define RMD_HOST_FLOAT3_MATH
+#include <cmath>
+inline float3 operator+(float3 a, float3 b) { return make_float3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline float3 operator-(float3 a, float3 b) { return make_float3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline float3 operator*(float3 a, float s) { return make_float3(a.x * s, a.y * s, a.z * s); }
+inline float3 operator*(float s, float3 a) { return make_float3(s * a.x, s * a.y, s * a.z); }
+inline float dot(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline float length(float3 v) { return sqrtf(dot(v, v)); }
+inline float3 normalize(float3 v) {
+  const float inv_len = 1.0f / sqrtf(dot(v, v));
+  return v * inv_len;
+}
+#endif
+
 #endif  // RMD_HOST_TYPES_H

@@ -4,7 +4,7 @@
   rpg_open_remode_amd/librmd_synth.so   synthetic sequence generator (host only)
   oracle/libremode_oracle*_s{3,5,7,9}.so  CPU oracle B (test infrastructure)
   oracle/_ref/libremode_ref_s{3,5,7,9}.so CPU oracle A, only where /root/reference exists
-  oracle/_ref/{dataset_main,depthmap_check}_ref  the reference's host sources, unmodified, on include/rmd/ (test infrastructure)
+  oracle/_ref/{dataset_main,depthmap_check,remode_node}_ref  the reference's host sources, unmodified, on include/rmd/ (test infrastructure)
 
 Run as `python -m rpg_open_remode_amd.build` or through __graft_entry__.build().
 """
@@ -84,8 +84,8 @@ REFERENCE = "/root/reference"
 
 
 def reference_host_program_cmds(out_dir):
-    """The reference's HOST sources for the path -- src/depthmap.cpp (rmd::Depthmap), test/dataset.cpp, test/dataset_main.cpp --
-    compiled UNMODIFIED, where they lie under /root/reference, against include/rmd/ (this repository's drop-in headers first,
+    """The reference's HOST sources around the path -- src/depthmap.cpp (rmd::Depthmap), test/dataset.cpp, test/dataset_main.cpp,
+    src/depthmap_node.cpp, src/publisher.cpp, src/main_ros.cpp -- compiled UNMODIFIED, where they lie under /root/reference, against include/rmd/ (this repository's drop-in headers first,
     the reference's include/ only for depthmap.h, which has no counterpart here) and the test-only Eigen / Boost / OpenCV stand-ins
     of tests/cpp/stubs.  Test infrastructure: {program: command}."""
     stubs = os.path.join(ROOT, "tests", "cpp", "stubs")
@@ -98,18 +98,23 @@ def reference_host_program_cmds(out_dir):
         ["-o", os.path.join(out_dir, "dataset_main_ref")],
         "depthmap_check_ref": common + [ref("src", "depthmap.cpp"), os.path.join(ROOT, "tests", "cpp", "depthmap_check.cpp")] + link +
         ["-o", os.path.join(out_dir, "depthmap_check_ref")],
+        # the live system: main_ros.cpp + DepthmapNode + Publisher + Depthmap on stand-ins for roscpp / image_transport / pcl / cv_bridge /
+        # svo_msgs / vikit whose "topics" and "bag" are files (tests/cpp/stubs/ros/ros.h)
+        "remode_node_ref": common + ["-pthread", ref("src", "depthmap.cpp"), ref("src", "publisher.cpp"), ref("src", "depthmap_node.cpp"),
+                                     ref("src", "main_ros.cpp")] + link + ["-o", os.path.join(out_dir, "remode_node_ref")],
     }
 
 
 def build_reference_host_programs(force=False, verbose=False):
-    """oracle/_ref/{dataset_main_ref,depthmap_check_ref}; only where /root/reference exists (the GPU box uses the prebuilt files)."""
+    """oracle/_ref/{dataset_main_ref,depthmap_check_ref,remode_node_ref}; only where /root/reference exists (the GPU box uses the prebuilt files)."""
     if not os.path.isdir(os.path.join(REFERENCE, "src")):
         return
     out_dir = os.path.join(ROOT, "oracle", "_ref")
     os.makedirs(out_dir, exist_ok=True)
     deps = [os.path.join(HERE, "librmd_hip.so"), os.path.join(ROOT, "tests", "cpp", "depthmap_check.cpp")]
-    for d in (os.path.join(ROOT, "include", "rmd"), os.path.join(ROOT, "tests", "cpp", "stubs", "opencv2")):
-        deps += [os.path.join(d, f) for f in os.listdir(d) if os.path.isfile(os.path.join(d, f))]
+    deps += [os.path.join(ROOT, "include", "rmd", f) for f in os.listdir(os.path.join(ROOT, "include", "rmd"))]
+    for d, _, files in os.walk(os.path.join(ROOT, "tests", "cpp", "stubs")):
+        deps += [os.path.join(d, f) for f in files]
     for name, cmd in reference_host_program_cmds(out_dir).items():
         if force or _newer(os.path.join(out_dir, name), deps):
             _run(cmd, verbose=verbose)

@@ -956,6 +956,8 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(SeedParams
   const int x = blockIdx.x * TILE_W + tx, y = blockIdx.y * TILE_H + ty;
   const bool in_image = x < P.w && y < P.h;
   const int gi = in_image ? y * P.stride + x : 0;
+  const unsigned long long t_start = P.trace ? wall_clock64() : 0ull;  // timeline probes (diagnostics)
+  unsigned long long t_loaded = 0ull;
   float mu = P.mu[gi], sigma_sq = P.sigma_sq[gi], a = P.a[gi], b = P.b[gi];
   if (FUSE_PREV) {
     const int conv_prev = P.conv[gi];
@@ -987,6 +989,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(SeedParams
     state = seed_check(P, x, y, sigma_sq, a, b, SIDE);
     P.conv[gi] = state;  // final for BORDER / CONVERGED / DIVERGED; UPDATE seeds are settled by the finalisation
   }
+  if (P.trace) t_loaded = wall_clock64();
   int n_valid = 0, i_first = 0;
   unsigned int n_steps = 0, n_evals = 0;
   const bool live = in_image && state == ST_UPDATE;
@@ -1033,6 +1036,9 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(SeedParams
   const int unit_items = unit_rounds * TILE_PIX;
   if (tile == 0 && tid < UNIT_SHARDS) M.shards_next[tid] = 0ull;  // the set the NEXT frame counts in (nobody reads it now)
   if (tile == 0 && tid == 0) { M.queue[1] = 0u; M.queue[5] = static_cast<unsigned int>(unit_items); }
+  if (P.trace && tid == 0)  // word 2 of the tile's slot: start (low 32 bits of the 10 ns clock), state ready and end relative to it
+    P.trace[static_cast<size_t>(tile) * FR_TRACE_WORDS + 2] = (t_start & 0xffffffffull) | (((t_loaded - t_start) & 0xffffull) << 32) |
+                                                             (((wall_clock64() - t_start) & 0xffffull) << 48);
   if (total == 0) return;
   const int n_u = units_of(total, unit_rounds);
   if (tid == 0) {

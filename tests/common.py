@@ -4,7 +4,7 @@ import functools
 import numpy as np
 
 import oracles as O
-from rpg_open_remode_amd import synth
+from rpg_open_remode_amd import api, synth
 
 PLANE_NAMES = ["mu", "sigma_sq", "a", "b", "convergence", "sum_templ", "const_templ_denom", "epipolar_matches"]
 
@@ -81,3 +81,33 @@ def apply_matcher(seeds, matcher):
     else:
         seeds.setOption(api.OPT_MATCHER, matcher)
     return seeds
+
+
+class OracleDepthmap:
+    """rmd::Depthmap's interface (depthmap.h:37-102) on Oracle B.  Test infrastructure."""
+
+    def __init__(self, seq, side):
+        self.seq, self.olib = seq, O.OracleLib("port", side)
+        self.seeds = O.Seeds(self.olib, seq.width, seq.height, seq.K)
+        self.den = O.Denoiser(self.olib, seq.width, seq.height)
+        self.depth, self.conv, self.ref, self.T_world_ref = None, None, None, api.SE3()
+
+    def setReferenceImage(self, img, T_curr_world, min_depth, max_depth):
+        self.den.set_large_sigma_sq(max_depth - min_depth)
+        self.seeds.set_reference(img.astype(np.float32) * np.float32(1.0 / 255.0), T_curr_world.data, min_depth, max_depth)
+        self.ref, self.T_world_ref = img.copy(), T_curr_world.inv()
+        return True
+
+    def update(self, img, T_curr_world):
+        self.seeds.update(img.astype(np.float32) * np.float32(1.0 / 255.0), T_curr_world.data)
+
+    def getConvergedPercentage(self):
+        return float(np.float32(self.seeds.converged_count()) / np.float32(self.seq.width * self.seq.height) * np.float32(100.0))
+
+    def getDistFromRef(self): return self.seeds.dist_from_ref()
+    def downloadDenoisedDepthmap(self, lam, iters): self.depth = self.den.denoise(self.seeds, lam, iters)
+    def getDepthmap(self): return self.depth
+    def downloadConvergenceMap(self): self.conv = self.seeds.download(4)
+    def getConvergenceMap(self): return self.conv
+    def getReferenceImage(self): return self.ref
+    def downloadPointCloud(self, denoised=True): return O.point_cloud(self.depth, self.conv, self.ref, self.seq.K, self.T_world_ref.data)

@@ -34,6 +34,12 @@
 
 namespace cv {
 
+struct Vec3b {
+  unsigned char val[3];
+  unsigned char& operator[](int i) { return val[i]; }
+  const unsigned char& operator[](int i) const { return val[i]; }
+};
+
 struct Size {
   int width, height;
   Size(int w = 0, int h = 0) : width(w), height(h) {}

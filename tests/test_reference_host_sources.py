@@ -150,3 +150,92 @@ def test_reference_depthmap_class_unmodified_equals_the_oracle(tmp_path, distort
     assert pct == np.float32(np.float32(count) / np.float32(px) * np.float32(100.0))
     assert dist == np.float32(orc.dist_from_ref())
     assert np.array_equal(coloured, scale_and_colour(depth))
+
+
+def _write_bag(path, seq, quats):
+    with open(path, "wb") as f:
+        f.write(struct.pack("3i", seq.n_frames, seq.width, seq.height))
+        for k in range(seq.n_frames):
+            f.write(np.asarray(quats[k], np.float64).tobytes())  # position xyz, orientation wxyz
+            f.write(np.asarray([seq.min_depth, seq.max_depth], np.float32).tobytes())
+            f.write(np.ascontiguousarray(seq.gray[k], np.uint8).tobytes())
+
+
+@pytest.mark.gpu
+def test_reference_ros_node_unmodified_equals_the_oracle_driven_state_machine(tmp_path):
+    """src/main_ros.cpp + depthmap_node.cpp + publisher.cpp + depthmap.cpp, unmodified, on file-backed stand-ins for ROS: fed 70
+    DenseInput messages, everything the node publishes (remode/depth, remode/pointcloud, remode/convergence) and WHEN it publishes it
+    must equal the Python restatement of the node (rpg_open_remode_amd/depthmap_node.py) driving the CPU oracle, whose point cloud is
+    oracle/host_steps.py::point_cloud -- this pins both restatements (SURVEY 8 f-3, f-4) to the reference's own code -- and the
+    library's own node (device point cloud kernel) on the same messages."""
+    from common import OracleDepthmap
+    from rpg_open_remode_amd import api
+    from rpg_open_remode_amd.depthmap_node import DepthmapNode
+    exe = _program("remode_node_ref")
+    seq = sequence(160, 120, 70)
+    w, h, n = seq.width, seq.height, seq.n_frames
+    poses7 = []  # the message carries position + quaternion (float64); the node builds SE3<float>(qw, qx, qy, qz, tx, ty, tz) from them
+    for k in range(n):
+        T_world_curr = api.SE3(seq.T_curr_world[k]).inv().data.reshape(3, 4).astype(np.float64)
+        q = D.quaternion_from_rotation(T_world_curr[:, :3])  # x, y, z, w
+        poses7.append([T_world_curr[0, 3], T_world_curr[1, 3], T_world_curr[2, 3], q[3], q[0], q[1], q[2]])
+    bag, params, topics = str(tmp_path / "bag.bin"), str(tmp_path / "params.txt"), str(tmp_path / "topics")
+    os.makedirs(topics)
+    _write_bag(bag, seq, poses7)
+    with open(params, "w") as f:
+        for name, v in (("cam_width", w), ("cam_height", h), ("cam_fx", seq.K[0]), ("cam_fy", seq.K[1]), ("cam_cx", seq.K[2]), ("cam_cy", seq.K[3]),
+                        ("ref_compl_perc", 10.0), ("max_dist_from_ref", 0.5), ("publish_conv_every_n", 10)):
+            f.write(f"remode/{name} {v}\n" if isinstance(v, int) else f"remode/{name} {float(np.float32(v))!r}\n")
+    env = dict(os.environ, RMD_STUB_BAG=bag, RMD_STUB_PARAMS=params, RMD_STUB_TOPIC_DIR=topics)
+    res = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:]
+    assert res.stdout.count("DEPTHMAP NODE: received image 160x120") == n and "ROS_ERROR" not in res.stdout
+    got_events = [tuple(l.split()) for l in open(os.path.join(topics, "events.txt")).read().splitlines()]
+
+    def run_python_node(depthmap):
+        events, payload = [], {}
+        box = {"k": 0}
+        def on(topic):
+            def cb(x):
+                i = sum(1 for e in events if e[1] == topic)
+                events.append((str(box["k"]), topic, str(i)))
+                payload[(topic, i)] = np.array(x, copy=True)
+            return cb
+        node = DepthmapNode(w, h, *seq.K, ref_compl_perc=10.0, max_dist_from_ref=0.5, publish_conv_every_n=10, patch_side=5, denoise_lambda=0.5,
+                            denoise_iterations=200, depthmap=depthmap, on_depthmap=on("remode_depth"), on_pointcloud=on("remode_pointcloud"),
+                            on_convergence=on("remode_convergence"))
+        for k in range(n):
+            box["k"] = k + 1  # messages delivered when the callback runs
+            p = poses7[k]
+            node.denseInput(seq.gray[k], (p[3], p[4], p[5], p[6], p[0], p[1], p[2]), np.float32(seq.min_depth), np.float32(seq.max_depth))
+        return events, payload, node
+
+    want_events, want, onode = run_python_node(OracleDepthmap(seq, 5))
+    assert got_events == want_events, (got_events, want_events)
+    assert onode.references_taken >= 3 and sum(1 for e in want_events if e[1] == "remode_pointcloud") >= 2
+
+    def read_topic(topic, i):
+        raw = open(os.path.join(topics, f"{topic}.{i}.bin"), "rb").read()
+        if topic == "remode_pointcloud":
+            (cnt,) = struct.unpack_from("i", raw)
+            return np.frombuffer(raw, np.float32, cnt * 4, 4).reshape(cnt, 4)
+        rows, cols, eb = struct.unpack_from("3i", raw)
+        if topic == "remode_depth":
+            assert eb == 4
+            return np.frombuffer(raw, np.float32, rows * cols, 12).reshape(rows, cols)
+        assert eb == 3
+        return np.frombuffer(raw, np.uint8, rows * cols * 3, 12).reshape(rows, cols, 3)
+
+    for (_, topic, i) in want_events:
+        got, exp = read_topic(topic, int(i)), want[(topic, int(i))]
+        assert got.shape == exp.shape, (topic, i)
+        assert O.count_mismatch(exp, got) == 0 if got.dtype == np.float32 else np.array_equal(exp, got), (topic, i)
+    clouds = [want[k] for k in sorted(want) if k[0] == "remode_pointcloud"]
+    assert len(clouds[-1]) > len(clouds[0]) > 100  # the reference's cloud accumulates over publications (publisher.cpp:83)
+
+    # the library's own node (api.Depthmap, device point-cloud kernel) on the same messages
+    hip_events, hip, _ = run_python_node(None)
+    assert hip_events == got_events
+    for (_, topic, i) in got_events:
+        got, mine = read_topic(topic, int(i)), hip[(topic, int(i))]
+        assert O.count_mismatch(got, mine) == 0 if got.dtype == np.float32 else np.array_equal(got, mine), (topic, i)

@@ -30,11 +30,21 @@ show = set(int(v) for v in a.show.split(","))
 print("search kernel only; us relative to its first workgroup start; busy = workgroups that searched at least one unit")
 print(f"{'frame':>5} | {'busy':>5} | 1st unit ready p50 {'p99':>6} | end p50 {'p90':>6} {'p99':>6} {'max':>7} | {'items':>8} {'units':>6} {'units/wg max':>12} {'windows':>7}")
 for k in range(a.frames - 1):
-    t = s.frameTraceDownload(k).astype(np.int64)
-    t = t[t[:, 0] != 0]
+    t_all = s.frameTraceDownload(k).astype(np.int64)
+    t = t_all[t_all[:, 0] != 0]
     if k + 1 not in show or len(t) == 0:
         continue
     t0 = t[:, 0].min()
+    w2 = t_all[:, 2]
+    w2 = w2[w2 != 0]
+    if len(w2):  # setup kernel probes: start (low 32 bits), state ready, end (deltas)
+        st = w2 & 0xffffffff
+        st = st - st.min()
+        rd, en = (w2 >> 32) & 0xffff, (w2 >> 48) & 0xffff
+        gap = (t0 & 0xffffffff) - ((w2 & 0xffffffff).min())
+        print(f"      setup kernel: workgroup start p50 {us(np.percentile(st, 50)):.1f} p99 {us(np.percentile(st, 99)):.1f} max {us(st.max()):.1f}; state ready after "
+              f"p50 {us(np.percentile(rd, 50)):.1f} p99 {us(np.percentile(rd, 99)):.1f}; workgroup lifetime p50 {us(np.percentile(en, 50)):.1f} p99 {us(np.percentile(en, 99)):.1f}; "
+              f"last end {us((st + en).max()):.1f}; first search workgroup starts {us(gap):.1f} after the first setup workgroup")
     b = t[t[:, 5] > 0]
     rd, ex = b[:, 1] - t0, b[:, 3] - t0
     print(f"{k + 1:5d} | {len(b):5d} | {us(np.percentile(rd, 50)):17.1f} {us(np.percentile(rd, 99)):6.1f} | {us(np.percentile(ex, 50)):7.1f} {us(np.percentile(ex, 90)):6.1f} "
