@@ -4,7 +4,7 @@
   rpg_open_remode_amd/librmd_synth.so   synthetic sequence generator (host only)
   oracle/libremode_oracle*_s{3,5,7,9}.so  CPU oracle B (test infrastructure)
   oracle/_ref/libremode_ref_s{3,5,7,9}.so CPU oracle A, only where /root/reference exists
-  oracle/_ref/{dataset_main,depthmap_check,remode_node}_ref  the reference's host sources, unmodified, on include/rmd/ (test infrastructure)
+  oracle/_ref/{dataset_main,depthmap_check,remode_node,rmd_gtests}_ref  the reference's host sources, unmodified, on include/rmd/ (test infrastructure)
 
 Run as `python -m rpg_open_remode_amd.build` or through __graft_entry__.build().
 """
@@ -98,6 +98,12 @@ def reference_host_program_cmds(out_dir):
         ["-o", os.path.join(out_dir, "dataset_main_ref")],
         "depthmap_check_ref": common + [ref("src", "depthmap.cpp"), os.path.join(ROOT, "tests", "cpp", "depthmap_check.cpp")] + link +
         ["-o", os.path.join(out_dir, "depthmap_check_ref")],
+        # the reference's own googletest suite for the path (seedMatrixInit, seedMatrixCheck, epipolarTest, epipolarMatchTest,
+        # deviceImageReduction.sum / .countEqual) with its main; device_image_test.cpp needs the test-only CUDA kernels copy.cu / sobel.cu
+        # (outside the path) and is left out
+        "rmd_gtests_ref": common + ["-pthread", "-DRMD_BUILD_TESTS=1", ref("src", "depthmap.cpp"), ref("test", "dataset.cpp"), ref("test", "seed_matrix_test.cpp"),
+                                    ref("test", "epipolar_test.cpp"), ref("test", "reduction_test.cpp"), ref("test", "main_test.cpp")] + link +
+        ["-o", os.path.join(out_dir, "rmd_gtests_ref")],
         # the live system: main_ros.cpp + DepthmapNode + Publisher + Depthmap on stand-ins for roscpp / image_transport / pcl / cv_bridge /
         # svo_msgs / vikit whose "topics" and "bag" are files (tests/cpp/stubs/ros/ros.h)
         "remode_node_ref": common + ["-pthread", ref("src", "depthmap.cpp"), ref("src", "publisher.cpp"), ref("src", "depthmap_node.cpp"),
@@ -106,7 +112,7 @@ def reference_host_program_cmds(out_dir):
 
 
 def build_reference_host_programs(force=False, verbose=False):
-    """oracle/_ref/{dataset_main_ref,depthmap_check_ref,remode_node_ref}; only where /root/reference exists (the GPU box uses the prebuilt files)."""
+    """oracle/_ref/{dataset_main,depthmap_check,remode_node,rmd_gtests}_ref; only where /root/reference exists (the GPU box uses the prebuilt files)."""
     if not os.path.isdir(os.path.join(REFERENCE, "src")):
         return
     out_dir = os.path.join(ROOT, "oracle", "_ref")

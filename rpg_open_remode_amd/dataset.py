@@ -296,10 +296,11 @@ def quaternion_from_rotation(R):
 
 
 def export_synthetic(root, width=640, height=480, n_frames=200, seed=0, image_ext="png", sequence_file=DEFAULT_SEQUENCE_FILE,
-                     depth_every=0):
+                     depth_every=0, only_frames=None):
     """Writes the synthetic over-table sequence (synth.py) in the reference's dataset layout, so that everything written
-    against that layout -- the reference's dataset_main included -- runs without the original download.
-    Frame 0 always gets its ground-truth .depth file (3 MB of ASCII at 640x480), every `depth_every`-th frame too if > 0."""
+    against that layout -- the reference's dataset_main and gtest sources included -- runs without the original download.
+    Frame 0 always gets its ground-truth .depth file (3 MB of ASCII at 640x480), every `depth_every`-th frame too if > 0.
+    `only_frames`: render just these frames (image + .depth each); the sequence file still lists all n_frames."""
     from . import synth
     os.makedirs(os.path.join(root, "images"), exist_ok=True)
     os.makedirs(os.path.join(root, "depthmaps"), exist_ok=True)
@@ -307,12 +308,13 @@ def export_synthetic(root, width=640, height=480, n_frames=200, seed=0, image_ex
     lines = []
     for k in range(n_frames):
         T = synth.pose(k, seed)
-        want_depth = k == 0 or (depth_every > 0 and k % depth_every == 0)
-        gray, rng = synth.render(width, height, T, seed, want_range=want_depth, K=K)
         name = f"scene_{k:03d}.{image_ext}"
-        write_gray_image(os.path.join(root, "images", name), gray)
-        if want_depth:
-            write_depth_file(os.path.join(root, "depthmaps", f"scene_{k:03d}.depth"), rng)
+        if only_frames is None or k in only_frames:
+            want_depth = only_frames is not None or k == 0 or (depth_every > 0 and k % depth_every == 0)
+            gray, rng = synth.render(width, height, T, seed, want_range=want_depth, K=K)
+            write_gray_image(os.path.join(root, "images", name), gray)
+            if want_depth:
+                write_depth_file(os.path.join(root, "depthmaps", f"scene_{k:03d}.depth"), rng)
         q = quaternion_from_rotation(T[:, :3])
         lines.append(f"{name} {T[0, 3]:.9g} {T[1, 3]:.9g} {T[2, 3]:.9g} {q[0]:.9g} {q[1]:.9g} {q[2]:.9g} {q[3]:.9g}")
     with open(os.path.join(root, sequence_file), "w") as f:

@@ -5,6 +5,7 @@
 #ifndef RMD_TEST_STUB_OPENCV
 #define RMD_TEST_STUB_OPENCV
 #include <chrono>
+#include <cstdint>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -38,6 +39,31 @@ struct Vec3b {
   unsigned char val[3];
   unsigned char& operator[](int i) { return val[i]; }
   const unsigned char& operator[](int i) const { return val[i]; }
+};
+
+struct Scalar {
+  double val[4];
+  Scalar(double v0 = 0, double v1 = 0, double v2 = 0, double v3 = 0) : val{v0, v1, v2, v3} {}
+};
+struct Point {
+  int x, y;
+  Point(int x_ = 0, int y_ = 0) : x(x_), y(y_) {}
+};
+enum { EVENT_LBUTTONDOWN = 1 };
+typedef void (*MouseCallback)(int event, int x, int y, int flags, void* userdata);
+inline void setMouseCallback(const std::string&, MouseCallback, void* = NULL) {}
+
+// cv::RNG: OpenCV's multiply-with-carry generator (state 2^32 - 1 by default, multiplier 4164903690)
+class RNG {
+ public:
+  uint64_t state;
+  RNG() : state(0xffffffffu) {}
+  unsigned next() {
+    state = static_cast<uint64_t>(static_cast<unsigned>(state)) * 4164903690u + static_cast<unsigned>(state >> 32);
+    return static_cast<unsigned>(state);
+  }
+  int uniform(int a, int b) { return a == b ? a : static_cast<int>(next() % static_cast<unsigned>(b - a) + a); }
+  float uniform(float a, float b) { return static_cast<float>(next()) * 2.3283064365386963e-10f * (b - a) + a; }
 };
 
 struct Size {
@@ -133,6 +159,9 @@ class Mat_ : public Mat {
  public:
   Mat_() : Mat() { type_ = StubType<T>::value; }
   Mat_(int r, int c) : Mat(r, c, StubType<T>::value) {}
+  Mat_(int r, int c, T value) : Mat(r, c, StubType<T>::value) {
+    for (size_t i = 0; i < static_cast<size_t>(r) * c; ++i) reinterpret_cast<T*>(data)[i] = value;
+  }
   Mat_(const Mat& m) : Mat(m) {}
   static Mat_ eye(int r, int c) {
     Mat_ m(r, c);
@@ -152,6 +181,30 @@ class Mat_ : public Mat {
   };
   Comma operator<<(T first) { return Comma(*this, first); }
 };
+
+// m == value on a single-channel int / float image: 8-bit mask, 255 where equal
+inline Mat operator==(const Mat& m, double value) {
+  Mat mask(m.rows, m.cols, CV_8UC1);
+  const size_t n = static_cast<size_t>(m.rows) * m.cols;
+  for (size_t i = 0; i < n; ++i) {
+    const double v = (m.type() & 7) == CV_32S ? reinterpret_cast<const int*>(m.data)[i] : (m.type() & 7) == CV_32F ? reinterpret_cast<const float*>(m.data)[i] : m.data[i];
+    mask.data[i] = v == value ? 255 : 0;
+  }
+  return mask;
+}
+inline int countNonZero(const Mat& m) {
+  int n = 0;
+  for (size_t i = 0; i < static_cast<size_t>(m.rows) * m.cols; ++i) n += m.data[i] != 0;
+  return n;
+}
+// cv::sum of a single-channel float image: accumulated in double, like OpenCV
+inline Scalar sum(const Mat& m) {
+  double s = 0.0;
+  for (size_t i = 0; i < static_cast<size_t>(m.rows) * m.cols; ++i) s += reinterpret_cast<const float*>(m.data)[i];
+  return Scalar(s);
+}
+inline void circle(Mat&, Point, int, const Scalar&, int = 1) {}
+inline void line(Mat&, Point, Point, const Scalar&, int = 1) {}
 
 inline void minMaxLoc(const Mat& m, double* min_val, double* max_val) {
   const size_t n = static_cast<size_t>(m.rows) * m.cols;

@@ -239,3 +239,21 @@ def test_reference_ros_node_unmodified_equals_the_oracle_driven_state_machine(tm
     for (_, topic, i) in got_events:
         got, mine = read_topic(topic, int(i)), hip[(topic, int(i))]
         assert O.count_mismatch(got, mine) == 0 if got.dtype == np.float32 else np.array_equal(got, mine), (topic, i)
+
+
+@pytest.mark.gpu
+def test_reference_gtest_suite_unmodified_passes_on_the_library(tmp_path):
+    """test/seed_matrix_test.cpp, epipolar_test.cpp, reduction_test.cpp with test/main_test.cpp -- the reference's own tests of the
+    path, compiled unmodified with -DRMD_BUILD_TESTS like its CMakeLists.txt:47 does -- run on a 640x480 sequence
+    in the dataset layout (they read entries 1, 20 and 199 and the ground-truth depth of entry 1): every one of them must pass."""
+    exe = _program("rmd_gtests_ref")
+    root = str(tmp_path / "over_table")
+    D.export_synthetic(root, 640, 480, 200, image_ext="pgm", only_frames={1, 20, 199})
+    env = dict(os.environ, RMD_TEST_DATA_PATH=root)
+    res = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
+    tail = res.stdout[-4000:]
+    assert res.returncode == 0, tail
+    for name in ("RMDCuTests.seedMatrixInit", "RMDCuTests.seedMatrixCheck", "RMDCuTests.epipolarTest", "RMDCuTests.epipolarMatchTest",
+                 "deviceImageReduction.sum", "deviceImageReduction.countEqual"):
+        assert f"[       OK ] {name}" in res.stdout, tail
+    assert "[  PASSED  ] 6 tests." in res.stdout and "FAILED" not in res.stdout and "Failure" not in res.stdout, tail
