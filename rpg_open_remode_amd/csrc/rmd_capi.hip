@@ -212,6 +212,21 @@ struct rmd_hip_seeds {
   hipStream_t copy_stream = nullptr;        // frame uploads and conversions run here, beside the previous frames' kernels
   void* cur_planes[SLOTS] = {};             // current-image planes (pitch of planes[CURR_IMG]), used in rotation; [0] is the handle's own
   int u8_pitch = 0, ingest_slot = 0;
+  // fused ingest (tile pipeline): the caller's frame is copied into one of SLOTS pinned buffers, a copy engine moves it to a staging
+  // buffer in HBM and then writes the frame's number next to it (copy stream); the setup kernel waits for that number itself,
+  // converts the frame into the current-image plane and tells the host through `h_progress` which frames it has consumed.
+  // No events, no cross-stream waits: neither queue ever holds a barrier packet for the other.
+  unsigned char* h_zc_u8[SLOTS] = {};
+  float* h_zc_f32[SLOTS] = {};
+  unsigned char* d_zc_u8[SLOTS] = {};
+  float* d_zc_f32[SLOTS] = {};
+  unsigned int* h_seq = nullptr;            // pinned, SLOTS words: the frame numbers the copy engine writes into d_zc_flag
+  unsigned int* d_zc_flag = nullptr;        // device: number of the last frame whose staging copy has completed
+  unsigned int* h_progress = nullptr;       // pinned: [0] number of the ingested frame whose setup kernel has started, [1] error bits
+  unsigned int zc_number = 0;               // ingested frames so far
+  int opt_fused_ingest = 1;                 // RMD_HIP_FUSED_INGEST=0 switches back to the copy-stream pipeline (A/B)
+  rmdk::IngestArgs pending_ingest;          // consumed by the next launch of the compact pipeline
+  bool has_pending_ingest = false;
   double ingest_us[4] = {0, 0, 0, 0};  // diagnostics (RMD_HIP_INGEST_PROFILE): host time waiting for a slot, copying, submitting; frames
   bool ingest_profile = false, ingest_host_wait = false;
   StageTimer timers[RMD_HIP_NUM_SEED_STAGES];
@@ -257,6 +272,8 @@ int seeds_sync(const rmd_hip_seeds* s) {
   TRY(seeds_flush(m));
   if (m->frame_ws.frame > 0) HIP_TRY(hipMemcpyAsync(m->frame_ws.h_error, m->frame_ws.d_error, sizeof(unsigned int), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  if (m->h_progress && m->h_progress[1] != 0u)
+    return fail(RMD_HIP_ERR_RUNTIME, "seed update: the staging copy of a host frame never completed; results are invalid");
   if (m->frame_ws.h_error && m->frame_ws.h_error[0] != 0u)
     return fail(RMD_HIP_ERR_RUNTIME, "seed update: a bounded wait inside the frame kernel ran out (error bits 0x%x); results are invalid",
                 m->frame_ws.h_error[0]);
@@ -323,7 +340,9 @@ int seeds_launch_update(rmd_hip_seeds* s) {
             Pt.trace = s->frame_ws.d_trace + static_cast<size_t>(s->trace_frame % rmdk::FR_TRACE_FRAMES) * s->frame_ws.trace_slice_u64();
             ++s->trace_frame;
           }
-          HIP_TRY(rmdk::launch_seed_pipeline_compact<SIDE>(Pt, s->matcher_ws, s->frame_ws, s->stream, s->num_cus, fuse, T_prev, 1 + s->opt_window));
+          HIP_TRY(rmdk::launch_seed_pipeline_compact<SIDE>(Pt, s->matcher_ws, s->frame_ws, s->stream, s->num_cus, fuse, T_prev, 1 + s->opt_window,
+                                                           s->has_pending_ingest ? &s->pending_ingest : nullptr));
+          s->has_pending_ingest = false;
         }
         else HIP_TRY(rmdk::launch_seed_update_tile<SIDE>(P, s->matcher_ws, s->stream, s->num_cus, s->opt_window, fuse, T_prev));
         s->P_pending = P;
@@ -510,6 +529,10 @@ int rmd_hip_seeds_destroy(rmd_hip_seeds_t* s) {
   for (int k = 0; k < rmd_hip_seeds::SLOTS; ++k) {
     if (s->h_u8[k]) (void)hipHostFree(s->h_u8[k]);
     if (s->h_f32[k]) (void)hipHostFree(s->h_f32[k]);
+    if (s->h_zc_u8[k]) (void)hipHostFree(s->h_zc_u8[k]);
+    if (s->h_zc_f32[k]) (void)hipHostFree(s->h_zc_f32[k]);
+    if (s->d_zc_u8[k]) (void)hipFree(s->d_zc_u8[k]);
+    if (s->d_zc_f32[k]) (void)hipFree(s->d_zc_f32[k]);
     if (s->d_u8[k]) (void)hipFree(s->d_u8[k]);
     if (s->staged[k]) (void)hipEventDestroy(s->staged[k]);
     if (s->frame_done[k]) (void)hipEventDestroy(s->frame_done[k]);
@@ -529,6 +552,9 @@ int rmd_hip_seeds_destroy(rmd_hip_seeds_t* s) {
   if (s->d_pc_points) (void)hipFree(s->d_pc_points);
   if (s->d_scalars) (void)hipFree(s->d_scalars);
   if (s->h_scalars) (void)hipHostFree(s->h_scalars);
+  if (s->h_progress) (void)hipHostFree(s->h_progress);
+  if (s->h_seq) (void)hipHostFree(s->h_seq);
+  if (s->d_zc_flag) (void)hipFree(s->d_zc_flag);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
   return RMD_HIP_OK;
@@ -641,19 +667,33 @@ int rmd_hip_seeds_update_device(rmd_hip_seeds_t* s, const float* dev_img, size_t
   return seeds_after_frame(s, T_curr_world);
 }
 
-// Frames that arrive in host memory go through a two-slot pipeline on a stream of their own, so that the upload (and for
-// 8-bit frames the conversion / undistortion) of frame k + 1 runs beside the kernels of frame k instead of in front of them,
-// and no call waits for the device:
-//   host      wait until slot's staging buffer has been read (two frames ago), copy the caller's frame into it (the caller's
-//             buffer is free on return, as with the reference's synchronous cudaMemcpy, seed_matrix.cu:128)
-//   copy      wait until the update that read the slot's plane (two frames ago) has run -> H2D -> [u8: x(1/255) / remap kernel]
+// Frames that arrive in host memory.  Two pipelines, both with SLOTS frames in flight and no call that waits for the device:
+//
+// (a) default, tile pipeline (ingest_current_fused): host copies the frame into pinned buffer n % SLOTS (the caller's buffer is free
+//     on return, as with the reference's synchronous cudaMemcpy, seed_matrix.cu:128); the copy stream moves it to a staging buffer in
+//     HBM and writes the frame's number behind it; the setup kernel of that frame waits for the number ITSELF and converts the frame
+//     into the current-image plane (x(1/255) for 8-bit frames).  No event, no cross-stream wait: a barrier packet on the compute
+//     queue cost 6 us per frame, an event record a little less, and a kernel that reads the pinned buffer across PCIe slows every
+//     load around it down (+5 us).  The host learns from a word the setup kernel writes into pinned memory which frames have been
+//     consumed.  640x480, 8-bit frames: 51.7 us per update against 48.6 us with resident frames; pipeline (b): 60.9 us.
+// (b) the other matchers, the reference frame, and 8-bit frames with lens undistortion (ingest_frame): upload and conversion /
+//     remap kernel on the copy stream, events between the two streams:
+//   host      wait until slot's staging buffer has been read (SLOTS frames ago), copy the caller's frame into it
+//   copy      wait until the update that read the slot's plane (SLOTS frames ago) has run -> H2D -> [u8: x(1/255) / remap kernel]
 //   compute   wait until the slot's plane is staged -> this frame's kernels -> mark the slot's plane free
-// The current image alternates between two planes; planes[CURR_IMG] always names the one of the latest frame.
+//     The current image rotates through SLOTS planes; planes[CURR_IMG] always names the one of the latest frame.
 static int ingest_init(rmd_hip_seeds* s) {
   if (s->copy_stream) return RMD_HIP_OK;
   HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
   s->ingest_profile = getenv("RMD_HIP_INGEST_PROFILE") != nullptr;
   if (const char* e = getenv("RMD_HIP_INGEST_HOST_WAIT")) s->ingest_host_wait = e[0] == '1';
+  if (const char* e = getenv("RMD_HIP_FUSED_INGEST")) s->opt_fused_ingest = e[0] != '0';
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_progress), 64, hipHostMallocMapped));
+  s->h_progress[0] = s->h_progress[1] = 0u;
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_seq), 64, hipHostMallocDefault));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_flag), 64));
+  HIP_TRY(hipMemset(s->d_zc_flag, 0, 64));
+  HIP_TRY(hipStreamSynchronize(nullptr));
   const rmd_hip_image& im = s->planes[RMD_HIP_PLANE_CURR_IMG];
   s->cur_planes[0] = im.data;
   for (int k = 1; k < rmd_hip_seeds::SLOTS; ++k) {
@@ -736,8 +776,79 @@ static int ingest_frame(rmd_hip_seeds* s, const unsigned char* host_gray, const 
 }
 
 // a host frame becomes the current image: stage it into the plane that is NOT being read by the update in flight
+// The fused path: frame n goes through pinned buffer and staging buffer n % SLOTS, last read by the copy engine / the setup kernel of
+// frame n - SLOTS.  That kernel has completed once the setup kernel of frame n - SLOTS + 1 has STARTED (same stream), which is
+// what h_progress reports.
+static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray, const float* host_f32, const float* T_curr_world) {
+  const double t_a = s->ingest_profile ? host_now_us() : 0.0;
+  const unsigned int n = ++s->zc_number;
+  const int k = static_cast<int>(n % rmd_hip_seeds::SLOTS);
+  if (n > static_cast<unsigned int>(rmd_hip_seeds::SLOTS)) {
+    const unsigned int need = n - rmd_hip_seeds::SLOTS + 1u;
+    volatile unsigned int* progress = s->h_progress;
+    if (*progress < need) {
+      const double t0 = host_now_us();
+      while (*progress < need) {
+        if (host_now_us() - t0 > 2000.0) {  // far behind (or another matcher ran the frames in between): an idle stream has read everything
+          HIP_TRY(hipStreamSynchronize(s->stream));
+          break;
+        }
+        __builtin_ia32_pause();
+      }
+    }
+  }
+  const double t_b = s->ingest_profile ? host_now_us() : 0.0;
+  rmdk::IngestArgs in;
+  if (host_gray) {
+    const size_t bytes = static_cast<size_t>(s->u8_pitch) * s->height;
+    if (!s->h_zc_u8[k]) {
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_zc_u8[k]), bytes, hipHostMallocDefault));
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_u8[k]), bytes));
+    }
+    if (s->u8_pitch == s->width) memcpy(s->h_zc_u8[k], host_gray, bytes);
+    else
+      for (int y = 0; y < s->height; ++y)
+        memcpy(s->h_zc_u8[k] + static_cast<size_t>(y) * s->u8_pitch, host_gray + static_cast<size_t>(y) * s->width, s->width);
+    HIP_TRY(hipMemcpyAsync(s->d_zc_u8[k], s->h_zc_u8[k], bytes, hipMemcpyHostToDevice, s->copy_stream));
+    in.u8 = reinterpret_cast<const unsigned int*>(s->d_zc_u8[k]);
+    in.pitch = s->u8_pitch;
+  } else {
+    const size_t bytes = static_cast<size_t>(s->width) * s->height * sizeof(float);
+    if (!s->h_zc_f32[k]) {
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_zc_f32[k]), bytes, hipHostMallocDefault));
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_f32[k]), bytes));
+    }
+    memcpy(s->h_zc_f32[k], host_f32, bytes);
+    HIP_TRY(hipMemcpyAsync(s->d_zc_f32[k], s->h_zc_f32[k], bytes, hipMemcpyHostToDevice, s->copy_stream));
+    in.f32 = s->d_zc_f32[k];
+  }
+  s->h_seq[k] = n;  // behind the frame on the same stream: when the kernel sees n, the frame is in HBM
+  HIP_TRY(hipMemcpyAsync(s->d_zc_flag, &s->h_seq[k], sizeof(unsigned int), hipMemcpyHostToDevice, s->copy_stream));
+  in.flag = s->d_zc_flag;
+  const double t_c = s->ingest_profile ? host_now_us() : 0.0;
+  rmd_hip_image& im = s->planes[RMD_HIP_PLANE_CURR_IMG];
+  im.data = s->cur_planes[0];  // one plane is enough: setup k writes it after search k - 1 has run (same stream)
+  in.dst = static_cast<float*>(im.data);
+  void* dev_progress = nullptr;
+  HIP_TRY(hipHostGetDevicePointer(&dev_progress, s->h_progress, 0));
+  in.progress = static_cast<unsigned int*>(dev_progress);
+  in.number = n;
+  s->pending_ingest = in;
+  s->has_pending_ingest = true;
+  s->P.cur = static_cast<const float*>(im.data);
+  s->P.cur_stride = s->P.stride;
+  const int rc = seeds_after_frame(s, T_curr_world);
+  if (s->ingest_profile) {
+    const double t_d = host_now_us();
+    s->ingest_us[0] += t_b - t_a; s->ingest_us[1] += t_c - t_b; s->ingest_us[2] += t_d - t_c; s->ingest_us[3] += 1.0;
+  }
+  return rc;
+}
+
 static int ingest_current(rmd_hip_seeds* s, const unsigned char* host_gray, const float* host_f32, const float* T_curr_world) {
   TRY(ingest_init(s));
+  if (s->opt_fused_ingest && s->opt_matcher == 3 && !(host_gray && s->d_undist_map1))
+    return ingest_current_fused(s, host_gray, host_f32, T_curr_world);
   const int k = s->ingest_slot;
   s->ingest_slot = (k + 1) % rmd_hip_seeds::SLOTS;
   rmd_hip_image& im = s->planes[RMD_HIP_PLANE_CURR_IMG];

@@ -946,6 +946,8 @@ RMDK_D void plan_units_in_kernel(const MatcherArgs& M, int n_tiles, int target_u
 // The unit list is built without a planning step: a tile reserves its units in the list of its shard (tile % 16) with one
 // returning atomic on the shard's counter; the unit size comes from the PREVIOUS frame's total work (the counters of three
 // consecutive frames rotate).  The search kernel reads the sixteen counts and walks the shards' lists as one list.
+constexpr int INGEST_WGS = 128;  // workgroups that bring a host frame into the current-image plane (the only ones that may wait)
+
 template <int SIDE, bool FUSE_PREV>
 __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(SeedParams P, MatcherArgs M, Pose T_ref_curr_prev, int target_units) {
   __shared__ int red_i[4];
@@ -958,6 +960,45 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(SeedParams
   const int gi = in_image ? y * P.stride + x : 0;
   const unsigned long long t_start = P.trace ? wall_clock64() : 0ull;  // timeline probes (diagnostics)
   unsigned long long t_loaded = 0ull;
+  // frame ingest (see MatcherArgs): the workgroups BELOW the tile grid (blockIdx.y >= tiles_y, at most INGEST_WGS of them, launched
+  // only when a host frame is pending) wait for the staging copy's flag and convert the staged frame into the current-image plane.
+  // Only these few workgroups ever wait: if every tile workgroup did, a device filled with waiting waves could keep a copy that is
+  // carried out by a blit kernel from ever running.  The wait is bounded; a copy that never arrives is reported through progress[1].
+  // Loads of the flag and of the staged frame are agent-scope: the copy may finish after this kernel has started.
+  const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+  if (static_cast<int>(blockIdx.y) >= M.tiles_y) {
+    const int iw = (static_cast<int>(blockIdx.y) - M.tiles_y) * gridDim.x + blockIdx.x;
+    if (iw >= M.ingest_wgs) return;
+    if (ld_agent(M.ingest_flag) < M.ingest_number) {
+      unsigned int spins = 0u;
+      while (ld_agent(M.ingest_flag) < M.ingest_number && ++spins < (1u << 18)) __builtin_amdgcn_s_sleep(16);
+      if (ld_agent(M.ingest_flag) < M.ingest_number && tid == 0) __hip_atomic_store(M.progress + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (M.ingest_u8) {  // x (1/255): Depthmap::inputImage's convertTo(CV_32F, 1.0f / 255.0f), depthmap.cpp:105 -- one fp32 multiply per pixel
+      const int per_row = M.ingest_pitch >> 2, total = per_row * P.h;
+      for (int d = iw * TILE_PIX + tid; d < total; d += M.ingest_wgs * TILE_PIX) {
+        const unsigned int v = ld_agent(M.ingest_u8 + d);
+        const int row = d / per_row, x4 = (d - row * per_row) * 4;
+        float* out = M.ingest_dst + static_cast<size_t>(row) * P.stride + x4;
+        const float f0 = static_cast<float>(v & 0xffu) * (1.0f / 255.0f), f1 = static_cast<float>((v >> 8) & 0xffu) * (1.0f / 255.0f);
+        const float f2 = static_cast<float>((v >> 16) & 0xffu) * (1.0f / 255.0f), f3 = static_cast<float>(v >> 24) * (1.0f / 255.0f);
+        if (x4 + 3 < P.w) *reinterpret_cast<float4*>(out) = make_float4(f0, f1, f2, f3);  // plane rows and x4 are multiples of 16 bytes
+        else {
+          if (x4 < P.w) out[0] = f0;
+          if (x4 + 1 < P.w) out[1] = f1;
+          if (x4 + 2 < P.w) out[2] = f2;
+        }
+      }
+    } else {
+      const int total = P.w * P.h;
+      for (int d = iw * TILE_PIX + tid; d < total; d += M.ingest_wgs * TILE_PIX) {
+        const int row = d / P.w;
+        M.ingest_dst[static_cast<size_t>(row) * P.stride + (d - row * P.w)] = __uint_as_float(ld_agent(reinterpret_cast<const unsigned int*>(M.ingest_f32) + d));
+      }
+    }
+    return;
+  }
+  if (M.progress && wg == 0 && tid == 0) __hip_atomic_store(M.progress, M.ingest_number, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   float mu = P.mu[gi], sigma_sq = P.sigma_sq[gi], a = P.a[gi], b = P.b[gi];
   if (FUSE_PREV) {
     const int conv_prev = P.conv[gi];
@@ -1137,10 +1178,14 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
 // The caller zeroes ws.d_shards and sets ws.frame = 0 whenever the sequence restarts.
 template <int SIDE>
 inline hipError_t launch_seed_pipeline_compact(const SeedParams& P, MatcherWorkspace& ws, FrameWorkspace& fws, hipStream_t stream, int num_cus,
-                                               bool fuse_prev, const Pose& T_ref_curr_prev, int target_mult = 1) {
+                                               bool fuse_prev, const Pose& T_ref_curr_prev, int target_mult = 1, const IngestArgs* ingest = nullptr) {
   using Smem = FrameSmem<SIDE>;
   MatcherArgs M = matcher_args(ws);
   M.trace = nullptr;
+  if (ingest) {
+    M.ingest_u8 = ingest->u8; M.ingest_f32 = ingest->f32; M.ingest_dst = ingest->dst; M.ingest_pitch = ingest->pitch;
+    M.ingest_flag = ingest->flag; M.progress = ingest->progress; M.ingest_number = ingest->number;
+  }
   auto search = seed_search_compact_kernel<SIDE>;
   bool& attr = fws.attr_set_compact[SIDE / 2 - 1];
   if (!attr) {
@@ -1153,7 +1198,14 @@ inline hipError_t launch_seed_pipeline_compact(const SeedParams& P, MatcherWorks
     attr = true;
   }
   const int resident = num_cus * fws.compact_wg_per_cu[SIDE / 2 - 1];
-  const dim3 tiles(ws.tiles_x, ws.tiles_y);
+  dim3 tiles(ws.tiles_x, ws.tiles_y);
+  M.tiles_y = ws.tiles_y;
+  if (M.ingest_u8 || M.ingest_f32) {  // the ingest workgroups: rows below the tile grid
+    const long long dwords = M.ingest_u8 ? static_cast<long long>(M.ingest_pitch >> 2) * P.h : static_cast<long long>(P.w) * P.h;
+    const long long want = (dwords + TILE_PIX - 1) / TILE_PIX;
+    M.ingest_wgs = static_cast<int>(want < INGEST_WGS ? want : INGEST_WGS);
+    tiles.y += static_cast<unsigned int>((M.ingest_wgs + ws.tiles_x - 1) / ws.tiles_x);
+  }
   if (fuse_prev) hipLaunchKernelGGL((seed_setup_compact_kernel<SIDE, true>), tiles, dim3(TILE_PIX), 0, stream, P, M, T_ref_curr_prev, resident * target_mult);
   else hipLaunchKernelGGL((seed_setup_compact_kernel<SIDE, false>), tiles, dim3(TILE_PIX), 0, stream, P, M, T_ref_curr_prev, resident * target_mult);
   hipLaunchKernelGGL(search, dim3(resident), dim3(TILE_PIX), sizeof(Smem), stream, P, M);

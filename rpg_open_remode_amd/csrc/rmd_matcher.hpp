@@ -124,7 +124,33 @@ struct MatcherArgs {
   unsigned long long* shards_next;        // cleared by this frame's setup for the next one
   int shard_cap;
   int tiles_x;
+  int tiles_y;
   unsigned long long* trace;  // this frame's slice of the timeline buffer, may be null (see trace_record)
+  // Frame ingest for frames handed over in host memory (compact pipeline): a copy engine brings the frame as it is into a staging
+  // buffer in HBM and then writes the frame's number into `ingest_flag`, both on the handle's copy stream, with NO ordering against
+  // the compute stream; a few extra workgroups of the setup kernel wait for the flag themselves (it has normally been set long
+  // before) and convert the staged frame into the current-image plane, which only the search kernel -- the next launch -- reads.
+  // Null pointers: the frame is resident already.
+  const unsigned int* ingest_u8;   // staged 8-bit rows of ingest_pitch bytes (a multiple of 4), four pixels per dword
+  const float* ingest_f32;         // or staged float rows of P.w elements, unpadded
+  float* ingest_dst;               // the current-image plane, row stride P.stride
+  int ingest_pitch;
+  int ingest_wgs;                  // workgroups below the tile grid that do the conversion
+  const unsigned int* ingest_flag; // device word: number of the last frame whose staging copy has completed
+  unsigned int* progress;          // pinned host words: [0] <- ingest_number when this setup starts (everything before it has
+                                   // completed: the host may reuse that frame's buffers), [1] |= 1 if the flag never came
+  unsigned int ingest_number;
+};
+
+// what the caller of the compact pipeline hands over when the frame came from host memory
+struct IngestArgs {
+  const unsigned int* u8 = nullptr;
+  const float* f32 = nullptr;
+  float* dst = nullptr;
+  int pitch = 0;
+  const unsigned int* flag = nullptr;
+  unsigned int* progress = nullptr;
+  unsigned int number = 0;
 };
 
 // Timeline probe of one workgroup (diagnostics): record `slot` of the frame's trace slice gets the workgroup's start and
@@ -847,13 +873,14 @@ __global__ __launch_bounds__(256) void seed_finalize_kernel(SeedParams P, Matche
 inline MatcherArgs matcher_args(const MatcherWorkspace& ws) {
   MatcherArgs M;
   M.mean = ws.d_mean; M.dir = ws.d_dir; M.lfirst = ws.d_lfirst; M.packed = ws.d_packed; M.best = ws.d_best;
-  M.tiles = ws.d_tiles; M.tile_plan = ws.d_tile_plan; M.tile_pending = ws.d_tile_pending; M.units = ws.d_units; M.tiles_x = ws.tiles_x;
+  M.tiles = ws.d_tiles; M.tile_plan = ws.d_tile_plan; M.tile_pending = ws.d_tile_pending; M.units = ws.d_units; M.tiles_x = ws.tiles_x; M.tiles_y = ws.tiles_y;
   M.queue = ws.d_queue;
   M.shards_cur = ws.d_shards + (ws.frame % 3) * UNIT_SHARDS;
   M.shards_prev = ws.frame > 0 ? ws.d_shards + ((ws.frame + 2) % 3) * UNIT_SHARDS : nullptr;
   M.shards_next = ws.d_shards + ((ws.frame + 1) % 3) * UNIT_SHARDS;
   M.shard_cap = ws.shard_cap;
   M.trace = nullptr;
+  M.ingest_u8 = nullptr; M.ingest_f32 = nullptr; M.ingest_dst = nullptr; M.ingest_pitch = 0; M.ingest_wgs = 0; M.ingest_flag = nullptr; M.progress = nullptr; M.ingest_number = 0u;
   return M;
 }
 

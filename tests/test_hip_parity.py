@@ -526,3 +526,35 @@ def test_point_cloud_ragged_size_and_intensity_round_trip():
     got = s.pointCloud()
     assert O.count_mismatch(want, got) == 0
     assert set(np.unique(got[:, 3]).astype(int)) == set(range(256))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(101, 67, 3), (640, 480, 9), (1280, 960, 9)])
+def test_host_frames_arriving_on_an_idle_device(size):
+    """Frames handed over in host memory (8-bit and float) while the device is idle: the setup kernel starts before the staging copy
+    has finished and its ingest workgroups have to wait for it -- without keeping the copy from running (at 1280x960 every tile
+    workgroup waiting filled the device and starved the blit kernel that carries the copy out).  Both paths must give the state of
+    the resident-frame path, bit for bit."""
+    import time
+    w, h, side = size
+    seq = sequence(w, h, 6)
+    cam = api.PinholeCamera(*seq.K)
+    u8, f32, res = (api.SeedMatrix(w, h, cam, patch_side=side) for _ in range(3))
+    u8.setReferenceImageU8(seq.gray[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    f32.setReferenceImage(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    res.setReferenceImage(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    planes = []
+    for im in seq.images:
+        d = api.DeviceImage(w, h, np.float32)
+        d.setDevData(im)
+        planes.append(d)
+    t0 = time.perf_counter()
+    for k in range(1, 6):
+        time.sleep(0.003)
+        u8.updateU8(seq.gray[k], seq.T_curr_world[k])
+        f32.update(seq.images[k], seq.T_curr_world[k])
+        res.updateDevice(planes[k].data, planes[k].stride, seq.T_curr_world[k])
+    want = res.state()
+    assert_states_equal(want, u8.state(), "8-bit host frames")
+    assert_states_equal(want, f32.state(), "float host frames")
+    assert time.perf_counter() - t0 < 5.0  # a wait that ran into its bound would take far longer

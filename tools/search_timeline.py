@@ -10,6 +10,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--size", default="640x480"); ap.add_argument("--frames", type=int, default=200)
 ap.add_argument("--side", type=int, default=9)
 ap.add_argument("--show", default="1,5,20,60,100,150,199")
+ap.add_argument("--u8", action="store_true", help="frames handed over as 8-bit host images (ingest fused into the setup kernel)")
 a = ap.parse_args()
 W, H = (int(v) for v in a.size.split("x"))
 seq = synth.Sequence(W, H, a.frames)
@@ -23,7 +24,10 @@ for rep in range(2):  # first pass warms up
     s.sync()
     s.setOption(api.OPT_COLLECT_STATS, 2)
     for k in range(1, a.frames):
-        s.updateDevice(frames[k].data, frames[k].stride, seq.T_curr_world[k])
+        if a.u8:
+            s.updateU8(seq.gray[k], seq.T_curr_world[k])
+        else:
+            s.updateDevice(frames[k].data, frames[k].stride, seq.T_curr_world[k])
     s.sync()
 us = lambda t: float(t) / 100.0
 show = set(int(v) for v in a.show.split(","))
