@@ -45,14 +45,14 @@ def main():
 
     def make(v):
         s = api.SeedMatrix(w, h, cam, patch_side=a.side)
-        if v >= 20:  # 21: everything beyond one round handed out in 1-round units; 2xy: local_max x * 256, y rounds per unit
+        if v in (31, 32):  # tile pipeline with 2x / 3x as many (smaller) work units
+            s.setOption(api.OPT_MATCHER, 3); s.setOption(api.OPT_WINDOW, v - 30)
+        elif v >= 20:  # 21: everything beyond one round handed out in 1-round units; 2xy: local_max x * 256, y rounds per unit
             s.setOption(api.OPT_MATCHER, 2)
             if v == 21:
                 s.setOption(api.OPT_LOCAL_MAX, 256); s.setOption(api.OPT_UNIT_ROUNDS, 1)
             else:
                 s.setOption(api.OPT_LOCAL_MAX, ((v // 10) % 100) * 256); s.setOption(api.OPT_UNIT_ROUNDS, v % 10)
-        elif v in (31, 32):  # tile pipeline with 2x / 3x as many (smaller) work units
-            s.setOption(api.OPT_MATCHER, 3); s.setOption(api.OPT_WINDOW, v - 30)
         else:
             s.setOption(api.OPT_MATCHER, v)
         return s
