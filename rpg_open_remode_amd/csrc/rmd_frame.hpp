@@ -155,6 +155,9 @@ struct FrameSmem {
   unsigned int packed[TILE_PIX];   // state << 16 | first in-image step << 8 | number of in-image steps
   int red[4][12];
   unsigned int bcast[8];
+#ifdef RMD_PROFILE_ROUNDS
+  unsigned long long prof[8];  // diagnostics build: [4] window policy, [5] staging, [6] rounds + barrier ticks; [0..3] per wave, ticks / count of rounds without (bits 0..23 / 56..63) and with (24..47 / 48..55) a fallback
+#endif
 };
 
 // One NCC evaluation at px; the LDS window has a run-time row stride.  Two sources for the current-image samples, same
@@ -345,12 +348,23 @@ RMDK_D void frame_stage_window(const SeedParams& P, FrameSmem<SIDE>& S, int tid,
   }
 }
 
+#ifdef RMD_PROFILE_ROUNDS
+RMDK_D unsigned long long prof_clock() {  // the 100 MHz wall clock, pinned in program order (diagnostics build only)
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+  return t;
+}
+#endif
 // Rounds of 256 NCC evaluations over work items [k0, k1) of the tile in LDS with window W; arg-max keys accumulate in S.best.
 // No barrier.
 template <int SIDE>
 RMDK_D void frame_rounds(const SeedParams& P, FrameSmem<SIDE>& S, int tid, int k0, int k1, const FrameWindow& W, unsigned int& n_fallback) {
   using Smem = FrameSmem<SIDE>;
   for (int r0 = k0; r0 < k1; r0 += TILE_PIX) {
+#ifdef RMD_PROFILE_ROUNDS
+    const unsigned long long prof_t0 = prof_clock();
+    const unsigned int prof_fb0 = n_fallback;
+#endif
     const int kk = r0 + tid;
     int p = -1;
     unsigned long long key = 0ull;
@@ -376,6 +390,13 @@ RMDK_D void frame_rounds(const SeedParams& P, FrameSmem<SIDE>& S, int tid, int k
     // one LDS atomic per evaluation: lanes of one seed hit one address and serialise inside the LDS, which is cheaper than a
     // segmented wave reduction first (12 ds_bpermute round trips)
     if (key != 0ull) atomicMax(&S.best[p], key);
+#ifdef RMD_PROFILE_ROUNDS
+    {  // diagnostics build only: ticks and count of this wave's rounds with / without an evaluation that left the LDS window
+      const bool fb = __any(n_fallback != prof_fb0);
+      const unsigned long long dt = prof_clock() - prof_t0;
+      if ((tid & 63) == 0) S.prof[tid >> 6] += fb ? (dt << 24) | (1ull << 48) : dt | (1ull << 56);
+    }
+#endif
   }
 }
 
@@ -392,6 +413,9 @@ RMDK_D void frame_search(const SeedParams& P, FrameSmem<SIDE>& S, int tid, int k
   while (k < k_end) {
     FrameWindow W = tile_win;
     int k1 = k_end;
+#ifdef RMD_PROFILE_ROUNDS
+    const unsigned long long prof_p0 = prof_clock();
+#endif
     if (!tile_win.valid) {
       // this lane's seed contributes steps [max(k - first, 0), min(kX - first, n) - 1] to the candidate range [k, kX)
       const int j0 = max(k - my_first, 0);
@@ -426,13 +450,25 @@ RMDK_D void frame_search(const SeedParams& P, FrameSmem<SIDE>& S, int tid, int k
         }
       }
       W.ws = (W.x1 - W.x0 + 1) | 1;
+#ifdef RMD_PROFILE_ROUNDS
+      const unsigned long long prof_p1 = prof_clock();
+#endif
       frame_stage_window<SIDE>(P, S, tid, W);
       ++n_windows;
       __syncthreads();
+#ifdef RMD_PROFILE_ROUNDS
+      if (tid == 0) { S.prof[4] += prof_p1 - prof_p0; S.prof[5] += prof_clock() - prof_p1; }
+#endif
     }
+#ifdef RMD_PROFILE_ROUNDS
+    const unsigned long long prof_r0 = prof_clock();
+#endif
     frame_rounds<SIDE>(P, S, tid, k, k1, W, n_fallback);
     k = k1;
     __syncthreads();  // the window may be re-staged; S.best is complete for [k_begin, k)
+#ifdef RMD_PROFILE_ROUNDS
+    if (tid == 0) S.prof[6] += prof_clock() - prof_r0;
+#endif
   }
 }
 
@@ -1078,9 +1114,11 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(SeedParams
   const int unit_items = unit_rounds * TILE_PIX;
   if (tile == 0 && tid < UNIT_SHARDS) M.shards_next[tid] = 0ull;  // the set the NEXT frame counts in (nobody reads it now)
   if (tile == 0 && tid == 0) { M.queue[1] = 0u; M.queue[5] = static_cast<unsigned int>(unit_items); }
+#ifndef RMD_PROFILE_ROUNDS
   if (P.trace && tid == 0)  // word 2 of the tile's slot: start (low 32 bits of the 10 ns clock), state ready and end relative to it
     P.trace[static_cast<size_t>(tile) * FR_TRACE_WORDS + 2] = (t_start & 0xffffffffull) | (((t_loaded - t_start) & 0xffffull) << 32) |
                                                              (((wall_clock64() - t_start) & 0xffffull) << 48);
+#endif
   if (total == 0) return;
   const int n_u = units_of(total, unit_rounds);
   if (tid == 0) {
@@ -1112,6 +1150,9 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
   int lds_tile = -1, x0 = 0, y0 = 0, total = 0;
   unsigned long long* const tr = P.trace && static_cast<int>(blockIdx.x) < M.tiles_x * ((P.h + TILE_H - 1) / TILE_H) ? P.trace + static_cast<size_t>(blockIdx.x) * FR_TRACE_WORDS : nullptr;
   if (tr && tid == 0) tr[0] = wall_clock64();
+#ifdef RMD_PROFILE_ROUNDS
+  if (tid < 8) S.prof[tid] = 0ull;
+#endif
   FrameWindow W;
   W.valid = false; W.x0 = W.y0 = 0; W.x1 = W.y1 = -1; W.ws = 1;
   unsigned int u = blockIdx.x;  // unit blockIdx.x is ours for free; further units come from the shared counter
@@ -1170,6 +1211,10 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
     if (tid == 0) {
       tr[3] = wall_clock64();
       tr[4] = n_items; tr[5] = n_done; tr[6] = static_cast<unsigned long long>(lds_tile >= 0 ? lds_tile : 0);
+#ifdef RMD_PROFILE_ROUNDS
+      tr[6] = S.prof[0];
+      tr[2] = (S.prof[4] & 0xfffffull) | ((S.prof[5] & 0xfffffull) << 20) | ((S.prof[6] & 0xffffffull) << 40);  // window policy, staging, rounds incl. barrier
+#endif
       tr[7] = fb | (static_cast<unsigned long long>(n_windows) << 32);
     }
   }
