@@ -429,12 +429,15 @@ RMDK_D void frame_search(const SeedParams& P, FrameSmem<SIDE>& S, int tid, int k
       if (!window_fits(W.x0, W.y0, W.x1, W.y1)) {
         const int kb = min(k_end, k + FR_UNIT_ITEMS), kc = min(k_end, k + TILE_PIX);
         int bx0, by0, bx1, by1, cx0, cy0, cx1, cy1;
-        seed_range_box<SIDE>(P, S, tid, my_n > 0 && my_first < kb && my_first + my_n > k, j0, min(kb - my_first, my_n) - 1, bx0, by0, bx1, by1);
+        const bool four = kb < k_end;  // else the 4-round box IS the box that has just failed (units of <= 4 rounds: always)
+        if (four) {
+          seed_range_box<SIDE>(P, S, tid, my_n > 0 && my_first < kb && my_first + my_n > k, j0, min(kb - my_first, my_n) - 1, bx0, by0, bx1, by1);
+          block_bbox<SIDE>(S, tid, bx0, by0, bx1, by1, 4);
+        }
         seed_range_box<SIDE>(P, S, tid, my_n > 0 && my_first < kc && my_first + my_n > k, j0, min(kc - my_first, my_n) - 1, cx0, cy0, cx1, cy1);
-        block_bbox<SIDE>(S, tid, bx0, by0, bx1, by1, 4);
         block_bbox<SIDE>(S, tid, cx0, cy0, cx1, cy1, 8);
         __syncthreads();
-        block_bbox_read<SIDE>(S, W.x0, W.y0, W.x1, W.y1, 4);
+        if (four) block_bbox_read<SIDE>(S, W.x0, W.y0, W.x1, W.y1, 4);
         k1 = kb;
         if (!window_fits(W.x0, W.y0, W.x1, W.y1)) {
           block_bbox_read<SIDE>(S, W.x0, W.y0, W.x1, W.y1, 8);
