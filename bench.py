@@ -313,10 +313,12 @@ def main():
                 u8_rate, f32_rate = host_pass(True), host_pass(False)
                 resident = total_units / max_elapsed / 1e6 / world
                 h2d = {"value": round(u8_rate, 1), "unit": "Mpix/s",
-                       "path": "rmd_hip_seeds_update_u8: 8-bit frames in pageable host memory -> pinned ring -> copy stream -> "
-                               "x(1/255) on the device (what Depthmap::inputImage feeds, depthmap.cpp:95-106)",
+                       "path": "rmd_hip_seeds_update_u8: 8-bit frames in pageable host memory -> pinned ring -> copy engine -> staging buffer in "
+                               "HBM; the update's own setup kernel waits for the copy's sequence number and applies x(1/255) (what "
+                               "Depthmap::inputImage feeds, depthmap.cpp:95-106); no event or wait between the copy and compute streams",
                        "float_frames_update_mpix_s": round(f32_rate, 1), "frac_of_resident": round(u8_rate / resident, 3),
-                       "bound": "PCIe Gen5 x16 63 GB/s = 205 000 Mpix/s of 8-bit frames: not the limit; host memcpy + launch latency are"}
+                       "bound": "PCIe Gen5 x16 63 GB/s = 205 000 Mpix/s of 8-bit frames: not the limit; the update kernels are (float frames: the host's "
+                                "1.2 MB copy into pinned memory, ~50 us per frame)"}
 
             def gpu_sample(n):
                 s2 = new_seeds()
