@@ -1038,6 +1038,26 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(SeedParams
     return;
   }
   if (M.progress && wg == 0 && tid == 0) __hip_atomic_store(M.progress, M.ingest_number, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // (computed here, at the top, so that its scalar loads travel with the kernel arguments)
+  // unit size: 1..4 rounds of 256 evaluations, from the previous frame's work (a frame differs little from the one before)
+  int unit_rounds = MAX_UNIT_ROUNDS;
+  if (M.shards_prev) {
+    // the previous frame's counters are not written by anybody while this kernel runs: read them through the scalar path (constant
+    // address space), which the compiler schedules with the kernel arguments at the top instead of as a vector-memory round trip
+    // between the tile's reduction and its reservation
+    typedef const __attribute__((address_space(4))) unsigned long long* const_u64_ptr;
+    const const_u64_ptr prev = (const_u64_ptr)(M.shards_prev);
+    unsigned long long items = 0;
+#pragma unroll
+    for (int q = 0; q < UNIT_SHARDS; ++q) items += prev[q] >> 32;
+    // (rounding to nearest instead of up, or aiming at 2x / 3x as many units, changes nothing measurable: 48.2 - 49.0 us per update)
+    const unsigned long long per_round = static_cast<unsigned long long>(target_units) * TILE_PIX;
+    static_assert(MAX_UNIT_ROUNDS == 4, "the ladder below is ceil(items / per_round) clamped to 1..4");
+    unit_rounds = items > 3 * per_round ? 4 : items > 2 * per_round ? 3 : items > per_round ? 2 : 1;  // no 64-bit division
+  }
+#ifdef RMD_PROFILE_ROUNDS
+  unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // fuse: start, triangulated, uncertainty, normpdf, end; segment done; run done
+#endif
   float mu = P.mu[gi], sigma_sq = P.sigma_sq[gi], a = P.a[gi], b = P.b[gi];
   if (FUSE_PREV) {
     const int conv_prev = P.conv[gi];
@@ -1059,7 +1079,13 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(SeedParams
       else P.match[y * P.stride2 + x] = make_float2(best_px.x, best_px.y);
       SeedParams Pprev = P;
       Pprev.T_ref_curr = T_ref_curr_prev;
+#ifdef RMD_PROFILE_ROUNDS
+      prof_t[0] = prof_clock();
+      const int what = seed_fuse_values(Pprev, x, y, state_prev, mu, sigma_sq, a, b, best_px, prof_t + 1);
+      prof_t[4] = prof_clock();
+#else
       const int what = seed_fuse_values(Pprev, x, y, state_prev, mu, sigma_sq, a, b, best_px);
+#endif
       if (what == 1) { P.sigma_sq[gi] = sigma_sq; P.mu[gi] = mu; P.a[gi] = a; P.b[gi] = b; }
       else if (what == 2) P.b[gi] = b;
     }
@@ -1075,7 +1101,13 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(SeedParams
   const bool live = in_image && state == ST_UPDATE;
   if (live) {
     const Segment seg = epipolar_segment(P, x, y, mu, sigma_sq);
+#ifdef RMD_PROFILE_ROUNDS
+    prof_t[5] = prof_clock();
+#endif
     const ValidRun run = find_valid_run(P, seg, SIDE);
+#ifdef RMD_PROFILE_ROUNDS
+    prof_t[6] = prof_clock();
+#endif
     n_valid = run.n_valid; i_first = run.i_first;
     M.best[gi] = 0ull;
     if (n_valid > 0) {
@@ -1104,19 +1136,17 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(SeedParams
   __syncthreads();
   const int total = red_i[0] + red_i[1] + red_i[2] + red_i[3];
   const int tile = blockIdx.y * M.tiles_x + blockIdx.x;
-  // unit size: 1..4 rounds of 256 evaluations, from the previous frame's work (a frame differs little from the one before)
-  int unit_rounds = MAX_UNIT_ROUNDS;
-  if (M.shards_prev) {
-    unsigned long long items = 0;
-#pragma unroll
-    for (int q = 0; q < UNIT_SHARDS; ++q) items += M.shards_prev[q] >> 32;
-    // (rounding to nearest instead of up, or aiming at 2x / 3x as many units, changes nothing measurable: 48.2 - 49.0 us per update)
-    const unsigned long long per_round = static_cast<unsigned long long>(target_units) * TILE_PIX;
-    unit_rounds = static_cast<int>(min(max((items + per_round - 1) / per_round, 1ull), static_cast<unsigned long long>(MAX_UNIT_ROUNDS)));
-  }
   const int unit_items = unit_rounds * TILE_PIX;
   if (tile == 0 && tid < UNIT_SHARDS) M.shards_next[tid] = 0ull;  // the set the NEXT frame counts in (nobody reads it now)
   if (tile == 0 && tid == 0) { M.queue[1] = 0u; M.queue[5] = static_cast<unsigned int>(unit_items); }
+#ifdef RMD_PROFILE_ROUNDS
+  if (P.trace && prof_t[0] != 0ull && prof_t[6] != 0ull) {  // any live lane that ran both the fusion and the set-up: phases of the setup chain, 10 ns ticks
+    auto d = [](unsigned long long a, unsigned long long b) { return static_cast<unsigned long long>(b > a ? (b - a > 511 ? 511 : b - a) : 0); };
+    const unsigned long long w = d(t_start, prof_t[0]) | (d(prof_t[0], prof_t[1]) << 9) | (d(prof_t[1], prof_t[2]) << 18) | (d(prof_t[2], prof_t[3]) << 27) |
+                                 (d(prof_t[3], prof_t[4]) << 36) | (d(prof_t[4], prof_t[5]) << 45) | (d(prof_t[5], prof_t[6]) << 54);
+    P.trace[static_cast<size_t>(tile) * FR_TRACE_WORDS + 2] = w;  // racing lanes: any one of them will do
+  }
+#endif
 #ifndef RMD_PROFILE_ROUNDS
   if (P.trace && tid == 0)  // word 2 of the tile's slot: start (low 32 bits of the 10 ns clock), state ready and end relative to it
     P.trace[static_cast<size_t>(tile) * FR_TRACE_WORDS + 2] = (t_start & 0xffffffffull) | (((t_loaded - t_start) & 0xffffull) << 32) |

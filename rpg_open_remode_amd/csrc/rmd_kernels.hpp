@@ -163,18 +163,33 @@ RMDK_D Segment epipolar_segment(const SeedParams& P, int x, int y, float mu, flo
 
 // seed_update.cu:58-119 for one pixel whose state (after matching) is `state`, on values in registers.
 // Returns 0: nothing changes, 1: (mu, sigma_sq, a, b) have been replaced by the posterior, 2: only b has changed (NO_MATCH).
-RMDK_D int seed_fuse_values(const SeedParams& P, int x, int y, int state, float& mu, float& sigma_sq, float& a, float& b, F2 match) {
+#ifdef RMD_PROFILE_ROUNDS
+RMDK_D unsigned long long prof_clock_k() {
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+  return t;
+}
+#define RMD_PROF_STAMP(k) do { if (prof) prof[k] = prof_clock_k(); } while (0)
+#else
+#define RMD_PROF_STAMP(k) do { } while (0)
+#endif
+RMDK_D int seed_fuse_values(const SeedParams& P, int x, int y, int state, float& mu, float& sigma_sq, float& a, float& b, F2 match,
+                            unsigned long long* prof = nullptr) {
+  (void)prof;
   if (state == ST_UPDATE) {
     const F3 f_ref = normalize3(cam2world(P.cam, static_cast<float>(x), static_cast<float>(y)));
     const F3 f_epi = normalize3(cam2world(P.cam, match.x, match.y));
     const F3 pt = triangulate(f_ref, f_epi, P.T_ref_curr);
+    RMD_PROF_STAMP(0);
     if (pt.z < 0.0f) return 0;
     const float depth = norm3(pt);
     const float tau = triangulation_uncertainty(depth, f_ref, pose_translation(P.T_ref_curr), P.one_pix_angle);
+    RMD_PROF_STAMP(1);
     const float tau_sq = tau * tau;
     const float s_sq = (tau_sq * sigma_sq) / (tau_sq + sigma_sq);
     const float m = s_sq * (mu / sigma_sq + depth / tau_sq);
     float c1 = (a / (a + b)) * normpdf(depth, mu, sigma_sq + tau_sq);
+    RMD_PROF_STAMP(2);
     float c2 = (b / (a + b)) * (1.0f / P.depth_range);
     const float norm_const = c1 + c2;
     c1 = c1 / norm_const;
