@@ -812,6 +812,8 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
     HIP_TRY(hipMemcpyAsync(s->d_zc_u8[k], s->h_zc_u8[k], bytes, hipMemcpyHostToDevice, s->copy_stream));
     in.u8 = reinterpret_cast<const unsigned int*>(s->d_zc_u8[k]);
     in.pitch = s->u8_pitch;
+    in.map1 = s->d_undist_map1;  // null without lens undistortion
+    in.map2 = s->d_undist_map2;
   } else {
     const size_t bytes = static_cast<size_t>(s->width) * s->height * sizeof(float);
     if (!s->h_zc_f32[k]) {
@@ -847,8 +849,7 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
 
 static int ingest_current(rmd_hip_seeds* s, const unsigned char* host_gray, const float* host_f32, const float* T_curr_world) {
   TRY(ingest_init(s));
-  if (s->opt_fused_ingest && s->opt_matcher == 3 && !(host_gray && s->d_undist_map1))
-    return ingest_current_fused(s, host_gray, host_f32, T_curr_world);
+  if (s->opt_fused_ingest && s->opt_matcher == 3) return ingest_current_fused(s, host_gray, host_f32, T_curr_world);
   const int k = s->ingest_slot;
   s->ingest_slot = (k + 1) % rmd_hip_seeds::SLOTS;
   rmd_hip_image& im = s->planes[RMD_HIP_PLANE_CURR_IMG];

@@ -986,6 +986,7 @@ RMDK_D void plan_units_in_kernel(const MatcherArgs& M, int n_tiles, int target_u
 // returning atomic on the shard's counter; the unit size comes from the PREVIOUS frame's total work (the counters of three
 // consecutive frames rotate).  The search kernel reads the sixteen counts and walks the shards' lists as one list.
 constexpr int INGEST_WGS = 128;  // workgroups that bring a host frame into the current-image plane (the only ones that may wait)
+constexpr int INGEST_WGS_REMAP = 512;  // with lens undistortion (two dependent round trips per pixel): a quarter of the chip's wave slots at most
 
 template <int SIDE, bool FUSE_PREV>
 __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(SeedParams P, MatcherArgs M, Pose T_ref_curr_prev, int target_units) {
@@ -1013,7 +1014,29 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(SeedParams
       while (ld_agent(M.ingest_flag) < M.ingest_number && ++spins < (1u << 18)) __builtin_amdgcn_s_sleep(16);
       if (ld_agent(M.ingest_flag) < M.ingest_number && tid == 0) __hip_atomic_store(M.progress + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (M.ingest_u8) {  // x (1/255): Depthmap::inputImage's convertTo(CV_32F, 1.0f / 255.0f), depthmap.cpp:105 -- one fp32 multiply per pixel
+    if (M.ingest_u8 && M.ingest_map1) {  // cv::remap through the undistortion maps first (depthmap.cpp:99), destination pixels four at a time per lane
+      const unsigned char* src = reinterpret_cast<const unsigned char*>(M.ingest_u8);
+      const int total = P.w * P.h, step = M.ingest_wgs * TILE_PIX;
+      for (int d0 = iw * TILE_PIX + tid; d0 < total; d0 += 4 * step) {
+        short2 m[4];
+        int f[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // all map entries of the batch are requested before the first source pixel
+          const int d = min(d0 + q * step, total - 1);
+          m[q] = M.ingest_map1[d];
+          f[q] = M.ingest_map2[d] & 1023;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int d = d0 + q * step;
+          if (d >= total) break;
+          const int row = d / P.w;
+          M.ingest_dst[static_cast<size_t>(row) * P.stride + (d - row * P.w)] = remap_u8_pixel(src, M.ingest_pitch, m[q], f[q], P.w, P.h, [](const unsigned char* p) {
+            return static_cast<int>(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          });
+        }
+      }
+    } else if (M.ingest_u8) {  // x (1/255): Depthmap::inputImage's convertTo(CV_32F, 1.0f / 255.0f), depthmap.cpp:105 -- one fp32 multiply per pixel
       const int per_row = M.ingest_pitch >> 2, total = per_row * P.h;
       for (int d = iw * TILE_PIX + tid; d < total; d += M.ingest_wgs * TILE_PIX) {
         const unsigned int v = ld_agent(M.ingest_u8 + d);
@@ -1263,6 +1286,7 @@ inline hipError_t launch_seed_pipeline_compact(const SeedParams& P, MatcherWorks
   M.trace = nullptr;
   if (ingest) {
     M.ingest_u8 = ingest->u8; M.ingest_f32 = ingest->f32; M.ingest_dst = ingest->dst; M.ingest_pitch = ingest->pitch;
+    M.ingest_map1 = ingest->map1; M.ingest_map2 = ingest->map2;
     M.ingest_flag = ingest->flag; M.progress = ingest->progress; M.ingest_number = ingest->number;
   }
   auto search = seed_search_compact_kernel<SIDE>;
@@ -1280,9 +1304,9 @@ inline hipError_t launch_seed_pipeline_compact(const SeedParams& P, MatcherWorks
   dim3 tiles(ws.tiles_x, ws.tiles_y);
   M.tiles_y = ws.tiles_y;
   if (M.ingest_u8 || M.ingest_f32) {  // the ingest workgroups: rows below the tile grid
-    const long long dwords = M.ingest_u8 ? static_cast<long long>(M.ingest_pitch >> 2) * P.h : static_cast<long long>(P.w) * P.h;
-    const long long want = (dwords + TILE_PIX - 1) / TILE_PIX;
-    M.ingest_wgs = static_cast<int>(want < INGEST_WGS ? want : INGEST_WGS);
+    const long long dwords = M.ingest_u8 && !M.ingest_map1 ? static_cast<long long>(M.ingest_pitch >> 2) * P.h : static_cast<long long>(P.w) * P.h;
+    const long long want = (dwords + TILE_PIX - 1) / TILE_PIX, cap = M.ingest_u8 && M.ingest_map1 ? INGEST_WGS_REMAP : INGEST_WGS;
+    M.ingest_wgs = static_cast<int>(want < cap ? want : cap);
     tiles.y += static_cast<unsigned int>((M.ingest_wgs + ws.tiles_x - 1) / ws.tiles_x);
   }
   const int target_units = resident * target_mult;

@@ -106,6 +106,24 @@ __global__ __launch_bounds__(256) void ingest_u8_kernel(const unsigned char* __r
 // 8-bit frame through the fixed-point maps of cv::initUndistortRectifyMap(..., CV_16SC2) with INTER_LINEAR and
 // BORDER_CONSTANT 0, then x(1/255).  map1 = integer source position, map2 = 5-bit fractions (fy << 5 | fx); the bilinear
 // weights are OpenCV's 15-bit table entries (32 - fy)(32 - fx) * 32 etc., the result (sum + 2^14) >> 15.  Integer arithmetic.
+// one destination pixel; `src` may be read with any load flavour through LOAD(ptr)
+template <typename LOAD>
+RMDK_D float remap_u8_pixel(const unsigned char* src, int src_pitch, short2 m, int f, int w, int h, LOAD load) {
+  const int fx = f & 31, fy = f >> 5;
+  const int sx = m.x, sy = m.y;
+  int v = 0;
+  if (!(sx >= w || sx + 1 < 0 || sy >= h || sy + 1 < 0)) {
+    const bool x0 = sx >= 0, x1 = sx + 1 < w, y0 = sy >= 0, y1 = sy + 1 < h;
+    const unsigned char* r0 = src + static_cast<ptrdiff_t>(sy) * src_pitch;
+    const unsigned char* r1 = r0 + src_pitch;
+    const int v00 = (x0 && y0) ? load(r0 + sx) : 0, v01 = (x1 && y0) ? load(r0 + sx + 1) : 0;
+    const int v10 = (x0 && y1) ? load(r1 + sx) : 0, v11 = (x1 && y1) ? load(r1 + sx + 1) : 0;
+    const int sum = v00 * ((32 - fy) * (32 - fx) * 32) + v01 * ((32 - fy) * fx * 32) + v10 * (fy * (32 - fx) * 32) + v11 * (fy * fx * 32);
+    v = (sum + (1 << 14)) >> 15;
+  }
+  return static_cast<float>(v) * (1.0f / 255.0f);
+}
+
 __global__ __launch_bounds__(256) void ingest_u8_remap_kernel(const unsigned char* __restrict__ src, int src_pitch,
                                                               const short2* __restrict__ map1, const unsigned short* __restrict__ map2,
                                                               float* __restrict__ dst, int dst_stride, int w, int h) {
@@ -114,19 +132,7 @@ __global__ __launch_bounds__(256) void ingest_u8_remap_kernel(const unsigned cha
   if (x >= w || y >= h) return;
   const short2 m = map1[static_cast<size_t>(y) * w + x];
   const int f = map2[static_cast<size_t>(y) * w + x] & 1023;
-  const int fx = f & 31, fy = f >> 5;
-  const int sx = m.x, sy = m.y;
-  int v = 0;
-  if (!(sx >= w || sx + 1 < 0 || sy >= h || sy + 1 < 0)) {
-    const bool x0 = sx >= 0, x1 = sx + 1 < w, y0 = sy >= 0, y1 = sy + 1 < h;
-    const unsigned char* r0 = src + static_cast<ptrdiff_t>(sy) * src_pitch;
-    const unsigned char* r1 = r0 + src_pitch;
-    const int v00 = (x0 && y0) ? r0[sx] : 0, v01 = (x1 && y0) ? r0[sx + 1] : 0;
-    const int v10 = (x0 && y1) ? r1[sx] : 0, v11 = (x1 && y1) ? r1[sx + 1] : 0;
-    const int sum = v00 * ((32 - fy) * (32 - fx) * 32) + v01 * ((32 - fy) * fx * 32) + v10 * (fy * (32 - fx) * 32) + v11 * (fy * fx * 32);
-    v = (sum + (1 << 14)) >> 15;
-  }
-  dst[static_cast<size_t>(y) * dst_stride + x] = static_cast<float>(v) * (1.0f / 255.0f);
+  dst[static_cast<size_t>(y) * dst_stride + x] = remap_u8_pixel(src, src_pitch, m, f, w, h, [](const unsigned char* p) { return static_cast<int>(*p); });
 }
 
 // ------------------------------------------------------------------------------------------

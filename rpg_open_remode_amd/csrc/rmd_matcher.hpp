@@ -135,6 +135,8 @@ struct MatcherArgs {
   const float* ingest_f32;         // or staged float rows of P.w elements, unpadded
   float* ingest_dst;               // the current-image plane, row stride P.stride
   int ingest_pitch;
+  const short2* ingest_map1;       // lens undistortion of 8-bit frames (Depthmap::initUndistortionMap): source pixel per destination pixel
+  const unsigned short* ingest_map2;  // ... and its 5-bit fractions; null = frames are used as they come
   int ingest_wgs;                  // workgroups below the tile grid that do the conversion
   const unsigned int* ingest_flag; // device word: number of the last frame whose staging copy has completed
   unsigned int* progress;          // pinned host words: [0] <- ingest_number when this setup starts (everything before it has
@@ -148,6 +150,8 @@ struct IngestArgs {
   const float* f32 = nullptr;
   float* dst = nullptr;
   int pitch = 0;
+  const short2* map1 = nullptr;
+  const unsigned short* map2 = nullptr;
   const unsigned int* flag = nullptr;
   unsigned int* progress = nullptr;
   unsigned int number = 0;
@@ -880,7 +884,7 @@ inline MatcherArgs matcher_args(const MatcherWorkspace& ws) {
   M.shards_next = ws.d_shards + ((ws.frame + 1) % 3) * UNIT_SHARDS;
   M.shard_cap = ws.shard_cap;
   M.trace = nullptr;
-  M.ingest_u8 = nullptr; M.ingest_f32 = nullptr; M.ingest_dst = nullptr; M.ingest_pitch = 0; M.ingest_wgs = 0; M.ingest_flag = nullptr; M.progress = nullptr; M.ingest_number = 0u;
+  M.ingest_u8 = nullptr; M.ingest_f32 = nullptr; M.ingest_dst = nullptr; M.ingest_pitch = 0; M.ingest_map1 = nullptr; M.ingest_map2 = nullptr; M.ingest_wgs = 0; M.ingest_flag = nullptr; M.progress = nullptr; M.ingest_number = 0u;
   return M;
 }
 

@@ -11,6 +11,9 @@ for im in seq.images:
     d = api.DeviceImage(W, H, np.float32); d.setDevData(im); frames.append(d)
 def rate(kind):
     s = api.SeedMatrix(W, H, api.PinholeCamera(*seq.K), patch_side=9)
+    if kind == "u8+undistort":  # 8-bit frames through the lens undistortion (Depthmap::initUndistortionMap)
+        s.initUndistortionMap(-0.25, 0.08, 1e-3, -7e-4)
+        kind = "u8"
     def one():
         if kind == "u8":
             s.setReferenceImageU8(seq.gray[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
@@ -28,6 +31,6 @@ def rate(kind):
     s.sync()
     t = time.perf_counter() - t0
     return t / 3 / (F - 1) * 1e6, t_sub / 3 / (F - 1) * 1e6
-for kind in ("resident", "u8", "f32", "resident", "u8"):
+for kind in ("resident", "u8", "f32", "resident", "u8", "u8+undistort"):
     us, sub = rate(kind)
-    print(f"{kind:9s}: {us:7.2f} us per update ({W * H / us:8.1f} Mpix/s); host submission {sub:6.2f} us per update")
+    print(f"{kind:12s}: {us:7.2f} us per update ({W * H / us:8.1f} Mpix/s); host submission {sub:6.2f} us per update")
