@@ -1082,10 +1082,15 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(SeedParams
   unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // fuse: start, triangulated, uncertainty, normpdf, end; segment done; run done
 #endif
   float mu = P.mu[gi], sigma_sq = P.sigma_sq[gi], a = P.a[gi], b = P.b[gi];
+  // what the planes hold now (known only when the previous frame's values were loaded for its finalisation): a seed that has
+  // converged or diverged keeps writing the same state and an empty descriptor, a third of this kernel's stores -- skipped
+  int conv_old = -1;
+  unsigned int packed_old = 0xffffffffu;
   if (FUSE_PREV) {
     const int conv_prev = P.conv[gi];
     const unsigned long long key = M.best[gi];
     const unsigned int packed_prev = M.packed[gi];
+    conv_old = conv_prev; packed_old = packed_prev;
     const float lfirst_prev = M.lfirst[gi];
     const float2 m_prev = M.mean[gi], d_prev = M.dir[gi];
     if (in_image && conv_prev == ST_UPDATE) {
@@ -1116,7 +1121,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(SeedParams
   int state = ST_BORDER;
   if (in_image) {
     state = seed_check(P, x, y, sigma_sq, a, b, SIDE);
-    P.conv[gi] = state;  // final for BORDER / CONVERGED / DIVERGED; UPDATE seeds are settled by the finalisation
+    if (state != conv_old) P.conv[gi] = state;  // final for BORDER / CONVERGED / DIVERGED; UPDATE seeds are settled by the finalisation
   }
   if (P.trace) t_loaded = wall_clock64();
   int n_valid = 0, i_first = 0;
@@ -1145,7 +1150,8 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(SeedParams
       }
     }
   }
-  if (in_image) M.packed[gi] = (static_cast<unsigned int>(i_first) << 16) | static_cast<unsigned int>(n_valid);
+  const unsigned int packed_new = (static_cast<unsigned int>(i_first) << 16) | static_cast<unsigned int>(n_valid);
+  if (in_image && packed_new != packed_old) M.packed[gi] = packed_new;
   if (P.stats) {
     const unsigned long long s_live = wave_sum_u64(live ? 1ull : 0ull);
     const unsigned long long s_steps = wave_sum_u64(static_cast<unsigned long long>(n_steps));
