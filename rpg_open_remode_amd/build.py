@@ -4,7 +4,7 @@
   rpg_open_remode_amd/librmd_synth.so   synthetic sequence generator (host only)
   oracle/libremode_oracle*_s{3,5,7,9}.so  CPU oracle B (test infrastructure)
   oracle/_ref/libremode_ref_s{3,5,7,9}.so CPU oracle A, only where /root/reference exists
-  oracle/_ref/{dataset_main,depthmap_check,remode_node,rmd_gtests}_ref  the reference's host sources, unmodified, on include/rmd/ (test infrastructure)
+  oracle/_ref/{dataset_main,dataset_check,depthmap_check,remode_node,rmd_gtests}_ref  the reference's host sources, unmodified, on include/rmd/ (test infrastructure)
 
 Run as `python -m rpg_open_remode_amd.build` or through __graft_entry__.build().
 """
@@ -98,6 +98,9 @@ def reference_host_program_cmds(out_dir):
         ["-o", os.path.join(out_dir, "dataset_main_ref")],
         "depthmap_check_ref": common + [ref("src", "depthmap.cpp"), os.path.join(ROOT, "tests", "cpp", "depthmap_check.cpp")] + link +
         ["-o", os.path.join(out_dir, "depthmap_check_ref")],
+        # rmd::test::Dataset alone (no device needed): the reference's reader on a directory written by dataset.py
+        "dataset_check_ref": common + ["-I" + ref("test"), ref("test", "dataset.cpp"), os.path.join(ROOT, "tests", "cpp", "dataset_check.cpp")] + link +
+        ["-o", os.path.join(out_dir, "dataset_check_ref")],
         # the reference's own googletest suite for the path (seedMatrixInit, seedMatrixCheck, epipolarTest, epipolarMatchTest,
         # deviceImageReduction.sum / .countEqual) with its main; device_image_test.cpp needs the test-only CUDA kernels copy.cu / sobel.cu
         # (outside the path) and is left out
@@ -117,7 +120,7 @@ def build_reference_host_programs(force=False, verbose=False):
         return
     out_dir = os.path.join(ROOT, "oracle", "_ref")
     os.makedirs(out_dir, exist_ok=True)
-    deps = [os.path.join(HERE, "librmd_hip.so"), os.path.join(ROOT, "tests", "cpp", "depthmap_check.cpp")]
+    deps = [os.path.join(HERE, "librmd_hip.so"), os.path.join(ROOT, "tests", "cpp", "depthmap_check.cpp"), os.path.join(ROOT, "tests", "cpp", "dataset_check.cpp")]
     deps += [os.path.join(ROOT, "include", "rmd", f) for f in os.listdir(os.path.join(ROOT, "include", "rmd"))]
     for d, _, files in os.walk(os.path.join(ROOT, "tests", "cpp", "stubs")):
         deps += [os.path.join(d, f) for f in files]

@@ -257,3 +257,41 @@ def test_reference_gtest_suite_unmodified_passes_on_the_library(tmp_path):
                  "deviceImageReduction.sum", "deviceImageReduction.countEqual"):
         assert f"[       OK ] {name}" in res.stdout, tail
     assert "[  PASSED  ] 6 tests." in res.stdout and "FAILED" not in res.stdout and "Failure" not in res.stdout, tail
+
+
+@pytest.mark.skipif(not HAVE_REFERENCE, reason="/root/reference not present")
+def test_reference_dataset_reader_equals_dataset_py(tmp_path):
+    """rmd::test::Dataset (test/dataset.cpp, unmodified) on a directory written by rpg_open_remode_amd/dataset.py: sequence file, file
+    names, poses (the fp32 quaternion constructor of se3.cuh), 8-bit images and the centimetre .depth files -- no device involved, so this
+    pins the Python reader / writer to the reference's own reader on the CPU."""
+    exe = str(tmp_path / "dataset_check_ref")
+    res = subprocess.run(B.reference_host_program_cmds(str(tmp_path))["dataset_check_ref"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert res.returncode == 0, res.stdout
+    root = str(tmp_path / "over_table")
+    w, h, n = 96, 72, 7
+    D.export_synthetic(root, w, h, n, image_ext="pgm", depth_every=3)
+    res = subprocess.run([exe, root, D.DEFAULT_SEQUENCE_FILE, str(w), str(h)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert res.returncode == 0, res.stdout
+    lines = res.stdout.strip().splitlines()
+    ds = D.Dataset(root)
+    assert ds.readDataSequence(0, 0)
+    entries = list(ds)
+    assert len(lines) == len(entries) == n
+    with_depth = 0
+    for line, e in zip(lines, entries):
+        tok = line.split()
+        assert tok[0] == e.getImageFileName() and tok[1] == e.getDepthmapFileName()
+        pose = np.array([int(t, 16) for t in tok[2:14]], np.uint32).view(np.float32)
+        assert np.array_equal(pose, np.asarray(ds.readCameraPose(e).data, np.float32))
+        img = ds.readImage(e)
+        assert tok[14:18] == ["img", str(w), str(h), str(int(img.astype(np.uint64).sum()))]
+        path = os.path.join(root, "depthmaps", e.getDepthmapFileName())
+        if os.path.exists(path):
+            dm = ds.readDepthmap(e, w, h)
+            assert tok[18] == "depth" and int(tok[19]) == w * h
+            assert float(tok[20]) == float(np.cumsum(dm.astype(np.float64).ravel())[-1])  # sequential, like the driver's loop
+            assert int(tok[21], 16) == int(dm.reshape(-1)[:1].view(np.uint32)[0]) and int(tok[22], 16) == int(dm.reshape(-1)[-1:].view(np.uint32)[0])
+            with_depth += 1
+        else:
+            assert tok[18:] == ["depth", "-"]
+    assert with_depth == 3  # frames 0, 3, 6
