@@ -223,7 +223,7 @@ struct rmd_hip_seeds {
   unsigned int* h_seq = nullptr;            // pinned, SLOTS words: the frame numbers the copy engine writes into d_zc_flag
   unsigned int* d_zc_flag = nullptr;        // device: number of the last frame whose staging copy has completed
   unsigned int* h_progress = nullptr;       // pinned: [0] number of the ingested frame whose setup kernel has started, [1] error bits
-  unsigned int zc_number = 0;               // ingested frames so far
+  unsigned long long zc_number = 0;         // ingested frames so far (the device sees the low 32 bits and compares modulo 2^32)
   int opt_fused_ingest = 1;                 // RMD_HIP_FUSED_INGEST=0 switches back to the copy-stream pipeline (A/B)
   rmdk::IngestArgs pending_ingest;          // consumed by the next launch of the compact pipeline
   bool has_pending_ingest = false;
@@ -781,14 +781,16 @@ static int ingest_frame(rmd_hip_seeds* s, const unsigned char* host_gray, const 
 // what h_progress reports.
 static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray, const float* host_f32, const float* T_curr_world) {
   const double t_a = s->ingest_profile ? host_now_us() : 0.0;
-  const unsigned int n = ++s->zc_number;
-  const int k = static_cast<int>(n % rmd_hip_seeds::SLOTS);
-  if (n > static_cast<unsigned int>(rmd_hip_seeds::SLOTS)) {
+  const unsigned long long n64 = ++s->zc_number;
+  const unsigned int n = static_cast<unsigned int>(n64);
+  const int k = static_cast<int>(n64 % rmd_hip_seeds::SLOTS);
+  if (n64 > static_cast<unsigned long long>(rmd_hip_seeds::SLOTS)) {
     const unsigned int need = n - rmd_hip_seeds::SLOTS + 1u;
     volatile unsigned int* progress = s->h_progress;
-    if (*progress < need) {
+    auto behind = [&]() { return static_cast<int>(*progress - need) < 0; };  // modulo 2^32, like the kernel's test
+    if (behind()) {
       const double t0 = host_now_us();
-      while (*progress < need) {
+      while (behind()) {
         if (host_now_us() - t0 > 2000.0) {  // far behind (or another matcher ran the frames in between): an idle stream has read everything
           HIP_TRY(hipStreamSynchronize(s->stream));
           break;

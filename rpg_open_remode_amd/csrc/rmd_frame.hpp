@@ -1009,10 +1009,12 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(SeedParams
   if (static_cast<int>(blockIdx.y) >= M.tiles_y) {
     const int iw = (static_cast<int>(blockIdx.y) - M.tiles_y) * gridDim.x + blockIdx.x;
     if (iw >= M.ingest_wgs) return;
-    if (ld_agent(M.ingest_flag) < M.ingest_number) {
+    // frame numbers are compared modulo 2^32 (a live system never stops counting): "behind" = the signed difference is negative
+    auto behind = [&]() { return static_cast<int>(ld_agent(M.ingest_flag) - M.ingest_number) < 0; };
+    if (behind()) {
       unsigned int spins = 0u;
-      while (ld_agent(M.ingest_flag) < M.ingest_number && ++spins < (1u << 18)) __builtin_amdgcn_s_sleep(16);
-      if (ld_agent(M.ingest_flag) < M.ingest_number && tid == 0) __hip_atomic_store(M.progress + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      while (behind() && ++spins < (1u << 18)) __builtin_amdgcn_s_sleep(16);
+      if (behind() && tid == 0) __hip_atomic_store(M.progress + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (M.ingest_u8 && M.ingest_map1) {  // cv::remap through the undistortion maps first (depthmap.cpp:99), destination pixels four at a time per lane
       const unsigned char* src = reinterpret_cast<const unsigned char*>(M.ingest_u8);
