@@ -39,6 +39,10 @@ for k in range(a.frames - 1):
     if k + 1 not in show or len(t) == 0:
         continue
     t0 = t[:, 0].min()
+    b = t[t[:, 5] > 0]
+    rd, ex = b[:, 1] - t0, b[:, 3] - t0
+    print(f"{k + 1:5d} | {len(b):5d} | {us(np.percentile(rd, 50)):17.1f} {us(np.percentile(rd, 99)):6.1f} | {us(np.percentile(ex, 50)):7.1f} {us(np.percentile(ex, 90)):6.1f} "
+          f"{us(np.percentile(ex, 99)):6.1f} {us(ex.max()):7.1f} | {int(b[:, 4].sum()):8d} {int(b[:, 5].sum()):6d} {int(b[:, 5].max()):12d} {int((b[:, 7] >> 32).sum()):7d}")
     w2 = t_all[:, 2]
     w2 = w2[w2 != 0]
     if len(w2):  # setup kernel probes: start (low 32 bits), state ready, end (deltas)
@@ -49,10 +53,6 @@ for k in range(a.frames - 1):
         print(f"      setup kernel: workgroup start p50 {us(np.percentile(st, 50)):.1f} p99 {us(np.percentile(st, 99)):.1f} max {us(st.max()):.1f}; state ready after "
               f"p50 {us(np.percentile(rd, 50)):.1f} p99 {us(np.percentile(rd, 99)):.1f}; workgroup lifetime p50 {us(np.percentile(en, 50)):.1f} p99 {us(np.percentile(en, 99)):.1f}; "
               f"last end {us((st + en).max()):.1f}; first search workgroup starts {us(gap):.1f} after the first setup workgroup")
-    b = t[t[:, 5] > 0]
-    rd, ex = b[:, 1] - t0, b[:, 3] - t0
-    print(f"{k + 1:5d} | {len(b):5d} | {us(np.percentile(rd, 50)):17.1f} {us(np.percentile(rd, 99)):6.1f} | {us(np.percentile(ex, 50)):7.1f} {us(np.percentile(ex, 90)):6.1f} "
-          f"{us(np.percentile(ex, 99)):6.1f} {us(ex.max()):7.1f} | {int(b[:, 4].sum()):8d} {int(b[:, 5].sum()):6d} {int(b[:, 5].max()):12d} {int((b[:, 7] >> 32).sum()):7d}")
     order = np.argsort(-(b[:, 3] - t0))[:5]
     print("      slowest workgroups (start, 1st unit ready, end; items, units, last tile (x, y), fallback evals of wave 0, windows staged):")
     tx = (W + 15) // 16
