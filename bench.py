@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample (0 disables)")
     ap.add_argument("--matcher", type=int, default=-1, help="A/B: 0 per-pixel kernel, 1 round-1 tile pipeline, 2 one-launch frame kernel, "
                     "3 tile pipeline with the compact search kernel (the library's default, used when the flag is absent)")
-    ap.add_argument("--window", type=int, default=0, help="search LDS window option (experiments)")
+    ap.add_argument("--unit-target", type=int, default=1, help="tile pipeline: work units aimed at per frame, in multiples of the resident search workgroups (experiments)")
     ap.add_argument("--size", default=f"{WIDTH}x{HEIGHT}", help="frame size WxH; 640x480 with 200 frames is the headline metric")
     ap.add_argument("--frames", type=int, default=0, help="frames per pass incl. the reference (default: 200; 500 at 1280x960, "
                     "1000 at 1920x1080, as BASELINE.json configures them)")
@@ -201,7 +201,7 @@ def main():
         s = api.SeedMatrix(W, H, api.PinholeCamera(*K), patch_side=SIDE)
         if args.matcher >= 0:
             s.setOption(api.OPT_MATCHER, args.matcher)
-            s.setOption(api.OPT_WINDOW, args.window)
+            s.setOption(api.OPT_UNIT_TARGET, args.unit_target)
         return s
 
     def set_ref(s):

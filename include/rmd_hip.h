@@ -70,6 +70,7 @@ extern "C" {
 typedef struct rmd_hip_image rmd_hip_image_t;
 typedef struct rmd_hip_seeds rmd_hip_seeds_t;
 typedef struct rmd_hip_denoiser rmd_hip_denoiser_t;
+typedef struct rmd_hip_batch rmd_hip_batch_t;
 
 /* ---- library ------------------------------------------------------------------------ */
 const char* rmd_hip_last_error(void);
@@ -129,7 +130,9 @@ int rmd_hip_seeds_download(const rmd_hip_seeds_t* s, int plane, void* host_dst);
 int rmd_hip_seeds_upload(rmd_hip_seeds_t* s, int plane, const float* host_src);
 /* getMu/getSigmaSq/getA/getB/getConvergence :170-193: a borrowed view, valid while `s` lives */
 int rmd_hip_seeds_plane(const rmd_hip_seeds_t* s, int plane, const rmd_hip_image_t** view);
-/* getConvergedCount :195-198 (count of CONVERGED in the convergence plane) */
+/* getConvergedCount :195-198 (count of CONVERGED in the convergence plane).  Right after an update of the tile pipeline this needs
+ * neither a kernel nor a device synchronisation: seed_check -- the update's first kernel -- decides the count, the update mirrors it to
+ * pinned memory, and the call returns as soon as that has happened (the NCC search of the same update may still be running). */
 int rmd_hip_seeds_converged_count(const rmd_hip_seeds_t* s, size_t* count);
 /* getDistFromRef :200-203 */
 /* Lens undistortion of the 8-bit frames handed to set_reference_u8 / update_u8, in front of the x(1/255) conversion:
@@ -154,17 +157,20 @@ int rmd_hip_seeds_dist_from_ref(const rmd_hip_seeds_t* s, float* dist);
 int rmd_hip_seeds_sync(const rmd_hip_seeds_t* s);
 
 /* knobs (not in the reference) */
-#define RMD_HIP_OPT_MATCHER 0      /* 0 = per-pixel kernel (the reference's shape), 1 = round-1 tile pipeline (66 KB search window), 2 = one-launch frame
-                                      kernel (experimental), 3 = tile pipeline with the compact search kernel (default) */
+#define RMD_HIP_OPT_MATCHER 0      /* 0 = per-pixel kernel (the reference's shape, A/B baseline), 3 = two-launch tile pipeline (default).  The retired
+                                      variants 1 (round-1 tile pipeline, 66 KB search window) and 2 (one-launch frame kernel) exist only in A/B builds
+                                      of the library (-DRMD_AB_MATCHERS, tools/ab_make.sh); elsewhere selecting them is an error */
 #define RMD_HIP_OPT_TIMING 1       /* 1 = bracket every update with HIP events on the handle's stream; 2 = one event pair
                                       around everything between timing_reset and the timing query (no markers in between) */
 #define RMD_HIP_OPT_COLLECT_STATS 2 /* 1 = count live seeds / search steps / NCC evaluations per update;
                                       2 = in-kernel timeline probes instead (see rmd_hip_seeds_trace_download) */
-#define RMD_HIP_OPT_WINDOW 3       /* search-kernel LDS window: 0 or 2 = large (133 x 104 texels, default), 1 = small (69 x 64), for experiments */
+#define RMD_HIP_OPT_WINDOW 3       /* A/B builds, matcher 1 only: LDS window of its search kernel, 0 or 2 = large (133 x 104 texels), 1 = small (69 x 64) */
 #define RMD_HIP_OPT_LAZY_FINALIZE 4 /* 1 (default) = defer an update's last kernel and fuse it into the next update */
 #define RMD_HIP_OPT_LOCAL_MAX 5     /* frame kernel: work items a tile keeps to itself before it hands its search out through the
                                       queue; 0 (default) = from the previous frame's load */
 #define RMD_HIP_OPT_UNIT_ROUNDS 6   /* frame kernel: rounds of 256 NCC evaluations per handed-out unit, 1..4; 0 (default) = from the load */
+#define RMD_HIP_OPT_UNIT_TARGET 7   /* tile pipeline: work units aimed at per frame, in multiples (1..4, default 1) of the resident search workgroups;
+                                      the unit size (1..4 rounds of 256 NCC evaluations) follows from the previous frame's work (experiments) */
 int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value);
 /* kernels of the seed path, for rmd_hip_seeds_timing */
 #define RMD_HIP_STAGE_SEED_INIT 0
@@ -176,15 +182,43 @@ int rmd_hip_seeds_timing(const rmd_hip_seeds_t* s, int stage, double* total_ms, 
 int rmd_hip_seeds_timing_reset(rmd_hip_seeds_t* s);
 /* out[0..2] = live seeds, epipolar steps visited, NCC evaluations of the last update (needs COLLECT_STATS) */
 int rmd_hip_seeds_last_stats(const rmd_hip_seeds_t* s, long long* out3);
-/* tile-kernel diagnostics of the last update (needs COLLECT_STATS): [0..2] as last_stats, [3..5] NCC evaluations served
- * from the LDS window / regular global reads / per-sample reads, [6] max work items of a tile, [7..9] summed workgroup
- * cycles in setup / staging / search, [11] max workgroup cycles, [12] tiles with work, [13] search rounds,
- * [14] max setup cycles, [15] max search cycles */
+/* diagnostics of the last update (needs COLLECT_STATS = 1): [0..2] as last_stats; the tile pipeline fills nothing else (its
+ * per-workgroup probes are the timeline, COLLECT_STATS = 2).  A/B builds, matcher 1: [3..5] NCC evaluations served from the LDS
+ * window / regular global reads / per-sample reads, [6] max work items of a tile, [7..9] summed workgroup cycles in setup / staging /
+ * search, [11] max workgroup cycles, [12] tiles with work, [13] search rounds, [14] max setup cycles, [15] max search cycles */
 int rmd_hip_seeds_last_diagnostics(const rmd_hip_seeds_t* s, long long* out16);
-/* timeline of update number `frame` (0 = first update after COLLECT_STATS was set to 2; the last 256 are kept): pairs
- * (start, end) in 10 ns ticks of the device wall clock, one pair per seed_setup workgroup (16x16 tile, row-major), then
- * seed_plan, then up to 1024 seed_search workgroups; zero pairs = not launched.  Needs 2*(tiles + 1025) words. */
+/* timeline of update number `frame` (0 = first update after COLLECT_STATS was set to 2; the last 256 are kept), tile pipeline: 8 words
+ * per 16x16 tile / search workgroup (row-major tiles; workgroup w of the search shares slot w): [0] search workgroup start, [1] its first unit
+ * staged, [2] setup tile: start | state ready << 32 | end << 48 (relative), [3] search workgroup end, [4] work items, [5] units,
+ * [6] last tile, [7] fallbacks | windows << 32; 10 ns ticks of the device wall clock.  Needs 8 * tiles words. */
 int rmd_hip_seeds_trace_download(rmd_hip_seeds_t* s, int frame, unsigned long long* out, size_t capacity, size_t* written);
+
+/* ---- batched mode: several independent SeedMatrix objects stepped by ONE launch pair ------------------------------------------
+ * BASELINE configs[3] / north_star "a batched mode shards independent image sequences": sequences do not interact (seed_matrix.cu
+ * keeps no state outside the object once the global texture references are gone), and a single 640x480 frame cannot occupy 256 CUs.
+ * A batch owns `n` (1..8) SeedMatrix objects of one size on the current device; each is a full rmd_hip_seeds_t -- set_reference*,
+ * download, plane views, converged_count, point_cloud, denoise all work per member, exactly as for a stand-alone object -- except
+ * that update* is issued for all members at once with the calls below (seed_matrix.cu:120-158 per member: same arithmetic, same
+ * results bit for bit as that member stepped alone) and that rmd_hip_batch_destroy releases the members. */
+int rmd_hip_batch_create(int n, int width, int height, float fx, float fy, float cx, float cy, int patch_side, int max_extent,
+                         rmd_hip_batch_t** out);
+int rmd_hip_batch_destroy(rmd_hip_batch_t* b);
+int rmd_hip_batch_size(const rmd_hip_batch_t* b, int* n);
+/* member `index` (borrowed: valid while the batch lives, not to be destroyed) */
+int rmd_hip_batch_member(rmd_hip_batch_t* b, int index, rmd_hip_seeds_t** member);
+/* SeedMatrix::update for every member i whose frame pointer is not NULL (a member without a frame in this step is left alone).
+ * T_curr_world: n x 12 floats.  Frames: device-resident (read in place until the next synchronising call, like
+ * rmd_hip_seeds_update_device), 8-bit gray host frames (x(1/255) and the member's lens undistortion on the device, like
+ * rmd_hip_seeds_update_u8) or float host frames (like rmd_hip_seeds_update); host frames have been copied when the call returns. */
+int rmd_hip_batch_update_device(rmd_hip_batch_t* b, const float* const* dev_imgs, const size_t* stride_elems, const float* T_curr_world);
+int rmd_hip_batch_update_u8(rmd_hip_batch_t* b, const unsigned char* const* host_gray, const float* T_curr_world);
+int rmd_hip_batch_update(rmd_hip_batch_t* b, const float* const* host_imgs, const float* T_curr_world);
+/* blocks until all work queued by the batch and its members has finished */
+int rmd_hip_batch_sync(rmd_hip_batch_t* b);
+/* RMD_HIP_OPT_TIMING (0 / 2: one HIP event pair on the batch's stream between timing_reset and timing) and RMD_HIP_OPT_UNIT_TARGET */
+int rmd_hip_batch_set_option(rmd_hip_batch_t* b, int option, int value);
+int rmd_hip_batch_timing_reset(rmd_hip_batch_t* b);
+int rmd_hip_batch_timing(rmd_hip_batch_t* b, double* total_ms, long* steps);
 
 /* ---- rmd::DepthmapDenoiser (depthmap_denoiser.cu) --------------------------------------- */
 int rmd_hip_denoiser_create(int width, int height, rmd_hip_denoiser_t** out); /* ctor :143-169 */

@@ -64,6 +64,17 @@ SIGNATURES = {
     "rmd_hip_seeds_init_undistortion_map": (_i, [_p, _f, _f, _f, _f]),
     "rmd_hip_seeds_undistortion_map": (_i, [_p, _p, _p]),
     "rmd_hip_compute_undistortion_map": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _p, _p]),
+    "rmd_hip_batch_create": (_i, [_i, _i, _i, _f, _f, _f, _f, _i, _i, _pp]),
+    "rmd_hip_batch_destroy": (_i, [_p]),
+    "rmd_hip_batch_size": (_i, [_p, _c.POINTER(_i)]),
+    "rmd_hip_batch_member": (_i, [_p, _i, _pp]),
+    "rmd_hip_batch_update_device": (_i, [_p, _p, _p, _p]),
+    "rmd_hip_batch_update_u8": (_i, [_p, _p, _p]),
+    "rmd_hip_batch_update": (_i, [_p, _p, _p]),
+    "rmd_hip_batch_sync": (_i, [_p]),
+    "rmd_hip_batch_set_option": (_i, [_p, _i, _i]),
+    "rmd_hip_batch_timing_reset": (_i, [_p]),
+    "rmd_hip_batch_timing": (_i, [_p, _c.POINTER(_c.c_double), _c.POINTER(_c.c_long)]),
     "rmd_hip_denoiser_create": (_i, [_i, _i, _pp]),
     "rmd_hip_denoiser_destroy": (_i, [_p]),
     "rmd_hip_denoiser_set_large_sigma_sq": (_i, [_p, _f]),

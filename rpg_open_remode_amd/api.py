@@ -12,6 +12,7 @@ test/dataset_main.cpp):
     rmd::ImageReducer<T>    include/rmd/reduction.cuh:26-62
     rmd::Depthmap           include/rmd/depthmap.h:34-129   (numpy arrays instead of cv::Mat)
     rmd::checkCudaDevice    include/rmd/check_cuda_device.cuh:24
+    SeedMatrixBatch         (not in the reference) several SeedMatrix objects whose update() calls are issued as one launch pair
 
 Everything computes on the GPU through librmd_hip.so; nothing here falls back to the CPU.
 """
@@ -22,14 +23,15 @@ import numpy as np
 from . import _lib
 from ._lib import RmdHipError, check
 
-__all__ = ["PinholeCamera", "SE3", "DeviceImage", "SeedMatrix", "DepthmapDenoiser", "ImageReducer", "Depthmap",
+__all__ = ["PinholeCamera", "SE3", "DeviceImage", "SeedMatrix", "SeedMatrixBatch", "DepthmapDenoiser", "ImageReducer", "Depthmap",
            "ConvergenceStates", "checkCudaDevice", "RmdHipError"]
 
 PLANE_MU, PLANE_SIGMA_SQ, PLANE_A, PLANE_B, PLANE_CONVERGENCE = 0, 1, 2, 3, 4
 PLANE_SUM_TEMPL, PLANE_CONST_TEMPL_DENOM, PLANE_EPIPOLAR_MATCHES, PLANE_REF_IMG, PLANE_CURR_IMG = 5, 6, 7, 8, 9
 KIND_F32, KIND_I32, KIND_F32X2 = 0, 1, 2
-OPT_MATCHER, OPT_TIMING, OPT_COLLECT_STATS, OPT_WINDOW, OPT_LAZY_FINALIZE, OPT_LOCAL_MAX, OPT_UNIT_ROUNDS = 0, 1, 2, 3, 4, 5, 6
-MATCHER_PIXEL, MATCHER_PIPELINE_R01, MATCHER_FRAME, MATCHER_PIPELINE = 0, 1, 2, 3
+OPT_MATCHER, OPT_TIMING, OPT_COLLECT_STATS, OPT_WINDOW, OPT_LAZY_FINALIZE, OPT_LOCAL_MAX, OPT_UNIT_ROUNDS, OPT_UNIT_TARGET = 0, 1, 2, 3, 4, 5, 6, 7
+MATCHER_PIXEL, MATCHER_PIPELINE = 0, 3
+MATCHER_PIPELINE_R01, MATCHER_FRAME = 1, 2  # retired variants: A/B builds of the library only (tools/ab_make.sh)
 STAGE_SEED_INIT, STAGE_UPDATE, STAGE_COUNT = 0, 1, 2
 DENOISE_OPT_TIMING, DENOISE_OPT_ITERS_PER_LAUNCH, DENOISE_OPT_GEOMETRY = 1, 2, 3
 
@@ -224,17 +226,21 @@ class ImageReducer:
 
 
 class SeedMatrix:
-    def __init__(self, width, height, cam, patch_side=5, max_extent=100):
+    def __init__(self, width, height, cam, patch_side=5, max_extent=100, _member_of=None, _ptr=None):
         self.width, self.height, self.patch_side = int(width), int(height), int(patch_side)
+        self._batch = _member_of  # a member of a SeedMatrixBatch is owned (and kept alive) by the batch
+        if _member_of is not None:
+            self.ptr = _ptr
+            return
         h = ctypes.c_void_p()
         check(_lib.lib().rmd_hip_seeds_create(self.width, self.height, cam.fx, cam.fy, cam.cx, cam.cy, int(patch_side),
                                               int(max_extent), ctypes.byref(h)))
         self.ptr = h.value
 
     def close(self):
-        if getattr(self, "ptr", None):
+        if getattr(self, "ptr", None) and self._batch is None:
             _lib.lib().rmd_hip_seeds_destroy(self.ptr)
-            self.ptr = None
+        self.ptr = None
 
     def __del__(self):
         try:
@@ -378,28 +384,16 @@ class SeedMatrix:
 
 
     def traceDownload(self, frame):
-        """Timeline of update `frame` since setOption(OPT_COLLECT_STATS, 2): dict of (n, 2) uint64 arrays of workgroup
-        (start, end) ticks (10 ns) for 'setup', 'plan', 'search' (only the workgroups that ran)."""
-        tiles = ((self.width + 15) // 16) * ((self.height + 15) // 16)
-        n = 2 * (tiles + 1025)
-        out = np.zeros(n, np.uint64)
-        written = ctypes.c_size_t()
-        check(_lib.lib().rmd_hip_seeds_trace_download(self.ptr, int(frame), out.ctypes.data, n, ctypes.byref(written)))
-        rec = out.reshape(-1, 2)
-        search = rec[tiles + 1:]
-        return {"setup": rec[:tiles], "plan": rec[tiles:tiles + 1], "search": search[search[:, 1] != 0]}
-
-    def frameTraceDownload(self, frame):
-        """Timeline of update `frame` of the one-launch frame kernel (OPT_MATCHER 2) since setOption(OPT_COLLECT_STATS, 2): an
-        (n_workgroups, 8) uint64 array -- start, first tile set up, no tiles left to claim, exit (10 ns ticks of the device
-        wall clock), work items of the tiles set up here (bits 32..: tiles handed out), units searched, tiles set up.  Rows
-        beyond the (persistent) grid are zero."""
+        """Timeline of update `frame` of the tile pipeline since setOption(OPT_COLLECT_STATS, 2): an (n_tiles, 8) uint64 array, see
+        rmd_hip_seeds_trace_download in include/rmd_hip.h (row t: setup tile t in word 2, search workgroup t in the other words)."""
         tiles = ((self.width + 15) // 16) * ((self.height + 15) // 16)
         n = tiles * 8
         out = np.zeros(n, np.uint64)
         written = ctypes.c_size_t()
         check(_lib.lib().rmd_hip_seeds_trace_download(self.ptr, int(frame), out.ctypes.data, n, ctypes.byref(written)))
         return out.reshape(-1, 8)
+
+    frameTraceDownload = traceDownload  # (name used by the timeline tools)
 
     def lastDiagnosticsRaw(self):
         out = np.zeros(16, np.int64)
@@ -413,6 +407,85 @@ class SeedMatrix:
                  "cycles_setup", "cycles_stage", "cycles_search", "_10", "max_wg_cycles", "tiles_with_work", "rounds",
                  "max_setup_cycles", "max_search_cycles"]
         return {n: int(v) for n, v in zip(names, out) if not n.startswith("_")}
+
+
+class SeedMatrixBatch:
+    """Several independent SeedMatrix objects of one size on one GPU whose update() calls are issued TOGETHER, as one launch pair
+    (rmd_hip_batch_*; BASELINE configs[3]: independent sequences).  `batch[i]` is a full SeedMatrix -- setReferenceImage*, downloads,
+    getters, getConvergedCount, pointCloud, use with DepthmapDenoiser -- whose update* methods are replaced by the batch's: per member
+    the arithmetic and the results are those of that member stepped alone (seed_matrix.cu:120-158)."""
+
+    def __init__(self, n, width, height, cam, patch_side=5, max_extent=100):
+        self.n, self.width, self.height, self.patch_side = int(n), int(width), int(height), int(patch_side)
+        h = ctypes.c_void_p()
+        check(_lib.lib().rmd_hip_batch_create(self.n, self.width, self.height, cam.fx, cam.fy, cam.cx, cam.cy, int(patch_side), int(max_extent),
+                                              ctypes.byref(h)))
+        self.ptr = h.value
+        self.members = []
+        for i in range(self.n):
+            m = ctypes.c_void_p()
+            check(_lib.lib().rmd_hip_batch_member(self.ptr, i, ctypes.byref(m)))
+            self.members.append(SeedMatrix(width, height, cam, patch_side, max_extent, _member_of=self, _ptr=m.value))
+
+    def __len__(self): return self.n
+    def __getitem__(self, i): return self.members[i]
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            for m in self.members:
+                m.ptr = None
+            _lib.lib().rmd_hip_batch_destroy(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _poses(self, poses):
+        T = np.zeros((self.n, 12), np.float32)
+        for i, p in enumerate(poses):
+            if p is not None:
+                T[i] = _as_pose(p)
+        return T
+
+    def updateDevice(self, dev_ptrs, strides, poses):
+        """dev_ptrs[i]: device address of member i's frame (None / 0: no frame for that member in this step)"""
+        ptrs = (ctypes.c_void_p * self.n)(*[int(p) if p else None for p in dev_ptrs])
+        st = (ctypes.c_size_t * self.n)(*[int(v) for v in strides])
+        T = self._poses(poses)
+        check(_lib.lib().rmd_hip_batch_update_device(self.ptr, ptrs, st, T.ctypes.data))
+        return True
+
+    def _host(self, fn, imgs, poses, dtype):
+        keep = [None if im is None else np.ascontiguousarray(im, dtype) for im in imgs]
+        for im in keep:
+            assert im is None or im.shape == (self.height, self.width)
+        ptrs = (ctypes.c_void_p * self.n)(*[None if im is None else im.ctypes.data for im in keep])
+        T = self._poses(poses)
+        check(fn(self.ptr, ptrs, T.ctypes.data))
+        return True
+
+    def updateU8(self, gray_frames, poses):
+        return self._host(_lib.lib().rmd_hip_batch_update_u8, gray_frames, poses, np.uint8)
+
+    def update(self, float_frames, poses):
+        return self._host(_lib.lib().rmd_hip_batch_update, float_frames, poses, np.float32)
+
+    def sync(self):
+        check(_lib.lib().rmd_hip_batch_sync(self.ptr))
+
+    def setOption(self, option, value):
+        check(_lib.lib().rmd_hip_batch_set_option(self.ptr, int(option), int(value)))
+
+    def timingReset(self):
+        check(_lib.lib().rmd_hip_batch_timing_reset(self.ptr))
+
+    def timing(self):
+        ms, n = ctypes.c_double(), ctypes.c_long()
+        check(_lib.lib().rmd_hip_batch_timing(self.ptr, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
 
 
 class DepthmapDenoiser:

@@ -13,8 +13,10 @@
 #include <string.h>
 #include <time.h>
 
+#include <condition_variable>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <tuple>
 #include <utility>
 #include <vector>
@@ -22,8 +24,12 @@
 #include "rmd_kernels.hpp"
 #include "rmd_matcher.hpp"
 #include "rmd_frame.hpp"
+#ifdef RMD_AB_MATCHERS  // retired variants of the update, A/B builds only (tools/ab_make.sh)
+#include "ab/rmd_matcher_r01.hpp"
+#include "ab/rmd_frame_one_launch.hpp"
+#endif
 
-#define RMD_HIP_VERSION_NUMBER 200
+#define RMD_HIP_VERSION_NUMBER 300
 
 
 namespace {
@@ -193,7 +199,14 @@ struct rmd_hip_seeds {
   hipStream_t stream = nullptr;
   unsigned long long* d_scalars = nullptr;  // [0] count result, [1..16] diagnostics
   unsigned long long* h_scalars = nullptr;  // pinned mirror
-  int opt_matcher = 3, opt_timing = 0, opt_stats = 0, opt_window = 0, opt_local_max = 0, opt_unit_rounds = 0;
+  int opt_matcher = 3, opt_timing = 0, opt_stats = 0, opt_window = 0, opt_local_max = 0, opt_unit_rounds = 0, opt_unit_target = 1;
+  // a SeedMatrix that is a member of a batch (rmd_hip_batch_*) shares the batch's streams and update workspace: its update
+  // kernels are launched by the batch, for all members at once; everything else (reference frames, observers) works per member
+  struct rmd_hip_batch* batch = nullptr;
+  int seq = 0;                              // index in the batch's workspace (0 for a plain SeedMatrix)
+  rmdk::MatcherWorkspace* mws = nullptr;    // the update workspace: &matcher_ws, or the batch's
+  bool async_count_valid = false;           // the pinned CONVERGED count of the workspace belongs to this handle's latest update ...
+  unsigned int async_number = 0;            // ... which carried this number
   hipEvent_t region_start = nullptr, region_stop = nullptr;
   long region_updates = 0;
   // deferred finalisation of the last tile-pipeline update (see rmd_matcher.hpp): pending until the next update()
@@ -225,8 +238,6 @@ struct rmd_hip_seeds {
   unsigned int* h_progress = nullptr;       // pinned: [0] number of the ingested frame whose setup kernel has started, [1] error bits
   unsigned long long zc_number = 0;         // ingested frames so far (the device sees the low 32 bits and compares modulo 2^32)
   int opt_fused_ingest = 1;                 // RMD_HIP_FUSED_INGEST=0 switches back to the copy-stream pipeline (A/B)
-  rmdk::IngestArgs pending_ingest;          // consumed by the next launch of the compact pipeline
-  bool has_pending_ingest = false;
   double ingest_us[4] = {0, 0, 0, 0};  // diagnostics (RMD_HIP_INGEST_PROFILE): host time waiting for a slot, copying, submitting; frames
   bool ingest_profile = false, ingest_host_wait = false;
   StageTimer timers[RMD_HIP_NUM_SEED_STAGES];
@@ -240,7 +251,30 @@ struct rmd_hip_seeds {
   unsigned int* d_pc_counts = nullptr;  // point cloud (allocated at the first request): per-block counts / offsets, [n_blocks] = total
   float4* d_pc_points = nullptr;        // W x H points
   rmdk::MatcherWorkspace matcher_ws;
+#ifdef RMD_AB_MATCHERS
   rmdk::FrameWorkspace frame_ws;
+#endif
+};
+
+// rmd_hip_batch_*: up to rmdk::MAX_BATCH SeedMatrix objects of one size whose update() calls are issued together, as ONE launch pair
+struct rmd_hip_batch {
+  int n = 0, device = 0, num_cus = 256;
+  rmd_hip_seeds* members[rmdk::MAX_BATCH] = {};
+  hipStream_t stream = nullptr, copy_stream = nullptr;
+  rmdk::MatcherWorkspace ws;
+  // frames handed over in host memory: the frames of one step, back to back, through SLOTS pinned buffers and SLOTS staging buffers
+  // (see ingest_current_fused: the same protocol, one sequence number per step)
+  static constexpr int SLOTS = 3;
+  unsigned char* h_stage[SLOTS] = {};
+  unsigned char* d_stage[SLOTS] = {};
+  size_t stage_bytes = 0;                   // capacity of each of the buffers above
+  unsigned int* h_seq = nullptr;
+  unsigned int* d_flag = nullptr;
+  unsigned int* h_progress = nullptr;
+  unsigned long long step_number = 0;
+  int opt_timing = 0, opt_unit_target = 1;
+  hipEvent_t region_start = nullptr, region_stop = nullptr;
+  long region_updates = 0;
 };
 
 namespace {
@@ -258,10 +292,22 @@ int dispatch_side(int side, F&& f) {
   }
 }
 
+// the deferred finalisation of this handle's last update, as a kernel of its own (an observer is about to look at the state)
 int seeds_flush(rmd_hip_seeds* s) {
   if (s->finalize_pending) {
     s->finalize_pending = false;
-    HIP_TRY(rmdk::launch_seed_finalize(s->P_pending, s->matcher_ws, s->stream));
+    HIP_TRY(rmdk::launch_seed_finalize(s->P_pending, *s->mws, s->stream, s->seq));
+  }
+  return RMD_HIP_OK;
+}
+
+// the error word the setup kernel's ingest workgroups raise when a staging copy never arrived: reported ONCE (the frames of that update are
+// invalid), then cleared, so that the handle is usable again from the next reference frame on
+int ingest_error_check(unsigned int* h_progress) {
+  if (h_progress && h_progress[1] != 0u) {
+    h_progress[1] = 0u;
+    return fail(RMD_HIP_ERR_RUNTIME, "seed update: the staging copy of a host frame did not complete within the kernel's bounded wait (about "
+                                     "0.1 s); the seed state is invalid until the next setReferenceImage");
   }
   return RMD_HIP_OK;
 }
@@ -270,13 +316,19 @@ int seeds_flush(rmd_hip_seeds* s) {
 int seeds_sync(const rmd_hip_seeds* s) {
   rmd_hip_seeds* m = const_cast<rmd_hip_seeds*>(s);
   TRY(seeds_flush(m));
+#ifdef RMD_AB_MATCHERS
   if (m->frame_ws.frame > 0) HIP_TRY(hipMemcpyAsync(m->frame_ws.h_error, m->frame_ws.d_error, sizeof(unsigned int), hipMemcpyDeviceToHost, s->stream));
+#endif
   HIP_TRY(hipStreamSynchronize(s->stream));
-  if (m->h_progress && m->h_progress[1] != 0u)
-    return fail(RMD_HIP_ERR_RUNTIME, "seed update: the staging copy of a host frame never completed; results are invalid");
-  if (m->frame_ws.h_error && m->frame_ws.h_error[0] != 0u)
-    return fail(RMD_HIP_ERR_RUNTIME, "seed update: a bounded wait inside the frame kernel ran out (error bits 0x%x); results are invalid",
-                m->frame_ws.h_error[0]);
+  TRY(ingest_error_check(m->batch ? m->batch->h_progress : m->h_progress));
+#ifdef RMD_AB_MATCHERS
+  if (m->frame_ws.h_error && m->frame_ws.h_error[0] != 0u) {
+    const unsigned int bits = m->frame_ws.h_error[0];
+    m->frame_ws.h_error[0] = 0u;
+    (void)hipMemsetAsync(m->frame_ws.d_error, 0, sizeof(unsigned int), s->stream);
+    return fail(RMD_HIP_ERR_RUNTIME, "seed update: a bounded wait inside the frame kernel ran out (error bits 0x%x); results are invalid", bits);
+  }
+#endif
   for (auto& t : m->timers) t.drain();
   if (m->stats_pending) {
     for (int k = 0; k < 16; ++k) m->last_stats[k] = static_cast<long long>(m->h_scalars[1 + k]);
@@ -302,7 +354,26 @@ int seeds_launch_init(rmd_hip_seeds* s) {
   });
 }
 
-int seeds_launch_update(rmd_hip_seeds* s) {
+// this handle's block of a launch of the update pipeline: the frame's parameters, the pending finalisation of its previous frame
+rmdk::SeqArgs seq_args_of(const rmd_hip_seeds* s, const rmdk::SeedParams& P) {
+  rmdk::SeqArgs Q;
+  memset(&Q, 0, sizeof(Q));
+  Q.P = P;
+  Q.fuse_prev = s->finalize_pending ? 1 : 0;
+  Q.T_ref_curr_prev = s->finalize_pending ? s->P_pending.T_ref_curr : P.T_ref_curr;
+  Q.active = 1;
+  return Q;
+}
+
+// per-handle part of a host frame that the setup kernel's ingest workgroups bring in (see ingest_current_fused / batch_update_host)
+struct PendingIngest {
+  rmdk::IngestArgs common;
+  const unsigned int* u8 = nullptr;
+  const float* f32 = nullptr;
+};
+
+int seeds_launch_update(rmd_hip_seeds* s, const PendingIngest* ingest = nullptr) {
+  if (s->batch) return fail(RMD_HIP_ERR_INVALID_ARG, "update: this SeedMatrix is a member of a batch; its updates are issued with rmd_hip_batch_update*");
   rmdk::SeedParams P = s->P;
   P.stats = nullptr;
   P.trace = nullptr;
@@ -315,6 +386,7 @@ int seeds_launch_update(rmd_hip_seeds* s) {
   }
   int rc;
   if (s->opt_timing == 2) ++s->region_updates;
+  s->async_count_valid = false;
   {
     ScopedStage st(s->opt_timing == 1 ? &s->timers[RMD_HIP_STAGE_UPDATE] : nullptr, s->stream);
     rc = dispatch_side(s->patch_side, [&](auto side) {
@@ -323,6 +395,7 @@ int seeds_launch_update(rmd_hip_seeds* s) {
         TRY(seeds_flush(s));
         const dim3 block(64, 4), grid((s->width + 63) / 64, (s->height + 3) / 4);
         hipLaunchKernelGGL((rmdk::seed_update_pixel_kernel<SIDE>), grid, block, 0, s->stream, P);
+#ifdef RMD_AB_MATCHERS
       } else if (s->opt_matcher == 2) {
         TRY(seeds_flush(s));
         unsigned long long* slice = nullptr;
@@ -331,24 +404,37 @@ int seeds_launch_update(rmd_hip_seeds* s) {
           ++s->trace_frame;
         }
         HIP_TRY(rmdk::launch_seed_frame<SIDE>(P, s->frame_ws, s->stream, s->num_cus, s->opt_local_max, s->opt_unit_rounds, slice));
-      } else {
+      } else if (s->opt_matcher == 1) {
         const bool fuse = s->finalize_pending;
         const rmdk::Pose T_prev = fuse ? s->P_pending.T_ref_curr : P.T_ref_curr;
-        if (s->opt_matcher == 3) {
-          rmdk::SeedParams Pt = P;
-          if (s->opt_stats == 2 && s->frame_ws.d_trace) {  // timeline probes of the search workgroups (same slices as the frame kernel's)
-            Pt.trace = s->frame_ws.d_trace + static_cast<size_t>(s->trace_frame % rmdk::FR_TRACE_FRAMES) * s->frame_ws.trace_slice_u64();
-            ++s->trace_frame;
-          }
-          HIP_TRY(rmdk::launch_seed_pipeline_compact<SIDE>(Pt, s->matcher_ws, s->frame_ws, s->stream, s->num_cus, fuse, T_prev, 1 + s->opt_window,
-                                                           s->has_pending_ingest ? &s->pending_ingest : nullptr));
-          s->has_pending_ingest = false;
-        }
-        else HIP_TRY(rmdk::launch_seed_update_tile<SIDE>(P, s->matcher_ws, s->stream, s->num_cus, s->opt_window, fuse, T_prev));
+        HIP_TRY(rmdk::launch_seed_update_tile<SIDE>(P, s->matcher_ws, s->stream, s->num_cus, s->opt_window, fuse, T_prev));
         s->P_pending = P;
         s->P_pending.stats = nullptr;
         s->P_pending.trace = nullptr;
         s->finalize_pending = true;
+        if (!s->opt_lazy || s->opt_stats == 1) TRY(seeds_flush(s));
+#endif
+      } else {
+        rmdk::SeedParams Pt = P;
+        if (s->opt_stats == 2 && s->matcher_ws.d_wg_trace) {  // timeline probes of the setup tiles and the search workgroups
+          Pt.trace = s->matcher_ws.d_wg_trace + static_cast<size_t>(s->trace_frame % rmdk::FR_TRACE_FRAMES) * s->matcher_ws.wg_trace_slice_u64();
+          ++s->trace_frame;
+        }
+        rmdk::BatchArgs<1> B;
+        B.seq[0] = seq_args_of(s, Pt);
+        if (ingest) {
+          B.seq[0].ingest_u8 = ingest->u8; B.seq[0].ingest_f32 = ingest->f32;
+          B.seq[0].ingest_dst = const_cast<float*>(P.cur);
+          B.seq[0].ingest_map1 = ingest->u8 ? s->d_undist_map1 : nullptr;  // null without lens undistortion
+          B.seq[0].ingest_map2 = ingest->u8 ? s->d_undist_map2 : nullptr;
+        }
+        HIP_TRY((rmdk::launch_seed_pipeline_compact<SIDE, 1>(B, 1, s->matcher_ws, s->stream, s->num_cus, s->opt_unit_target, ingest ? &ingest->common : nullptr)));
+        s->P_pending = P;
+        s->P_pending.stats = nullptr;
+        s->P_pending.trace = nullptr;
+        s->finalize_pending = true;
+        s->async_count_valid = true;  // the search kernel mirrors this frame's CONVERGED count to pinned memory
+        s->async_number = s->matcher_ws.update_number;
         if (!s->opt_lazy || s->opt_stats == 1) TRY(seeds_flush(s));
       }
       HIP_TRY(hipGetLastError());
@@ -378,18 +464,22 @@ int seeds_after_reference(rmd_hip_seeds* s, const float* T_curr_world, float min
   memcpy(T.d, T_curr_world, sizeof(T.d));
   s->T_world_ref = pose_inverse(T);
   TRY(seeds_launch_init(s));
-  // the frame kernel's load statistics belong to the old sequence
+  s->async_count_valid = false;
+  // the pipeline's load statistics (unit size from the previous frame's work) belong to the old sequence; in a batch the other
+  // members' next frame simply starts from the largest unit size again
+#ifdef RMD_AB_MATCHERS
   s->frame_ws.frame = 0;
   HIP_TRY(hipMemsetAsync(s->frame_ws.d_ctl, 0, 3 * rmdk::FR_CTL_WORDS * sizeof(unsigned int), s->stream));
-  s->matcher_ws.frame = 0;
-  HIP_TRY(hipMemsetAsync(s->matcher_ws.d_shards, 0, 3 * rmdk::UNIT_SHARDS * sizeof(unsigned long long), s->stream));
+#endif
+  s->mws->frame = 0;
+  HIP_TRY(hipMemsetAsync(s->mws->d_shards, 0, 3 * rmdk::UNIT_SHARDS * sizeof(unsigned long long), s->stream));
   s->has_reference = true;
   // the reference synchronises here (seed_matrix.cu:113); so do we: the host image is borrowed
   return seeds_sync(s);
 }
 
 // common tail of update (seed_matrix.cu:124-157) once the frame is in planes[CURR_IMG]
-int seeds_after_frame(rmd_hip_seeds* s, const float* T_curr_world) {
+void seeds_frame_pose(rmd_hip_seeds* s, const float* T_curr_world) {
   rmdk::Pose T;
   memcpy(T.d, T_curr_world, sizeof(T.d));
   const rmdk::Pose T_curr_ref = pose_compose(T, s->T_world_ref);
@@ -397,7 +487,10 @@ int seeds_after_frame(rmd_hip_seeds* s, const float* T_curr_world) {
   s->dist_from_ref = sqrtf(tx * tx + ty * ty + tz * tz);
   s->P.T_curr_ref = T_curr_ref;
   s->P.T_ref_curr = pose_inverse(T_curr_ref);
-  return seeds_launch_update(s);
+}
+int seeds_after_frame(rmd_hip_seeds* s, const float* T_curr_world, const PendingIngest* ingest = nullptr) {
+  seeds_frame_pose(s, T_curr_world);
+  return seeds_launch_update(s, ingest);
 }
 
 }  // namespace
@@ -517,7 +610,12 @@ int rmd_hip_image_info(const rmd_hip_image_t* img, int* kind, int* width, int* h
 }
 
 // ---- SeedMatrix -----------------------------------------------------------------------------
+static int seeds_destroy_impl(rmd_hip_seeds* s);
 int rmd_hip_seeds_destroy(rmd_hip_seeds_t* s) {
+  if (s && s->batch) return fail(RMD_HIP_ERR_INVALID_ARG, "seeds_destroy: this SeedMatrix belongs to a batch (rmd_hip_batch_destroy releases it)");
+  return seeds_destroy_impl(s);
+}
+static int seeds_destroy_impl(rmd_hip_seeds* s) {
   if (!s) return RMD_HIP_OK;
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
@@ -539,13 +637,15 @@ int rmd_hip_seeds_destroy(rmd_hip_seeds_t* s) {
     if (k > 0 && s->cur_planes[k]) (void)hipFree(s->cur_planes[k]);  // [0] belongs to planes[]
   }
   if (s->cur_planes[0]) s->planes[RMD_HIP_PLANE_CURR_IMG].data = s->cur_planes[0];
-  if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
+  if (s->copy_stream && !s->batch) (void)hipStreamDestroy(s->copy_stream);
   if (s->region_start) (void)hipEventDestroy(s->region_start);
   if (s->region_stop) (void)hipEventDestroy(s->region_stop);
   for (auto& pl : s->planes)
     if (pl.owns && pl.data) (void)hipFree(pl.data);
   s->matcher_ws.release();
+#ifdef RMD_AB_MATCHERS
   s->frame_ws.release();
+#endif
   if (s->d_undist_map1) (void)hipFree(s->d_undist_map1);
   if (s->d_undist_map2) (void)hipFree(s->d_undist_map2);
   if (s->d_pc_counts) (void)hipFree(s->d_pc_counts);
@@ -555,15 +655,23 @@ int rmd_hip_seeds_destroy(rmd_hip_seeds_t* s) {
   if (s->h_progress) (void)hipHostFree(s->h_progress);
   if (s->h_seq) (void)hipHostFree(s->h_seq);
   if (s->d_zc_flag) (void)hipFree(s->d_zc_flag);
-  if (s->stream) (void)hipStreamDestroy(s->stream);
+  if (s->stream && !s->batch) (void)hipStreamDestroy(s->stream);
   delete s;
   return RMD_HIP_OK;
 }
 
 static int ingest_init(rmd_hip_seeds* s);
+static int seeds_create_impl(int width, int height, float fx, float fy, float cx, float cy, int patch_side, int max_extent, rmd_hip_batch* batch, int seq,
+                             rmd_hip_seeds_t** out);
 
 int rmd_hip_seeds_create(int width, int height, float fx, float fy, float cx, float cy, int patch_side, int max_extent,
                          rmd_hip_seeds_t** out) {
+  return seeds_create_impl(width, height, fx, fy, cx, cy, patch_side, max_extent, nullptr, 0, out);
+}
+
+// batch != null: member `seq` of that batch -- the batch's streams and update workspace instead of its own
+static int seeds_create_impl(int width, int height, float fx, float fy, float cx, float cy, int patch_side, int max_extent, rmd_hip_batch* batch, int seq,
+                             rmd_hip_seeds_t** out) {
   if (!out) return fail(RMD_HIP_ERR_INVALID_ARG, "seeds_create: null output");
   *out = nullptr;
   if (width <= 0 || height <= 0) return fail(RMD_HIP_ERR_INVALID_ARG, "seeds_create: bad size %dx%d", width, height);
@@ -577,8 +685,11 @@ int rmd_hip_seeds_create(int width, int height, float fx, float fy, float cx, fl
   if (!s) return fail(RMD_HIP_ERR_RUNTIME, "seeds_create: out of host memory");
   s->width = width; s->height = height; s->patch_side = patch_side;
   (void)hipGetDevice(&s->device);
-  auto bail = [&](int rc) { rmd_hip_seeds_destroy(s); return rc; };
-  if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess)
+  s->batch = batch; s->seq = seq;
+  s->mws = batch ? &batch->ws : &s->matcher_ws;
+  auto bail = [&](int rc) { seeds_destroy_impl(s); return rc; };
+  if (batch) { s->stream = batch->stream; s->copy_stream = batch->copy_stream; }
+  else if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess)
     return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: hipStreamCreate failed"));
   for (int p = 0; p < RMD_HIP_NUM_PLANES; ++p) {
     const int kind = p == RMD_HIP_PLANE_CONVERGENCE ? RMD_HIP_KIND_I32
@@ -591,7 +702,7 @@ int rmd_hip_seeds_create(int width, int height, float fx, float fy, float cx, fl
   if (hipMalloc(reinterpret_cast<void**>(&s->d_scalars), 17 * sizeof(unsigned long long)) != hipSuccess ||
       hipHostMalloc(reinterpret_cast<void**>(&s->h_scalars), 17 * sizeof(unsigned long long)) != hipSuccess)
     return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: scalar buffers"));
-  (void)hipMemset(s->d_scalars, 0, 17 * sizeof(unsigned long long));
+  if (hipMemset(s->d_scalars, 0, 17 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: scalar buffers"));
   memset(s->h_scalars, 0, 17 * sizeof(unsigned long long));
   rmdk::SeedParams& P = s->P;
   memset(&P, 0, sizeof(P));
@@ -612,13 +723,16 @@ int rmd_hip_seeds_create(int width, int height, float fx, float fy, float cx, fl
   P.cam = rmdk::Cam{fx, fy, cx, cy};
   P.one_pix_angle = atan2f(1.0f, 2.0f * fx) * 2.0f;  // pinhole_camera.cuh:56-59
   P.max_extent = static_cast<float>(max_extent);
-  const int rcw = s->matcher_ws.allocate(width, height, P.stride);
-  if (rcw != 0) return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: matcher workspace"));
+  if (!batch && s->matcher_ws.allocate(width, height, P.stride) != 0) return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: update workspace"));
+  if (batch && (batch->ws.stride != P.stride || batch->ws.tiles_x != (width + rmdk::TILE_W - 1) / rmdk::TILE_W || batch->ws.tiles_y != (height + rmdk::TILE_H - 1) / rmdk::TILE_H))
+    return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: the batch's workspace has another geometry"));
+#ifdef RMD_AB_MATCHERS
   if (s->frame_ws.allocate(width, height, P.stride) != 0) return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: frame workspace"));
+#endif
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) s->num_cus = prop.multiProcessorCount;
   int lds = 0;
-  if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, s->device) == hipSuccess && lds > 0) s->matcher_ws.lds_bytes = lds;
+  if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, s->device) == hipSuccess && lds > 0) s->mws->lds_bytes = lds;
   if (hipDeviceSynchronize() != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: device synchronisation failed"));  // all fills done
   if (ingest_init(s) != RMD_HIP_OK) return bail(RMD_HIP_ERR_RUNTIME);  // the copy stream is created right next to the compute stream
   *out = s;
@@ -683,8 +797,8 @@ int rmd_hip_seeds_update_device(rmd_hip_seeds_t* s, const float* dev_img, size_t
 //   compute   wait until the slot's plane is staged -> this frame's kernels -> mark the slot's plane free
 //     The current image rotates through SLOTS planes; planes[CURR_IMG] always names the one of the latest frame.
 static int ingest_init(rmd_hip_seeds* s) {
-  if (s->copy_stream) return RMD_HIP_OK;
-  HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+  if (s->h_progress) return RMD_HIP_OK;
+  if (!s->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));  // (a batch member uses the batch's)
   s->ingest_profile = getenv("RMD_HIP_INGEST_PROFILE") != nullptr;
   if (const char* e = getenv("RMD_HIP_INGEST_HOST_WAIT")) s->ingest_host_wait = e[0] == '1';
   if (const char* e = getenv("RMD_HIP_FUSED_INGEST")) s->opt_fused_ingest = e[0] != '0';
@@ -722,6 +836,94 @@ static double host_now_us() {
   return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
 }
 
+static inline void cpu_relax() {  // a polite spin, whatever the host architecture
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield" ::: "memory");
+#else
+  std::this_thread::yield();
+#endif
+}
+
+// Copy of a caller's frame into a pinned staging buffer.  A float VGA frame is 1.2 MB: one core moves it in ~50 us, which made the host,
+// not the GPU, the bound of update(float*) -- the reference's own signature (seed_matrix.cu:120-128).  Frames of 256 KB and more are
+// split across a few persistent helper threads (created at the first such copy, parked on a condition variable in between).
+namespace {
+class CopyPool {
+ public:
+  static CopyPool& instance() {
+    static CopyPool pool;
+    return pool;
+  }
+  void copy(void* dst, const void* src, size_t bytes) {
+    const int parts = n_workers_ + 1;
+    if (n_workers_ == 0 || bytes < kMinBytes) {
+      memcpy(dst, src, bytes);
+      return;
+    }
+    std::lock_guard<std::mutex> one_copy_at_a_time(call_mutex_);
+    const size_t chunk = ((bytes + parts - 1) / parts + 4095) & ~static_cast<size_t>(4095);
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      dst_ = static_cast<char*>(dst); src_ = static_cast<const char*>(src); bytes_ = bytes; chunk_ = chunk;
+      pending_ = n_workers_;
+      ++generation_;
+    }
+    cv_.notify_all();
+    const size_t mine = static_cast<size_t>(n_workers_) * chunk;  // the caller takes the last part
+    if (mine < bytes) memcpy(dst_ + mine, src_ + mine, bytes - mine);
+    // the helpers' parts take a few microseconds: spin for them (a condition variable would cost more than the copy)
+    while (__atomic_load_n(&pending_, __ATOMIC_ACQUIRE) != 0) cpu_relax();
+  }
+
+ private:
+  static constexpr size_t kMinBytes = 256 * 1024;
+  CopyPool() {
+    int n = 3;
+    if (const char* e = getenv("RMD_HIP_COPY_THREADS")) n = atoi(e) - 1;
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw != 0 && static_cast<unsigned>(n + 1) > hw) n = static_cast<int>(hw) - 1;
+    if (n < 0) n = 0;
+    if (n > 15) n = 15;
+    for (int i = 0; i < n; ++i) workers_.emplace_back([this, i] { run(i); });
+    n_workers_ = n;
+  }
+  ~CopyPool() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : workers_) t.join();
+  }
+  void run(int index) {
+    unsigned long long seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> lk(m_);
+      cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
+      if (stop_) return;
+      seen = generation_;
+      char* dst = dst_; const char* src = src_; const size_t bytes = bytes_, chunk = chunk_;
+      lk.unlock();
+      const size_t off = static_cast<size_t>(index) * chunk;
+      if (off < bytes) memcpy(dst + off, src + off, bytes - off < chunk ? bytes - off : chunk);
+      __atomic_fetch_sub(&pending_, 1, __ATOMIC_RELEASE);
+    }
+  }
+  std::vector<std::thread> workers_;
+  int n_workers_ = 0;
+  std::mutex m_, call_mutex_;
+  std::condition_variable cv_;
+  bool stop_ = false;
+  unsigned long long generation_ = 0;
+  char* dst_ = nullptr; const char* src_ = nullptr;
+  size_t bytes_ = 0, chunk_ = 0;
+  int pending_ = 0;
+};
+}  // namespace
+static inline void host_copy(void* dst, const void* src, size_t bytes) { CopyPool::instance().copy(dst, src, bytes); }
+
 static int ingest_frame(rmd_hip_seeds* s, const unsigned char* host_gray, const float* host_f32, void* dst, size_t dst_pitch, bool dst_is_ref, int k) {
   const double t_a = s->ingest_profile ? host_now_us() : 0.0;
   HIP_TRY(hipEventSynchronize(s->staged[k]));  // the upload that last used this slot's staging buffers has run
@@ -739,7 +941,7 @@ static int ingest_frame(rmd_hip_seeds* s, const unsigned char* host_gray, const 
         memcpy(s->h_u8[k] + static_cast<size_t>(y) * s->u8_pitch, host_gray + static_cast<size_t>(y) * s->width, s->width);
   } else {
     if (!s->h_f32[k]) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_f32[k]), row_f32 * s->height));
-    memcpy(s->h_f32[k], host_f32, row_f32 * s->height);
+    host_copy(s->h_f32[k], host_f32, row_f32 * s->height);
   }
   const double t_c = s->ingest_profile ? host_now_us() : 0.0;
   if (dst_is_ref) {  // everything issued so far may read the reference plane
@@ -779,69 +981,69 @@ static int ingest_frame(rmd_hip_seeds* s, const unsigned char* host_gray, const 
 // The fused path: frame n goes through pinned buffer and staging buffer n % SLOTS, last read by the copy engine / the setup kernel of
 // frame n - SLOTS.  That kernel has completed once the setup kernel of frame n - SLOTS + 1 has STARTED (same stream), which is
 // what h_progress reports.
+// Wait (on the host, without touching the device) until the setup kernel of step `need` has started, as reported through the pinned word
+// `progress`: the staging buffers of SLOTS steps ago are free then.  Numbers are compared modulo 2^32 like the kernel's test.
+static int wait_for_progress(volatile unsigned int* progress, unsigned int need, hipStream_t stream) {
+  auto behind = [&]() { return static_cast<int>(*progress - need) < 0; };
+  if (behind()) {
+    const double t0 = host_now_us();
+    while (behind()) {
+      if (host_now_us() - t0 > 2000.0) {  // far behind (or another matcher ran the frames in between): an idle stream has read everything
+        HIP_TRY(hipStreamSynchronize(stream));
+        break;
+      }
+      cpu_relax();
+    }
+  }
+  return RMD_HIP_OK;
+}
+
 static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray, const float* host_f32, const float* T_curr_world) {
   const double t_a = s->ingest_profile ? host_now_us() : 0.0;
   const unsigned long long n64 = ++s->zc_number;
   const unsigned int n = static_cast<unsigned int>(n64);
   const int k = static_cast<int>(n64 % rmd_hip_seeds::SLOTS);
-  if (n64 > static_cast<unsigned long long>(rmd_hip_seeds::SLOTS)) {
-    const unsigned int need = n - rmd_hip_seeds::SLOTS + 1u;
-    volatile unsigned int* progress = s->h_progress;
-    auto behind = [&]() { return static_cast<int>(*progress - need) < 0; };  // modulo 2^32, like the kernel's test
-    if (behind()) {
-      const double t0 = host_now_us();
-      while (behind()) {
-        if (host_now_us() - t0 > 2000.0) {  // far behind (or another matcher ran the frames in between): an idle stream has read everything
-          HIP_TRY(hipStreamSynchronize(s->stream));
-          break;
-        }
-        __builtin_ia32_pause();
-      }
-    }
-  }
+  if (n64 > static_cast<unsigned long long>(rmd_hip_seeds::SLOTS)) TRY(wait_for_progress(s->h_progress, n - rmd_hip_seeds::SLOTS + 1u, s->stream));
   const double t_b = s->ingest_profile ? host_now_us() : 0.0;
-  rmdk::IngestArgs in;
+  PendingIngest in;
   if (host_gray) {
     const size_t bytes = static_cast<size_t>(s->u8_pitch) * s->height;
     if (!s->h_zc_u8[k]) {
       HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_zc_u8[k]), bytes, hipHostMallocDefault));
       HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_u8[k]), bytes));
     }
-    if (s->u8_pitch == s->width) memcpy(s->h_zc_u8[k], host_gray, bytes);
+    if (s->u8_pitch == s->width) host_copy(s->h_zc_u8[k], host_gray, bytes);
     else
       for (int y = 0; y < s->height; ++y)
         memcpy(s->h_zc_u8[k] + static_cast<size_t>(y) * s->u8_pitch, host_gray + static_cast<size_t>(y) * s->width, s->width);
     HIP_TRY(hipMemcpyAsync(s->d_zc_u8[k], s->h_zc_u8[k], bytes, hipMemcpyHostToDevice, s->copy_stream));
     in.u8 = reinterpret_cast<const unsigned int*>(s->d_zc_u8[k]);
-    in.pitch = s->u8_pitch;
-    in.map1 = s->d_undist_map1;  // null without lens undistortion
-    in.map2 = s->d_undist_map2;
+    in.common.kind = 1;
+    in.common.pitch = s->u8_pitch;
   } else {
     const size_t bytes = static_cast<size_t>(s->width) * s->height * sizeof(float);
     if (!s->h_zc_f32[k]) {
       HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_zc_f32[k]), bytes, hipHostMallocDefault));
       HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_f32[k]), bytes));
     }
-    memcpy(s->h_zc_f32[k], host_f32, bytes);
+    host_copy(s->h_zc_f32[k], host_f32, bytes);
     HIP_TRY(hipMemcpyAsync(s->d_zc_f32[k], s->h_zc_f32[k], bytes, hipMemcpyHostToDevice, s->copy_stream));
     in.f32 = s->d_zc_f32[k];
+    in.common.kind = 2;
   }
   s->h_seq[k] = n;  // behind the frame on the same stream: when the kernel sees n, the frame is in HBM
   HIP_TRY(hipMemcpyAsync(s->d_zc_flag, &s->h_seq[k], sizeof(unsigned int), hipMemcpyHostToDevice, s->copy_stream));
-  in.flag = s->d_zc_flag;
+  in.common.flag = s->d_zc_flag;
   const double t_c = s->ingest_profile ? host_now_us() : 0.0;
   rmd_hip_image& im = s->planes[RMD_HIP_PLANE_CURR_IMG];
   im.data = s->cur_planes[0];  // one plane is enough: setup k writes it after search k - 1 has run (same stream)
-  in.dst = static_cast<float*>(im.data);
   void* dev_progress = nullptr;
   HIP_TRY(hipHostGetDevicePointer(&dev_progress, s->h_progress, 0));
-  in.progress = static_cast<unsigned int*>(dev_progress);
-  in.number = n;
-  s->pending_ingest = in;
-  s->has_pending_ingest = true;
+  in.common.progress = static_cast<unsigned int*>(dev_progress);
+  in.common.number = n;
   s->P.cur = static_cast<const float*>(im.data);
   s->P.cur_stride = s->P.stride;
-  const int rc = seeds_after_frame(s, T_curr_world);
+  const int rc = seeds_after_frame(s, T_curr_world, &in);
   if (s->ingest_profile) {
     const double t_d = host_now_us();
     s->ingest_us[0] += t_b - t_a; s->ingest_us[1] += t_c - t_b; s->ingest_us[2] += t_d - t_c; s->ingest_us[3] += 1.0;
@@ -972,6 +1174,7 @@ int rmd_hip_seeds_upload(rmd_hip_seeds_t* s, int plane, const float* host_src) {
   if (plane < RMD_HIP_PLANE_MU || plane > RMD_HIP_PLANE_B) return fail(RMD_HIP_ERR_INVALID_ARG, "seeds_upload: plane %d", plane);
   TRY(seeds_bind_device(s));
   TRY(seeds_sync(s));
+  s->async_count_valid = false;
   const rmd_hip_image& im = s->planes[plane];
   const size_t row = static_cast<size_t>(im.width) * 4;
   HIP_TRY(hipMemcpy2D(im.data, im.pitch, host_src, row, row, im.height, hipMemcpyHostToDevice));
@@ -989,6 +1192,31 @@ int rmd_hip_seeds_converged_count(const rmd_hip_seeds_t* s, size_t* count) {
   if (!s || !count) return fail(RMD_HIP_ERR_INVALID_ARG, "converged_count: null argument");
   TRY(seeds_bind_device(s));
   rmd_hip_seeds* m = const_cast<rmd_hip_seeds*>(s);
+  if (m->async_count_valid) {
+    // The latest thing that happened to the seed state is an update of the tile pipeline: its setup kernel -- which IS seed_check
+    // (seed_matrix.cu:139-142) -- counted the seeds it found CONVERGED and the search kernel's last workgroup mirrored the sum,
+    // stamped with the update's number, to pinned memory.  Nothing later in the update changes that count (the matcher only turns
+    // UPDATE into NO_MATCH), so it is what countEqual(convergence, CONVERGED) returns after the whole update -- without waiting
+    // for the search, without a kernel and without flushing the deferred finalisation.
+    volatile unsigned long long* word = m->mws->h_conv + m->seq;
+    const unsigned int want = m->async_number;
+    const double t0 = host_now_us();
+    bool synced = false;
+    for (;;) {
+      const unsigned long long v = *word;
+      if (static_cast<unsigned int>(v >> 32) == want) {
+        *count = static_cast<size_t>(v & 0xffffffffull);
+        return ingest_error_check(m->batch ? m->batch->h_progress : m->h_progress);
+      }
+      if (synced) break;  // cannot happen; fall through to the counting kernel
+      if (host_now_us() - t0 > 2000.0) {
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        synced = true;
+        continue;
+      }
+      cpu_relax();
+    }
+  }
   TRY(seeds_flush(m));
   HIP_TRY(hipMemsetAsync(m->d_scalars, 0, sizeof(unsigned long long), m->stream));
   {
@@ -1059,16 +1287,30 @@ int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value) {
   if (!s) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: null handle");
   switch (option) {
     case RMD_HIP_OPT_MATCHER:
+#ifdef RMD_AB_MATCHERS
       if (value < 0 || value > 3) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: matcher %d", value);
+#else
+      if (value != 0 && value != 3)
+        return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: matcher %d is not part of this build (0 = per-pixel kernel, 3 = tile pipeline; the retired "
+                                             "variants 1 and 2 exist in A/B builds only, tools/ab_make.sh)", value);
+#endif
+      if (s->batch && value != 3) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: members of a batch use the tile pipeline");
       if (value != s->opt_matcher) {  // each matcher keeps its own per-frame state: settle the old one first
         TRY(seeds_bind_device(s));
         TRY(seeds_sync(s));
+#ifdef RMD_AB_MATCHERS
         s->frame_ws.frame = 0;
         HIP_TRY(hipMemsetAsync(s->frame_ws.d_ctl, 0, 3 * rmdk::FR_CTL_WORDS * sizeof(unsigned int), s->stream));
-        s->matcher_ws.frame = 0;
-        HIP_TRY(hipMemsetAsync(s->matcher_ws.d_shards, 0, 3 * rmdk::UNIT_SHARDS * sizeof(unsigned long long), s->stream));
+#endif
+        s->mws->frame = 0;
+        HIP_TRY(hipMemsetAsync(s->mws->d_shards, 0, 3 * rmdk::UNIT_SHARDS * sizeof(unsigned long long), s->stream));
+        s->async_count_valid = false;
       }
       s->opt_matcher = value;
+      return RMD_HIP_OK;
+    case RMD_HIP_OPT_UNIT_TARGET:
+      if (value < 1 || value > 4) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: unit target %d outside 1..4", value);
+      s->opt_unit_target = value;
       return RMD_HIP_OK;
     case RMD_HIP_OPT_LOCAL_MAX:
       if (value < 0) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: local_max %d", value);
@@ -1092,16 +1334,22 @@ int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value) {
     case RMD_HIP_OPT_COLLECT_STATS:
       s->opt_stats = value == 2 ? 2 : (value != 0);
       if (s->opt_stats == 2) {  // (re)start a timeline: zeroed buffer, frame counter 0
+        if (s->batch) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: timeline probes are for plain SeedMatrix handles");
         TRY(seeds_bind_device(s));
         rmdk::MatcherWorkspace& ws = s->matcher_ws;
+        const size_t wbytes = ws.wg_trace_slice_u64() * rmdk::FR_TRACE_FRAMES * sizeof(unsigned long long);
+        if (!ws.d_wg_trace) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ws.d_wg_trace), wbytes));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        HIP_TRY(hipMemset(ws.d_wg_trace, 0, wbytes));
+#ifdef RMD_AB_MATCHERS
         const size_t bytes = ws.trace_slice_u64() * rmdk::TRACE_FRAMES * sizeof(unsigned long long);
         if (!ws.d_trace) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ws.d_trace), bytes));
         rmdk::FrameWorkspace& fw = s->frame_ws;
         const size_t fbytes = fw.trace_slice_u64() * rmdk::FR_TRACE_FRAMES * sizeof(unsigned long long);
         if (!fw.d_trace) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&fw.d_trace), fbytes));
-        HIP_TRY(hipStreamSynchronize(s->stream));
         HIP_TRY(hipMemset(ws.d_trace, 0, bytes));
         HIP_TRY(hipMemset(fw.d_trace, 0, fbytes));
+#endif
         HIP_TRY(hipDeviceSynchronize());
         s->trace_frame = 0;
       }
@@ -1162,10 +1410,20 @@ int rmd_hip_seeds_last_diagnostics(const rmd_hip_seeds_t* s, long long* out16) {
 int rmd_hip_seeds_trace_download(rmd_hip_seeds_t* s, int frame, unsigned long long* out, size_t capacity, size_t* written) {
   if (!s || !out || !written) return fail(RMD_HIP_ERR_INVALID_ARG, "trace_download: null argument");
   const rmdk::MatcherWorkspace& ws = s->matcher_ws;
-  if (!ws.d_trace) return fail(RMD_HIP_ERR_NOT_READY, "trace_download: set RMD_HIP_OPT_COLLECT_STATS to 2 first");
+  if (!ws.d_wg_trace) return fail(RMD_HIP_ERR_NOT_READY, "trace_download: set RMD_HIP_OPT_COLLECT_STATS to 2 first");
   if (frame < 0 || frame >= s->trace_frame || frame < s->trace_frame - rmdk::TRACE_FRAMES)
     return fail(RMD_HIP_ERR_INVALID_ARG, "trace_download: frame not in the buffer");
-  if (s->opt_matcher == 2 || s->opt_matcher == 3) {  // frame kernel / compact search: FR_TRACE_WORDS words per workgroup (256 front slots, then the tile grid)
+  if (s->opt_matcher == 3) {  // tile pipeline: FR_TRACE_WORDS words per tile / search workgroup
+    const size_t fn = ws.wg_trace_slice_u64();
+    if (capacity < fn) return fail(RMD_HIP_ERR_INVALID_ARG, "trace_download: buffer too small (%zu words needed)", fn);
+    TRY(seeds_bind_device(s));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipMemcpy(out, ws.d_wg_trace + static_cast<size_t>(frame % rmdk::FR_TRACE_FRAMES) * fn, fn * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    *written = fn;
+    return RMD_HIP_OK;
+  }
+#ifdef RMD_AB_MATCHERS
+  if (s->opt_matcher == 2) {  // one-launch frame kernel: FR_TRACE_WORDS words per workgroup (256 front slots, then the tile grid)
     const rmdk::FrameWorkspace& fw = s->frame_ws;
     const size_t fn = fw.trace_slice_u64();
     if (capacity < fn) return fail(RMD_HIP_ERR_INVALID_ARG, "trace_download: buffer too small (%zu words needed)", fn);
@@ -1183,7 +1441,294 @@ int rmd_hip_seeds_trace_download(rmd_hip_seeds_t* s, int frame, unsigned long lo
                     hipMemcpyDeviceToHost));
   *written = n;
   return RMD_HIP_OK;
+#else
+  return fail(RMD_HIP_ERR_INVALID_ARG, "trace_download: timeline probes exist for the tile pipeline (matcher 3) only in this build");
+#endif
 }
+
+}  // extern "C"
+
+// ---- batches of SeedMatrix objects ----------------------------------------------------------
+// BASELINE configs[3] / SURVEY 8(e): independent sequences.  One MI355X is far from full with one 640x480 sequence (a frame is ~2
+// rounds of work per workgroup and a third of it is a latency chain), so up to MAX_BATCH sequences of one size are stepped TOGETHER:
+// one setup launch + one search launch per step for all of them, unit lists and the persistent search workgroups shared.
+namespace {
+
+int batch_bind_device(const rmd_hip_batch* b) {
+  int cur = -1;
+  HIP_TRY(hipGetDevice(&cur));
+  if (cur != b->device) HIP_TRY(hipSetDevice(b->device));
+  return RMD_HIP_OK;
+}
+
+// one step: the update pipeline for every member whose bit is set in `active` (their frames are in place: P.cur / the staged host frames)
+int batch_launch(rmd_hip_batch* b, unsigned int active, const rmdk::IngestArgs* ingest, const unsigned char* d_stage, size_t frame_bytes) {
+  rmdk::BatchArgs<rmdk::MAX_BATCH> B;
+  memset(&B, 0, sizeof(B));
+  for (int i = 0; i < b->n; ++i) {
+    rmd_hip_seeds* m = b->members[i];
+    rmdk::SeedParams P = m->P;
+    P.stats = nullptr; P.trace = nullptr;
+    B.seq[i] = seq_args_of(m, P);
+    B.seq[i].active = (active >> i) & 1u;
+    if (!B.seq[i].active) B.seq[i].fuse_prev = 0;
+    if (ingest && B.seq[i].active) {
+      const unsigned char* src = d_stage + static_cast<size_t>(i) * frame_bytes;
+      if (ingest->kind == 1) {
+        B.seq[i].ingest_u8 = reinterpret_cast<const unsigned int*>(src);
+        B.seq[i].ingest_map1 = m->d_undist_map1;
+        B.seq[i].ingest_map2 = m->d_undist_map2;
+      } else {
+        B.seq[i].ingest_f32 = reinterpret_cast<const float*>(src);
+      }
+      B.seq[i].ingest_dst = const_cast<float*>(P.cur);
+    }
+  }
+  if (b->opt_timing == 2) ++b->region_updates;
+  const int rc = dispatch_side(b->members[0]->patch_side, [&](auto side) {
+    constexpr int SIDE = decltype(side)::value;
+    if (b->n == 1) {
+      rmdk::BatchArgs<1> B1;
+      B1.seq[0] = B.seq[0];
+      HIP_TRY((rmdk::launch_seed_pipeline_compact<SIDE, 1>(B1, 1, b->ws, b->stream, b->num_cus, b->opt_unit_target, ingest)));
+    } else {
+      HIP_TRY((rmdk::launch_seed_pipeline_compact<SIDE, rmdk::MAX_BATCH>(B, b->n, b->ws, b->stream, b->num_cus, b->opt_unit_target, ingest)));
+    }
+    return RMD_HIP_OK;
+  });
+  TRY(rc);
+  for (int i = 0; i < b->n; ++i) {
+    if (!((active >> i) & 1u)) continue;
+    rmd_hip_seeds* m = b->members[i];
+    m->P_pending = m->P;
+    m->P_pending.stats = nullptr; m->P_pending.trace = nullptr;
+    m->finalize_pending = true;
+    m->async_count_valid = true;
+    m->async_number = b->ws.update_number;
+  }
+  return RMD_HIP_OK;
+}
+
+// frames in host memory (8-bit gray if `gray`, else float): the protocol of ingest_current_fused with ONE sequence number per step
+int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const float* const* f32, const float* T_curr_world) {
+  TRY(batch_bind_device(b));
+  const rmd_hip_seeds* m0 = b->members[0];
+  const int u8_pitch = (m0->width + 3) / 4 * 4;
+  const size_t frame_bytes = gray ? static_cast<size_t>(u8_pitch) * m0->height : static_cast<size_t>(m0->width) * m0->height * sizeof(float);
+  unsigned int active = 0;
+  for (int i = 0; i < b->n; ++i) {
+    if (!(gray ? static_cast<const void*>(gray[i]) : static_cast<const void*>(f32[i]))) continue;
+    if (!b->members[i]->has_reference) return fail(RMD_HIP_ERR_NOT_READY, "batch update: member %d has no reference image", i);
+    active |= 1u << i;
+  }
+  if (!active) return RMD_HIP_OK;
+  const unsigned long long n64 = ++b->step_number;
+  const unsigned int n = static_cast<unsigned int>(n64);
+  const int k = static_cast<int>(n64 % rmd_hip_batch::SLOTS);
+  if (n64 > static_cast<unsigned long long>(rmd_hip_batch::SLOTS)) TRY(wait_for_progress(b->h_progress, n - rmd_hip_batch::SLOTS + 1u, b->stream));
+  const size_t need = static_cast<size_t>(b->n) * static_cast<size_t>(m0->width) * m0->height * sizeof(float);  // float frames: the larger kind
+  if (b->stage_bytes < need) {
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipStreamSynchronize(b->copy_stream));
+    for (int q = 0; q < rmd_hip_batch::SLOTS; ++q) {
+      if (b->h_stage[q]) (void)hipHostFree(b->h_stage[q]);
+      if (b->d_stage[q]) (void)hipFree(b->d_stage[q]);
+      b->h_stage[q] = nullptr; b->d_stage[q] = nullptr;
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_stage[q]), need, hipHostMallocDefault));
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_stage[q]), need));
+    }
+    b->stage_bytes = need;
+  }
+  int first = -1, last = -1;
+  for (int i = 0; i < b->n; ++i) {
+    if (!((active >> i) & 1u)) continue;
+    unsigned char* dst = b->h_stage[k] + static_cast<size_t>(i) * frame_bytes;
+    if (gray) {
+      if (u8_pitch == m0->width) host_copy(dst, gray[i], frame_bytes);
+      else
+        for (int y = 0; y < m0->height; ++y) memcpy(dst + static_cast<size_t>(y) * u8_pitch, gray[i] + static_cast<size_t>(y) * m0->width, m0->width);
+    } else {
+      host_copy(dst, f32[i], frame_bytes);
+    }
+    if (first < 0) first = i;
+    last = i;
+  }
+  const size_t off = static_cast<size_t>(first) * frame_bytes, len = static_cast<size_t>(last - first + 1) * frame_bytes;
+  HIP_TRY(hipMemcpyAsync(b->d_stage[k] + off, b->h_stage[k] + off, len, hipMemcpyHostToDevice, b->copy_stream));
+  b->h_seq[k] = n;  // behind the frames on the same stream: when the kernel sees n, they are in HBM
+  HIP_TRY(hipMemcpyAsync(b->d_flag, &b->h_seq[k], sizeof(unsigned int), hipMemcpyHostToDevice, b->copy_stream));
+  rmdk::IngestArgs in;
+  in.kind = gray ? 1 : 2;
+  in.pitch = u8_pitch;
+  in.flag = b->d_flag;
+  void* dev_progress = nullptr;
+  HIP_TRY(hipHostGetDevicePointer(&dev_progress, b->h_progress, 0));
+  in.progress = static_cast<unsigned int*>(dev_progress);
+  in.number = n;
+  for (int i = 0; i < b->n; ++i) {
+    if (!((active >> i) & 1u)) continue;
+    rmd_hip_seeds* m = b->members[i];
+    m->P.cur = static_cast<const float*>(m->planes[RMD_HIP_PLANE_CURR_IMG].data);  // setup k writes it after search k - 1 has run (same stream)
+    m->P.cur_stride = m->P.stride;
+    seeds_frame_pose(m, T_curr_world + 12 * i);
+  }
+  return batch_launch(b, active, &in, b->d_stage[k], frame_bytes);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rmd_hip_batch_destroy(rmd_hip_batch_t* b) {
+  if (!b) return RMD_HIP_OK;
+  (void)hipSetDevice(b->device);
+  if (b->stream) (void)hipStreamSynchronize(b->stream);
+  if (b->copy_stream) (void)hipStreamSynchronize(b->copy_stream);
+  for (int i = 0; i < rmdk::MAX_BATCH; ++i)
+    if (b->members[i]) (void)seeds_destroy_impl(b->members[i]);
+  for (int q = 0; q < rmd_hip_batch::SLOTS; ++q) {
+    if (b->h_stage[q]) (void)hipHostFree(b->h_stage[q]);
+    if (b->d_stage[q]) (void)hipFree(b->d_stage[q]);
+  }
+  if (b->h_seq) (void)hipHostFree(b->h_seq);
+  if (b->h_progress) (void)hipHostFree(b->h_progress);
+  if (b->d_flag) (void)hipFree(b->d_flag);
+  if (b->region_start) (void)hipEventDestroy(b->region_start);
+  if (b->region_stop) (void)hipEventDestroy(b->region_stop);
+  b->ws.release();
+  if (b->copy_stream) (void)hipStreamDestroy(b->copy_stream);
+  if (b->stream) (void)hipStreamDestroy(b->stream);
+  delete b;
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_batch_create(int n, int width, int height, float fx, float fy, float cx, float cy, int patch_side, int max_extent, rmd_hip_batch_t** out) {
+  if (!out) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_create: null output");
+  *out = nullptr;
+  if (n < 1 || n > rmdk::MAX_BATCH) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_create: %d sequences (1..%d)", n, rmdk::MAX_BATCH);
+  if (width <= 0 || height <= 0) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_create: bad size %dx%d", width, height);
+  int ndev = 0;
+  TRY(rmd_hip_device_count(&ndev));
+  rmd_hip_batch* b = new (std::nothrow) rmd_hip_batch();
+  if (!b) return fail(RMD_HIP_ERR_RUNTIME, "batch_create: out of host memory");
+  (void)hipGetDevice(&b->device);
+  auto bail = [&](int rc) { rmd_hip_batch_destroy(b); return rc; };
+  if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: hipStreamCreate failed"));
+  const size_t pitch = (static_cast<size_t>(width) * 4 + 255) / 256 * 256;  // as image_alloc lays the members' planes out
+  if (b->ws.allocate(width, height, static_cast<int>(pitch / 4), n) != 0) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: update workspace"));
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, b->device) == hipSuccess && prop.multiProcessorCount > 0) b->num_cus = prop.multiProcessorCount;
+  if (hipHostMalloc(reinterpret_cast<void**>(&b->h_progress), 64, hipHostMallocMapped) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&b->h_seq), 64, hipHostMallocDefault) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&b->d_flag), 64) != hipSuccess || hipMemset(b->d_flag, 0, 64) != hipSuccess)
+    return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: ingest words"));
+  b->h_progress[0] = b->h_progress[1] = 0u;
+  for (int i = 0; i < n; ++i) {
+    const int rc = seeds_create_impl(width, height, fx, fy, cx, cy, patch_side, max_extent, b, i, &b->members[i]);
+    if (rc != RMD_HIP_OK) return bail(rc);
+    b->n = i + 1;
+  }
+  if (hipDeviceSynchronize() != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: device synchronisation failed"));
+  *out = b;
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_batch_size(const rmd_hip_batch_t* b, int* n) {
+  if (!b || !n) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_size: null argument");
+  *n = b->n;
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_batch_member(rmd_hip_batch_t* b, int index, rmd_hip_seeds_t** member) {
+  if (!b || !member) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_member: null argument");
+  if (index < 0 || index >= b->n) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_member: index %d outside [0, %d)", index, b->n);
+  *member = b->members[index];
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_batch_update_device(rmd_hip_batch_t* b, const float* const* dev_imgs, const size_t* stride_elems, const float* T_curr_world) {
+  if (!b || !dev_imgs || !stride_elems || !T_curr_world) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_update_device: null argument");
+  TRY(batch_bind_device(b));
+  unsigned int active = 0;
+  for (int i = 0; i < b->n; ++i) {
+    if (!dev_imgs[i]) continue;
+    rmd_hip_seeds* m = b->members[i];
+    if (!m->has_reference) return fail(RMD_HIP_ERR_NOT_READY, "batch_update_device: member %d has no reference image", i);
+    if (stride_elems[i] < static_cast<size_t>(m->width)) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_update_device: stride < width (member %d)", i);
+    active |= 1u << i;
+  }
+  if (!active) return RMD_HIP_OK;
+  for (int i = 0; i < b->n; ++i) {
+    if (!((active >> i) & 1u)) continue;
+    rmd_hip_seeds* m = b->members[i];
+    m->P.cur = dev_imgs[i];  // zero copy, like rmd_hip_seeds_update_device
+    m->P.cur_stride = static_cast<int>(stride_elems[i]);
+    seeds_frame_pose(m, T_curr_world + 12 * i);
+  }
+  return batch_launch(b, active, nullptr, nullptr, 0);
+}
+
+int rmd_hip_batch_update_u8(rmd_hip_batch_t* b, const unsigned char* const* host_gray, const float* T_curr_world) {
+  if (!b || !host_gray || !T_curr_world) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_update_u8: null argument");
+  return batch_update_host(b, host_gray, nullptr, T_curr_world);
+}
+
+int rmd_hip_batch_update(rmd_hip_batch_t* b, const float* const* host_imgs, const float* T_curr_world) {
+  if (!b || !host_imgs || !T_curr_world) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_update: null argument");
+  return batch_update_host(b, nullptr, host_imgs, T_curr_world);
+}
+
+int rmd_hip_batch_sync(rmd_hip_batch_t* b) {
+  if (!b) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_sync: null handle");
+  TRY(batch_bind_device(b));
+  for (int i = 0; i < b->n; ++i) TRY(seeds_flush(b->members[i]));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return ingest_error_check(b->h_progress);
+}
+
+int rmd_hip_batch_set_option(rmd_hip_batch_t* b, int option, int value) {
+  if (!b) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_set_option: null handle");
+  switch (option) {
+    case RMD_HIP_OPT_TIMING:
+      if (value != 0 && value != 2) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_set_option: timing mode %d (0 or 2)", value);
+      b->opt_timing = value;
+      return RMD_HIP_OK;
+    case RMD_HIP_OPT_UNIT_TARGET:
+      if (value < 1 || value > 4) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_set_option: unit target %d outside 1..4", value);
+      b->opt_unit_target = value;
+      return RMD_HIP_OK;
+    default: return fail(RMD_HIP_ERR_INVALID_ARG, "batch_set_option: unknown option %d", option);
+  }
+}
+
+int rmd_hip_batch_timing_reset(rmd_hip_batch_t* b) {
+  if (!b) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_timing_reset: null handle");
+  TRY(rmd_hip_batch_sync(b));
+  if (!b->region_start) HIP_TRY(hipEventCreate(&b->region_start));
+  HIP_TRY(hipEventRecord(b->region_start, b->stream));
+  b->region_updates = 0;
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_batch_timing(rmd_hip_batch_t* b, double* total_ms, long* steps) {
+  if (!b) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_timing: null handle");
+  if (!b->region_start) return fail(RMD_HIP_ERR_NOT_READY, "batch_timing: call timing_reset first");
+  TRY(batch_bind_device(b));
+  if (!b->region_stop) HIP_TRY(hipEventCreate(&b->region_stop));
+  for (int i = 0; i < b->n; ++i) TRY(seeds_flush(b->members[i]));  // the deferred finalisations belong to the region
+  HIP_TRY(hipEventRecord(b->region_stop, b->stream));
+  HIP_TRY(hipEventSynchronize(b->region_stop));
+  float ms = 0.0f;
+  HIP_TRY(hipEventElapsedTime(&ms, b->region_start, b->region_stop));
+  if (total_ms) *total_ms = ms;
+  if (steps) *steps = b->region_updates;
+  return RMD_HIP_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
 
 // ---- DepthmapDenoiser -----------------------------------------------------------------------
 int rmd_hip_denoiser_destroy(rmd_hip_denoiser_t* d) {

@@ -179,17 +179,19 @@ RMDK_D unsigned long long prof_clock_k() {
 #else
 #define RMD_PROF_STAMP(k) do { } while (0)
 #endif
-RMDK_D int seed_fuse_values(const SeedParams& P, int x, int y, int state, float& mu, float& sigma_sq, float& a, float& b, F2 match,
+// T_ref_curr: the pose of the frame the match was found in (P.T_ref_curr, or the previous frame's when that frame's finalisation runs
+// fused into the next frame's setup kernel).
+RMDK_D int seed_fuse_values(const SeedParams& P, const Pose& T_ref_curr, int x, int y, int state, float& mu, float& sigma_sq, float& a, float& b, F2 match,
                             unsigned long long* prof = nullptr) {
   (void)prof;
   if (state == ST_UPDATE) {
     const F3 f_ref = normalize3(cam2world(P.cam, static_cast<float>(x), static_cast<float>(y)));
     const F3 f_epi = normalize3(cam2world(P.cam, match.x, match.y));
-    const F3 pt = triangulate(f_ref, f_epi, P.T_ref_curr);
+    const F3 pt = triangulate(f_ref, f_epi, T_ref_curr);
     RMD_PROF_STAMP(0);
     if (pt.z < 0.0f) return 0;
     const float depth = norm3(pt);
-    const float tau = triangulation_uncertainty(depth, f_ref, pose_translation(P.T_ref_curr), P.one_pix_angle);
+    const float tau = triangulation_uncertainty(depth, f_ref, pose_translation(T_ref_curr), P.one_pix_angle);
     RMD_PROF_STAMP(1);
     const float tau_sq = tau * tau;
     const float s_sq = (tau_sq * sigma_sq) / (tau_sq + sigma_sq);
@@ -223,7 +225,7 @@ RMDK_D int seed_fuse_values(const SeedParams& P, int x, int y, int state, float&
 // ... and on the planes of the SeedMatrix
 RMDK_D void seed_fuse(const SeedParams& P, int x, int y, int i, int state, float mu, float sigma_sq, float a, float b,
                       F2 match) {
-  const int what = seed_fuse_values(P, x, y, state, mu, sigma_sq, a, b, match);
+  const int what = seed_fuse_values(P, P.T_ref_curr, x, y, state, mu, sigma_sq, a, b, match);
   if (what == 1) {
     P.sigma_sq[i] = sigma_sq;
     P.mu[i] = mu;

@@ -195,18 +195,25 @@ class Denoiser:
         return out
 
 
+def _bits(a):
+    """the bit patterns of a float array with every NaN mapped to one value: +0 and -0 stay different"""
+    a = np.ascontiguousarray(a)
+    u = a.view(np.uint32 if a.dtype.itemsize == 4 else np.uint64).copy()
+    u[np.isnan(a)] = 0x7fc00000 if a.dtype.itemsize == 4 else 0x7ff8000000000000
+    return u
+
+
 def planes_equal(a, b):
-    """bit-level equality that treats any NaN as equal to any NaN"""
-    a, b = np.asarray(a), np.asarray(b)
-    if a.dtype.kind == "f":
-        return bool(np.array_equal(a, b, equal_nan=True))
-    return bool(np.array_equal(a, b))
+    """bit-level equality (the sign of zero included) that treats any NaN as equal to any NaN"""
+    return count_mismatch(a, b) == 0
 
 
 def count_mismatch(a, b):
     a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape or a.dtype != b.dtype:
+        return max(a.size, b.size)
     if a.dtype.kind == "f":
-        return int(np.count_nonzero(~((a == b) | (np.isnan(a) & np.isnan(b)))))
+        return int(np.count_nonzero(_bits(a) != _bits(b)))
     return int(np.count_nonzero(a != b))
 
 

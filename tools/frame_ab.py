@@ -46,7 +46,7 @@ def main():
     def make(v):
         s = api.SeedMatrix(w, h, cam, patch_side=a.side)
         if v in (31, 32):  # tile pipeline with 2x / 3x as many (smaller) work units
-            s.setOption(api.OPT_MATCHER, 3); s.setOption(api.OPT_WINDOW, v - 30)
+            s.setOption(api.OPT_MATCHER, 3); s.setOption(api.OPT_UNIT_TARGET, v - 29)
         elif v >= 20:  # 21: everything beyond one round handed out in 1-round units; 2xy: local_max x * 256, y rounds per unit
             s.setOption(api.OPT_MATCHER, 2)
             if v == 21:
