@@ -171,6 +171,9 @@ int rmd_hip_seeds_sync(const rmd_hip_seeds_t* s);
 #define RMD_HIP_OPT_UNIT_ROUNDS 6   /* frame kernel: rounds of 256 NCC evaluations per handed-out unit, 1..4; 0 (default) = from the load */
 #define RMD_HIP_OPT_UNIT_TARGET 7   /* tile pipeline: work units aimed at per frame, in multiples (1..4, default 1) of the resident search workgroups;
                                       the unit size (1..4 rounds of 256 NCC evaluations) follows from the previous frame's work (experiments) */
+#define RMD_HIP_OPT_SEARCH_FLAGS 8  /* tile pipeline, A/B switches of the search kernel's unit loop (default 6): 1 = claim and fetch the next
+                                      unit while the current one is searched, 2 = sixteen hand-out counters instead of one, 4 = use the tile's sample
+                                      box that the setup kernel sends along with the unit */
 int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value);
 /* kernels of the seed path, for rmd_hip_seeds_timing */
 #define RMD_HIP_STAGE_SEED_INIT 0
@@ -250,6 +253,9 @@ int rmd_hip_reduce_count_eq_i32(const rmd_hip_image_t* img, int value, size_t* c
 int rmd_hip_reduce_sum_f32_raw(const float* dev_data, size_t stride_elems, size_t width, size_t height, float* sum);
 int rmd_hip_reduce_sum_i32_raw(const int* dev_data, size_t stride_elems, size_t width, size_t height, int* sum);
 int rmd_hip_reduce_count_eq_i32_raw(const int* dev_data, size_t stride_elems, size_t width, size_t height, int value, size_t* count);
+
+/* ---- self test: the VALU (DPP) wave reductions / scans of the kernels against their shuffle forms; *mismatching_lanes must be 0 */
+int rmd_hip_selftest_wave_primitives(int* mismatching_lanes);
 
 /* ---- arithmetic-contract self test (device side of csrc/rmd_math.h) ---------------------- */
 /* op: 0 expf, 1 sinf, 2 acosf, 3 rsqrtf, 4 sqrtf, 5 x/y, 6 lerp(t=x, a=y, b=z); n host floats in, n out */

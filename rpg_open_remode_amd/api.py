@@ -29,7 +29,7 @@ __all__ = ["PinholeCamera", "SE3", "DeviceImage", "SeedMatrix", "SeedMatrixBatch
 PLANE_MU, PLANE_SIGMA_SQ, PLANE_A, PLANE_B, PLANE_CONVERGENCE = 0, 1, 2, 3, 4
 PLANE_SUM_TEMPL, PLANE_CONST_TEMPL_DENOM, PLANE_EPIPOLAR_MATCHES, PLANE_REF_IMG, PLANE_CURR_IMG = 5, 6, 7, 8, 9
 KIND_F32, KIND_I32, KIND_F32X2 = 0, 1, 2
-OPT_MATCHER, OPT_TIMING, OPT_COLLECT_STATS, OPT_WINDOW, OPT_LAZY_FINALIZE, OPT_LOCAL_MAX, OPT_UNIT_ROUNDS, OPT_UNIT_TARGET = 0, 1, 2, 3, 4, 5, 6, 7
+OPT_MATCHER, OPT_TIMING, OPT_COLLECT_STATS, OPT_WINDOW, OPT_LAZY_FINALIZE, OPT_LOCAL_MAX, OPT_UNIT_ROUNDS, OPT_UNIT_TARGET, OPT_SEARCH_FLAGS = 0, 1, 2, 3, 4, 5, 6, 7, 8
 MATCHER_PIXEL, MATCHER_PIPELINE = 0, 3
 MATCHER_PIPELINE_R01, MATCHER_FRAME = 1, 2  # retired variants: A/B builds of the library only (tools/ab_make.sh)
 STAGE_SEED_INIT, STAGE_UPDATE, STAGE_COUNT = 0, 1, 2

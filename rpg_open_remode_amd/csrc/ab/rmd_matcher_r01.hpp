@@ -260,14 +260,14 @@ __global__ __launch_bounds__(PLAN_THREADS) void seed_plan_kernel(MatcherArgs M, 
 #pragma unroll
   for (int q = 0; q < PLAN_TILES_IN_REGS; ++q) {
     const int n_u = units_of(tot[q], unit_rounds);  // 0 for tiles beyond this thread's run
-    for (int u = 0; u < n_u; ++u) M.units[base + u] = make_uint2(static_cast<unsigned int>(t_first + q), static_cast<unsigned int>(u * unit_items));
+    for (int u = 0; u < n_u; ++u) reinterpret_cast<uint2*>(M.units)[base + u] = make_uint2(static_cast<unsigned int>(t_first + q), static_cast<unsigned int>(u * unit_items));
     base += n_u;
   }
   for (int q = PLAN_TILES_IN_REGS; q < c_tiles; ++q) {
     const int t = t_first + q;
     if (t >= n_tiles) break;
     const int n_u = units_of(static_cast<int>(M.tile_plan[t]), unit_rounds);
-    for (int u = 0; u < n_u; ++u) M.units[base + u] = make_uint2(static_cast<unsigned int>(t), static_cast<unsigned int>(u * unit_items));
+    for (int u = 0; u < n_u; ++u) reinterpret_cast<uint2*>(M.units)[base + u] = make_uint2(static_cast<unsigned int>(t), static_cast<unsigned int>(u * unit_items));
     base += n_u;
   }
   if (M.trace && tid == 0)  // the unit size rides in the top byte of the end time stamp
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_search_kernel(SeedParams P, Mat
     const long long t0 = P.stats ? clock64() : 0;
     if (u >= n_units) break;
     ++my_units;
-    const uint2 unit = M.units[u];
+    const uint2 unit = reinterpret_cast<const uint2*>(M.units)[u];
     const int tile = static_cast<int>(unit.x);
     const int first = static_cast<int>(unit.y);
     const TileInfo ti = M.tiles[tile];

@@ -1312,6 +1312,10 @@ int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value) {
       if (value < 1 || value > 4) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: unit target %d outside 1..4", value);
       s->opt_unit_target = value;
       return RMD_HIP_OK;
+    case RMD_HIP_OPT_SEARCH_FLAGS:
+      if (value < 0 || value > 7) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: search flags %d outside 0..7", value);
+      s->mws->search_flags = value;
+      return RMD_HIP_OK;
     case RMD_HIP_OPT_LOCAL_MAX:
       if (value < 0) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: local_max %d", value);
       s->opt_local_max = value;
@@ -1698,6 +1702,10 @@ int rmd_hip_batch_set_option(rmd_hip_batch_t* b, int option, int value) {
       if (value < 1 || value > 4) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_set_option: unit target %d outside 1..4", value);
       b->opt_unit_target = value;
       return RMD_HIP_OK;
+    case RMD_HIP_OPT_SEARCH_FLAGS:
+      if (value < 0 || value > 7) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_set_option: search flags %d outside 0..7", value);
+      b->ws.search_flags = value;
+      return RMD_HIP_OK;
     default: return fail(RMD_HIP_ERR_INVALID_ARG, "batch_set_option: unknown option %d", option);
   }
 }
@@ -2050,6 +2058,24 @@ int rmd_hip_reduce_count_eq_i32_raw(const int* dev_data, size_t stride_elems, si
   unsigned long long r = 0;
   TRY(reduce_u64_dev(true, dev_data, stride_elems, width, height, value, &r));
   *count = static_cast<size_t>(r);
+  return RMD_HIP_OK;
+}
+
+// ---- self test of the wave primitives the kernels rely on -----------------------------------
+int rmd_hip_selftest_wave_primitives(int* mismatching_lanes) {
+  if (!mismatching_lanes) return fail(RMD_HIP_ERR_INVALID_ARG, "selftest: null output");
+  unsigned int* d = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), sizeof(unsigned int)));
+  hipError_t e = hipMemset(d, 0, sizeof(unsigned int));
+  if (e == hipSuccess) {
+    for (unsigned int seed = 1; seed <= 8; ++seed) hipLaunchKernelGGL(rmdk::wave_primitives_selftest_kernel, dim3(64), dim3(64), 0, nullptr, seed, d);
+    e = hipGetLastError();
+  }
+  unsigned int bad = 0;
+  if (e == hipSuccess) e = hipMemcpy(&bad, d, sizeof(bad), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(RMD_HIP_ERR_RUNTIME, "selftest: %s", hipGetErrorString(e));
+  *mismatching_lanes = static_cast<int>(bad);
   return RMD_HIP_OK;
 }
 

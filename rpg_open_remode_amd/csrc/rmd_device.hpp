@@ -47,6 +47,28 @@ RMDK_D F3 pose_translation(const Pose& p) { return F3{p.d[3], p.d[7], p.d[11]}; 
 
 RMDK_D int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// Wave64 reductions / scans on the VALU's data-parallel-primitive path (DPP: row shifts inside rows of 16 lanes, then the two row
+// broadcasts of the gfx9 family), with ALL 64 lanes active.  __shfl_xor / __shfl_up go through the LDS crossbar (ds_bpermute: an LDS
+// instruction and its latency per step); these are plain VALU instructions.  The inclusive scan leaves the total in lane 63.
+enum : int { DPP_ROW_SHR = 0x110, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143 };
+struct WaveAdd { static constexpr int identity = 0; RMDK_D static int op(int a, int b) { return a + b; } };
+struct WaveMin { static constexpr int identity = 0x7fffffff; RMDK_D static int op(int a, int b) { return a < b ? a : b; } };
+struct WaveMax { static constexpr int identity = -0x7fffffff - 1; RMDK_D static int op(int a, int b) { return a > b ? a : b; } };
+template <typename OP>
+RMDK_D int wave_scan_i32(int v) {  // lane i <- op over lanes 0..i
+  v = OP::op(v, __builtin_amdgcn_update_dpp(OP::identity, v, DPP_ROW_SHR | 1, 0xf, 0xf, false));
+  v = OP::op(v, __builtin_amdgcn_update_dpp(OP::identity, v, DPP_ROW_SHR | 2, 0xf, 0xf, false));
+  v = OP::op(v, __builtin_amdgcn_update_dpp(OP::identity, v, DPP_ROW_SHR | 4, 0xf, 0xf, false));
+  v = OP::op(v, __builtin_amdgcn_update_dpp(OP::identity, v, DPP_ROW_SHR | 8, 0xf, 0xf, false));
+  v = OP::op(v, __builtin_amdgcn_update_dpp(OP::identity, v, DPP_ROW_BCAST15, 0xa, 0xf, false));
+  v = OP::op(v, __builtin_amdgcn_update_dpp(OP::identity, v, DPP_ROW_BCAST31, 0xc, 0xf, false));
+  return v;
+}
+template <typename OP>
+RMDK_D int wave_reduce_i32(int v) {  // the same value in every lane (a scalar register)
+  return __builtin_amdgcn_readlane(wave_scan_i32<OP>(v), 63);
+}
+
 // One fetch through a clamp-addressed, linear-filtered, unnormalised 2-D "texture"
 // (texture_memory.cuh:45-66) from a pitched plane in global memory.  General form:
 // any coordinate, clamping at the edges.  Used by the per-pixel matcher and as the

@@ -34,6 +34,7 @@ namespace rmdk {
 #endif
 constexpr int FR_WIN_CAP = 5632;  // texels of the LDS window (22 KB); any shape with (width | 1) * height <= FR_WIN_CAP
 constexpr int FR_UNIT_ROUNDS = 4, FR_UNIT_ITEMS = FR_UNIT_ROUNDS * TILE_PIX;
+enum : int { SEARCH_PREFETCH = 1, SEARCH_SHARDED_HANDOUT = 2, SEARCH_TILE_BOX = 4, SEARCH_FLAGS_DEFAULT = 6 };  // MatcherArgs::search_flags (A/B switches of the search kernel's unit loop)
 constexpr int FR_TRACE_FRAMES = 256, FR_TRACE_WORDS = 8;  // per workgroup: start, setup done, own tile done, exit (10 ns ticks), work items, units searched
 
 // ---- agent-scope accessors (global address space, sc1) ---------------------------------------------------------------
@@ -55,7 +56,7 @@ struct FrameSmem {
   int prefix[TILE_PIX + 1];
   unsigned int packed[TILE_PIX];   // state << 16 | first in-image step << 8 | number of in-image steps
   int red[4][12];
-  unsigned int bcast[8];
+  alignas(16) unsigned int bcast[8];  // [0] the workgroup's next unit, [4..7] its entry (written by an LDS-direct load)
 #ifdef RMD_PROFILE_ROUNDS
   unsigned long long prof[8];  // diagnostics build: [4] window policy, [5] staging, [6] rounds + barrier ticks; [0..3] per wave, ticks / count of rounds without (bits 0..23 / 56..63) and with (24..47 / 48..55) a fallback
 #endif
@@ -139,11 +140,8 @@ RMDK_D void seed_range_box(const SeedParams& P, const FrameSmem<SIDE>& S, int ti
 // min / max of four ints over the workgroup (all 256 threads call; result uniform)
 template <int SIDE>
 RMDK_D void block_bbox(FrameSmem<SIDE>& S, int tid, int& x0, int& y0, int& x1, int& y1, int slot) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    x0 = min(x0, __shfl_xor(x0, off, 64)); y0 = min(y0, __shfl_xor(y0, off, 64));
-    x1 = max(x1, __shfl_xor(x1, off, 64)); y1 = max(y1, __shfl_xor(y1, off, 64));
-  }
+  x0 = wave_reduce_i32<WaveMin>(x0); y0 = wave_reduce_i32<WaveMin>(y0);
+  x1 = wave_reduce_i32<WaveMax>(x1); y1 = wave_reduce_i32<WaveMax>(y1);
   const int wave = tid >> 6;
   if ((tid & 63) == 0) { S.red[wave][slot] = x0; S.red[wave][slot + 1] = y0; S.red[wave][slot + 2] = x1; S.red[wave][slot + 3] = y1; }
 }
@@ -318,6 +316,28 @@ RMDK_D void frame_search(const SeedParams& P, FrameSmem<SIDE>& S, int tid, int k
   }
 }
 
+// Exclusive prefix of the per-seed step counts of the tile in LDS (S.packed, this thread's own entry) -> S.prefix[0..256]; returns the
+// total.  Ends with a barrier.
+template <int SIDE>
+RMDK_D int frame_prefix(FrameSmem<SIDE>& S, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int n_valid = static_cast<int>(S.packed[tid] & 0xffu);
+  const int incl = wave_scan_i32<WaveAdd>(n_valid);
+  if (lane == 63) S.red[wave][4] = incl;
+  __syncthreads();
+  int wave_off = 0, total = 0;
+#pragma unroll
+  for (int wv = 0; wv < 4; ++wv) {
+    const int v = S.red[wv][4];
+    wave_off += wv < wave ? v : 0;
+    total += v;
+  }
+  S.prefix[tid] = wave_off + incl - n_valid;
+  if (tid == 0) S.prefix[TILE_PIX] = total;
+  __syncthreads();
+  return total;
+}
+
 // Exclusive prefix of the step counts (S.packed) -> S.prefix[0..256], and the texel box of all samples of the tile.  If that
 // box fits the LDS window it is staged right away (W.valid).  Returns the tile's number of work items.  Ends with a barrier.
 template <int SIDE>
@@ -325,12 +345,7 @@ RMDK_D int frame_prefix_and_window(const SeedParams& P, FrameSmem<SIDE>& S, int 
   const int lane = tid & 63, wave = tid >> 6;
   const unsigned int pk = S.packed[tid];
   const int n_valid = static_cast<int>(pk & 0xffu);
-  int incl = n_valid;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int v = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += v;
-  }
+  const int incl = wave_scan_i32<WaveAdd>(n_valid);
   int bx0, by0, bx1, by1;
   seed_range_box<SIDE>(P, S, tid, n_valid > 0, 0, n_valid - 1, bx0, by0, bx1, by1);
   block_bbox<SIDE>(S, tid, bx0, by0, bx1, by1, 0);
@@ -366,8 +381,9 @@ constexpr int INGEST_WGS_REMAP = 512;  // with lens undistortion (two dependent 
 
 template <int SIDE, int NSEQ>
 __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<NSEQ> B, MatcherArgs M, int target_units) {
-  __shared__ int red_i[4], red_c[4];
+  __shared__ int red_i[4], red_c[4], red_b[4][4];
   __shared__ unsigned int s_base;
+  constexpr int HALF = SIDE / 2;
   const int seq = NSEQ == 1 ? 0 : static_cast<int>(blockIdx.z);
   // one sequence: the named argument, which the compiler fetches with a few wide scalar loads at the top of the kernel; several: the
   // argument segment indexed by the sequence number (see BatchArgs), copied once so that its loads are issued here too and not one
@@ -448,6 +464,20 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
     }
     return;
   }
+#ifdef RMD_PROFILE_ROUNDS
+  unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // fuse: start, triangulated, uncertainty, normpdf, end; segment done; run done
+#endif
+  // the seed's state: requested before anything else, so that the scalar-load chains below (kernel arguments, the previous frame's
+  // counters) run while these are in flight
+  float mu = P.mu[gi], sigma_sq = P.sigma_sq[gi], a = P.a[gi], b = P.b[gi];
+  // ... and, when the previous frame's finalisation runs here, what that needs: the state it left, its arg-max key, its search descriptor
+  // (requested whether or not a finalisation is pending -- it nearly always is, and a conditional load costs a register shuffle and a
+  // wait at the point where the two paths meet)
+  int conv_prev = P.conv[gi];
+  unsigned long long key = M.best[gm];
+  unsigned int packed_prev = M.packed[gm];
+  float lfirst_prev = M.lfirst[gm];
+  float2 m_prev = M.mean[gm], d_prev = M.dir[gm];
   if (M.progress && wg == 0 && seq == 0 && tid == 0) __hip_atomic_store(M.progress, M.ingest_number, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   // (computed here, at the top, so that its scalar loads travel with the kernel arguments)
   // unit size: 1..4 rounds of 256 evaluations, from the previous frame's work (a frame differs little from the one before)
@@ -466,21 +496,16 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
     static_assert(MAX_UNIT_ROUNDS == 4, "the ladder below is ceil(items / per_round) clamped to 1..4");
     unit_rounds = items > 3 * per_round ? 4 : items > 2 * per_round ? 3 : items > per_round ? 2 : 1;  // no 64-bit division
   }
-#ifdef RMD_PROFILE_ROUNDS
-  unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // fuse: start, triangulated, uncertainty, normpdf, end; segment done; run done
-#endif
-  float mu = P.mu[gi], sigma_sq = P.sigma_sq[gi], a = P.a[gi], b = P.b[gi];
   // what the planes hold now (known only when the previous frame's values were loaded for its finalisation): a seed that has
   // converged or diverged keeps writing the same state and an empty descriptor, a third of this kernel's stores -- skipped
   int conv_old = -1;
   unsigned int packed_old = 0xffffffffu;
   if (Q.fuse_prev) {  // uniform over the workgroup
-    const int conv_prev = P.conv[gi];
-    const unsigned long long key = M.best[gm];
-    const unsigned int packed_prev = M.packed[gm];
+    // Everything requested above is in flight together: left alone the compiler sinks each load into the branch that consumes it (state
+    // -> key -> descriptor: three dependent memory round trips on every live lane's chain).  The empty statement below "reads" every
+    // value, so the loads stay where they were issued and are waited for once.
+    asm volatile("" : "+v"(conv_prev), "+v"(key), "+v"(packed_prev), "+v"(lfirst_prev), "+v"(m_prev.x), "+v"(m_prev.y), "+v"(d_prev.x), "+v"(d_prev.y));
     conv_old = conv_prev; packed_old = packed_prev;
-    const float lfirst_prev = M.lfirst[gm];
-    const float2 m_prev = M.mean[gm], d_prev = M.dir[gm];
     if (in_image && conv_prev == ST_UPDATE) {
       F2 best_px = F2{0.0f, 0.0f};
       float best_ncc = -1.0f;
@@ -512,6 +537,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
   if (P.trace) t_loaded = wall_clock64();
   int n_valid = 0, i_first = 0;
   unsigned int n_steps = 0, n_evals = 0;
+  int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = -1, by1 = -1;  // texel box of this seed's samples (see seed_range_box)
   const bool live = in_image && state == ST_UPDATE;
   if (live) {
     const Segment seg = epipolar_segment(P, x, y, mu, sigma_sq);
@@ -528,6 +554,12 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
       M.mean[gm] = make_float2(seg.mean.x, seg.mean.y);
       M.dir[gm] = make_float2(seg.dir.x, seg.dir.y);
       M.lfirst[gm] = run.l_first;
+      // the positions are monotone along the run: its two ends bound every sample; a sample at p touches texels
+      // floor(p) - HALF .. floor(p) + HALF + 1, one more for the replayed roundings (a box that misses a sample costs speed only)
+      bx0 = max(static_cast<int>(floorf(fminf(run.px_first.x, run.px_last.x))) - HALF - 1, 0);
+      by0 = max(static_cast<int>(floorf(fminf(run.px_first.y, run.px_last.y))) - HALF - 1, 0);
+      bx1 = min(static_cast<int>(floorf(fmaxf(run.px_first.x, run.px_last.x))) + HALF + 2, P.w - 1);
+      by1 = min(static_cast<int>(floorf(fmaxf(run.px_first.y, run.px_last.y))) + HALF + 2, P.h - 1);
     }
     if (P.stats) {  // diagnostics only: the full walk, counting what the reference would visit / evaluate
       for (float l = -seg.half_length; l <= seg.half_length; l += 0.7f, ++n_steps) {
@@ -544,20 +576,23 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
     const unsigned long long s_evals = wave_sum_u64(static_cast<unsigned long long>(n_evals));
     if (lane == 0 && s_live) { atomicAdd(&P.stats[0], s_live); atomicAdd(&P.stats[1], s_steps); atomicAdd(&P.stats[2], s_evals); }
   }
-  int tot = n_valid;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
+  const int tot = wave_reduce_i32<WaveAdd>(n_valid);
   // seeds that this frame's check found CONVERGED: what getConvergedCount() reports after this update (seed_matrix.cu:195-198 counts
   // the plane that seed_check has just rewritten; the matcher only ever turns UPDATE into NO_MATCH)
   const int n_conv = __popcll(__ballot(in_image && state == ST_CONVERGED));
-  if (lane == 0) { red_i[wave] = tot; red_c[wave] = n_conv; }
+  // ... and the texel box of ALL samples of the tile: it travels with the tile's work units, so that the search kernel can request
+  // the tile's window of the current image together with the tile's descriptors (one memory round trip less per tile)
+  bx0 = wave_reduce_i32<WaveMin>(bx0); by0 = wave_reduce_i32<WaveMin>(by0);
+  bx1 = wave_reduce_i32<WaveMax>(bx1); by1 = wave_reduce_i32<WaveMax>(by1);
+  if (lane == 0) { red_i[wave] = tot; red_c[wave] = n_conv; red_b[wave][0] = bx0; red_b[wave][1] = by0; red_b[wave][2] = bx1; red_b[wave][3] = by1; }
   __syncthreads();
   const int total = red_i[0] + red_i[1] + red_i[2] + red_i[3];
   const int tile = blockIdx.y * M.tiles_x + blockIdx.x;                      // within the sequence
   const int tile_g = (NSEQ == 1 ? 0 : seq * M.n_tiles) + tile;               // within the launch
   const int unit_items = unit_rounds * TILE_PIX;
   if (tile_g == 0 && tid < UNIT_SHARDS) M.shards_next[tid] = 0ull;  // the set the NEXT frame counts in (nobody reads it now)
-  if (tile_g == 0 && tid == 0) { M.queue[1] = 0u; M.queue[5] = static_cast<unsigned int>(unit_items); }
+  if (tile_g == 0 && tid < UNIT_SHARDS) M.handout[tid * HANDOUT_STRIDE] = 0u;  // the search kernel's hand-out counters
+  if (tile_g == 0 && tid == 0) M.queue[5] = static_cast<unsigned int>(unit_items);
   if (tid == 0) M.tile_conv[tile_g] = static_cast<unsigned int>(red_c[0] + red_c[1] + red_c[2] + red_c[3]);
 #ifdef RMD_PROFILE_ROUNDS
   if (P.trace && prof_t[0] != 0ull && prof_t[6] != 0ull) {  // any live lane that ran both the fusion and the set-up: phases of the setup chain, 10 ns ticks
@@ -579,8 +614,15 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
     s_base = static_cast<unsigned int>(old);  // units reserved so far in this shard
   }
   __syncthreads();
-  if (tid < n_u) M.units[static_cast<size_t>(tile_g % UNIT_SHARDS) * M.shard_cap + s_base + tid] =
-      make_uint2(static_cast<unsigned int>(tile_g), static_cast<unsigned int>(tid * unit_items));
+  if (tid < n_u) {
+    const int x0 = min(min(red_b[0][0], red_b[1][0]), min(red_b[2][0], red_b[3][0])), y0 = min(min(red_b[0][1], red_b[1][1]), min(red_b[2][1], red_b[3][1]));
+    const int x1 = max(max(red_b[0][2], red_b[1][2]), max(red_b[2][2], red_b[3][2])), y1 = max(max(red_b[0][3], red_b[1][3]), max(red_b[2][3], red_b[3][3]));
+    const bool boxed = window_fits(x0, y0, x1, y1);  // (coordinates are < 2^15: they pack into 16 bits each)
+    M.units[static_cast<size_t>(tile_g % UNIT_SHARDS) * M.shard_cap + s_base + tid] =
+        make_uint4(static_cast<unsigned int>(tile_g), static_cast<unsigned int>(tid * unit_items) | (boxed ? UNIT_TILE_BOX : 0u),
+                   boxed ? static_cast<unsigned int>(x0) | (static_cast<unsigned int>(y0) << 16) : 0u,
+                   boxed ? static_cast<unsigned int>(x1) | (static_cast<unsigned int>(y1) << 16) : 0u);
+  }
   if (tid == 0) M.tile_plan[tile_g] = static_cast<unsigned int>(total);
 }
 
@@ -630,22 +672,47 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
   }
   FrameWindow W;
   W.valid = false; W.x0 = W.y0 = 0; W.x1 = W.y1 = -1; W.ws = 1;
-  unsigned int u = blockIdx.x;  // unit blockIdx.x is ours for free; further units come from the shared counter
-  while (u < n_units) {
+  // unit g of the sixteen lists read as one list
+  auto entry_of = [&](unsigned int g) {
     int sh = 0;
 #pragma unroll
-    for (int q = 1; q < UNIT_SHARDS; ++q) sh += u >= shard_first[q] ? 1 : 0;
+    for (int q = 1; q < UNIT_SHARDS; ++q) sh += g >= shard_first[q] ? 1 : 0;
     unsigned int sh_first = 0u;
 #pragma unroll
-    for (int q = 1; q < UNIT_SHARDS; ++q) sh_first = u >= shard_first[q] ? shard_first[q] : sh_first;
-    const uint2 unit = M.units[static_cast<size_t>(sh) * M.shard_cap + (u - sh_first)];
-    const int tile = static_cast<int>(unit.x), first = static_cast<int>(unit.y);
+    for (int q = 1; q < UNIT_SHARDS; ++q) sh_first = g >= shard_first[q] ? shard_first[q] : sh_first;
+    return M.units[static_cast<size_t>(sh) * M.shard_cap + (g - sh_first)];
+  };
+  // Unit blockIdx.x is ours for free.  When there are more units than workgroups the rest is handed out by sixteen counters (workgroup
+  // b draws from counter b % 16, which deals the units gridDim + b % 16 + 16 k: one counter word for a thousand workgroups serialises
+  // their returning atomics for 12 us), and the NEXT unit is claimed and its entry fetched while the current one is being searched: the
+  // atomic is issued before the tile's descriptors are requested, the entry -- by an LDS-direct load, it never occupies registers
+  // across the NCC block -- once they have arrived; both are consumed after the rounds.
+  const bool handout = n_units > gridDim.x;
+  const bool prefetch = (M.search_flags & SEARCH_PREFETCH) != 0, sharded = (M.search_flags & SEARCH_SHARDED_HANDOUT) != 0;
+  const unsigned int cls = sharded ? blockIdx.x & (UNIT_SHARDS - 1) : 0u;
+  const unsigned int cls_step = sharded ? UNIT_SHARDS : 1u;
+  unsigned int u = blockIdx.x;
+  int tile = 0, first = 0;
+  unsigned int box0 = 0u, box1 = 0u;
+  bool boxed = false;
+  auto take = [&](const uint4& e) {  // uniform over the workgroup: scalar registers
+    tile = __builtin_amdgcn_readfirstlane(static_cast<int>(e.x));
+    const unsigned int fy = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(e.y)));
+    first = static_cast<int>(fy & ~UNIT_TILE_BOX);
+    boxed = (fy & UNIT_TILE_BOX) != 0u && (M.search_flags & SEARCH_TILE_BOX) != 0;
+    box0 = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(e.z)));
+    box1 = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(e.w)));
+  };
+  if (u < n_units) take(entry_of(u));
+  while (u < n_units) {
+    unsigned int nxt_k = 0u;
+    if (handout && prefetch && tid == 0) nxt_k = atomicAdd(&M.handout[cls * HANDOUT_STRIDE], 1u);
     if (tile != lds_tile) {
       if (lds_tile >= 0) {  // hand the previous tile's keys over
         const unsigned long long key = S.best[tid];
         if (key != 0ull) atomicMax(&M.best[so + static_cast<size_t>(y0 + ty) * Qp->P.stride + x0 + tx], key);
       }
-      const int seq = NSEQ == 1 ? 0 : __builtin_amdgcn_readfirstlane(tile / M.n_tiles);
+      const int seq = NSEQ == 1 ? 0 : tile / M.n_tiles;
       const int tile_s = NSEQ == 1 ? tile : tile - seq * M.n_tiles;  // within its sequence
       if (NSEQ > 1) Qp = seq_table() + seq;
       so = NSEQ == 1 ? 0 : static_cast<size_t>(seq) * M.seq_plane;
@@ -653,34 +720,72 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
       const int tile_y = tile_s / M.tiles_x, tile_x = tile_s - tile_y * M.tiles_x;
       x0 = tile_x * TILE_W; y0 = tile_y * TILE_H;
       const int x = x0 + tx, y = y0 + ty;
-      unsigned int pk = 0u;
-      {  // one batch of loads (a lane outside a ragged tile reads element 0; values of seeds without work are not used)
-        const int gi = (x < P.w && y < P.h) ? y * P.stride + x : 0;
-        const size_t gm = so + gi;
-        const unsigned int packed = M.packed[gm];  // first in-image step << 16 | number of in-image steps
-        const float2 m = M.mean[gm], d = M.dir[gm];
-        const float lf = M.lfirst[gm], st = P.sum_templ[gi], dn = P.denom[gi];
-        if (x < P.w && y < P.h) pk = ((packed >> 16) << 8) | (packed & 0xffu);
-        S.mean_x[tid] = m.x; S.mean_y[tid] = m.y; S.dir_x[tid] = d.x; S.dir_y[tid] = d.y;
-        S.l_first[tid] = lf;
-        S.sum_templ[tid] = st; S.denom[tid] = dn;
+      // ONE batch of loads: the tile's descriptors, its patch halo of the reference image and -- when the setup kernel found that the box
+      // of all the tile's samples fits the LDS window and sent it along with the unit -- that window of the current image
+      // (a lane outside a ragged tile reads element 0; values of seeds without work are not used)
+      const int gi = (x < P.w && y < P.h) ? y * P.stride + x : 0;
+      const size_t gm = so + gi;
+      const unsigned int packed = M.packed[gm];  // first in-image step << 16 | number of in-image steps
+      const float2 m = M.mean[gm], d = M.dir[gm];
+      const float lf = M.lfirst[gm], st = P.sum_templ[gi], dn = P.denom[gi];
+      constexpr int REF_N = Smem::REF_H * Smem::REF_W, REF_PER = (REF_N + TILE_PIX - 1) / TILE_PIX;
+      float refv[REF_PER];
+#pragma unroll
+      for (int q = 0; q < REF_PER; ++q) {
+        const int i = min(tid + q * TILE_PIX, REF_N - 1);
+        const int ry = i / Smem::REF_W, rx = i - ry * Smem::REF_W;
+        refv[q] = P.ref[clampi(y0 - HALF + ry, 0, P.h - 1) * P.stride + clampi(x0 - HALF + rx, 0, P.w - 1)];
       }
+      if (boxed) {
+        W.x0 = static_cast<int>(box0 & 0xffffu); W.y0 = static_cast<int>(box0 >> 16);
+        W.x1 = static_cast<int>(box1 & 0xffffu); W.y1 = static_cast<int>(box1 >> 16);
+        W.ws = (W.x1 - W.x0 + 1) | 1;
+        W.valid = true;
+        frame_stage_window<SIDE>(P, S, tid, W);
+      }
+      unsigned int pk = 0u;
+      if (x < P.w && y < P.h) pk = ((packed >> 16) << 8) | (packed & 0xffu);
+      S.mean_x[tid] = m.x; S.mean_y[tid] = m.y; S.dir_x[tid] = d.x; S.dir_y[tid] = d.y;
+      S.l_first[tid] = lf;
+      S.sum_templ[tid] = st; S.denom[tid] = dn;
       S.packed[tid] = pk;
       S.best[tid] = 0ull;
-      for (int i = tid; i < Smem::REF_H * Smem::REF_W; i += TILE_PIX) {
-        const int ry = i / Smem::REF_W, rx = i - ry * Smem::REF_W;
-        S.ref[i] = P.ref[clampi(y0 - HALF + ry, 0, P.h - 1) * P.stride + clampi(x0 - HALF + rx, 0, P.w - 1)];
-      }
-      total = frame_prefix_and_window<SIDE>(P, S, tid, W);  // barriers inside
+#pragma unroll
+      for (int q = 0; q < REF_PER; ++q)
+        if (tid + q * TILE_PIX < REF_N) S.ref[tid + q * TILE_PIX] = refv[q];
+      total = boxed ? frame_prefix<SIDE>(S, tid) : frame_prefix_and_window<SIDE>(P, S, tid, W);  // barriers inside
       lds_tile = tile;
       if (tr && tid == 0 && n_done == 0) tr[1] = wall_clock64();
     }
+    if (handout && prefetch && tid == 0) {
+      const unsigned int u_next = gridDim.x + cls + cls_step * nxt_k;
+      S.bcast[0] = u_next;
+      if (u_next < n_units) {
+        int sh = 0;
+#pragma unroll
+        for (int q = 1; q < UNIT_SHARDS; ++q) sh += u_next >= shard_first[q] ? 1 : 0;
+        unsigned int sh_first = 0u;
+#pragma unroll
+        for (int q = 1; q < UNIT_SHARDS; ++q) sh_first = u_next >= shard_first[q] ? shard_first[q] : sh_first;
+        const uint4* src = M.units + static_cast<size_t>(sh) * M.shard_cap + (u_next - sh_first);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(S.bcast + 4), 16, 0, 0);
+      }
+    }
     frame_search<SIDE>(Qp->P, S, tid, first, min(first + unit_items, total), W, n_fallback, n_windows);  // ends with a barrier
     ++n_done; n_items += static_cast<unsigned int>(min(first + unit_items, total) - first);
-    if (n_units <= gridDim.x) break;  // light frame: every unit had its own workgroup, nothing to hand out
-    if (tid == 0) S.bcast[0] = gridDim.x + atomicAdd(&M.queue[1], 1u);
+    if (!handout) break;  // light frame: every unit had its own workgroup, nothing to hand out
+    if (!prefetch && tid == 0) {  // (A/B: claim and fetch the next unit only now)
+      const unsigned int u_next = gridDim.x + cls + cls_step * atomicAdd(&M.handout[cls * HANDOUT_STRIDE], 1u);
+      S.bcast[0] = u_next;
+      if (u_next < n_units) {
+        const uint4 e = entry_of(u_next);
+        S.bcast[4] = e.x; S.bcast[5] = e.y; S.bcast[6] = e.z; S.bcast[7] = e.w;
+      }
+    }
+    drain_vmem();  // the LDS-direct load of the next entry has landed (it was issued before the rounds)
     __syncthreads();
-    u = S.bcast[0];
+    u = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(S.bcast[0])));
+    take(make_uint4(S.bcast[4], S.bcast[5], S.bcast[6], S.bcast[7]));
     __syncthreads();
   }
   if (lds_tile >= 0) {

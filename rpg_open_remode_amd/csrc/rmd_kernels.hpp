@@ -668,6 +668,28 @@ __global__ __launch_bounds__(256) void tv_iterate_blocked_kernel(TvParams P, con
 
 // ------------------------------------------------------------------------------------------
 // device side of the arithmetic contract, for the self test
+// self test of the DPP wave primitives of rmd_device.hpp against the shuffle forms: mismatching lanes -> *bad
+__global__ __launch_bounds__(64) void wave_primitives_selftest_kernel(unsigned int seed, unsigned int* bad) {
+  const int lane = threadIdx.x;
+  unsigned int h = seed * 2654435761u + static_cast<unsigned int>(lane) * 40503u + blockIdx.x * 97u;
+  h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+  const int v = static_cast<int>(h % 2001u) - 1000;
+  int add = v, mn = v, mx = v;
+  for (int off = 32; off > 0; off >>= 1) {
+    add += __shfl_xor(add, off, 64);
+    mn = min(mn, __shfl_xor(mn, off, 64));
+    mx = max(mx, __shfl_xor(mx, off, 64));
+  }
+  int incl = v;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  const bool ok = wave_reduce_i32<WaveAdd>(v) == add && wave_reduce_i32<WaveMin>(v) == mn && wave_reduce_i32<WaveMax>(v) == mx &&
+                  wave_scan_i32<WaveAdd>(v) == incl;
+  if (!ok) atomicAdd(bad, 1u);
+}
+
 __global__ void math_eval_kernel(int op, const float* x, const float* y, const float* z, float* out, size_t n) {
   const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;

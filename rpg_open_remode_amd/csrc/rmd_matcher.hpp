@@ -31,7 +31,9 @@ constexpr int TILE_W = 16, TILE_H = 16, TILE_PIX = TILE_W * TILE_H;
 constexpr int MAX_UNIT_ROUNDS = 4;  // a work unit is 1..4 rounds of the 256 lanes (chosen per frame by seed_plan)
 constexpr int MIN_UNIT_ITEMS = TILE_PIX;
 constexpr int MAX_ITEMS_PER_TILE = TILE_PIX * 144;
-constexpr int UNIT_SHARDS = 16;  // plan-free pipeline: unit lists / counters, tile t -> shard t % UNIT_SHARDS
+constexpr int UNIT_SHARDS = 16;  // unit lists / counters, tile t -> shard t % UNIT_SHARDS; hand-out counters of the search, workgroup b -> b % UNIT_SHARDS
+constexpr int HANDOUT_STRIDE = 32;  // words between two hand-out counters (128 B: one L2 line each)
+constexpr unsigned int UNIT_TILE_BOX = 0x80000000u;  // flag in a unit's first-item word: words 2, 3 hold the texel box of ALL samples of the unit's tile, and it fits the LDS window
 constexpr int TRACE_FRAMES = 256, TRACE_MAX_SEARCH_WGS = 1024;  // diagnostics (trace_record)
 
 constexpr int MAX_BATCH = 8;  // sequences one launch pair can carry (the per-sequence parameter blocks travel as kernel arguments: 4 KB)
@@ -56,7 +58,8 @@ struct MatcherWorkspace {
   TileInfo* d_tiles = nullptr;           // round-1 pipeline only (A/B builds)
   unsigned int* d_tile_plan = nullptr;   // per tile: work items
   unsigned int* d_tile_conv = nullptr;   // per tile: seeds that seed_check found CONVERGED in this frame
-  uint2* d_units = nullptr;         // (tile, first item)
+  uint4* d_units = nullptr;         // work units: (tile, first item | UNIT_TILE_BOX, the tile's sample box x0 | y0 << 16, x1 | y1 << 16)
+  unsigned int* d_handout = nullptr;  // UNIT_SHARDS hand-out counters of the search kernel, HANDOUT_STRIDE words apart
   // counters of the current frame: [0] work units (round-1 plan kernel), [1] units handed out beyond the static first round,
   // [5] items per unit
   unsigned int* d_queue = nullptr;
@@ -67,6 +70,7 @@ struct MatcherWorkspace {
   unsigned int update_number = 0;          // launch pairs so far (modulo 2^32), stamped into h_conv
   int shard_cap = 0;                       // unit-list entries per shard
   int lds_bytes = 160 * 1024;              // LDS per CU of the handle's device (gfx950: 160 KB)
+  int search_flags = 6;                    // SEARCH_FLAGS_DEFAULT (experiments: RMD_HIP_OPT_SEARCH_FLAGS)
   unsigned long long* d_trace = nullptr;   // diagnostics, allocated on demand: TRACE_FRAMES slices of trace_slice_u64() words (round-1 pipeline)
   unsigned long long* d_wg_trace = nullptr;  // diagnostics, allocated on demand: FR_TRACE_FRAMES slices of wg_trace_slice_u64() words (probes of the search workgroups)
   int max_units = 0;
@@ -95,7 +99,9 @@ struct MatcherWorkspace {
     shard_cap = static_cast<int>((n_tiles_all + UNIT_SHARDS - 1) / UNIT_SHARDS) * units_per_tile;  // tiles of a shard x units of a tile
     max_units = static_cast<int>(n_tiles_all + UNIT_SHARDS) * units_per_tile;
     if (max_units < UNIT_SHARDS * shard_cap) max_units = UNIT_SHARDS * shard_cap;
-    if (hipMalloc(reinterpret_cast<void**>(&d_units), static_cast<size_t>(max_units) * sizeof(uint2)) != hipSuccess) return -1;
+    if (hipMalloc(reinterpret_cast<void**>(&d_units), static_cast<size_t>(max_units) * sizeof(uint4)) != hipSuccess) return -1;
+    if (hipMalloc(reinterpret_cast<void**>(&d_handout), UNIT_SHARDS * HANDOUT_STRIDE * sizeof(unsigned int)) != hipSuccess) return -1;
+    if (hipMemset(d_handout, 0, UNIT_SHARDS * HANDOUT_STRIDE * sizeof(unsigned int)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_queue), 8 * sizeof(unsigned int)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_shards), 3 * UNIT_SHARDS * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (hipHostMalloc(reinterpret_cast<void**>(&h_conv), MAX_BATCH * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) return -1;
@@ -114,12 +120,12 @@ struct MatcherWorkspace {
   size_t trace_slice_u64() const { return 2 * (static_cast<size_t>(tiles_x) * tiles_y + 1 + TRACE_MAX_SEARCH_WGS); }
   size_t wg_trace_slice_u64() const { return static_cast<size_t>(tiles_x) * tiles_y * 8; }  // FR_TRACE_WORDS per workgroup / tile
   void release() {
-    void* all[] = {d_mean, d_dir, d_lfirst, d_packed, d_best, d_tiles, d_tile_plan, d_tile_conv, d_units, d_queue, d_shards, d_trace, d_wg_trace};
+    void* all[] = {d_mean, d_dir, d_lfirst, d_packed, d_best, d_tiles, d_tile_plan, d_tile_conv, d_units, d_handout, d_queue, d_shards, d_trace, d_wg_trace};
     for (void* p : all)
       if (p) (void)hipFree(p);
     if (h_conv) (void)hipHostFree(h_conv);
     d_mean = d_dir = nullptr; d_lfirst = nullptr; d_packed = nullptr; d_best = nullptr;
-    d_tiles = nullptr; d_tile_plan = nullptr; d_tile_conv = nullptr; d_units = nullptr; d_queue = nullptr; d_shards = nullptr; d_trace = nullptr;
+    d_tiles = nullptr; d_tile_plan = nullptr; d_tile_conv = nullptr; d_units = nullptr; d_handout = nullptr; d_queue = nullptr; d_shards = nullptr; d_trace = nullptr;
     d_wg_trace = nullptr; h_conv = nullptr; d_conv = nullptr;
   }
 };
@@ -135,7 +141,8 @@ struct MatcherArgs {
   TileInfo* tiles;
   unsigned int* tile_plan;
   unsigned int* tile_conv;
-  uint2* units;
+  uint4* units;
+  unsigned int* handout;     // UNIT_SHARDS counters, HANDOUT_STRIDE words apart (zero at the search kernel's launch)
   unsigned int* queue;       // this frame's counters (see MatcherWorkspace)
   unsigned long long* shards_cur;         // this frame's shard counters (zero at launch)
   const unsigned long long* shards_prev;  // the previous frame's (null: no previous frame)
@@ -147,6 +154,7 @@ struct MatcherArgs {
   int tiles_y;
   int n_tiles;               // tiles of one sequence
   int n_seq;
+  int search_flags;          // SEARCH_* (rmd_frame.hpp)
   unsigned long long* trace;  // this frame's slice of the timeline buffer, may be null (round-1 pipeline, see trace_record)
   // Frame ingest for frames handed over in host memory: a copy engine brings the frames of all sequences of the launch as they are
   // into staging buffers in HBM and then writes the step's number into `ingest_flag`, both on the copy stream, with NO ordering
@@ -464,12 +472,13 @@ inline MatcherArgs matcher_args(const MatcherWorkspace& ws) {
   MatcherArgs M;
   M.mean = ws.d_mean; M.dir = ws.d_dir; M.lfirst = ws.d_lfirst; M.packed = ws.d_packed; M.best = ws.d_best;
   M.seq_plane = ws.seq_plane;
-  M.tiles = ws.d_tiles; M.tile_plan = ws.d_tile_plan; M.tile_conv = ws.d_tile_conv; M.units = ws.d_units;
+  M.tiles = ws.d_tiles; M.tile_plan = ws.d_tile_plan; M.tile_conv = ws.d_tile_conv; M.units = ws.d_units; M.handout = ws.d_handout;
   M.tiles_x = ws.tiles_x; M.tiles_y = ws.tiles_y; M.n_tiles = ws.tiles_x * ws.tiles_y; M.n_seq = ws.n_seq;
   M.queue = ws.d_queue;
   M.shards_cur = ws.d_shards + (ws.frame % 3) * UNIT_SHARDS;
   M.shards_prev = ws.frame > 0 ? ws.d_shards + ((ws.frame + 2) % 3) * UNIT_SHARDS : nullptr;
   M.shards_next = ws.d_shards + ((ws.frame + 1) % 3) * UNIT_SHARDS;
+  M.search_flags = ws.search_flags;
   M.conv_out = ws.d_conv;
   M.update_number = ws.update_number;
   M.shard_cap = ws.shard_cap;

@@ -3,6 +3,8 @@ and reports errors the way the header says (no compute calls here)."""
 import ctypes
 import os
 
+import pytest
+
 from rpg_open_remode_amd import _lib
 
 
@@ -65,3 +67,13 @@ def test_product_never_touches_the_oracle():
                     if needle in text and f != "build.py":
                         offenders.append((f, needle))
     assert not offenders, offenders
+
+
+@pytest.mark.gpu
+def test_wave_primitives_selftest():
+    """the DPP reductions / scans the kernels use equal their shuffle forms on the device"""
+    import ctypes
+    from rpg_open_remode_amd import _lib
+    bad = ctypes.c_int(-1)
+    _lib.check(_lib.lib().rmd_hip_selftest_wave_primitives(ctypes.byref(bad)))
+    assert bad.value == 0

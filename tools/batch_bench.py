@@ -11,21 +11,26 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--b", default="1,2,4,8"); ap.add_argument("--size", default="640x480"); ap.add_argument("--frames", type=int, default=200)
 ap.add_argument("--passes", type=int, default=3); ap.add_argument("--side", type=int, default=9); ap.add_argument("--u8", action="store_true")
 ap.add_argument("--unit-target", type=int, default=1); ap.add_argument("--same-scene", action="store_true")
+ap.add_argument("--flags", default="6", help="comma-separated RMD_HIP_OPT_SEARCH_FLAGS values to run one after the other")
 ap.add_argument("--per-step", action="store_true", help="also: one more pass with a synchronisation after every step, wall time of selected steps")
 a = ap.parse_args()
 W, H = (int(v) for v in a.size.split("x"))
 F = a.frames
 sizes = [int(v) for v in a.b.split(",")]
 n_max = max(sizes)
-seqs = [synth.Sequence(W, H, F, 0 if a.same_scene else s) for s in range(n_max)]
+seqs = [synth.Sequence(W, H, F, s) for s in range(1 if a.same_scene else n_max)]
+if a.same_scene:
+    seqs = seqs * n_max  # one rendering, the same work for every member
 dev = []
-for seq in seqs:
+for seq in seqs[:1] if a.same_scene else seqs:
     fr = []
     for k in range(F):
         d = api.DeviceImage(W, H, np.float32)
         d.setDevData(seq.images[k])
         fr.append(d)
     dev.append(fr)
+if a.same_scene:
+    dev = dev * n_max
 
 
 def run_pass(b, n):
@@ -40,9 +45,10 @@ def run_pass(b, n):
             b.updateDevice([dev[i][k].data for i in range(n)], [dev[i][k].stride for i in range(n)], poses)
 
 
-for n in sizes:
+for n, flags in [(n, f) for f in (int(v) for v in a.flags.split(",")) for n in sizes]:
     b = api.SeedMatrixBatch(n, W, H, api.PinholeCamera(*seqs[0].K), patch_side=a.side)
     b.setOption(api.OPT_UNIT_TARGET, a.unit_target)
+    b.setOption(api.OPT_SEARCH_FLAGS, flags)
     run_pass(b, n)
     b.sync()
     b.setOption(api.OPT_TIMING, 2)
@@ -55,7 +61,7 @@ for n in sizes:
     ms, steps = b.timing()
     upd = n * a.passes * (F - 1)
     conv = [b[i].getConvergedCount() for i in range(n)]
-    print(f"batch of {n} ({'8-bit host frames' if a.u8 else 'resident frames'}): {W * H * upd / dt / 1e6:.0f} Mpix/s, {dt / (a.passes * (F - 1)) * 1e6:.1f} us per step "
+    print(f"[flags {flags}] batch of {n} ({'8-bit host frames' if a.u8 else 'resident frames'}): {W * H * upd / dt / 1e6:.0f} Mpix/s, {dt / (a.passes * (F - 1)) * 1e6:.1f} us per step "
           f"({dt / upd * 1e6:.1f} us per sequence update; device {ms / max(steps, 1) * 1e3:.1f} us per step); converged {conv}", flush=True)
     if a.per_step:
         for i in range(n):
