@@ -12,18 +12,23 @@ At N = 1 the default workload is BASELINE.json configs[1]: the 640x480 synthetic
 200 iterations) that is reported separately.  `--size 1280x960 --frames 500` is configs[2], `--size 1920x1080 --frames 1000
 --tv-iters 500` is configs[4]; they are labelled as such and are not the headline metric.
 
-value = W * H * (F-1) * K / elapsed: pixels of update() calls over the wall time of the K passes (setReferenceImage is
-inside the timed region, its pixels are not counted).  All frames are resident in HBM before the timed region starts; the
-timed region is bracketed by barrier + device synchronisation on both sides and the MAX over ranks is taken.  For N > 1
-every rank runs its own independent sequence on its own GPU (weak scaling, no data-path collective) and rank 0 prints the
-aggregate.  The rate with the per-frame host-to-device copy included (test/dataset_main.cpp:101-103) is
-reported in the same line as `h2d_inclusive`.
+value = W * H * (F-1) * K / elapsed, measured the way SURVEY.md 8(d) / test/dataset_main.cpp:101-103 define the metric: the
+frame upload is INSIDE update().  Every frame starts as an 8-bit gray image in pageable host memory (what the camera / the
+dataset reader delivers and what Depthmap::inputImage receives, depthmap.cpp:95-106) and is handed to rmd_hip_seeds_update_u8;
+the timed region is bracketed by barrier + device synchronisation on both sides and the MAX over ranks is taken.  The same passes
+with the frames already resident in HBM (`resident`) and with float frames through update(float*), the reference's own signature
+(`float_frames`), are measured right after and reported in the same line.  For N > 1 every rank runs its own independent sequence
+on its own GPU (weak scaling, no data-path collective) and rank 0 prints the aggregate.
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel, algorithmic bytes / HIP-event time on the
-stream the kernels run on), "roofline_valu" / "roofline_flops" (the roofs that actually bind the NCC search),
-"roofline_denoiser", "cpu_baseline" (the reference's own kernels on the host cores over a bounded sample of the same frames).
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel, algorithmic bytes / HIP-event time on the stream the
+kernels run on), "roofline_valu" / "roofline_flops" (the roofs that actually bind the NCC search), "roofline_denoiser",
+"heavy_prefix" (updates 1..20 of a pass, every seed live), "batched_per_gpu" (B independent sequences stepped by one launch pair
+per step, rmd_hip_batch_*), "cpu_baseline" (the reference's own kernels on the host cores) and "parity_vs_glibc_reference" (how
+far the result is from the untouched reference, measured on the same run).
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import subprocess
@@ -47,8 +52,7 @@ TV_LAMBDA, TV_ITERS = 0.5, 200
 KNOWN_CONFIGS = {(640, 480, 200): "configs[1]", (1280, 960, 500): "configs[2]", (1920, 1080, 1000): "configs[4]"}
 PARITY_NOTE = ("bit-identical (all state planes, convergence masks, TV-L1 output) to the reference's own kernels compiled for the "
                "CPU with IEEE fp32, no contraction and the shared expf/sinf/acosf of csrc/rmd_math.h (tests/: golden fixtures "
-               "generated from /root/reference); that build differs from the reference linked against glibc's libm by RMSE "
-               "3e-4 m (DESIGN.md 2)")
+               "generated from /root/reference); distance to the reference linked against glibc's libm: parity_vs_glibc_reference")
 
 
 def parse():
@@ -56,16 +60,19 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5, help="timed passes over the sequence (one step = setReference + F-1 updates)")
     ap.add_argument("--warmup", type=int, default=1, help="untimed passes before the timed region")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample (0 disables)")
-    ap.add_argument("--matcher", type=int, default=-1, help="A/B: 0 per-pixel kernel, 1 round-1 tile pipeline, 2 one-launch frame kernel, "
-                    "3 tile pipeline with the compact search kernel (the library's default, used when the flag is absent)")
+    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="budget of the cpu_baseline run (0 disables it and the glibc parity figures)")
+    ap.add_argument("--matcher", type=int, default=-1, help="A/B: 0 per-pixel kernel, 3 tile pipeline (the library's default, used when the flag "
+                    "is absent); 1 / 2 (retired variants) only with an A/B build of the library")
     ap.add_argument("--unit-target", type=int, default=1, help="tile pipeline: work units aimed at per frame, in multiples of the resident search workgroups (experiments)")
     ap.add_argument("--size", default=f"{WIDTH}x{HEIGHT}", help="frame size WxH; 640x480 with 200 frames is the headline metric")
     ap.add_argument("--frames", type=int, default=0, help="frames per pass incl. the reference (default: 200; 500 at 1280x960, "
                     "1000 at 1920x1080, as BASELINE.json configures them)")
     ap.add_argument("--tv-iters", type=int, default=0, help="TV-L1 iterations of the separately reported denoise (default 200; 500 at 1920x1080)")
+    ap.add_argument("--resident", action="store_true", help="timed region with the frames already resident in HBM (rmd_hip_seeds_update_device) instead "
+                    "of 8-bit frames from host memory; the line says so")
+    ap.add_argument("--batch", default="2,4,8", help="batch sizes of the batched_per_gpu section (empty: skip it)")
     ap.add_argument("--dist", action="store_true", help="create the torch.distributed (RCCL) group even for a single rank")
-    ap.add_argument("--no-extras", action="store_true", help="skip the H2D / statistics / CPU passes (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true", help="the timed region and the denoise only (profiling runs)")
     ap.add_argument("--rendezvous-only", action="store_true", help="launch-path check, no measurement: join the process group (gloo when "
                     "there is no GPU), run the barriers and the throughput gather with zero work, print {\"rendezvous\": ...} and exit")
     return ap.parse_args()
@@ -78,6 +85,16 @@ def resolve_workload(args):
     return w, h, frames, tv_iters
 
 
+def kernel_source_sha256():
+    """hash of everything that is compiled into librmd_hip.so: committed counter files (profiles/traffic.json) carry the hash of the
+    sources they were measured on, and a figure derived from them is refused when the kernels have changed since"""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "rpg_open_remode_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def load_counters(path):
     try:
         return json.load(open(path))
@@ -85,20 +102,23 @@ def load_counters(path):
         return None
 
 
-def valu_roofline(avg_launch_s, traffic_path):
+def valu_roofline(avg_launch_s, counters, n_sequences=1):
     """The roof that actually binds the seed update: VALU issue.  Wave-instruction counts per update() come from
-    the committed PMC pass over the same complete passes (profiles/traffic.json, SQ_INSTS_VALU), the launch time from this run."""
-    t = load_counters(traffic_path)
-    if not t or avg_launch_s <= 0:
+    the committed PMC pass over the same complete passes (profiles/traffic.json, SQ_INSTS_VALU) -- accepted only if that file was
+    measured on the kernel sources of this build --, the launch time from this run."""
+    if not counters or avg_launch_s <= 0:
         return None
+    if counters.get("kernel_source_sha256") != kernel_source_sha256():
+        return {"bound": "valu", "stale": True, "note": "profiles/traffic.json was measured on other kernel sources (kernel_source_sha256 differs): "
+                "re-run tools/profile_r03.sh; no figure is derived from stale instruction counts"}
     try:
-        n = float(sum(t["valu_wave_instructions_per_update"].values()))
+        n = float(sum(counters["valu_wave_instructions_per_update"].values())) * n_sequences
     except Exception:
         return None
     achieved = n / avg_launch_s / 1e9
     return {"bound": "valu", "kernel": "seed_update", "achieved": round(achieved, 1), "peak": round(VALU_PEAK_GINST_S, 1),
             "unit": "G wave-instructions/s", "frac": round(achieved / VALU_PEAK_GINST_S, 4),
-            "wave_instructions_per_launch": int(n), "source": "profiles/traffic.json (rocprofv3 --pmc SQ_INSTS_VALU, whole passes)"}
+            "wave_instructions_per_launch": int(n), "source": "profiles/traffic.json (rocprofv3 --pmc SQ_INSTS_VALU, whole passes, same kernel sources)"}
 
 
 def flops_roofline(avg_launch_s, ncc_evals_per_update, side):
@@ -111,11 +131,13 @@ def flops_roofline(avg_launch_s, ncc_evals_per_update, side):
             "definition": f"{NCC_FLOP_PER_TAP} flop x {side * side} taps x NCC evaluations (SURVEY.md 8d), evaluations counted by this run"}
 
 
-def cpu_baseline(frame_fn, width, height, K, n_frames, side, min_depth, max_depth, budget_s, gpu_sample_fn):
-    """The reference's own kernels (oracle/_ref, built from /root/reference for the host) over the first frames
-    of the same sequence, all host cores, until `budget_s` is used up."""
+def cpu_reference_run(frame_fn, width, height, K, n_frames, side, min_depth, max_depth, budget_s, tv_iters):
+    """The reference's own kernels (oracle/_ref, built from /root/reference for the host, glibc libm: the UNTOUCHED reference) over the
+    same sequence, all host cores, until `budget_s` is used up (the whole sequence fits on the GPU box's cores).  Returns the
+    cpu_baseline object, the number of updates run, the oracle's state after its last update, its TV-L1 result on that state (None if
+    the run was cut short) and the oracle kind."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # idle OpenMP workers must not spin while the GPU sample is timed
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # idle OpenMP workers must not spin while the GPU is timed
     import oracles as O
     kind = "reference" if O.available("ref", side) else "port"
     olib = O.OracleLib("ref" if kind == "reference" else "port", side)
@@ -131,13 +153,17 @@ def cpu_baseline(frame_fn, width, height, K, n_frames, side, min_depth, max_dept
         s.update(img, T)
     dt = time.perf_counter() - t0
     mpix = width * height * n / dt / 1e6
+    what = ("the reference's own seed_matrix.cu kernels compiled for the host (oracle/Makefile), glibc libm" if kind == "reference"
+            else "CPU restatement of the reference (oracle/remode_oracle.cpp)")
     out = {"value": round(mpix, 4), "unit": "Mpix/s", "cores": int(cores), "kind": kind,
-           "sample": f"updates 1..{n} of the same {width}x{height} sequence (patch side {side}), {dt:.1f} s"}
-    time.sleep(0.3)
-    gpu_same = gpu_sample_fn(n)
-    if gpu_same:
-        out["gpu_same_sample"] = round(gpu_same, 2)
-    return out
+           "sample": f"updates 1..{n} of the same {width}x{height} sequence (patch side {side}), {dt:.1f} s; {what}"}
+    state = s.state()
+    den = None
+    if n == n_frames - 1:
+        d = O.Denoiser(olib, width, height)
+        d.set_large_sigma_sq(max_depth - min_depth)
+        den = d.denoise(s, TV_LAMBDA, tv_iters)
+    return out, n, state, den, kind
 
 
 def main():
@@ -178,50 +204,77 @@ def main():
     if not api.checkCudaDevice(dev_index):
         raise SystemExit("no usable HIP device")
 
-    # one independent sequence per rank (scene / trajectory seed = rank), rendered on the host frame by frame and made
-    # resident through the library's own rmd::DeviceImage (not torch: torch is here for torch.distributed only)
+    # one independent sequence per rank (scene / trajectory seed = rank), rendered on the host frame by frame: the 8-bit frames stay
+    # in pageable host memory (the timed region hands them over like a camera driver would); a float copy of every frame is made
+    # resident through the library's own rmd::DeviceImage for the `resident` figure (torch is here for torch.distributed only)
     K = synth.intrinsics(W, H)
-    keep_host = headline or F <= 200  # the 8-bit frames stay on the host for the H2D-inclusive pass
-    frames, poses, gray = [], [], []
-    range0 = None
-    for k in range(F):
-        T = synth.pose(k, rank)
-        g, rng = synth.render(W, H, T, rank, want_range=(k == 0), K=K)
-        if k == 0:
-            range0 = rng
-        d = api.DeviceImage(W, H, np.float32)
-        d.setDevData(synth.to_float_image(g))
-        frames.append(d)
-        poses.append(np.ascontiguousarray(synth.invert_pose(T).astype(np.float32).reshape(12)))
-        if keep_host:
+
+    def render_scene(scene, want_resident):
+        gray, poses, dev = [], [], []
+        rng0 = None
+        for k in range(F):
+            T = synth.pose(k, scene)
+            g, rng = synth.render(W, H, T, scene, want_range=(k == 0), K=K)
+            if k == 0:
+                rng0 = rng
             gray.append(g)
-    min_depth, max_depth = float(range0.min()), float(range0.max())
+            poses.append(np.ascontiguousarray(synth.invert_pose(T).astype(np.float32).reshape(12)))
+            if want_resident:
+                d = api.DeviceImage(W, H, np.float32)
+                d.setDevData(synth.to_float_image(g))
+                dev.append(d)
+        return {"gray": gray, "poses": poses, "dev": dev, "min": float(rng0.min()), "max": float(rng0.max())}
+
+    t_render = time.perf_counter()
+    seq = render_scene(rank, True)
+    render_s = time.perf_counter() - t_render
+    gray, poses, frames = seq["gray"], seq["poses"], seq["dev"]
+    min_depth, max_depth = seq["min"], seq["max"]
 
     def new_seeds():
         s = api.SeedMatrix(W, H, api.PinholeCamera(*K), patch_side=SIDE)
         if args.matcher >= 0:
             s.setOption(api.OPT_MATCHER, args.matcher)
-            s.setOption(api.OPT_UNIT_TARGET, args.unit_target)
+        s.setOption(api.OPT_UNIT_TARGET, args.unit_target)
         return s
 
-    def set_ref(s):
+    def pass_resident(s, n_updates=None):
+        """one step: the reference frame, then updates 1..F-1 (or the first n_updates of them), frames resident in HBM"""
         s.setReferenceImageDevice(frames[0].data, frames[0].stride, poses[0], min_depth, max_depth)
-
-    def run_pass(s, n_updates=None):
-        """one step: the reference frame, then updates 1..F-1 (or the first n_updates of them)"""
-        set_ref(s)
         for k in range(1, (F if n_updates is None else n_updates + 1)):
             s.updateDevice(frames[k].data, frames[k].stride, poses[k])
 
+    def pass_u8(s, n_updates=None):
+        """the same step with every frame handed over as an 8-bit image in pageable host memory"""
+        s.setReferenceImageU8(gray[0], poses[0], min_depth, max_depth)
+        for k in range(1, (F if n_updates is None else n_updates + 1)):
+            s.updateU8(gray[k], poses[k])
+
+    run_pass = pass_resident if args.resident else pass_u8
+
+    def timed(s, one_pass, passes):
+        """(wall seconds, device ms of the region, update() calls in it) of `passes` complete passes"""
+        s.sync()
+        s.setOption(api.OPT_TIMING, 2)  # one HIP event pair around the timed region, on the stream the kernels run on
+        s.timingReset()  # records the region's start event on the (idle) stream: nothing but the timed launches follows it
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            one_pass(s)
+        s.sync()
+        dt = time.perf_counter() - t0
+        ms, n = s.timing(api.STAGE_UPDATE)
+        s.setOption(api.OPT_TIMING, 0)
+        return dt, ms, n
+
     seeds = new_seeds()
-    for _ in range(args.warmup):  # W untimed passes (clocks, code objects, allocator)
+    for _ in range(args.warmup):  # W untimed passes (clocks, code objects, allocator, staging buffers)
         run_pass(seeds)
     seeds.sync()
-    seeds.setOption(api.OPT_TIMING, 2)  # one HIP event pair around the timed region, on the stream the kernels run on
+    seeds.setOption(api.OPT_TIMING, 2)
 
     batch.barrier(device)
     torch.cuda.synchronize()
-    seeds.timingReset()  # records the region's start event on the (idle) stream: nothing but the timed launches follows it
+    seeds.timingReset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run_pass(seeds)
@@ -230,6 +283,7 @@ def main():
     elapsed = time.perf_counter() - t0
     batch.barrier(device)
     kernel_ms, kernel_updates = seeds.timing(api.STAGE_UPDATE)  # device time of the region / update() calls in it
+    seeds.setOption(api.OPT_TIMING, 0)
     converged = seeds.getConvergedCount()
     n_updates = (F - 1) * args.steps
     units = float(W * H * n_updates)
@@ -244,17 +298,18 @@ def main():
         den.setOption(api.DENOISE_OPT_TIMING, 1)
         den.denoise(seeds.getMu(), seeds.getSigmaSq(), seeds.getA(), seeds.getB(), TV_LAMBDA, 10, download=True)  # warm
         td = time.perf_counter()
-        den.denoise(seeds.getMu(), seeds.getSigmaSq(), seeds.getA(), seeds.getB(), TV_LAMBDA, tv_iters, download=True)
+        hip_denoised = den.denoise(seeds.getMu(), seeds.getSigmaSq(), seeds.getA(), seeds.getB(), TV_LAMBDA, tv_iters, download=True)
         denoise_wall_ms = (time.perf_counter() - td) * 1e3
         tv_ms, tv_launches = den.timing()
 
         counters = load_counters(os.path.join(ROOT, "profiles", "traffic.json")) if headline else None
+        fresh = bool(counters) and counters.get("kernel_source_sha256") == kernel_source_sha256()
         avg_kernel_s = kernel_ms / max(kernel_updates, 1) / 1e3
         achieved = FUSED_BYTES_PER_PIXEL * W * H / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
         roofline = {"bound": "hbm", "kernel": "seed_update (fused seed_check+epipolar_match+triangulation+seed_update)",
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": counters.get("seed_update_bytes_per_launch") if counters else None,
+                    "traffic": counters.get("seed_update_bytes_per_launch") if fresh else None,
                     "avg_launch_us": round(avg_kernel_s * 1e6, 2), "launches": kernel_updates,
                     "algorithmic_bytes_per_launch": FUSED_BYTES_PER_PIXEL * W * H,
                     "note": "device time of the timed region (one HIP event pair on the kernels' stream, seed_init of each pass "
@@ -264,7 +319,7 @@ def main():
         tv_iters_per_launch = tv_iters / max(tv_launches, 1)
         tv_achieved = TV_BYTES_PER_PIXEL_ITER * W * H * tv_iters_per_launch / tv_avg_s / 1e9 if tv_avg_s > 0 else 0.0
         tv_traffic = None
-        if counters:
+        if fresh:
             tv_traffic = (counters.get("tv_bytes_per_launch") or {}).get(f"{W}x{H}")
         roofline_tv = {"bound": "hbm", "kernel": "tv_iterate", "achieved": round(tv_achieved, 2), "peak": HBM_PEAK_GBS,
                        "unit": "GB/s", "frac": round(tv_achieved / HBM_PEAK_GBS, 5), "traffic": tv_traffic,
@@ -272,12 +327,13 @@ def main():
                        "iterations_per_launch": round(tv_iters_per_launch, 2),
                        "denoise_wall_ms": round(denoise_wall_ms, 3), "iterations": tv_iters}
 
-        search_stats, h2d, cpu = None, None, None
+        search_stats, cpu, glibc, resident, floats, heavy, batched, other_path = None, None, None, None, None, None, None, None
+        extra_passes = max(1, min(args.steps, 3))
         if not args.no_extras:
             # search statistics of the timed workload (separate pass over the same sequence, diagnostics counters on)
             s3 = new_seeds()
             s3.setOption(api.OPT_COLLECT_STATS, 1)
-            set_ref(s3)
+            s3.setReferenceImageDevice(frames[0].data, frames[0].stride, poses[0], min_depth, max_depth)
             tot = {"live_seeds": 0, "steps": 0, "ncc_evals": 0}
             for k in range(1, F):
                 s3.updateDevice(frames[k].data, frames[k].stride, poses[k])
@@ -287,57 +343,140 @@ def main():
             search_stats = {k: round(v / (F - 1), 1) for k, v in tot.items()}
             del s3
 
-            # H2D-inclusive rate (SURVEY.md 8d / test/dataset_main.cpp:101-103: the frame upload is inside the timed calls):
-            # frames start in pageable host memory; float frames through update(), 8-bit frames through update_u8()
-            if keep_host:
-                def host_pass(use_u8):
-                    s4 = new_seeds()
-                    imgs = gray if use_u8 else [synth.to_float_image(g) for g in gray]
-                    def one():
-                        if use_u8:
-                            s4.setReferenceImageU8(imgs[0], poses[0], min_depth, max_depth)
-                            for k in range(1, F):
-                                s4.updateU8(imgs[k], poses[k])
-                        else:
-                            s4.setReferenceImage(imgs[0], poses[0], min_depth, max_depth)
-                            for k in range(1, F):
-                                s4.update(imgs[k], poses[k])
-                    for _ in range(2):  # untimed: staging buffers, copy engine clocks
-                        one()
-                    s4.sync()
-                    ts = time.perf_counter()
-                    for _ in range(3):
-                        one()
-                    s4.sync()
-                    return W * H * (F - 1) * 3 / (time.perf_counter() - ts) / 1e6
-                u8_rate, f32_rate = host_pass(True), host_pass(False)
-                resident = total_units / max_elapsed / 1e6 / world
-                h2d = {"value": round(u8_rate, 1), "unit": "Mpix/s",
-                       "path": "rmd_hip_seeds_update_u8: 8-bit frames in pageable host memory -> pinned ring -> copy engine -> staging buffer in "
-                               "HBM; the update's own setup kernel waits for the copy's sequence number and applies x(1/255) (what "
-                               "Depthmap::inputImage feeds, depthmap.cpp:95-106); no event or wait between the copy and compute streams",
-                       "float_frames_update_mpix_s": round(f32_rate, 1), "frac_of_resident": round(u8_rate / resident, 3),
-                       "bound": "PCIe Gen5 x16 63 GB/s = 205 000 Mpix/s of 8-bit frames: not the limit; the update kernels are (float frames: the host's "
-                                "1.2 MB copy into pinned memory, ~50 us per frame)"}
+            # the other frame sources, measured like the timed region (complete passes, one event pair, synchronised on both sides)
+            def rate(one_pass):
+                s4 = new_seeds()
+                one_pass(s4)  # untimed: staging buffers, copy engine clocks
+                dt, ms, n = timed(s4, one_pass, extra_passes)
+                return {"value": round(W * H * (F - 1) * extra_passes / dt / 1e6, 1), "unit": "Mpix/s", "us_per_update_wall": round(dt / n * 1e6, 2),
+                        "us_per_update_device": round(ms / n * 1e3, 2), "passes": extra_passes}
+            if args.resident:
+                other_path = dict(rate(pass_u8), path="rmd_hip_seeds_update_u8: 8-bit frames in pageable host memory (SURVEY.md 8d: the upload inside update())")
+            else:
+                resident = dict(rate(pass_resident), path="rmd_hip_seeds_update_device: frames already resident in HBM, read in place")
 
-            def gpu_sample(n):
-                s2 = new_seeds()
-                run_pass(s2, n)
-                s2.sync()
-                ts = time.perf_counter()
-                run_pass(s2, n)
-                s2.sync()
-                return W * H * n / (time.perf_counter() - ts) / 1e6
+            if F <= 500:
+                fimgs = [synth.to_float_image(g) for g in gray]
 
-            if args.cpu_seconds > 0 and world == 1 and keep_host:  # an N = 1 figure; at N > 1 the other ranks would spin beside it
+                def pass_float(s):
+                    s.setReferenceImage(fimgs[0], poses[0], min_depth, max_depth)
+                    for k in range(1, F):
+                        s.update(fimgs[k], poses[k])
+                floats = dict(rate(pass_float), path="rmd_hip_seeds_update: float frames in pageable host memory, the reference's own signature "
+                              "(seed_matrix.cu:120-128); the host copy of the frame into the pinned ring is split across a few host threads")
+                del fimgs
+
+            # updates 1..20 of a pass: every seed is live and searches its full range (the heaviest twentieth of the job)
+            s5 = new_seeds()
+            run_pass(s5, 20)
+            s5.sync()
+            s5.setOption(api.OPT_TIMING, 2)
+            hp_ms, hp_n = 0.0, 0
+            for _ in range(3):
+                if args.resident:
+                    s5.setReferenceImageDevice(frames[0].data, frames[0].stride, poses[0], min_depth, max_depth)
+                else:
+                    s5.setReferenceImageU8(gray[0], poses[0], min_depth, max_depth)
+                s5.sync()
+                s5.timingReset()
+                for k in range(1, 21):
+                    if args.resident:
+                        s5.updateDevice(frames[k].data, frames[k].stride, poses[k])
+                    else:
+                        s5.updateU8(gray[k], poses[k])
+                ms, n = s5.timing(api.STAGE_UPDATE)
+                hp_ms += ms
+                hp_n += n
+            heavy = {"updates": "1..20 of a pass (3 repetitions)", "us_per_update_device": round(hp_ms / max(hp_n, 1) * 1e3, 2)}
+            if fresh and counters.get("valu_wave_instructions_first20_per_update"):
+                n_inst = float(sum(counters["valu_wave_instructions_first20_per_update"].values()))
+                heavy["valu_frac"] = round(n_inst / (hp_ms / max(hp_n, 1) / 1e3) / 1e9 / VALU_PEAK_GINST_S, 4)
+            del s5
+
+            # batched mode: B independent sequences (scenes 0..B-1) stepped by ONE launch pair per step (rmd_hip_batch_*)
+            sizes = [int(v) for v in args.batch.split(",") if v.strip()] if (args.batch and world == 1 and W * H <= 1280 * 960) else []
+            if sizes:
+                t_render = time.perf_counter()
+                scenes = {rank: seq}
+                for sc in range(max(sizes)):
+                    if sc not in scenes:
+                        scenes[sc] = render_scene(sc, True)
+                batched = {"what": "B independent sequences of this workload (scenes 0..B-1) on ONE GPU, stepped together: one setup + one search launch "
+                                   "per step for all of them (rmd_hip_batch_update_*); aggregate Mpix/s over all B sequences; every member is bit-identical "
+                                   "to the same sequence run alone (tests/test_batch.py)",
+                           "host_render_s": round(time.perf_counter() - t_render, 1)}
+                for B in sizes:
+                    sc = [scenes[i] for i in range(B)]
+                    bm = api.SeedMatrixBatch(B, W, H, api.PinholeCamera(*K), patch_side=SIDE)
+                    bm.setOption(api.OPT_UNIT_TARGET, args.unit_target)
+
+                    def bpass(use_u8):
+                        for i in range(B):
+                            if use_u8:
+                                bm[i].setReferenceImageU8(sc[i]["gray"][0], sc[i]["poses"][0], sc[i]["min"], sc[i]["max"])
+                            else:
+                                bm[i].setReferenceImageDevice(sc[i]["dev"][0].data, sc[i]["dev"][0].stride, sc[i]["poses"][0], sc[i]["min"], sc[i]["max"])
+                        for k in range(1, F):
+                            p = [sc[i]["poses"][k] for i in range(B)]
+                            if use_u8:
+                                bm.updateU8([sc[i]["gray"][k] for i in range(B)], p)
+                            else:
+                                bm.updateDevice([sc[i]["dev"][k].data for i in range(B)], [sc[i]["dev"][k].stride for i in range(B)], p)
+                    entry = {}
+                    for use_u8, name in ((False, "resident"), (True, "u8_host_frames")):
+                        bpass(use_u8)
+                        bm.sync()
+                        bm.setOption(api.OPT_TIMING, 2)
+                        bm.timingReset()
+                        tb = time.perf_counter()
+                        for _ in range(extra_passes):
+                            bpass(use_u8)
+                        bm.sync()
+                        dtb = time.perf_counter() - tb
+                        msb, nb = bm.timing()
+                        bm.setOption(api.OPT_TIMING, 0)
+                        entry[name] = {"value": round(W * H * (F - 1) * B * extra_passes / dtb / 1e6, 1), "unit": "Mpix/s",
+                                       "us_per_step_wall": round(dtb / nb * 1e6, 2), "us_per_step_device": round(msb / nb * 1e3, 2),
+                                       "us_per_sequence_update": round(dtb / nb / B * 1e6, 2)}
+                    rv = valu_roofline(entry["resident"]["us_per_step_device"] / 1e6, counters, n_sequences=B)
+                    if rv and not rv.get("stale"):
+                        entry["roofline_valu_frac"] = rv["frac"]
+                    entry["converged_seeds_at_end"] = [bm[i].getConvergedCount() for i in range(B)]
+                    batched[f"B={B}"] = entry
+                    del bm
+
+            # CPU baseline = the untouched reference on the host cores; the same run gives the distance of the GPU result from it
+            if args.cpu_seconds > 0 and world == 1 and F <= 500:
                 try:
-                    cpu = cpu_baseline(lambda k: (synth.to_float_image(gray[k]), poses[k]), W, H, K, F, SIDE, min_depth, max_depth,
-                                       args.cpu_seconds, gpu_sample)
+                    cpu, n_cpu, ref_state, ref_den, kind = cpu_reference_run(lambda k: (synth.to_float_image(gray[k]), poses[k]), W, H, K, F, SIDE,
+                                                                             min_depth, max_depth, args.cpu_seconds, tv_iters)
+                    time.sleep(0.3)
+                    s2 = new_seeds()
+                    pass_resident(s2, n_cpu)
+                    s2.sync()
+                    ts = time.perf_counter()
+                    pass_resident(s2, n_cpu)
+                    s2.sync()
+                    cpu["gpu_same_sample"] = round(W * H * n_cpu / (time.perf_counter() - ts) / 1e6, 2)
+                    if kind == "reference":
+                        sys.path.insert(0, os.path.join(ROOT, "tests"))
+                        import glibc_parity
+                        hip_state = {p: s2.download(p) for p in range(5)}
+                        full = ref_den is not None and n_cpu == F - 1
+                        glibc = glibc_parity.compare(ref_state, hip_state, ref_den if full else None, hip_denoised if full else None)
+                        glibc["after_updates"] = n_cpu
+                        glibc["reference"] = ("the reference's seed_matrix.cu / depthmap_denoiser.cu compiled unmodified for the host against glibc's libm "
+                                              "(Oracle A); the HIP path equals that build with expf/sinf/acosf from csrc/rmd_math.h bit for bit")
+                        glibc["asserted_in"] = "tests/test_parity_glibc.py"
+                    del s2
                 except Exception as e:  # the bench line must survive a missing oracle
                     cpu = {"value": None, "unit": "Mpix/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
 
         value = total_units / max_elapsed / 1e6
         label = cfg_name or "non-BASELINE workload"
+        source = ("frames already resident in HBM (rmd_hip_seeds_update_device)" if args.resident else
+                  "every frame an 8-bit image in pageable host memory handed to rmd_hip_seeds_update_u8: the H2D copy and the x(1/255) conversion are "
+                  "inside the timed update() calls (SURVEY.md 8d, test/dataset_main.cpp:101-103)")
         result = {
             "metric": f"Mpix/s depth-filter updates ({W}x{H}, {F} frames)", "value": round(value, 2), "unit": "Mpix/s",
             "n_gpus": world, "control_plane": batch.backend_name(), "steps": args.steps, "warmup": args.warmup,
@@ -345,15 +484,18 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{label}: {W}x{H} synthetic over-table sequence; one step = setReferenceImage(frame 0) + update() on "
                                    f"frames 1..{F - 1} ({F - 1} updates); NCC patch side {SIDE} (half-patch 4), max epipolar extent "
-                                   f"100 px; one independent sequence per GPU; timed region = {args.steps} complete passes",
-                       "frames_per_pass": F, "updates_timed": n_updates, "frames_resident_in_hbm": True,
-                       "matcher": {-1: "library default (tile pipeline, compact search kernel)", 0: "per-pixel kernel", 1: "round-1 tile pipeline",
-                                   2: "one-launch frame kernel", 3: "tile pipeline, compact search kernel"}.get(args.matcher, str(args.matcher)), "converged_seeds_at_end": converged,
-                       "mean_per_update": search_stats, "us_per_update_wall": round(max_elapsed / n_updates * 1e6, 3)},
+                                   f"100 px; one independent sequence per GPU; timed region = {args.steps} complete passes; frame source: {source}",
+                       "frames_per_pass": F, "updates_timed": n_updates, "frames_resident_in_hbm": bool(args.resident), "h2d_inclusive": not args.resident,
+                       "matcher": {-1: "library default (two-launch tile pipeline)", 0: "per-pixel kernel", 1: "round-1 tile pipeline (A/B build)",
+                                   2: "one-launch frame kernel (A/B build)", 3: "two-launch tile pipeline"}.get(args.matcher, str(args.matcher)),
+                       "converged_seeds_at_end": converged, "mean_per_update": search_stats,
+                       "us_per_update_wall": round(max_elapsed / n_updates * 1e6, 3), "host_render_s": round(render_s, 1)},
             "roofline": roofline,
-            "roofline_valu": valu_roofline(avg_kernel_s, os.path.join(ROOT, "profiles", "traffic.json")) if headline else None,
+            "roofline_valu": valu_roofline(avg_kernel_s, counters) if headline else None,
             "roofline_flops": flops_roofline(avg_kernel_s, search_stats["ncc_evals"] if search_stats else None, SIDE),
-            "roofline_denoiser": roofline_tv, "cpu_baseline": cpu, "h2d_inclusive": h2d, "parity": PARITY_NOTE,
+            "roofline_denoiser": roofline_tv, "cpu_baseline": cpu,
+            "resident": resident, "h2d_inclusive": other_path, "float_frames": floats, "heavy_prefix": heavy, "batched_per_gpu": batched,
+            "parity": PARITY_NOTE, "parity_vs_glibc_reference": glibc,
             "per_rank": [{"elapsed_s": round(r[0], 6), "mpix": r[1] / 1e6, "updates": int(r[2]), "converged": int(r[3])} for r in per_rank],
         }
     batch.barrier(device)

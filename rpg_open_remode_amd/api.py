@@ -118,7 +118,16 @@ class SE3:
 
 
 def _as_pose(T):
-    return np.ascontiguousarray(T.data if isinstance(T, SE3) else T, np.float32).reshape(12)
+    if isinstance(T, SE3):
+        T = T.data
+    if type(T) is np.ndarray and T.dtype == np.float32 and T.size == 12 and T.flags.c_contiguous:
+        return T  # (the per-frame calls of a streaming host: no temporary)
+    return np.ascontiguousarray(T, np.float32).reshape(12)
+
+
+def _ptr(a):
+    """address of an ndarray's data (ndarray.ctypes builds a helper object on every access: microseconds per frame)"""
+    return a.__array_interface__["data"][0]
 
 
 _KIND_OF = {np.dtype(np.float32): KIND_F32, np.dtype(np.int32): KIND_I32}
@@ -260,7 +269,7 @@ class SeedMatrix:
         img = np.ascontiguousarray(host_curr_img, np.float32)
         assert img.shape == (self.height, self.width)
         T = _as_pose(T_curr_world)
-        check(_lib.lib().rmd_hip_seeds_update(self.ptr, img.ctypes.data, T.ctypes.data))
+        check(_lib.lib().rmd_hip_seeds_update(self.ptr, _ptr(img), _ptr(T)))
         return True
 
     def setReferenceImageU8(self, gray_u8, T_curr_world, min_depth, max_depth):
@@ -274,7 +283,7 @@ class SeedMatrix:
         img = np.ascontiguousarray(gray_u8, np.uint8)
         assert img.shape == (self.height, self.width)
         T = _as_pose(T_curr_world)
-        check(_lib.lib().rmd_hip_seeds_update_u8(self.ptr, img.ctypes.data, T.ctypes.data))
+        check(_lib.lib().rmd_hip_seeds_update_u8(self.ptr, _ptr(img), _ptr(T)))
         return True
 
     def setReferenceImageDevice(self, dev_ptr, stride_elems, T_curr_world, min_depth, max_depth):
@@ -285,7 +294,7 @@ class SeedMatrix:
 
     def updateDevice(self, dev_ptr, stride_elems, T_curr_world):
         T = _as_pose(T_curr_world)
-        check(_lib.lib().rmd_hip_seeds_update_device(self.ptr, dev_ptr, int(stride_elems), T.ctypes.data))
+        check(_lib.lib().rmd_hip_seeds_update_device(self.ptr, dev_ptr, int(stride_elems), _ptr(T)))
         return True
 
     # --- downloads, seed_matrix.cu:160-168,205-230 ---
@@ -421,6 +430,9 @@ class SeedMatrixBatch:
         check(_lib.lib().rmd_hip_batch_create(self.n, self.width, self.height, cam.fx, cam.fy, cam.cx, cam.cy, int(patch_side), int(max_extent),
                                               ctypes.byref(h)))
         self.ptr = h.value
+        self._T = np.zeros((self.n, 12), np.float32)  # per-step argument blocks, reused
+        self._ptrs = (ctypes.c_void_p * self.n)()
+        self._strides = (ctypes.c_size_t * self.n)()
         self.members = []
         for i in range(self.n):
             m = ctypes.c_void_p()
@@ -444,7 +456,7 @@ class SeedMatrixBatch:
             pass
 
     def _poses(self, poses):
-        T = np.zeros((self.n, 12), np.float32)
+        T = self._T
         for i, p in enumerate(poses):
             if p is not None:
                 T[i] = _as_pose(p)
@@ -452,19 +464,22 @@ class SeedMatrixBatch:
 
     def updateDevice(self, dev_ptrs, strides, poses):
         """dev_ptrs[i]: device address of member i's frame (None / 0: no frame for that member in this step)"""
-        ptrs = (ctypes.c_void_p * self.n)(*[int(p) if p else None for p in dev_ptrs])
-        st = (ctypes.c_size_t * self.n)(*[int(v) for v in strides])
+        ptrs, st = self._ptrs, self._strides
+        for i in range(self.n):
+            ptrs[i] = int(dev_ptrs[i]) if dev_ptrs[i] else None
+            st[i] = int(strides[i])
         T = self._poses(poses)
-        check(_lib.lib().rmd_hip_batch_update_device(self.ptr, ptrs, st, T.ctypes.data))
+        check(_lib.lib().rmd_hip_batch_update_device(self.ptr, ptrs, st, _ptr(T)))
         return True
 
     def _host(self, fn, imgs, poses, dtype):
         keep = [None if im is None else np.ascontiguousarray(im, dtype) for im in imgs]
-        for im in keep:
+        ptrs = self._ptrs
+        for i, im in enumerate(keep):
             assert im is None or im.shape == (self.height, self.width)
-        ptrs = (ctypes.c_void_p * self.n)(*[None if im is None else im.ctypes.data for im in keep])
+            ptrs[i] = None if im is None else _ptr(im)
         T = self._poses(poses)
-        check(fn(self.ptr, ptrs, T.ctypes.data))
+        check(fn(self.ptr, ptrs, _ptr(T)))
         return True
 
     def updateU8(self, gray_frames, poses):

@@ -864,21 +864,22 @@ class CopyPool {
     }
     std::lock_guard<std::mutex> one_copy_at_a_time(call_mutex_);
     const size_t chunk = ((bytes + parts - 1) / parts + 4095) & ~static_cast<size_t>(4095);
-    {
+    dst_ = static_cast<char*>(dst); src_ = static_cast<const char*>(src); bytes_ = bytes; chunk_ = chunk;
+    __atomic_store_n(&pending_, n_workers_, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&generation_, 1ull, __ATOMIC_RELEASE);  // publishes the job to the helpers that are polling
+    if (__atomic_load_n(&parked_, __ATOMIC_ACQUIRE) != 0) {    // ... and wakes those that went to sleep
       std::lock_guard<std::mutex> lk(m_);
-      dst_ = static_cast<char*>(dst); src_ = static_cast<const char*>(src); bytes_ = bytes; chunk_ = chunk;
-      pending_ = n_workers_;
-      ++generation_;
+      cv_.notify_all();
     }
-    cv_.notify_all();
     const size_t mine = static_cast<size_t>(n_workers_) * chunk;  // the caller takes the last part
     if (mine < bytes) memcpy(dst_ + mine, src_ + mine, bytes - mine);
-    // the helpers' parts take a few microseconds: spin for them (a condition variable would cost more than the copy)
-    while (__atomic_load_n(&pending_, __ATOMIC_ACQUIRE) != 0) cpu_relax();
+    while (__atomic_load_n(&pending_, __ATOMIC_ACQUIRE) != 0) cpu_relax();  // the helpers' parts take a few microseconds
   }
 
  private:
   static constexpr size_t kMinBytes = 256 * 1024;
+  static constexpr double kPollUs = 300.0;  // a helper polls for this long after its last job before it goes to sleep: frames of a
+                                            // stream arrive every few tens of microseconds, and waking a sleeping thread costs more than the copy
   CopyPool() {
     int n = 3;
     if (const char* e = getenv("RMD_HIP_COPY_THREADS")) n = atoi(e) - 1;
@@ -886,13 +887,13 @@ class CopyPool {
     if (hw != 0 && static_cast<unsigned>(n + 1) > hw) n = static_cast<int>(hw) - 1;
     if (n < 0) n = 0;
     if (n > 15) n = 15;
-    for (int i = 0; i < n; ++i) workers_.emplace_back([this, i] { run(i); });
     n_workers_ = n;
+    for (int i = 0; i < n; ++i) workers_.emplace_back([this, i] { run(i); });
   }
   ~CopyPool() {
     {
       std::lock_guard<std::mutex> lk(m_);
-      stop_ = true;
+      __atomic_store_n(&stop_, true, __ATOMIC_RELEASE);
     }
     cv_.notify_all();
     for (auto& t : workers_) t.join();
@@ -900,14 +901,22 @@ class CopyPool {
   void run(int index) {
     unsigned long long seen = 0;
     for (;;) {
-      std::unique_lock<std::mutex> lk(m_);
-      cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
-      if (stop_) return;
-      seen = generation_;
-      char* dst = dst_; const char* src = src_; const size_t bytes = bytes_, chunk = chunk_;
-      lk.unlock();
-      const size_t off = static_cast<size_t>(index) * chunk;
-      if (off < bytes) memcpy(dst + off, src + off, bytes - off < chunk ? bytes - off : chunk);
+      // poll for a new job, then sleep
+      const double t0 = host_now_us();
+      unsigned int spins = 0;
+      while (__atomic_load_n(&generation_, __ATOMIC_ACQUIRE) == seen && !__atomic_load_n(&stop_, __ATOMIC_ACQUIRE)) {
+        cpu_relax();
+        if ((++spins & 63u) == 0u && host_now_us() - t0 > kPollUs) {
+          std::unique_lock<std::mutex> lk(m_);
+          __atomic_fetch_add(&parked_, 1, __ATOMIC_ACQ_REL);
+          cv_.wait(lk, [&] { return __atomic_load_n(&stop_, __ATOMIC_ACQUIRE) || __atomic_load_n(&generation_, __ATOMIC_ACQUIRE) != seen; });
+          __atomic_fetch_sub(&parked_, 1, __ATOMIC_ACQ_REL);
+        }
+      }
+      if (__atomic_load_n(&stop_, __ATOMIC_ACQUIRE)) return;
+      seen = __atomic_load_n(&generation_, __ATOMIC_ACQUIRE);
+      const size_t off = static_cast<size_t>(index) * chunk_;
+      if (off < bytes_) memcpy(dst_ + off, src_ + off, bytes_ - off < chunk_ ? bytes_ - off : chunk_);
       __atomic_fetch_sub(&pending_, 1, __ATOMIC_RELEASE);
     }
   }
@@ -917,6 +926,7 @@ class CopyPool {
   std::condition_variable cv_;
   bool stop_ = false;
   unsigned long long generation_ = 0;
+  int parked_ = 0;
   char* dst_ = nullptr; const char* src_ = nullptr;
   size_t bytes_ = 0, chunk_ = 0;
   int pending_ = 0;

@@ -1,0 +1,39 @@
+"""How far the HIP path is from the UNTOUCHED reference (Oracle A: the reference's own kernels compiled for the CPU against glibc's
+libm, oracle/_ref/libremode_ref_s<side>.so) -- the figures behind north_star's "depth RMSE within 1e-4 of the reference, convergence
+masks bit-exact".  The HIP path is bit-identical to the reference built with the shared expf/sinf/acosf of csrc/rmd_math.h (A'); A
+and A' differ in the last ulp of those three functions, and the depth filter amplifies a last-ulp difference wherever two NCC
+candidates are nearly tied.  Test infrastructure: used by tests/test_parity_glibc.py (asserted bounds) and by bench.py (reported)."""
+import numpy as np
+
+CONVERGED = 1
+
+
+def compare(ref_state, hip_state, ref_denoised=None, hip_denoised=None, tol=1e-4):
+    """ref_state / hip_state: {plane: array} as returned by Seeds.state() (0 mu, 1 sigma_sq, 2 a, 3 b, 4 convergence).  Returns a dict."""
+    rc, hc = ref_state[4], hip_state[4]
+    n = rc.size
+    both = (rc == CONVERGED) & (hc == CONVERGED)
+    d_all = np.abs(ref_state[0].astype(np.float64) - hip_state[0].astype(np.float64))
+    d = d_all[both]
+    fin = np.isfinite(d_all)
+    out = {
+        "pixels": int(n),
+        "convergence_state_mismatches": int(np.count_nonzero(rc != hc)),
+        "converged_mask_mismatches": int(np.count_nonzero((rc == CONVERGED) != (hc == CONVERGED))),
+        "converged_in_both": int(both.sum()),
+        "depth_rmse_converged_m": float(np.sqrt(np.mean(d * d))) if d.size else 0.0,
+        "depth_median_abs_diff_converged_m": float(np.median(d)) if d.size else 0.0,
+        "depth_frac_beyond_tol_converged": float(np.mean(d > tol)) if d.size else 0.0,
+        "depth_rmse_all_seeds_m": float(np.sqrt(np.mean(d_all[fin] ** 2))) if fin.any() else 0.0,
+        "depth_frac_bit_identical": float(np.mean(ref_state[0].view(np.uint32) == hip_state[0].view(np.uint32))),
+        "tol_m": tol,
+    }
+    if ref_denoised is not None and hip_denoised is not None:
+        dd = np.abs(ref_denoised.astype(np.float64) - hip_denoised.astype(np.float64))
+        fin = np.isfinite(dd)
+        out["denoised_rmse_m"] = float(np.sqrt(np.mean(dd[fin] ** 2)))
+        out["denoised_median_abs_diff_m"] = float(np.median(dd[fin]))
+        out["denoised_frac_beyond_tol"] = float(np.mean(dd[fin] > tol))
+        ddc = dd[both & fin]
+        out["denoised_rmse_converged_m"] = float(np.sqrt(np.mean(ddc * ddc))) if ddc.size else 0.0
+    return out

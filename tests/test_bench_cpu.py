@@ -54,13 +54,30 @@ def test_rooflines():
     t = json.load(open(path))
     assert t["algorithmic_bytes_per_update"] == 52 * 640 * 480
     assert t["seed_update_bytes_per_launch"] >= t["algorithmic_bytes_per_update"]  # measured traffic cannot be below the compulsory bytes
-    r = b.valu_roofline(60e-6, path)
+    # instruction counts are only used with the kernel sources they were measured on
+    fresh = dict(t, kernel_source_sha256=b.kernel_source_sha256())
+    r = b.valu_roofline(60e-6, fresh)
     assert r["bound"] == "valu" and 0.0 < r["frac"] < 1.0 and r["peak"] == 1228.8
-    assert b.valu_roofline(60e-6, os.path.join(ROOT, "no_such_file.json")) is None
+    r4 = b.valu_roofline(4 * 60e-6, fresh, n_sequences=4)  # a batch of 4 sequences in 4x the time: the same fraction
+    assert abs(r4["frac"] - r["frac"]) < 1e-3
+    stale = b.valu_roofline(60e-6, dict(t, kernel_source_sha256="0" * 64))
+    assert stale["stale"] is True and "frac" not in stale
+    assert b.valu_roofline(60e-6, None) is None
+    assert b.load_counters(os.path.join(ROOT, "no_such_file.json")) is None
     f = b.flops_roofline(60e-6, 489000.0, 9)
     assert f["flop_per_launch"] == 14 * 81 * 489000 and f["peak"] == 157.3
     assert abs(f["achieved"] - 14 * 81 * 489000 / 60e-6 / 1e12) < 0.01
     assert b.flops_roofline(60e-6, None, 9) is None
+
+
+def test_committed_counters_belong_to_the_committed_kernels():
+    """profiles/traffic.json carries the hash of the kernel sources it was measured on; a commit that changes the kernels without
+    re-measuring makes bench.py drop roofline_valu (stale) instead of reporting a figure for code that no longer exists"""
+    b, _ = _bench([])
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    if t.get("kernel_source_sha256") != b.kernel_source_sha256():
+        pytest.skip("kernel sources changed since the last PMC pass (tools/profile_r03.sh): bench.py reports roofline_valu as stale")
+    assert b.valu_roofline(46e-6, t)["frac"] > 0.1
 
 
 def _free_port():

@@ -8,23 +8,45 @@ from collections import defaultdict
 raw, out = sys.argv[1], sys.argv[2]
 
 
-def per_kernel(sub):
-    """{kernel short name: {counter: (sum over dispatches, number of dispatches)}}"""
-    agg = defaultdict(lambda: defaultdict(float))
-    disp = defaultdict(set)
+KEYS = ("seed_setup", "seed_plan", "seed_search", "seed_finalize", "seed_init", "tv_iterate", "tv_prepare")
+
+
+def per_kernel(sub, first=None):
+    """{kernel short name: {counter: sum over dispatches}}, {kernel: number of dispatches}; first = n: only the first n dispatches of
+    every kernel (in dispatch order)"""
+    rows = []
     for f in glob.glob(os.path.join(raw, sub, "**", "*counter_collection.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
-            n = r["Kernel_Name"]
-            for key in ("seed_setup", "seed_plan", "seed_search", "seed_finalize", "seed_init", "tv_iterate", "tv_prepare"):
-                if key in n:
-                    agg[key][r["Counter_Name"]] += float(r["Counter_Value"])
-                    disp[key].add(r["Dispatch_Id"])
+        rows += list(csv.DictReader(open(f)))
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    agg = defaultdict(lambda: defaultdict(float))
+    disp = defaultdict(dict)
+    for r in rows:
+        n = r["Kernel_Name"]
+        for key in KEYS:
+            if key in n:
+                ids = disp[key]
+                if r["Dispatch_Id"] not in ids:
+                    if first is not None and len(ids) >= first:
+                        break
+                    ids[r["Dispatch_Id"]] = True
+                agg[key][r["Counter_Name"]] += float(r["Counter_Value"])
+                break
     return agg, {k: len(v) for k, v in disp.items()}
 
 
+def kernel_source_sha256():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_hash", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.kernel_source_sha256()
+
+
 W, H, UPDATES = 640, 480, 199
-res = {"source": "rocprofv3 --pmc passes of `python bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-extras` (tools/profile_r02.sh): one complete pass "
-                 "of configs[1] (setReferenceImage + 199 update() calls) followed by the TV-L1 denoise; sums over the pass divided by 199",
+res = {"source": "rocprofv3 --pmc passes of `python bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-extras` (tools/profile_r03.sh): one complete pass "
+                 "of configs[1] (setReferenceImage + 199 update() calls, 8-bit frames from host memory) followed by the TV-L1 denoise; sums over the pass "
+                 "divided by 199",
+       "kernel_source_sha256": kernel_source_sha256(),
        "unit_note": "FETCH_SIZE / WRITE_SIZE are KiB at the L2<->fabric interface (Infinity-Cache hits included). MI355X_MICROARCH.md: on gfx950 "
                     "FETCH_SIZE tallies 64 B per 128 B request for wide coalesced reads; these kernels mostly load dwords, for which the counter is "
                     "uncalibrated, so read bytes are given raw and doubled (the doubled figure is what bench.py reports as roofline.traffic)",
@@ -41,6 +63,10 @@ if insts:
     res["lds_bank_conflict_cycles_per_update"] = {k: round(insts[k]["SQ_LDS_BANK_CONFLICT"] / UPDATES) for k in seed_k if k in insts}
     res["waves_per_update"] = {k: round(insts[k]["SQ_WAVES"] / UPDATES, 1) for k in seed_k if k in insts}
     res["dispatches_in_the_pass"] = n_i
+    i20, _ = per_kernel("pmc_insts", first=20)  # updates 1..20 of the pass: every seed live (bench.py's heavy_prefix)
+    res["valu_wave_instructions_first20_per_update"] = {k: round(i20[k]["SQ_INSTS_VALU"] / 20) for k in ("seed_setup", "seed_search") if k in i20}
+    res["lds_wave_instructions_first20_per_update"] = {k: round(i20[k]["SQ_INSTS_LDS"] / 20) for k in ("seed_setup", "seed_search") if k in i20}
+    res["lds_bank_conflict_cycles_first20_per_update"] = {k: round(i20[k]["SQ_LDS_BANK_CONFLICT"] / 20) for k in ("seed_setup", "seed_search") if k in i20}
 if fetch and write:
     fk = {k: fetch[k]["FETCH_SIZE"] / UPDATES for k in seed_k if k in fetch}
     wk = {k: write[k]["WRITE_SIZE"] / UPDATES for k in seed_k if k in write}

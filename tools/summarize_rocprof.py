@@ -64,9 +64,11 @@ def main():
         for n, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
             v2 = sorted(v)
             lines.append(f"{n:60s} {len(v):6d} {sum(v) / len(v):10.2f} {v2[len(v2) // 2]:10.2f} {v2[-1]:10.2f}  {'/'.join(str(x) for x in res[n])}")
-    # --- counters
+    # --- counters, one section PER PASS (sub-directory of the raw output): passes of different jobs (e.g. the 640x480 sequence and the
+    # 1920x1080 denoiser run) must never be merged into one table
     counters = {}
     for sub in sorted(os.listdir(raw)):
+        per_pass = {}
         for f in find(raw, sub, "*counter_collection.csv"):
             with open(f) as fh:
                 rows = list(csv.DictReader(fh))
@@ -77,23 +79,29 @@ def main():
                 agg[n][r["Counter_Name"]] += float(r["Counter_Value"])
                 cnt[n].add(r.get("Dispatch_Id", ""))
             for n in agg:
+                per_pass.setdefault(n, {})
                 for c, v in agg[n].items():
-                    counters.setdefault(n, {})[c] = v / max(1, len(cnt[n]))
-                counters[n]["_dispatches_" + sub] = len(cnt[n])
+                    per_pass[n][c] = v / max(1, len(cnt[n]))
+                per_pass[n]["_dispatches"] = len(cnt[n])
+        if per_pass:
+            counters[sub] = per_pass
     if counters:
-        lines.append("")
-        lines.append("# PMC counters, mean per dispatch (separate rocprofv3 --pmc passes)")
-        for n, cs in counters.items():
-            lines.append(f"[{n}]")
-            for c, v in sorted(cs.items()):
-                lines.append(f"    {c:28s} {v:18.1f}")
-            fs, ws = cs.get("FETCH_SIZE"), cs.get("WRITE_SIZE")
-            if fs is not None:
-                # rocprofv3 reports KiB; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE counts 64 B per 128 B request for wide
-                # coalesced reads -> doubled figure given as the upper estimate
-                lines.append(f"    -> HBM read bytes/dispatch: {fs * 1024:.0f} (raw), {2 * fs * 1024:.0f} (x2 gfx950 correction)")
-            if ws is not None:
-                lines.append(f"    -> HBM write bytes/dispatch: {ws * 1024:.0f}")
+        cmdfile = os.path.join(raw, "commands.txt")
+        cmds = dict(l.rstrip("\n").split("\t", 1) for l in open(cmdfile)) if os.path.exists(cmdfile) else {}
+        for sub, per_pass in counters.items():
+            lines.append("")
+            lines.append(f"# PMC counters of pass '{sub}', mean per dispatch" + (f"  ({cmds[sub]})" if sub in cmds else ""))
+            for n, cs in per_pass.items():
+                lines.append(f"[{n}]")
+                for c, v in sorted(cs.items()):
+                    lines.append(f"    {c:28s} {v:18.1f}")
+                fs, ws = cs.get("FETCH_SIZE"), cs.get("WRITE_SIZE")
+                if fs is not None:
+                    # rocprofv3 reports KiB; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE counts 64 B per 128 B request for wide
+                    # coalesced reads -> doubled figure given as the upper estimate
+                    lines.append(f"    -> HBM read bytes/dispatch: {fs * 1024:.0f} (raw), {2 * fs * 1024:.0f} (x2 gfx950 correction)")
+                if ws is not None:
+                    lines.append(f"    -> HBM write bytes/dispatch: {ws * 1024:.0f}")
         json.dump(counters, open(os.path.join(out, f"{tag}_counters.json"), "w"), indent=1)
     open(os.path.join(out, f"{tag}_rocprof_summary.txt"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
