@@ -188,6 +188,17 @@ int image_alloc(rmd_hip_image* img, int kind, int width, int height) {
 
 }  // namespace
 
+// The "frame n has arrived" word that follows every staged host frame on the copy stream.  A pinned -> device copy of up to 16 KB
+// is carried out by a shader kernel of the runtime (__amd_rocclr_copyBuffer, tools/ubench/copy_path.hip), which needs wave slots of
+// its own: behind a thousand persistent search workgroups it ran 7 us on average and up to 98 us, and the setup kernel's ingest
+// workgroups waited for it.  From 64 KB on the copy goes to the SDMA engine like the frame itself.  So the flag is 64 KB of the same
+// number: whichever of its words the engine writes first or last, a reader of word 0 sees either the old number or the new one, and
+// the new one only after the frame copy in front of it (same stream) has completed.
+constexpr size_t FLAG_WORDS = 16384;
+static void fill_flag_block(unsigned int* block, unsigned int n) {
+  for (size_t i = 0; i < FLAG_WORDS; ++i) block[i] = n;
+}
+
 // ---- rmd::SeedMatrix ------------------------------------------------------------------------
 struct rmd_hip_seeds {
   int width = 0, height = 0, patch_side = 5, device = 0, num_cus = 256;
@@ -233,8 +244,8 @@ struct rmd_hip_seeds {
   float* h_zc_f32[SLOTS] = {};
   unsigned char* d_zc_u8[SLOTS] = {};
   float* d_zc_f32[SLOTS] = {};
-  unsigned int* h_seq = nullptr;            // pinned, SLOTS words: the frame numbers the copy engine writes into d_zc_flag
-  unsigned int* d_zc_flag = nullptr;        // device: number of the last frame whose staging copy has completed
+  unsigned int* h_seq = nullptr;            // pinned, SLOTS blocks of FLAG_WORDS words: the frame number, repeated, that the copy engine writes into d_zc_flag
+  unsigned int* d_zc_flag = nullptr;        // device, FLAG_WORDS words: number of the last frame whose staging copy has completed
   unsigned int* h_progress = nullptr;       // pinned: [0] number of the ingested frame whose setup kernel has started, [1] error bits
   unsigned long long zc_number = 0;         // ingested frames so far (the device sees the low 32 bits and compares modulo 2^32)
   int opt_fused_ingest = 1;                 // RMD_HIP_FUSED_INGEST=0 switches back to the copy-stream pipeline (A/B)
@@ -804,9 +815,9 @@ static int ingest_init(rmd_hip_seeds* s) {
   if (const char* e = getenv("RMD_HIP_FUSED_INGEST")) s->opt_fused_ingest = e[0] != '0';
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_progress), 64, hipHostMallocMapped));
   s->h_progress[0] = s->h_progress[1] = 0u;
-  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_seq), 64, hipHostMallocDefault));
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_flag), 64));
-  HIP_TRY(hipMemset(s->d_zc_flag, 0, 64));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_seq), rmd_hip_seeds::SLOTS * FLAG_WORDS * sizeof(unsigned int), hipHostMallocDefault));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_flag), FLAG_WORDS * sizeof(unsigned int)));
+  HIP_TRY(hipMemset(s->d_zc_flag, 0, FLAG_WORDS * sizeof(unsigned int)));
   HIP_TRY(hipStreamSynchronize(nullptr));
   const rmd_hip_image& im = s->planes[RMD_HIP_PLANE_CURR_IMG];
   s->cur_planes[0] = im.data;
@@ -1041,8 +1052,8 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
     in.f32 = s->d_zc_f32[k];
     in.common.kind = 2;
   }
-  s->h_seq[k] = n;  // behind the frame on the same stream: when the kernel sees n, the frame is in HBM
-  HIP_TRY(hipMemcpyAsync(s->d_zc_flag, &s->h_seq[k], sizeof(unsigned int), hipMemcpyHostToDevice, s->copy_stream));
+  fill_flag_block(s->h_seq + k * FLAG_WORDS, n);  // behind the frame on the same stream: when the kernel sees n, the frame is in HBM
+  HIP_TRY(hipMemcpyAsync(s->d_zc_flag, s->h_seq + k * FLAG_WORDS, FLAG_WORDS * sizeof(unsigned int), hipMemcpyHostToDevice, s->copy_stream));
   in.common.flag = s->d_zc_flag;
   const double t_c = s->ingest_profile ? host_now_us() : 0.0;
   rmd_hip_image& im = s->planes[RMD_HIP_PLANE_CURR_IMG];
@@ -1569,8 +1580,8 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
   }
   const size_t off = static_cast<size_t>(first) * frame_bytes, len = static_cast<size_t>(last - first + 1) * frame_bytes;
   HIP_TRY(hipMemcpyAsync(b->d_stage[k] + off, b->h_stage[k] + off, len, hipMemcpyHostToDevice, b->copy_stream));
-  b->h_seq[k] = n;  // behind the frames on the same stream: when the kernel sees n, they are in HBM
-  HIP_TRY(hipMemcpyAsync(b->d_flag, &b->h_seq[k], sizeof(unsigned int), hipMemcpyHostToDevice, b->copy_stream));
+  fill_flag_block(b->h_seq + k * FLAG_WORDS, n);  // behind the frames on the same stream: when the kernel sees n, they are in HBM
+  HIP_TRY(hipMemcpyAsync(b->d_flag, b->h_seq + k * FLAG_WORDS, FLAG_WORDS * sizeof(unsigned int), hipMemcpyHostToDevice, b->copy_stream));
   rmdk::IngestArgs in;
   in.kind = gray ? 1 : 2;
   in.pitch = u8_pitch;
@@ -1634,8 +1645,9 @@ int rmd_hip_batch_create(int n, int width, int height, float fx, float fy, float
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, b->device) == hipSuccess && prop.multiProcessorCount > 0) b->num_cus = prop.multiProcessorCount;
   if (hipHostMalloc(reinterpret_cast<void**>(&b->h_progress), 64, hipHostMallocMapped) != hipSuccess ||
-      hipHostMalloc(reinterpret_cast<void**>(&b->h_seq), 64, hipHostMallocDefault) != hipSuccess ||
-      hipMalloc(reinterpret_cast<void**>(&b->d_flag), 64) != hipSuccess || hipMemset(b->d_flag, 0, 64) != hipSuccess)
+      hipHostMalloc(reinterpret_cast<void**>(&b->h_seq), rmd_hip_batch::SLOTS * FLAG_WORDS * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&b->d_flag), FLAG_WORDS * sizeof(unsigned int)) != hipSuccess ||
+      hipMemset(b->d_flag, 0, FLAG_WORDS * sizeof(unsigned int)) != hipSuccess)
     return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: ingest words"));
   b->h_progress[0] = b->h_progress[1] = 0u;
   for (int i = 0; i < n; ++i) {

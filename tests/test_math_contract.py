@@ -1,6 +1,10 @@
-"""The shared arithmetic contract (csrc/rmd_math.h) on the host: the fp64-evaluated expf / sinf / acosf must be
-(almost always) the correctly rounded fp32 result, and glibc's fp32 functions must lie within 1 ulp of them.
-The device side of the same header is compared bit for bit in tests/test_hip_parity.py."""
+"""The shared arithmetic contract (csrc/rmd_math.h) on the host: expf / sinf / acosf restate glibc 2.35's routines and must equal
+the host libm's results bit for bit (oracle/libm_exhaustive covers all 2^32 arguments; a strided sample of it runs here), and must
+lie within 1 ulp of the mathematically exact values.  The device side of the same header is compared bit for bit in
+tests/test_hip_parity.py."""
+import os
+import subprocess
+
 import numpy as np
 
 import oracles as O
@@ -11,7 +15,19 @@ def _eval(fn, xs):
     return np.array([fn(float(v)) for v in xs], np.float32)
 
 
-def test_transcendentals_are_correctly_rounded():
+def test_transcendentals_equal_the_host_libm_on_a_strided_sample_of_all_floats():
+    """every 1021st float (4.2 million arguments per function, all exponents, both signs, NaNs and infinities included); the full
+    run (`oracle/libm_exhaustive 1`, ~30 s on 8 cores) was 0 differences of 3 x 2^32 on glibc 2.35 / x86-64 with FMA"""
+    exe = os.path.join(O.ORACLE_DIR, "libm_exhaustive")
+    if not os.path.exists(exe):
+        import pytest
+        pytest.skip("oracle/libm_exhaustive not built")
+    res = subprocess.run([exe, "1021"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout
+    assert res.stdout.count(" 0 differ") == 3, res.stdout
+
+
+def test_transcendentals_within_one_ulp_of_exact():
     lib = O.OracleLib("port", 5).lib
     rng = np.random.default_rng(3)
     cases = [
@@ -25,7 +41,6 @@ def test_transcendentals_are_correctly_rounded():
         exact = ref(xs.astype(np.float64)).astype(np.float32)  # numpy fp64 libm, rounded once
         d = ulp_distance(got, exact)
         assert d.max() <= 1, (fn, d.max())
-        assert (d != 0).mean() < 1e-3, (fn, (d != 0).mean())
 
 
 def test_special_values():
@@ -53,11 +68,18 @@ def test_texture_filter_rule():
     assert np.isnan(f(float("nan"), 1.0)) and np.isnan(f(1.0, float("inf")))
 
 
-def test_glibc_within_one_ulp_of_contract():
-    import math
+def test_contract_equals_this_process_libm():
+    """the same comparison through Python's ctypes on the libm of this process (random arguments in the ranges the filter uses)"""
+    import ctypes
+    import ctypes.util
+    libm = ctypes.CDLL(ctypes.util.find_library("m"))
     lib = O.OracleLib("port", 5).lib
     rng = np.random.default_rng(5)
-    xs = rng.uniform(-1, 1, 5000).astype(np.float32)
-    mine = _eval(lib.orc_math_acosf, xs)
-    glibc = np.array([np.float32(math.acos(float(x))) for x in xs], np.float32)  # double acos rounded: == correctly rounded
-    assert ulp_distance(mine, glibc).max() <= 1
+    for name, mine, xs in (("expf", lib.orc_math_expf, rng.uniform(-110, 0, 20000)), ("sinf", lib.orc_math_sinf, rng.uniform(0, 3.2, 20000)),
+                           ("acosf", lib.orc_math_acosf, rng.uniform(-1, 1, 20000))):
+        f = getattr(libm, name)
+        f.restype, f.argtypes = ctypes.c_float, [ctypes.c_float]
+        xs = xs.astype(np.float32)
+        a = _eval(mine, xs)
+        b = np.array([f(float(v)) for v in xs], np.float32)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), name

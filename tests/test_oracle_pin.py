@@ -8,8 +8,8 @@
     test/epipolar_test.cpp:206-220 (epipolarMatchTest), test/reduction_test.cpp:24-122.
  3. B in its default build (rmd_math.h transcendentals) must equal, bit for bit, Oracle A rebuilt with ONLY
     expf/sinf/acosf swapped for rmd_math.h ("ref_rmd").  That build is what the HIP path is held to.
- 4. The effect of that libm swap on the reference itself is measured (median 5e-6 m, ~2 % of pixels beyond
-    1e-4 m, <0.1 % of convergence states) -- the floor for any implementation with a different libm.
+ 4. That swap changes nothing: csrc/rmd_math.h restates glibc 2.35's expf / sinf / acosf and equals them for every float argument
+    (oracle/libm_exhaustive.cpp), so A (system libm) == A' (shared math) bit for bit.
 """
 import numpy as np
 import pytest
@@ -200,22 +200,17 @@ def test_port_equals_reference_built_on_shared_math_bit_for_bit(side):
 
 @needs_ref
 @pytest.mark.parametrize("side", [5, 9])
-def test_libm_sensitivity_of_the_reference_itself(side):
-    """What swapping glibc's expf/sinf/acosf for rmd_math.h (<= 1 ulp apart) does to the reference's own output
-    after 30 updates.  The filter amplifies last-ulp differences wherever two NCC candidates are nearly tied, so
-    a small tail of pixels moves by millimetres; this is the noise floor of ANY implementation that does not
-    share the reference's libm (the real CUDA build, with -use_fast_math, included)."""
+def test_reference_with_system_libm_equals_reference_with_shared_math(side):
+    """A == A': the reference's own kernels linked against the system's libm (glibc 2.35) and the same kernels with expf / sinf /
+    acosf taken from csrc/rmd_math.h produce the same bits -- csrc/rmd_math.h restates glibc's routines and agrees with them for
+    every float argument (oracle/libm_exhaustive.cpp, tests/test_math_contract.py).  So "bit-identical to the oracle" means
+    bit-identical to the UNMODIFIED reference as it builds on this host.  (Until round 3 the shared functions were correctly
+    rounded fp64 evaluations, <= 1 ulp from glibc's, and 199 updates amplified that to an RMSE of 3.6e-4 m at 640x480,
+    profiles/r03_parity_glibc.txt.)"""
     seq = sequence(160, 120, 31)
     _, ref = _run("ref", side, seq, 30)
     _, port = _run("ref_rmd", side, seq, 30)
-    r, p = ref[-1], port[-1]
-    # the matcher contains no transcendental: the first update's matches agree exactly
-    assert O.planes_equal(ref[0][O.PLANE_MATCH], port[0][O.PLANE_MATCH])
+    for k, (r, p) in enumerate(zip(ref, port)):
+        assert_states_equal(r, p, f"side {side} update {k + 1}: glibc build vs shared-math build of the reference")
     n = seq.width * seq.height
-    mask_mismatch = O.count_mismatch(r[O.PLANE_CONV], p[O.PLANE_CONV])
-    assert mask_mismatch <= 1e-3 * n, f"{mask_mismatch} of {n} convergence states differ"
-    d = np.abs(r[O.PLANE_MU].astype(np.float64) - p[O.PLANE_MU])
-    assert np.median(d) <= 2e-5
-    assert (d > 1e-4).mean() <= 0.05
-    assert rmse(r[O.PLANE_MU], p[O.PLANE_MU]) <= 1e-3
-    assert (r[O.PLANE_CONV] == O.CONVERGED).sum() > 0.05 * n
+    assert (ref[-1][O.PLANE_CONV] == O.CONVERGED).sum() > 0.05 * n
