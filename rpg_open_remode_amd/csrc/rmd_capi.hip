@@ -214,7 +214,8 @@ struct rmd_hip_seeds {
   // a SeedMatrix that is a member of a batch (rmd_hip_batch_*) shares the batch's streams and update workspace: its update
   // kernels are launched by the batch, for all members at once; everything else (reference frames, observers) works per member
   struct rmd_hip_batch* batch = nullptr;
-  int seq = 0;                              // index in the batch's workspace (0 for a plain SeedMatrix)
+  int seq = 0;                              // index in its group's workspace (0 for a plain SeedMatrix)
+  int batch_index = 0;                      // index in the batch
   rmdk::MatcherWorkspace* mws = nullptr;    // the update workspace: &matcher_ws, or the batch's
   bool async_count_valid = false;           // the pinned CONVERGED count of the workspace belongs to this handle's latest update ...
   unsigned int async_number = 0;            // ... which carried this number
@@ -271,8 +272,22 @@ struct rmd_hip_seeds {
 struct rmd_hip_batch {
   int n = 0, device = 0, num_cus = 256;
   rmd_hip_seeds* members[rmdk::MAX_BATCH] = {};
-  hipStream_t stream = nullptr, copy_stream = nullptr;
-  rmdk::MatcherWorkspace ws;
+  // The members are stepped in up to two GROUPS, each with its own stream and update workspace: one launch pair per group and step,
+  // the two pairs issued back to back on the two streams.  While one group's setup kernel runs its latency chain, or its search is down
+  // to its last units, the other group's kernels fill the chip (2 x 2 sequences: 12 400 Mpix/s against 10 800 for one group of 4).
+  struct Group {
+    hipStream_t stream = nullptr;
+    rmdk::MatcherWorkspace ws;
+    int first = 0, n = 0;                   // members [first, first + n)
+    unsigned int* h_progress = nullptr;     // pinned: [0] step whose setup kernel has started, [1] error bits (see ingest_current_fused)
+    unsigned long long slot_step[3] = {0, 0, 0};  // host frames: the step of this group's last launch that read staging slot k (0: none)
+    unsigned long long last_step = 0;       // ... and of its last launch altogether
+    hipEvent_t ev = nullptr;                // fork / join of the region timer
+  };
+  static constexpr int MAX_GROUPS = 2;
+  int n_groups = 0;
+  Group groups[MAX_GROUPS];
+  hipStream_t copy_stream = nullptr;
   // frames handed over in host memory: the frames of one step, back to back, through SLOTS pinned buffers and SLOTS staging buffers
   // (see ingest_current_fused: the same protocol, one sequence number per step)
   static constexpr int SLOTS = 3;
@@ -281,11 +296,11 @@ struct rmd_hip_batch {
   size_t stage_bytes = 0;                   // capacity of each of the buffers above
   unsigned int* h_seq = nullptr;
   unsigned int* d_flag = nullptr;
-  unsigned int* h_progress = nullptr;
   unsigned long long step_number = 0;
   int opt_timing = 0, opt_unit_target = 1;
   hipEvent_t region_start = nullptr, region_stop = nullptr;
   long region_updates = 0;
+  Group& group_of(int member) { return groups[(n_groups > 1 && member >= groups[1].first) ? 1 : 0]; }
 };
 
 namespace {
@@ -331,7 +346,7 @@ int seeds_sync(const rmd_hip_seeds* s) {
   if (m->frame_ws.frame > 0) HIP_TRY(hipMemcpyAsync(m->frame_ws.h_error, m->frame_ws.d_error, sizeof(unsigned int), hipMemcpyDeviceToHost, s->stream));
 #endif
   HIP_TRY(hipStreamSynchronize(s->stream));
-  TRY(ingest_error_check(m->batch ? m->batch->h_progress : m->h_progress));
+  TRY(ingest_error_check(m->batch ? m->batch->group_of(m->batch_index).h_progress : m->h_progress));
 #ifdef RMD_AB_MATCHERS
   if (m->frame_ws.h_error && m->frame_ws.h_error[0] != 0u) {
     const unsigned int bits = m->frame_ws.h_error[0];
@@ -696,10 +711,12 @@ static int seeds_create_impl(int width, int height, float fx, float fy, float cx
   if (!s) return fail(RMD_HIP_ERR_RUNTIME, "seeds_create: out of host memory");
   s->width = width; s->height = height; s->patch_side = patch_side;
   (void)hipGetDevice(&s->device);
-  s->batch = batch; s->seq = seq;
-  s->mws = batch ? &batch->ws : &s->matcher_ws;
+  s->batch = batch; s->batch_index = seq;
+  rmd_hip_batch::Group* grp = batch ? &batch->group_of(seq) : nullptr;
+  s->seq = batch ? seq - grp->first : 0;
+  s->mws = batch ? &grp->ws : &s->matcher_ws;
   auto bail = [&](int rc) { seeds_destroy_impl(s); return rc; };
-  if (batch) { s->stream = batch->stream; s->copy_stream = batch->copy_stream; }
+  if (batch) { s->stream = grp->stream; s->copy_stream = batch->copy_stream; }
   else if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess)
     return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: hipStreamCreate failed"));
   for (int p = 0; p < RMD_HIP_NUM_PLANES; ++p) {
@@ -735,7 +752,7 @@ static int seeds_create_impl(int width, int height, float fx, float fy, float cx
   P.one_pix_angle = atan2f(1.0f, 2.0f * fx) * 2.0f;  // pinhole_camera.cuh:56-59
   P.max_extent = static_cast<float>(max_extent);
   if (!batch && s->matcher_ws.allocate(width, height, P.stride) != 0) return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: update workspace"));
-  if (batch && (batch->ws.stride != P.stride || batch->ws.tiles_x != (width + rmdk::TILE_W - 1) / rmdk::TILE_W || batch->ws.tiles_y != (height + rmdk::TILE_H - 1) / rmdk::TILE_H))
+  if (batch && (grp->ws.stride != P.stride || grp->ws.tiles_x != (width + rmdk::TILE_W - 1) / rmdk::TILE_W || grp->ws.tiles_y != (height + rmdk::TILE_H - 1) / rmdk::TILE_H))
     return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: the batch's workspace has another geometry"));
 #ifdef RMD_AB_MATCHERS
   if (s->frame_ws.allocate(width, height, P.stride) != 0) return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: frame workspace"));
@@ -1227,7 +1244,7 @@ int rmd_hip_seeds_converged_count(const rmd_hip_seeds_t* s, size_t* count) {
       const unsigned long long v = *word;
       if (static_cast<unsigned int>(v >> 32) == want) {
         *count = static_cast<size_t>(v & 0xffffffffull);
-        return ingest_error_check(m->batch ? m->batch->h_progress : m->h_progress);
+        return ingest_error_check(m->batch ? m->batch->group_of(m->batch_index).h_progress : m->h_progress);
       }
       if (synced) break;  // cannot happen; fall through to the counting kernel
       if (host_now_us() - t0 > 2000.0) {
@@ -1486,50 +1503,63 @@ int batch_bind_device(const rmd_hip_batch* b) {
   return RMD_HIP_OK;
 }
 
-// one step: the update pipeline for every member whose bit is set in `active` (their frames are in place: P.cur / the staged host frames)
+// one step: the update pipeline for every member whose bit is set in `active` (their frames are in place: P.cur / the staged host
+// frames), one launch pair per group
 int batch_launch(rmd_hip_batch* b, unsigned int active, const rmdk::IngestArgs* ingest, const unsigned char* d_stage, size_t frame_bytes) {
-  rmdk::BatchArgs<rmdk::MAX_BATCH> B;
-  memset(&B, 0, sizeof(B));
-  for (int i = 0; i < b->n; ++i) {
-    rmd_hip_seeds* m = b->members[i];
-    rmdk::SeedParams P = m->P;
-    P.stats = nullptr; P.trace = nullptr;
-    B.seq[i] = seq_args_of(m, P);
-    B.seq[i].active = (active >> i) & 1u;
-    if (!B.seq[i].active) B.seq[i].fuse_prev = 0;
-    if (ingest && B.seq[i].active) {
-      const unsigned char* src = d_stage + static_cast<size_t>(i) * frame_bytes;
-      if (ingest->kind == 1) {
-        B.seq[i].ingest_u8 = reinterpret_cast<const unsigned int*>(src);
-        B.seq[i].ingest_map1 = m->d_undist_map1;
-        B.seq[i].ingest_map2 = m->d_undist_map2;
-      } else {
-        B.seq[i].ingest_f32 = reinterpret_cast<const float*>(src);
-      }
-      B.seq[i].ingest_dst = const_cast<float*>(P.cur);
-    }
-  }
   if (b->opt_timing == 2) ++b->region_updates;
-  const int rc = dispatch_side(b->members[0]->patch_side, [&](auto side) {
-    constexpr int SIDE = decltype(side)::value;
-    if (b->n == 1) {
-      rmdk::BatchArgs<1> B1;
-      B1.seq[0] = B.seq[0];
-      HIP_TRY((rmdk::launch_seed_pipeline_compact<SIDE, 1>(B1, 1, b->ws, b->stream, b->num_cus, b->opt_unit_target, ingest)));
-    } else {
-      HIP_TRY((rmdk::launch_seed_pipeline_compact<SIDE, rmdk::MAX_BATCH>(B, b->n, b->ws, b->stream, b->num_cus, b->opt_unit_target, ingest)));
+  for (int g = 0; g < b->n_groups; ++g) {
+    rmd_hip_batch::Group& G = b->groups[g];
+    const unsigned int g_active = (active >> G.first) & ((1u << G.n) - 1u);
+    if (!g_active) continue;
+    rmdk::BatchArgs<rmdk::MAX_BATCH> B;
+    memset(&B, 0, sizeof(B));
+    for (int j = 0; j < G.n; ++j) {
+      rmd_hip_seeds* m = b->members[G.first + j];
+      rmdk::SeedParams P = m->P;
+      P.stats = nullptr; P.trace = nullptr;
+      B.seq[j] = seq_args_of(m, P);
+      B.seq[j].active = (g_active >> j) & 1u;
+      if (!B.seq[j].active) B.seq[j].fuse_prev = 0;
+      if (ingest && B.seq[j].active) {
+        const unsigned char* src = d_stage + static_cast<size_t>(G.first + j) * frame_bytes;
+        if (ingest->kind == 1) {
+          B.seq[j].ingest_u8 = reinterpret_cast<const unsigned int*>(src);
+          B.seq[j].ingest_map1 = m->d_undist_map1;
+          B.seq[j].ingest_map2 = m->d_undist_map2;
+        } else {
+          B.seq[j].ingest_f32 = reinterpret_cast<const float*>(src);
+        }
+        B.seq[j].ingest_dst = const_cast<float*>(P.cur);
+      }
     }
-    return RMD_HIP_OK;
-  });
-  TRY(rc);
-  for (int i = 0; i < b->n; ++i) {
-    if (!((active >> i) & 1u)) continue;
-    rmd_hip_seeds* m = b->members[i];
-    m->P_pending = m->P;
-    m->P_pending.stats = nullptr; m->P_pending.trace = nullptr;
-    m->finalize_pending = true;
-    m->async_count_valid = true;
-    m->async_number = b->ws.update_number;
+    rmdk::IngestArgs in;
+    if (ingest) {
+      in = *ingest;
+      void* dev_progress = nullptr;
+      HIP_TRY(hipHostGetDevicePointer(&dev_progress, G.h_progress, 0));
+      in.progress = static_cast<unsigned int*>(dev_progress);
+    }
+    const int rc = dispatch_side(b->members[0]->patch_side, [&](auto side) {
+      constexpr int SIDE = decltype(side)::value;
+      if (G.n == 1) {
+        rmdk::BatchArgs<1> B1;
+        B1.seq[0] = B.seq[0];
+        HIP_TRY((rmdk::launch_seed_pipeline_compact<SIDE, 1>(B1, 1, G.ws, G.stream, b->num_cus, b->opt_unit_target, ingest ? &in : nullptr)));
+      } else {
+        HIP_TRY((rmdk::launch_seed_pipeline_compact<SIDE, rmdk::MAX_BATCH>(B, G.n, G.ws, G.stream, b->num_cus, b->opt_unit_target, ingest ? &in : nullptr)));
+      }
+      return RMD_HIP_OK;
+    });
+    TRY(rc);
+    for (int j = 0; j < G.n; ++j) {
+      if (!((g_active >> j) & 1u)) continue;
+      rmd_hip_seeds* m = b->members[G.first + j];
+      m->P_pending = m->P;
+      m->P_pending.stats = nullptr; m->P_pending.trace = nullptr;
+      m->finalize_pending = true;
+      m->async_count_valid = true;
+      m->async_number = G.ws.update_number;
+    }
   }
   return RMD_HIP_OK;
 }
@@ -1550,10 +1580,19 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
   const unsigned long long n64 = ++b->step_number;
   const unsigned int n = static_cast<unsigned int>(n64);
   const int k = static_cast<int>(n64 % rmd_hip_batch::SLOTS);
-  if (n64 > static_cast<unsigned long long>(rmd_hip_batch::SLOTS)) TRY(wait_for_progress(b->h_progress, n - rmd_hip_batch::SLOTS + 1u, b->stream));
+  // Slot k was last read by the setup kernels of the step recorded in slot_step[k]; such a kernel is done once a LATER setup kernel of
+  // the same group has started (the progress word), or, if the group has not been launched since, once its stream is idle.
+  static_assert(rmd_hip_batch::SLOTS == 3, "Group::slot_step");
+  for (int g = 0; g < b->n_groups; ++g) {
+    rmd_hip_batch::Group& G = b->groups[g];
+    const unsigned long long used = G.slot_step[k];
+    if (!used) continue;
+    if (G.last_step > used) TRY(wait_for_progress(G.h_progress, static_cast<unsigned int>(used) + 1u, G.stream));
+    else HIP_TRY(hipStreamSynchronize(G.stream));
+  }
   const size_t need = static_cast<size_t>(b->n) * static_cast<size_t>(m0->width) * m0->height * sizeof(float);  // float frames: the larger kind
   if (b->stage_bytes < need) {
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    for (int g = 0; g < b->n_groups; ++g) HIP_TRY(hipStreamSynchronize(b->groups[g].stream));
     HIP_TRY(hipStreamSynchronize(b->copy_stream));
     for (int q = 0; q < rmd_hip_batch::SLOTS; ++q) {
       if (b->h_stage[q]) (void)hipHostFree(b->h_stage[q]);
@@ -1586,9 +1625,6 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
   in.kind = gray ? 1 : 2;
   in.pitch = u8_pitch;
   in.flag = b->d_flag;
-  void* dev_progress = nullptr;
-  HIP_TRY(hipHostGetDevicePointer(&dev_progress, b->h_progress, 0));
-  in.progress = static_cast<unsigned int*>(dev_progress);
   in.number = n;
   for (int i = 0; i < b->n; ++i) {
     if (!((active >> i) & 1u)) continue;
@@ -1596,6 +1632,10 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
     m->P.cur = static_cast<const float*>(m->planes[RMD_HIP_PLANE_CURR_IMG].data);  // setup k writes it after search k - 1 has run (same stream)
     m->P.cur_stride = m->P.stride;
     seeds_frame_pose(m, T_curr_world + 12 * i);
+  }
+  for (int g = 0; g < b->n_groups; ++g) {
+    rmd_hip_batch::Group& G = b->groups[g];
+    if ((active >> G.first) & ((1u << G.n) - 1u)) { G.slot_step[k] = n64; G.last_step = n64; }
   }
   return batch_launch(b, active, &in, b->d_stage[k], frame_bytes);
 }
@@ -1607,7 +1647,8 @@ extern "C" {
 int rmd_hip_batch_destroy(rmd_hip_batch_t* b) {
   if (!b) return RMD_HIP_OK;
   (void)hipSetDevice(b->device);
-  if (b->stream) (void)hipStreamSynchronize(b->stream);
+  for (auto& G : b->groups)
+    if (G.stream) (void)hipStreamSynchronize(G.stream);
   if (b->copy_stream) (void)hipStreamSynchronize(b->copy_stream);
   for (int i = 0; i < rmdk::MAX_BATCH; ++i)
     if (b->members[i]) (void)seeds_destroy_impl(b->members[i]);
@@ -1616,13 +1657,17 @@ int rmd_hip_batch_destroy(rmd_hip_batch_t* b) {
     if (b->d_stage[q]) (void)hipFree(b->d_stage[q]);
   }
   if (b->h_seq) (void)hipHostFree(b->h_seq);
-  if (b->h_progress) (void)hipHostFree(b->h_progress);
   if (b->d_flag) (void)hipFree(b->d_flag);
   if (b->region_start) (void)hipEventDestroy(b->region_start);
   if (b->region_stop) (void)hipEventDestroy(b->region_stop);
-  b->ws.release();
+  for (auto& G : b->groups) {
+    G.ws.release();
+    if (G.h_progress) (void)hipHostFree(G.h_progress);
+    if (G.ev) (void)hipEventDestroy(G.ev);
+  }
   if (b->copy_stream) (void)hipStreamDestroy(b->copy_stream);
-  if (b->stream) (void)hipStreamDestroy(b->stream);
+  for (auto& G : b->groups)
+    if (G.stream) (void)hipStreamDestroy(G.stream);
   delete b;
   return RMD_HIP_OK;
 }
@@ -1638,22 +1683,32 @@ int rmd_hip_batch_create(int n, int width, int height, float fx, float fy, float
   if (!b) return fail(RMD_HIP_ERR_RUNTIME, "batch_create: out of host memory");
   (void)hipGetDevice(&b->device);
   auto bail = [&](int rc) { rmd_hip_batch_destroy(b); return rc; };
-  if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking) != hipSuccess)
-    return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: hipStreamCreate failed"));
+  int want_groups = n >= 2 ? 2 : 1;
+  if (const char* e = getenv("RMD_HIP_BATCH_GROUPS")) want_groups = atoi(e) >= 2 && n >= 2 ? 2 : 1;  // (A/B)
+  b->n_groups = want_groups;
+  b->opt_unit_target = 1;  // (2x / 3x as many, smaller units: +4 % with one group of 4, nothing with two groups)
   const size_t pitch = (static_cast<size_t>(width) * 4 + 255) / 256 * 256;  // as image_alloc lays the members' planes out
-  if (b->ws.allocate(width, height, static_cast<int>(pitch / 4), n) != 0) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: update workspace"));
+  for (int g = 0; g < b->n_groups; ++g) {
+    rmd_hip_batch::Group& G = b->groups[g];
+    G.first = g == 0 ? 0 : (n + 1) / 2;
+    G.n = b->n_groups == 1 ? n : (g == 0 ? (n + 1) / 2 : n / 2);
+    if (hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: hipStreamCreate failed"));
+    if (G.ws.allocate(width, height, static_cast<int>(pitch / 4), G.n) != 0) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: update workspace"));
+    if (hipHostMalloc(reinterpret_cast<void**>(&G.h_progress), 64, hipHostMallocMapped) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: progress words"));
+    G.h_progress[0] = G.h_progress[1] = 0u;
+    if (hipEventCreate(&G.ev) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: event"));
+  }
+  if (hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: hipStreamCreate failed"));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, b->device) == hipSuccess && prop.multiProcessorCount > 0) b->num_cus = prop.multiProcessorCount;
-  if (hipHostMalloc(reinterpret_cast<void**>(&b->h_progress), 64, hipHostMallocMapped) != hipSuccess ||
-      hipHostMalloc(reinterpret_cast<void**>(&b->h_seq), rmd_hip_batch::SLOTS * FLAG_WORDS * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess ||
+  if (hipHostMalloc(reinterpret_cast<void**>(&b->h_seq), rmd_hip_batch::SLOTS * FLAG_WORDS * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&b->d_flag), FLAG_WORDS * sizeof(unsigned int)) != hipSuccess ||
       hipMemset(b->d_flag, 0, FLAG_WORDS * sizeof(unsigned int)) != hipSuccess)
     return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: ingest words"));
-  b->h_progress[0] = b->h_progress[1] = 0u;
+  b->n = n;  // (group_of needs it while the members are created)
   for (int i = 0; i < n; ++i) {
     const int rc = seeds_create_impl(width, height, fx, fy, cx, cy, patch_side, max_extent, b, i, &b->members[i]);
     if (rc != RMD_HIP_OK) return bail(rc);
-    b->n = i + 1;
   }
   if (hipDeviceSynchronize() != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: device synchronisation failed"));
   *out = b;
@@ -1709,8 +1764,9 @@ int rmd_hip_batch_sync(rmd_hip_batch_t* b) {
   if (!b) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_sync: null handle");
   TRY(batch_bind_device(b));
   for (int i = 0; i < b->n; ++i) TRY(seeds_flush(b->members[i]));
-  HIP_TRY(hipStreamSynchronize(b->stream));
-  return ingest_error_check(b->h_progress);
+  for (int g = 0; g < b->n_groups; ++g) HIP_TRY(hipStreamSynchronize(b->groups[g].stream));
+  for (int g = 0; g < b->n_groups; ++g) TRY(ingest_error_check(b->groups[g].h_progress));
+  return RMD_HIP_OK;
 }
 
 int rmd_hip_batch_set_option(rmd_hip_batch_t* b, int option, int value) {
@@ -1726,17 +1782,20 @@ int rmd_hip_batch_set_option(rmd_hip_batch_t* b, int option, int value) {
       return RMD_HIP_OK;
     case RMD_HIP_OPT_SEARCH_FLAGS:
       if (value < 0 || value > 7) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_set_option: search flags %d outside 0..7", value);
-      b->ws.search_flags = value;
+      for (int g = 0; g < b->n_groups; ++g) b->groups[g].ws.search_flags = value;
       return RMD_HIP_OK;
     default: return fail(RMD_HIP_ERR_INVALID_ARG, "batch_set_option: unknown option %d", option);
   }
 }
 
+// the region timer spans both groups' streams: it starts when stream 0 reaches the start event (stream 1 waits for that event) and stops
+// when both streams have run everything queued before the query
 int rmd_hip_batch_timing_reset(rmd_hip_batch_t* b) {
   if (!b) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_timing_reset: null handle");
   TRY(rmd_hip_batch_sync(b));
   if (!b->region_start) HIP_TRY(hipEventCreate(&b->region_start));
-  HIP_TRY(hipEventRecord(b->region_start, b->stream));
+  HIP_TRY(hipEventRecord(b->region_start, b->groups[0].stream));
+  for (int g = 1; g < b->n_groups; ++g) HIP_TRY(hipStreamWaitEvent(b->groups[g].stream, b->region_start, 0));
   b->region_updates = 0;
   return RMD_HIP_OK;
 }
@@ -1747,7 +1806,11 @@ int rmd_hip_batch_timing(rmd_hip_batch_t* b, double* total_ms, long* steps) {
   TRY(batch_bind_device(b));
   if (!b->region_stop) HIP_TRY(hipEventCreate(&b->region_stop));
   for (int i = 0; i < b->n; ++i) TRY(seeds_flush(b->members[i]));  // the deferred finalisations belong to the region
-  HIP_TRY(hipEventRecord(b->region_stop, b->stream));
+  for (int g = 1; g < b->n_groups; ++g) {
+    HIP_TRY(hipEventRecord(b->groups[g].ev, b->groups[g].stream));
+    HIP_TRY(hipStreamWaitEvent(b->groups[0].stream, b->groups[g].ev, 0));
+  }
+  HIP_TRY(hipEventRecord(b->region_stop, b->groups[0].stream));
   HIP_TRY(hipEventSynchronize(b->region_stop));
   float ms = 0.0f;
   HIP_TRY(hipEventElapsedTime(&ms, b->region_start, b->region_stop));

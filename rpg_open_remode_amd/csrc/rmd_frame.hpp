@@ -478,7 +478,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
   unsigned int packed_prev = M.packed[gm];
   float lfirst_prev = M.lfirst[gm];
   float2 m_prev = M.mean[gm], d_prev = M.dir[gm];
-  if (M.progress && wg == 0 && seq == 0 && tid == 0) __hip_atomic_store(M.progress, M.ingest_number, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (M.progress && wg == 0 && seq == M.housekeeper && tid == 0) __hip_atomic_store(M.progress, M.ingest_number, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   // (computed here, at the top, so that its scalar loads travel with the kernel arguments)
   // unit size: 1..4 rounds of 256 evaluations, from the previous frame's work (a frame differs little from the one before)
   int unit_rounds = MAX_UNIT_ROUNDS;
@@ -590,9 +590,12 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
   const int tile = blockIdx.y * M.tiles_x + blockIdx.x;                      // within the sequence
   const int tile_g = (NSEQ == 1 ? 0 : seq * M.n_tiles) + tile;               // within the launch
   const int unit_items = unit_rounds * TILE_PIX;
-  if (tile_g == 0 && tid < UNIT_SHARDS) M.shards_next[tid] = 0ull;  // the set the NEXT frame counts in (nobody reads it now)
-  if (tile_g == 0 && tid < UNIT_SHARDS) M.handout[tid * HANDOUT_STRIDE] = 0u;  // the search kernel's hand-out counters
-  if (tile_g == 0 && tid == 0) M.queue[5] = static_cast<unsigned int>(unit_items);
+  // the launch's housekeeping falls to tile 0 of its first sequence that has a frame (M.housekeeper: a sequence that sits the step out
+  // leaves at the top of the kernel)
+  const bool keeper = tile == 0 && seq == M.housekeeper;
+  if (keeper && tid < UNIT_SHARDS) M.shards_next[tid] = 0ull;  // the set the NEXT frame counts in (nobody reads it now)
+  if (keeper && tid < UNIT_SHARDS) M.handout[tid * HANDOUT_STRIDE] = 0u;  // the search kernel's hand-out counters
+  if (keeper && tid == 0) M.queue[5] = static_cast<unsigned int>(unit_items);
   if (tid == 0) M.tile_conv[tile_g] = static_cast<unsigned int>(red_c[0] + red_c[1] + red_c[2] + red_c[3]);
 #ifdef RMD_PROFILE_ROUNDS
   if (P.trace && prof_t[0] != 0ull && prof_t[6] != 0ull) {  // any live lane that ran both the fusion and the set-up: phases of the setup chain, 10 ns ticks
@@ -816,6 +819,9 @@ inline hipError_t launch_seed_pipeline_compact(const BatchArgs<NSEQ>& B, int n_s
   ++ws.update_number;
   MatcherArgs M = matcher_args(ws);
   M.n_seq = n_seq;
+  M.housekeeper = 0;
+  for (int q = n_seq - 1; q >= 0; --q)
+    if (B.seq[q].active) M.housekeeper = q;
   if (ingest && ingest->kind) {
     M.ingest_kind = ingest->kind; M.ingest_pitch = ingest->pitch;
     M.ingest_flag = ingest->flag; M.progress = ingest->progress; M.ingest_number = ingest->number;

@@ -154,6 +154,7 @@ struct MatcherArgs {
   int tiles_y;
   int n_tiles;               // tiles of one sequence
   int n_seq;
+  int housekeeper;           // the first sequence of the launch that has a frame: tile 0 of it resets the counters of the next launch
   int search_flags;          // SEARCH_* (rmd_frame.hpp)
   unsigned long long* trace;  // this frame's slice of the timeline buffer, may be null (round-1 pipeline, see trace_record)
   // Frame ingest for frames handed over in host memory: a copy engine brings the frames of all sequences of the launch as they are
@@ -479,6 +480,7 @@ inline MatcherArgs matcher_args(const MatcherWorkspace& ws) {
   M.shards_prev = ws.frame > 0 ? ws.d_shards + ((ws.frame + 2) % 3) * UNIT_SHARDS : nullptr;
   M.shards_next = ws.d_shards + ((ws.frame + 1) % 3) * UNIT_SHARDS;
   M.search_flags = ws.search_flags;
+  M.housekeeper = 0;
   M.conv_out = ws.d_conv;
   M.update_number = ws.update_number;
   M.shard_cap = ws.shard_cap;
