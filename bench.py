@@ -141,7 +141,12 @@ def cpu_reference_run(frame_fn, width, height, K, n_frames, side, min_depth, max
     import oracles as O
     kind = "reference" if O.available("ref", side) else "port"
     olib = O.OracleLib("ref" if kind == "reference" else "port", side)
-    cores = olib.lib.ref_max_threads() if kind == "reference" else olib.lib.orc_max_threads()
+    # as many OpenMP threads as the process may really use: a container that sees 256 cores but has a CPU quota of 16 is throttled for
+    # most of every scheduling period when all visible cores spin up (the figure would be the throttle's, not the cores')
+    from rpg_open_remode_amd import synth as _synth
+    visible = olib.lib.ref_max_threads() if kind == "reference" else olib.lib.orc_max_threads()
+    cores = max(1, min(int(visible), _synth.effective_cpus()))
+    (olib.lib.ref_set_num_threads if kind == "reference" else olib.lib.orc_set_num_threads)(cores)
     s = O.Seeds(olib, width, height, K)
     img0, T0 = frame_fn(0)
     s.set_reference(img0, T0, min_depth, max_depth)
@@ -156,7 +161,8 @@ def cpu_reference_run(frame_fn, width, height, K, n_frames, side, min_depth, max
     what = ("the reference's own seed_matrix.cu kernels compiled for the host (oracle/Makefile), glibc libm" if kind == "reference"
             else "CPU restatement of the reference (oracle/remode_oracle.cpp)")
     out = {"value": round(mpix, 4), "unit": "Mpix/s", "cores": int(cores), "kind": kind,
-           "sample": f"updates 1..{n} of the same {width}x{height} sequence (patch side {side}), {dt:.1f} s; {what}"}
+           "sample": f"updates 1..{n} of the same {width}x{height} sequence (patch side {side}), {dt:.1f} s; {what}; {cores} OpenMP threads = the CPUs this "
+                     f"process may use (CPU quota / affinity; {int(visible)} cores visible)"}
     state = s.state()
     den = None
     if n == n_frames - 1:

@@ -28,19 +28,16 @@ typedef ConvergenceStates::ConvergenceState ConvergenceState;
 
 class SeedMatrix {
  public:
-  SeedMatrix(const size_t& width, const size_t& height, const PinholeCamera& cam) : handle_(NULL), mu_(NULL), sigma_(NULL), a_(NULL), b_(NULL), conv_(NULL) {
+  SeedMatrix(const size_t& width, const size_t& height, const PinholeCamera& cam)
+      : handle_(NULL), owns_(true), mu_(NULL), sigma_(NULL), a_(NULL), b_(NULL), conv_(NULL) {
     detail::throw_on_error(rmd_hip_seeds_create(static_cast<int>(width), static_cast<int>(height), cam.fx, cam.fy, cam.cx, cam.cy,
                                                 RMD_CORR_PATCH_SIDE, RMD_MAX_EXTENT_EPIPOLAR_SEARCH, &handle_),
                            "SeedMatrix: unable to create");
-    mu_ = view<float>(RMD_HIP_PLANE_MU);
-    sigma_ = view<float>(RMD_HIP_PLANE_SIGMA_SQ);
-    a_ = view<float>(RMD_HIP_PLANE_A);
-    b_ = view<float>(RMD_HIP_PLANE_B);
-    conv_ = view<int>(RMD_HIP_PLANE_CONVERGENCE);
+    make_views();
   }
   ~SeedMatrix() {
     delete mu_; delete sigma_; delete a_; delete b_; delete conv_;
-    rmd_hip_seeds_destroy(handle_);
+    if (owns_) rmd_hip_seeds_destroy(handle_);
   }
 
   bool setReferenceImage(float* host_ref_img_align_row_maj, const SE3<float>& T_curr_world, const float& min_depth, const float& max_depth) {
@@ -97,6 +94,16 @@ class SeedMatrix {
   rmd_hip_seeds_t* handle() const { return handle_; }
 
  private:
+  friend class SeedMatrixBatch;
+  // a member of a SeedMatrixBatch (seed_matrix_batch.cuh): the batch owns the handle
+  explicit SeedMatrix(rmd_hip_seeds_t* member) : handle_(member), owns_(false), mu_(NULL), sigma_(NULL), a_(NULL), b_(NULL), conv_(NULL) { make_views(); }
+  void make_views() {
+    mu_ = view<float>(RMD_HIP_PLANE_MU);
+    sigma_ = view<float>(RMD_HIP_PLANE_SIGMA_SQ);
+    a_ = view<float>(RMD_HIP_PLANE_A);
+    b_ = view<float>(RMD_HIP_PLANE_B);
+    conv_ = view<int>(RMD_HIP_PLANE_CONVERGENCE);
+  }
   SeedMatrix(const SeedMatrix&);
   SeedMatrix& operator=(const SeedMatrix&);
   void download(int plane, void* dst) const {
@@ -109,6 +116,7 @@ class SeedMatrix {
     return new DeviceImage<T>(v);
   }
   rmd_hip_seeds_t* handle_;
+  bool owns_;
   DeviceImage<float>*mu_, *sigma_, *a_, *b_;
   DeviceImage<int>* conv_;
 };

@@ -188,16 +188,21 @@ int image_alloc(rmd_hip_image* img, int kind, int width, int height) {
 
 }  // namespace
 
-// The "frame n has arrived" word that follows every staged host frame on the copy stream.  A pinned -> device copy of up to 16 KB
-// is carried out by a shader kernel of the runtime (__amd_rocclr_copyBuffer, tools/ubench/copy_path.hip), which needs wave slots of
-// its own: behind a thousand persistent search workgroups it ran 7 us on average and up to 98 us, and the setup kernel's ingest
-// workgroups waited for it.  From 64 KB on the copy goes to the SDMA engine like the frame itself.  So the flag is 64 KB of the same
-// number: whichever of its words the engine writes first or last, a reader of word 0 sees either the old number or the new one, and
-// the new one only after the frame copy in front of it (same stream) has completed.
-constexpr size_t FLAG_WORDS = 16384;
+// The "frame n has arrived" word that follows every staged host frame on the copy stream: a 4-byte pinned -> device copy, which the
+// runtime carries out with a small shader kernel (__amd_rocclr_copyBuffer; copies of 64 KB and more go to the SDMA engine,
+// tools/ubench/copy_path.hip).  Measured and rejected: a 64 KB block of the same number, so that the flag travels by SDMA like the
+// frame and needs no wave slots behind the persistent search workgroups -- 2.6 % faster when it works (48.1 against 49.4 us per
+// update) but two dependent SDMA transfers per frame on one stream intermittently lag a frame behind (61 - 79 us per update in one run
+// of three).  FLAG_WORDS > 1 re-creates that variant.
+constexpr size_t FLAG_WORDS = 1;
 static void fill_flag_block(unsigned int* block, unsigned int n) {
   for (size_t i = 0; i < FLAG_WORDS; ++i) block[i] = n;
 }
+constexpr size_t FLAG_ALLOC_BYTES = FLAG_WORDS * sizeof(unsigned int) < 64 ? 64 : FLAG_WORDS * sizeof(unsigned int);
+constexpr size_t FLAG_SLOT_WORDS = FLAG_WORDS < 16 ? 16 : FLAG_WORDS;  // pinned source blocks, one per slot, a cache line apart
+
+static unsigned long g_progress_timeouts = 0;  // diagnostics (RMD_HIP_INGEST_PROFILE): waits for a staging slot that gave up after 2 ms
+static double g_progress_max_wait_us = 0.0;    // ... and the longest such wait
 
 // ---- rmd::SeedMatrix ------------------------------------------------------------------------
 struct rmd_hip_seeds {
@@ -245,8 +250,8 @@ struct rmd_hip_seeds {
   float* h_zc_f32[SLOTS] = {};
   unsigned char* d_zc_u8[SLOTS] = {};
   float* d_zc_f32[SLOTS] = {};
-  unsigned int* h_seq = nullptr;            // pinned, SLOTS blocks of FLAG_WORDS words: the frame number, repeated, that the copy engine writes into d_zc_flag
-  unsigned int* d_zc_flag = nullptr;        // device, FLAG_WORDS words: number of the last frame whose staging copy has completed
+  unsigned int* h_seq = nullptr;            // pinned, one block per slot: the frame number the copy stream writes into d_zc_flag
+  unsigned int* d_zc_flag = nullptr;        // device: number of the last frame whose staging copy has completed
   unsigned int* h_progress = nullptr;       // pinned: [0] number of the ingested frame whose setup kernel has started, [1] error bits
   unsigned long long zc_number = 0;         // ingested frames so far (the device sees the low 32 bits and compares modulo 2^32)
   int opt_fused_ingest = 1;                 // RMD_HIP_FUSED_INGEST=0 switches back to the copy-stream pipeline (A/B)
@@ -648,8 +653,9 @@ static int seeds_destroy_impl(rmd_hip_seeds* s) {
   for (auto& t : s->timers) t.destroy();
   if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);
   if (s->ingest_profile && s->ingest_us[3] > 0)
-    fprintf(stderr, "[rmd_hip ingest] %.0f frames: wait for slot %.2f us, host copy %.2f us, submit %.2f us per frame\n", s->ingest_us[3],
-            s->ingest_us[0] / s->ingest_us[3], s->ingest_us[1] / s->ingest_us[3], s->ingest_us[2] / s->ingest_us[3]);
+    fprintf(stderr, "[rmd_hip ingest] %.0f frames: wait for slot %.2f us, host copy %.2f us, submit %.2f us per frame; longest wait %.0f us, %lu waits gave up after 2 ms\n",
+            s->ingest_us[3], s->ingest_us[0] / s->ingest_us[3], s->ingest_us[1] / s->ingest_us[3], s->ingest_us[2] / s->ingest_us[3], g_progress_max_wait_us,
+            g_progress_timeouts);
   for (int k = 0; k < rmd_hip_seeds::SLOTS; ++k) {
     if (s->h_u8[k]) (void)hipHostFree(s->h_u8[k]);
     if (s->h_f32[k]) (void)hipHostFree(s->h_f32[k]);
@@ -832,9 +838,9 @@ static int ingest_init(rmd_hip_seeds* s) {
   if (const char* e = getenv("RMD_HIP_FUSED_INGEST")) s->opt_fused_ingest = e[0] != '0';
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_progress), 64, hipHostMallocMapped));
   s->h_progress[0] = s->h_progress[1] = 0u;
-  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_seq), rmd_hip_seeds::SLOTS * FLAG_WORDS * sizeof(unsigned int), hipHostMallocDefault));
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_flag), FLAG_WORDS * sizeof(unsigned int)));
-  HIP_TRY(hipMemset(s->d_zc_flag, 0, FLAG_WORDS * sizeof(unsigned int)));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_seq), rmd_hip_seeds::SLOTS * FLAG_SLOT_WORDS * sizeof(unsigned int), hipHostMallocDefault));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_flag), FLAG_ALLOC_BYTES));
+  HIP_TRY(hipMemset(s->d_zc_flag, 0, FLAG_ALLOC_BYTES));
   HIP_TRY(hipStreamSynchronize(nullptr));
   const rmd_hip_image& im = s->planes[RMD_HIP_PLANE_CURR_IMG];
   s->cur_planes[0] = im.data;
@@ -884,6 +890,21 @@ class CopyPool {
     static CopyPool pool;
     return pool;
   }
+  struct Segment { void* dst; const void* src; };
+  // several buffers of `bytes` each (the frames of one batch step): the participants take whole buffers in turn
+  void copy_many(const Segment* segs, int n, size_t bytes) {
+    if (n == 1) { copy(segs[0].dst, segs[0].src, bytes); return; }
+    if (n_workers_ == 0 || bytes * static_cast<size_t>(n) < kMinBytes) {
+      for (int i = 0; i < n; ++i) memcpy(segs[i].dst, segs[i].src, bytes);
+      return;
+    }
+    std::lock_guard<std::mutex> one_copy_at_a_time(call_mutex_);
+    segs_ = segs; n_segs_ = n; bytes_ = bytes;
+    post();
+    for (int i = n_workers_; i < n; i += n_workers_ + 1) memcpy(segs[i].dst, segs[i].src, bytes);  // the caller's share
+    wait();
+    segs_ = nullptr; n_segs_ = 0;
+  }
   void copy(void* dst, const void* src, size_t bytes) {
     const int parts = n_workers_ + 1;
     if (n_workers_ == 0 || bytes < kMinBytes) {
@@ -893,21 +914,29 @@ class CopyPool {
     std::lock_guard<std::mutex> one_copy_at_a_time(call_mutex_);
     const size_t chunk = ((bytes + parts - 1) / parts + 4095) & ~static_cast<size_t>(4095);
     dst_ = static_cast<char*>(dst); src_ = static_cast<const char*>(src); bytes_ = bytes; chunk_ = chunk;
+    post();
+    const size_t mine = static_cast<size_t>(n_workers_) * chunk;  // the caller takes the last part
+    if (mine < bytes) memcpy(dst_ + mine, src_ + mine, bytes - mine);
+    wait();
+  }
+
+ private:
+  void post() {
     __atomic_store_n(&pending_, n_workers_, __ATOMIC_RELAXED);
     __atomic_fetch_add(&generation_, 1ull, __ATOMIC_RELEASE);  // publishes the job to the helpers that are polling
     if (__atomic_load_n(&parked_, __ATOMIC_ACQUIRE) != 0) {    // ... and wakes those that went to sleep
       std::lock_guard<std::mutex> lk(m_);
       cv_.notify_all();
     }
-    const size_t mine = static_cast<size_t>(n_workers_) * chunk;  // the caller takes the last part
-    if (mine < bytes) memcpy(dst_ + mine, src_ + mine, bytes - mine);
+  }
+  void wait() {
     while (__atomic_load_n(&pending_, __ATOMIC_ACQUIRE) != 0) cpu_relax();  // the helpers' parts take a few microseconds
   }
-
- private:
-  static constexpr size_t kMinBytes = 256 * 1024;
-  static constexpr double kPollUs = 300.0;  // a helper polls for this long after its last job before it goes to sleep: frames of a
-                                            // stream arrive every few tens of microseconds, and waking a sleeping thread costs more than the copy
+  static constexpr size_t kMinBytes = 1024 * 1024;  // 8-bit VGA frames (300 KB) are copied by the caller alone
+  // A helper does NOT poll for its next job: it sleeps on the condition variable.  Polling helpers (300 us after their last job) made
+  // the copy of a float frame three times faster, but four busy threads per stream ran the process into its container's CPU quota on
+  // the measurement box: one run in four lost 50 - 70 ms to a throttled thread (RMD_HIP_INGEST_PROFILE: "longest wait 58945 us").
+  static constexpr double kPollUs = 0.0;
   CopyPool() {
     int n = 3;
     if (const char* e = getenv("RMD_HIP_COPY_THREADS")) n = atoi(e) - 1;
@@ -943,8 +972,12 @@ class CopyPool {
       }
       if (__atomic_load_n(&stop_, __ATOMIC_ACQUIRE)) return;
       seen = __atomic_load_n(&generation_, __ATOMIC_ACQUIRE);
-      const size_t off = static_cast<size_t>(index) * chunk_;
-      if (off < bytes_) memcpy(dst_ + off, src_ + off, bytes_ - off < chunk_ ? bytes_ - off : chunk_);
+      if (segs_) {
+        for (int i = index; i < n_segs_; i += n_workers_ + 1) memcpy(segs_[i].dst, segs_[i].src, bytes_);
+      } else {
+        const size_t off = static_cast<size_t>(index) * chunk_;
+        if (off < bytes_) memcpy(dst_ + off, src_ + off, bytes_ - off < chunk_ ? bytes_ - off : chunk_);
+      }
       __atomic_fetch_sub(&pending_, 1, __ATOMIC_RELEASE);
     }
   }
@@ -956,6 +989,8 @@ class CopyPool {
   unsigned long long generation_ = 0;
   int parked_ = 0;
   char* dst_ = nullptr; const char* src_ = nullptr;
+  const Segment* segs_ = nullptr;
+  int n_segs_ = 0;
   size_t bytes_ = 0, chunk_ = 0;
   int pending_ = 0;
 };
@@ -1027,11 +1062,14 @@ static int wait_for_progress(volatile unsigned int* progress, unsigned int need,
     const double t0 = host_now_us();
     while (behind()) {
       if (host_now_us() - t0 > 2000.0) {  // far behind (or another matcher ran the frames in between): an idle stream has read everything
+        ++g_progress_timeouts;
         HIP_TRY(hipStreamSynchronize(stream));
         break;
       }
       cpu_relax();
     }
+    const double w = host_now_us() - t0;
+    if (w > g_progress_max_wait_us) g_progress_max_wait_us = w;
   }
   return RMD_HIP_OK;
 }
@@ -1069,8 +1107,8 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
     in.f32 = s->d_zc_f32[k];
     in.common.kind = 2;
   }
-  fill_flag_block(s->h_seq + k * FLAG_WORDS, n);  // behind the frame on the same stream: when the kernel sees n, the frame is in HBM
-  HIP_TRY(hipMemcpyAsync(s->d_zc_flag, s->h_seq + k * FLAG_WORDS, FLAG_WORDS * sizeof(unsigned int), hipMemcpyHostToDevice, s->copy_stream));
+  fill_flag_block(s->h_seq + k * FLAG_SLOT_WORDS, n);  // behind the frame on the same stream: when the kernel sees n, the frame is in HBM
+  HIP_TRY(hipMemcpyAsync(s->d_zc_flag, s->h_seq + k * FLAG_SLOT_WORDS, FLAG_WORDS * sizeof(unsigned int), hipMemcpyHostToDevice, s->copy_stream));
   in.common.flag = s->d_zc_flag;
   const double t_c = s->ingest_profile ? host_now_us() : 0.0;
   rmd_hip_image& im = s->planes[RMD_HIP_PLANE_CURR_IMG];
@@ -1603,24 +1641,26 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
     }
     b->stage_bytes = need;
   }
-  int first = -1, last = -1;
+  int first = -1, last = -1, n_segs = 0;
+  CopyPool::Segment segs[rmdk::MAX_BATCH];
   for (int i = 0; i < b->n; ++i) {
     if (!((active >> i) & 1u)) continue;
     unsigned char* dst = b->h_stage[k] + static_cast<size_t>(i) * frame_bytes;
-    if (gray) {
-      if (u8_pitch == m0->width) host_copy(dst, gray[i], frame_bytes);
-      else
-        for (int y = 0; y < m0->height; ++y) memcpy(dst + static_cast<size_t>(y) * u8_pitch, gray[i] + static_cast<size_t>(y) * m0->width, m0->width);
+    if (gray && u8_pitch != m0->width) {
+      for (int y = 0; y < m0->height; ++y) memcpy(dst + static_cast<size_t>(y) * u8_pitch, gray[i] + static_cast<size_t>(y) * m0->width, m0->width);
     } else {
-      host_copy(dst, f32[i], frame_bytes);
+      segs[n_segs].dst = dst;
+      segs[n_segs].src = gray ? static_cast<const void*>(gray[i]) : static_cast<const void*>(f32[i]);
+      ++n_segs;
     }
     if (first < 0) first = i;
     last = i;
   }
+  if (n_segs) CopyPool::instance().copy_many(segs, n_segs, frame_bytes);  // the frames of the step, spread over the copy threads
   const size_t off = static_cast<size_t>(first) * frame_bytes, len = static_cast<size_t>(last - first + 1) * frame_bytes;
   HIP_TRY(hipMemcpyAsync(b->d_stage[k] + off, b->h_stage[k] + off, len, hipMemcpyHostToDevice, b->copy_stream));
-  fill_flag_block(b->h_seq + k * FLAG_WORDS, n);  // behind the frames on the same stream: when the kernel sees n, they are in HBM
-  HIP_TRY(hipMemcpyAsync(b->d_flag, b->h_seq + k * FLAG_WORDS, FLAG_WORDS * sizeof(unsigned int), hipMemcpyHostToDevice, b->copy_stream));
+  fill_flag_block(b->h_seq + k * FLAG_SLOT_WORDS, n);  // behind the frames on the same stream: when the kernel sees n, they are in HBM
+  HIP_TRY(hipMemcpyAsync(b->d_flag, b->h_seq + k * FLAG_SLOT_WORDS, FLAG_WORDS * sizeof(unsigned int), hipMemcpyHostToDevice, b->copy_stream));
   rmdk::IngestArgs in;
   in.kind = gray ? 1 : 2;
   in.pitch = u8_pitch;
@@ -1701,9 +1741,8 @@ int rmd_hip_batch_create(int n, int width, int height, float fx, float fy, float
   if (hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: hipStreamCreate failed"));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, b->device) == hipSuccess && prop.multiProcessorCount > 0) b->num_cus = prop.multiProcessorCount;
-  if (hipHostMalloc(reinterpret_cast<void**>(&b->h_seq), rmd_hip_batch::SLOTS * FLAG_WORDS * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess ||
-      hipMalloc(reinterpret_cast<void**>(&b->d_flag), FLAG_WORDS * sizeof(unsigned int)) != hipSuccess ||
-      hipMemset(b->d_flag, 0, FLAG_WORDS * sizeof(unsigned int)) != hipSuccess)
+  if (hipHostMalloc(reinterpret_cast<void**>(&b->h_seq), rmd_hip_batch::SLOTS * FLAG_SLOT_WORDS * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&b->d_flag), FLAG_ALLOC_BYTES) != hipSuccess || hipMemset(b->d_flag, 0, FLAG_ALLOC_BYTES) != hipSuccess)
     return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: ingest words"));
   b->n = n;  // (group_of needs it while the members are created)
   for (int i = 0; i < n; ++i) {

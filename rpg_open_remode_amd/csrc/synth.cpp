@@ -10,6 +10,7 @@
 // T_world_cam as 3x4 row-major [R|t] (se3.cuh:72-77), depth = range along the
 // pixel's ray in metres (seed_update.cu:81 uses norm(P), dataset.cpp:178 stores cm).
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <string.h>
 
@@ -98,6 +99,11 @@ void rmd_synth_pose(int k, unsigned seed, double* T_world_cam) {
   T_world_cam[3] = px; T_world_cam[7] = py; T_world_cam[11] = pz;
 }
 
+// threads of the row loop below (0: the OpenMP default).  A container with a CPU quota far below its visible core count (16 of 256 on
+// the measurement box) is throttled for most of every scheduling period when all visible cores spin up.
+static int g_render_threads = 0;
+void rmd_synth_set_threads(int n) { g_render_threads = n > 0 ? n : 0; }
+
 // Render one frame.  gray: w*h bytes; range: w*h floats (may be NULL).
 int rmd_synth_render(int w, int h, double fx, double fy, double cx, double cy, const double* T_world_cam, unsigned seed,
                      uint8_t* gray, float* range) {
@@ -106,7 +112,8 @@ int rmd_synth_render(int w, int h, double fx, double fy, double cx, double cy, c
   scene_boxes(seed, boxes);
   const double* T = T_world_cam;
   const double o[3] = {T[3], T[7], T[11]};
-#pragma omp parallel for schedule(static)
+  const int n_threads = g_render_threads > 0 ? g_render_threads : omp_get_max_threads();
+#pragma omp parallel for schedule(static) num_threads(n_threads)
   for (int v = 0; v < h; ++v) {
     for (int u = 0; u < w; ++u) {
       const double dc[3] = {(u - cx) / fx, (v - cy) / fy, 1.0};

@@ -25,8 +25,31 @@ def _lib():
         lib.rmd_synth_render.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.c_double] * 4 + [
             ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p]
         lib.rmd_synth_render.restype = ctypes.c_int
+        lib.rmd_synth_set_threads.argtypes = [ctypes.c_int]
+        lib.rmd_synth_set_threads.restype = None
+        lib.rmd_synth_set_threads(effective_cpus())
         _LIB = lib
     return _LIB
+
+
+def effective_cpus():
+    """CPUs this process may really use: the cgroup CPU quota if there is one (a container that sees 256 cores may be limited to
+    16 CPUs' worth of time per period -- spinning up all visible cores gets it throttled), else the affinity mask / core count."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+            break
+        except Exception:
+            continue
+    return max(1, n)
 
 
 def intrinsics(width, height):

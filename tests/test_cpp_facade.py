@@ -70,3 +70,35 @@ def test_reference_style_cpp_flow_equals_oracle(tmp_path, side):
     from rpg_open_remode_amd import api
     want = O.point_cloud(planes[5], planes[4], seq.gray[0], seq.K, api.SE3(seq.T_curr_world[0]).inv().data)
     assert n_points == n_conv > 100 and O.count_mismatch(want, cloud) == 0
+
+
+def _build_batch_check(tmp_path, side):
+    exe = str(tmp_path / f"batch_check_s{side}")
+    cmd = ["g++", "-std=c++11", "-O1", "-Wall", "-Werror", f"-DRMD_CORR_PATCH_SIDE={side}", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cpp", "batch_check.cpp"), "-L" + PKG, "-lrmd_hip", "-Wl,-rpath," + PKG, "-o", exe]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert res.returncode == 0, res.stdout
+    return exe
+
+
+def test_batch_header_compiles_with_plain_gxx(tmp_path):
+    _build_batch_check(tmp_path, 5)
+
+
+@pytest.mark.gpu
+def test_cpp_batch_equals_standalone_objects(tmp_path):
+    """rmd::SeedMatrixBatch (include/rmd/seed_matrix_batch.cuh): three sequences stepped together through the C++ headers equal three
+    stand-alone rmd::SeedMatrix objects, plane for plane, and feed rmd::DepthmapDenoiser like them"""
+    exe = _build_batch_check(tmp_path, 9)
+    seqs = [sequence(160, 120, 12, scene) for scene in range(3)]
+    inp = str(tmp_path / "in.bin")
+    with open(inp, "wb") as f:
+        f.write(struct.pack("4i", 3, 160, 120, 12))
+        f.write(np.asarray(seqs[0].K, np.float32).tobytes())
+        f.write(np.asarray([min(s.min_depth for s in seqs), max(s.max_depth for s in seqs)], np.float32).tobytes())
+        for s in seqs:
+            for im, T in zip(s.images, s.T_curr_world):
+                f.write(im.tobytes())
+                f.write(T.tobytes())
+    res = subprocess.run([exe, inp], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert res.returncode == 0 and "batch == stand-alone" in res.stdout, res.stdout
