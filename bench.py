@@ -50,9 +50,10 @@ NCC_FLOP_PER_TAP = 14       # 3 FMA + 1 bilinear fetch per tap
 WIDTH, HEIGHT, FRAMES, SIDE = 640, 480, 200, 9
 TV_LAMBDA, TV_ITERS = 0.5, 200
 KNOWN_CONFIGS = {(640, 480, 200): "configs[1]", (1280, 960, 500): "configs[2]", (1920, 1080, 1000): "configs[4]"}
-PARITY_NOTE = ("bit-identical (all state planes, convergence masks, TV-L1 output) to the reference's own kernels compiled for the "
-               "CPU with IEEE fp32, no contraction and the shared expf/sinf/acosf of csrc/rmd_math.h (tests/: golden fixtures "
-               "generated from /root/reference); distance to the reference linked against glibc's libm: parity_vs_glibc_reference")
+PARITY_NOTE = ("bit-identical (all state planes, convergence masks, TV-L1 output) to the reference's own kernels compiled UNMODIFIED for the "
+               "CPU (IEEE fp32, no contraction) and linked against the system's libm (glibc 2.35): the expf/sinf/acosf of csrc/rmd_math.h "
+               "restate glibc's routines and equal them for all 2^32 arguments (oracle/libm_exhaustive.cpp); golden fixtures generated from "
+               "/root/reference in tests/golden; measured on this run: parity_vs_glibc_reference")
 
 
 def parse():
@@ -86,10 +87,11 @@ def resolve_workload(args):
 
 
 def kernel_source_sha256():
-    """hash of everything that is compiled into librmd_hip.so: committed counter files (profiles/traffic.json) carry the hash of the
-    sources they were measured on, and a figure derived from them is refused when the kernels have changed since"""
+    """hash of the device code of librmd_hip.so (the kernel headers; the host orchestration in rmd_capi.hip is not part of it):
+    committed counter files (profiles/traffic.json) carry the hash of the sources they were measured on, and a figure derived from
+    them is refused when the kernels have changed since"""
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "rpg_open_remode_amd", "csrc", "*.h*"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "rpg_open_remode_amd", "csrc", "*.hpp")) + glob.glob(os.path.join(ROOT, "rpg_open_remode_amd", "csrc", "*.h"))):
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()

@@ -188,18 +188,43 @@ int image_alloc(rmd_hip_image* img, int kind, int width, int height) {
 
 }  // namespace
 
-// The "frame n has arrived" word that follows every staged host frame on the copy stream: a 4-byte pinned -> device copy, which the
-// runtime carries out with a small shader kernel (__amd_rocclr_copyBuffer; copies of 64 KB and more go to the SDMA engine,
-// tools/ubench/copy_path.hip).  Measured and rejected: a 64 KB block of the same number, so that the flag travels by SDMA like the
-// frame and needs no wave slots behind the persistent search workgroups -- 2.6 % faster when it works (48.1 against 49.4 us per
-// update) but two dependent SDMA transfers per frame on one stream intermittently lag a frame behind (61 - 79 us per update in one run
-// of three).  FLAG_WORDS > 1 re-creates that variant.
-constexpr size_t FLAG_WORDS = 1;
-static void fill_flag_block(unsigned int* block, unsigned int n) {
-  for (size_t i = 0; i < FLAG_WORDS; ++i) block[i] = n;
+// The "frame n has arrived" word that follows every staged host frame on the copy stream.  A pinned -> device copy of up to 16 KB
+// is carried out by a shader kernel of the runtime (__amd_rocclr_copyBuffer, tools/ubench/copy_path.hip), which needs wave slots of
+// its own: behind a thousand persistent search workgroups it ran 7 us on average and up to 98 us, and with two stream groups of a
+// batch overlapping there is hardly ever a gap for it (8-bit host frames, batch of 8: 8 700 instead of 12 000 Mpix/s).  From 64 KB on
+// a copy goes to the SDMA engine like the frame itself.  So the flag is 64 KB of the same number: whichever of its words the engine
+// writes first or last, a reader of word 0 sees either the old number or the new one, and the new one only after the frame copy in
+// front of it (same stream) has completed.  The 64 KB form costs the copy engine 7 us more per frame, all of it latency when the
+// device is waiting for the frame (live use: the node asks for the converged count after every update, so the host never runs ahead):
+// there the 4-byte form is used -- the device has caught up, so the shader copy finds an empty chip (flag_words()).
+constexpr size_t FLAG_WORDS = 16384;
+static void fill_flag_block(unsigned int* block, unsigned int n, size_t words) {
+  for (size_t i = 0; i < words; ++i) block[i] = n;
+}
+// how many words of the flag block to send behind frame `n`: 1 when the device has already started the previous frame (it is waiting for
+// this one, or about to), the whole block while the host runs ahead of it
+static size_t flag_words(const unsigned int* h_progress, unsigned int n) {
+  const unsigned int started = *static_cast<const volatile unsigned int*>(h_progress);
+  return static_cast<int>(started - (n - 1u)) >= 0 ? 1 : FLAG_WORDS;
 }
 constexpr size_t FLAG_ALLOC_BYTES = FLAG_WORDS * sizeof(unsigned int) < 64 ? 64 : FLAG_WORDS * sizeof(unsigned int);
 constexpr size_t FLAG_SLOT_WORDS = FLAG_WORDS < 16 ? 16 : FLAG_WORDS;  // pinned source blocks, one per slot, a cache line apart
+
+// Streams that must run CONCURRENTLY are created on different priority levels.  The runtime keeps one pool of (at most four) hardware
+// queues per priority level and maps a new stream to the least-used queue of its level's pool; once a process holds more than four
+// streams of one level, two of them share a hardware queue and their kernels serialise -- a handle's copy stream behind its compute
+// stream (measured: 3300 instead of 4630 Mpix/s with host frames), or the two stream groups of a batch behind each other (93 instead of
+// 59 us per step for two sequences).  Streams of different levels never share a queue.  level 0: compute (normal priority), 1: a
+// batch's second stream group (high), 2: copy streams (low: they carry copy-engine commands and a 4-byte flag write).
+static hipError_t create_stream(hipStream_t* out, int level) {
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest)
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+  if (level == 2)
+    if (const char* e = getenv("RMD_HIP_COPY_STREAM_LEVEL")) level = atoi(e);  // (A/B)
+  const int prio = level == 0 ? (least + greatest) / 2 : level == 1 ? greatest : least;  // numerically smaller = higher priority
+  return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio);
+}
 
 static unsigned long g_progress_timeouts = 0;  // diagnostics (RMD_HIP_INGEST_PROFILE): waits for a staging slot that gave up after 2 ms
 static double g_progress_max_wait_us = 0.0;    // ... and the longest such wait
@@ -723,7 +748,7 @@ static int seeds_create_impl(int width, int height, float fx, float fy, float cx
   s->mws = batch ? &grp->ws : &s->matcher_ws;
   auto bail = [&](int rc) { seeds_destroy_impl(s); return rc; };
   if (batch) { s->stream = grp->stream; s->copy_stream = batch->copy_stream; }
-  else if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess)
+  else if (create_stream(&s->stream, 0) != hipSuccess)
     return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: hipStreamCreate failed"));
   for (int p = 0; p < RMD_HIP_NUM_PLANES; ++p) {
     const int kind = p == RMD_HIP_PLANE_CONVERGENCE ? RMD_HIP_KIND_I32
@@ -832,7 +857,7 @@ int rmd_hip_seeds_update_device(rmd_hip_seeds_t* s, const float* dev_img, size_t
 //     The current image rotates through SLOTS planes; planes[CURR_IMG] always names the one of the latest frame.
 static int ingest_init(rmd_hip_seeds* s) {
   if (s->h_progress) return RMD_HIP_OK;
-  if (!s->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));  // (a batch member uses the batch's)
+  if (!s->copy_stream) HIP_TRY(create_stream(&s->copy_stream, 2));  // (a batch member uses the batch's)
   s->ingest_profile = getenv("RMD_HIP_INGEST_PROFILE") != nullptr;
   if (const char* e = getenv("RMD_HIP_INGEST_HOST_WAIT")) s->ingest_host_wait = e[0] == '1';
   if (const char* e = getenv("RMD_HIP_FUSED_INGEST")) s->opt_fused_ingest = e[0] != '0';
@@ -1107,8 +1132,9 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
     in.f32 = s->d_zc_f32[k];
     in.common.kind = 2;
   }
-  fill_flag_block(s->h_seq + k * FLAG_SLOT_WORDS, n);  // behind the frame on the same stream: when the kernel sees n, the frame is in HBM
-  HIP_TRY(hipMemcpyAsync(s->d_zc_flag, s->h_seq + k * FLAG_SLOT_WORDS, FLAG_WORDS * sizeof(unsigned int), hipMemcpyHostToDevice, s->copy_stream));
+  const size_t fw = flag_words(s->h_progress, n);
+  fill_flag_block(s->h_seq + k * FLAG_SLOT_WORDS, n, fw);  // behind the frame on the same stream: when the kernel sees n, the frame is in HBM
+  HIP_TRY(hipMemcpyAsync(s->d_zc_flag, s->h_seq + k * FLAG_SLOT_WORDS, fw * sizeof(unsigned int), hipMemcpyHostToDevice, s->copy_stream));
   in.common.flag = s->d_zc_flag;
   const double t_c = s->ingest_profile ? host_now_us() : 0.0;
   rmd_hip_image& im = s->planes[RMD_HIP_PLANE_CURR_IMG];
@@ -1659,8 +1685,11 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
   if (n_segs) CopyPool::instance().copy_many(segs, n_segs, frame_bytes);  // the frames of the step, spread over the copy threads
   const size_t off = static_cast<size_t>(first) * frame_bytes, len = static_cast<size_t>(last - first + 1) * frame_bytes;
   HIP_TRY(hipMemcpyAsync(b->d_stage[k] + off, b->h_stage[k] + off, len, hipMemcpyHostToDevice, b->copy_stream));
-  fill_flag_block(b->h_seq + k * FLAG_SLOT_WORDS, n);  // behind the frames on the same stream: when the kernel sees n, they are in HBM
-  HIP_TRY(hipMemcpyAsync(b->d_flag, b->h_seq + k * FLAG_SLOT_WORDS, FLAG_WORDS * sizeof(unsigned int), hipMemcpyHostToDevice, b->copy_stream));
+  size_t fw = 1;
+  for (int g = 0; g < b->n_groups; ++g)
+    if (b->groups[g].last_step != 0 && flag_words(b->groups[g].h_progress, static_cast<unsigned int>(b->groups[g].last_step) + 1u) != 1) fw = FLAG_WORDS;
+  fill_flag_block(b->h_seq + k * FLAG_SLOT_WORDS, n, fw);  // behind the frames on the same stream: when the kernel sees n, they are in HBM
+  HIP_TRY(hipMemcpyAsync(b->d_flag, b->h_seq + k * FLAG_SLOT_WORDS, fw * sizeof(unsigned int), hipMemcpyHostToDevice, b->copy_stream));
   rmdk::IngestArgs in;
   in.kind = gray ? 1 : 2;
   in.pitch = u8_pitch;
@@ -1732,13 +1761,13 @@ int rmd_hip_batch_create(int n, int width, int height, float fx, float fy, float
     rmd_hip_batch::Group& G = b->groups[g];
     G.first = g == 0 ? 0 : (n + 1) / 2;
     G.n = b->n_groups == 1 ? n : (g == 0 ? (n + 1) / 2 : n / 2);
-    if (hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: hipStreamCreate failed"));
+    if (create_stream(&G.stream, g) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: hipStreamCreate failed"));
     if (G.ws.allocate(width, height, static_cast<int>(pitch / 4), G.n) != 0) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: update workspace"));
     if (hipHostMalloc(reinterpret_cast<void**>(&G.h_progress), 64, hipHostMallocMapped) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: progress words"));
     G.h_progress[0] = G.h_progress[1] = 0u;
     if (hipEventCreate(&G.ev) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: event"));
   }
-  if (hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: hipStreamCreate failed"));
+  if (create_stream(&b->copy_stream, 2) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: hipStreamCreate failed"));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, b->device) == hipSuccess && prop.multiProcessorCount > 0) b->num_cus = prop.multiProcessorCount;
   if (hipHostMalloc(reinterpret_cast<void**>(&b->h_seq), rmd_hip_batch::SLOTS * FLAG_SLOT_WORDS * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess ||
