@@ -433,21 +433,31 @@ class SeedMatrixBatch:
         self._T = np.zeros((self.n, 12), np.float32)  # per-step argument blocks, reused
         self._ptrs = (ctypes.c_void_p * self.n)()
         self._strides = (ctypes.c_size_t * self.n)()
-        self.members = []
+        self._cam, self._max_extent = cam, max_extent
+        self._member_ptrs = []
         for i in range(self.n):
             m = ctypes.c_void_p()
             check(_lib.lib().rmd_hip_batch_member(self.ptr, i, ctypes.byref(m)))
-            self.members.append(SeedMatrix(width, height, cam, patch_side, max_extent, _member_of=self, _ptr=m.value))
+            self._member_ptrs.append(m.value)
 
     def __len__(self): return self.n
-    def __getitem__(self, i): return self.members[i]
+
+    def __getitem__(self, i):
+        """member i as a SeedMatrix.  A fresh wrapper every time: it keeps the batch alive, the batch does not keep it (a reference cycle
+        would leave destroyed-looking batches -- and their streams -- around until the garbage collector runs)"""
+        if not self.ptr:
+            raise RmdHipError(_lib.ERR_INVALID_ARG, "the batch has been closed")
+        return SeedMatrix(self.width, self.height, self._cam, self.patch_side, self._max_extent, _member_of=self, _ptr=self._member_ptrs[i])
+
+    @property
+    def members(self):
+        return [self[i] for i in range(self.n)]
 
     def close(self):
         if getattr(self, "ptr", None):
-            for m in self.members:
-                m.ptr = None
             _lib.lib().rmd_hip_batch_destroy(self.ptr)
             self.ptr = None
+            self._member_ptrs = [None] * self.n
 
     def __del__(self):
         try:

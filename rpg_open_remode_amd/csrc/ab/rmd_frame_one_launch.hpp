@@ -145,32 +145,7 @@ RMDK_D int frame_finalize_seed(const SeedParams& P, int x, int y, int gi, unsign
   return state;
 }
 
-// Exclusive prefix of the per-seed step counts of the tile in LDS (S.packed) -> S.prefix[0..256]; returns the total.
-// Ends with a barrier.
-template <int SIDE>
-RMDK_D int frame_prefix(FrameSmem<SIDE>& S, int tid) {
-  const int lane = tid & 63, wave = tid >> 6;
-  const int n_valid = static_cast<int>(S.packed[tid] & 0xffu);
-  int incl = n_valid;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int v = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += v;
-  }
-  if (lane == 63) S.red[wave][0] = incl;
-  __syncthreads();
-  int wave_off = 0, total = 0;
-#pragma unroll
-  for (int wv = 0; wv < 4; ++wv) {
-    const int v = S.red[wv][0];
-    wave_off += wv < wave ? v : 0;
-    total += v;
-  }
-  S.prefix[tid] = wave_off + incl - n_valid;
-  if (tid == 0) S.prefix[TILE_PIX] = total;
-  __syncthreads();
-  return total;
-}
+// (frame_prefix: rmd_frame.hpp)
 
 // Stage the tile's patch halo of the reference image (24 x 24 texels at SIDE 9, clamped at the image border like the
 // reference's clamp-addressed texture, epipolar_match.cu:107-110).  No barrier.

@@ -3,7 +3,7 @@
 # paths, batched mode (one launch pair for B sequences, two stream groups), stream-level alternatives, live use, the reference's own
 # programs on the library.  Output: gpurun_out/summary_<tag>/.   usage: tools/evidence_r03.sh <tag> [parts: sizes,host,batch,live,ref]
 set -u
-TAG=${1:-r03}; PARTS=${2:-sizes,host,batch,live,ref}
+TAG=${1:-r03}; PARTS=${2:-sizes,host,batch,live,ref,nranks,abmatch}
 export TMPDIR=/tmp
 ROOT=$(pwd)
 SUM=$ROOT/gpurun_out/summary_$TAG
@@ -41,3 +41,18 @@ if [[ $PARTS == *ref* ]]; then
   rm -rf "$D"
 fi
 ls -la "$SUM"
+if [[ $PARTS == *nranks* ]]; then
+  echo "== two ranks (one GPU on this box: both ranks compute on device 0; the launch path the driver uses for --gpus N)"
+  mkdir -p "$SUM/${TAG}_nranks"
+  timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --dist --steps 3 --warmup 1 --no-extras > "$SUM/${TAG}_nranks/one_rank_rccl.json" 2> "$SUM/${TAG}_nranks/one_rank.err"; cut -c1-160 "$SUM/${TAG}_nranks/one_rank_rccl.json"
+  timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus 2 --steps 3 --warmup 1 --no-extras > "$SUM/${TAG}_nranks/two_ranks_one_gpu.json" 2> "$SUM/${TAG}_nranks/two_ranks.err"; cut -c1-160 "$SUM/${TAG}_nranks/two_ranks_one_gpu.json"
+fi
+if [[ $PARTS == *abmatch* ]]; then
+  echo "== retired matchers (A/B build of the library, build_ab/librmd_hip_ab.so): parity test of variants 1, 2, 21"
+  if [ -f build_ab/librmd_hip_ab.so ]; then
+    cp rpg_open_remode_amd/librmd_hip.so /tmp/librmd_hip_product.so
+    cp build_ab/librmd_hip_ab.so rpg_open_remode_amd/librmd_hip.so
+    python -m pytest tests/test_hip_parity.py -q -k "other_matchers" 2>&1 | tail -2 | tee "$SUM/${TAG}_ab_matchers_parity.txt"
+    cp /tmp/librmd_hip_product.so rpg_open_remode_amd/librmd_hip.so
+  fi
+fi
