@@ -197,6 +197,43 @@ int image_alloc(rmd_hip_image* img, int kind, int width, int height) {
 // front of it (same stream) has completed.  The 64 KB form costs the copy engine 7 us more per frame, all of it latency when the
 // device is waiting for the frame (live use: the node asks for the converged count after every update, so the host never runs ahead):
 // there the 4-byte form is used -- the device has caught up, so the shader copy finds an empty chip (flag_words()).
+// How a frame that was handed over in host memory reaches the device.  The caller's buffer is always copied into a pinned ring first (the
+// caller may reuse it when update() returns); from there
+//   staged    the copy engine brings it into a staging buffer in HBM, followed by its arrival flag, with no ordering against the compute
+//             stream; the ingest workgroups of the frame's setup kernel wait for the flag and convert the frame into the current-image
+//             plane (rmdk::MatcherArgs);
+//   in place  the ingest workgroups read the pinned ring themselves over the host link: no copy engine, no staging, no flag.
+// "+ ahead" (single sequences): frame n + 1 is converted during the SEARCH kernel of frame n whenever it has arrived (staged) or been
+// handed over (in place) by the time setup n runs (rmdk::MatcherArgs::ahead); setup n + 1 then finds nothing left to do.
+// Defaults (measured, profiles/r03_h2d.txt): a single sequence uses staged + ahead -- the copy engine does not touch the CUs, whereas
+// link reads issued by a CU delay the loads of the workgroups it shares its memory pipeline with (in place + ahead: search +4.5 us per
+// update); a batch uses in place -- its setup kernels are long enough to hide the link time and the copy engine's 25-30 us of fixed
+// cost per copy is what bounds a step of 4..8 frames (8 sequences: 10 470 -> 12 740 Mpix/s).  Frames that go through the lens-
+// undistortion maps are always staged, without ahead (the remap gathers single bytes).  A/B: RMD_HIP_HOST_FRAMES =
+// staged | staged_ahead | inplace | inplace_ahead.
+enum { HOST_FRAMES_DEFAULT = -1, HOST_FRAMES_STAGED = 0, HOST_FRAMES_STAGED_AHEAD = 1, HOST_FRAMES_INPLACE = 2, HOST_FRAMES_INPLACE_AHEAD = 3 };
+static int host_frames_mode(bool batch) {
+  static const int forced = [] {
+    const char* e = getenv("RMD_HIP_HOST_FRAMES");
+    if (e && !strcmp(e, "staged")) return static_cast<int>(HOST_FRAMES_STAGED);
+    if (e && !strcmp(e, "staged_ahead")) return static_cast<int>(HOST_FRAMES_STAGED_AHEAD);
+    if (e && !strcmp(e, "inplace")) return static_cast<int>(HOST_FRAMES_INPLACE);
+    if (e && !strcmp(e, "inplace_ahead")) return static_cast<int>(HOST_FRAMES_INPLACE_AHEAD);
+    return static_cast<int>(HOST_FRAMES_DEFAULT);
+  }();
+  if (forced != HOST_FRAMES_DEFAULT) return forced;
+  return batch ? HOST_FRAMES_INPLACE : HOST_FRAMES_STAGED_AHEAD;
+}
+static bool frame_in_place(bool batch, bool remap) {
+  const int m = host_frames_mode(batch);
+  return !remap && (m == HOST_FRAMES_INPLACE || m == HOST_FRAMES_INPLACE_AHEAD);
+}
+static bool frame_ahead(bool remap) {
+  const int m = host_frames_mode(false);
+  return !remap && (m == HOST_FRAMES_STAGED_AHEAD || m == HOST_FRAMES_INPLACE_AHEAD);
+}
+constexpr int AHEAD_WGS = 128;  // workgroups of the search kernel that bring the next frame in (MatcherArgs::ahead)
+
 constexpr size_t FLAG_WORDS = 16384;
 static void fill_flag_block(unsigned int* block, unsigned int n, size_t words) {
   for (size_t i = 0; i < words; ++i) block[i] = n;
@@ -271,12 +308,18 @@ struct rmd_hip_seeds {
   // buffer in HBM and then writes the frame's number next to it (copy stream); the setup kernel waits for that number itself,
   // converts the frame into the current-image plane and tells the host through `h_progress` which frames it has consumed.
   // No events, no cross-stream waits: neither queue ever holds a barrier packet for the other.
-  unsigned char* h_zc_u8[SLOTS] = {};
-  float* h_zc_f32[SLOTS] = {};
-  unsigned char* d_zc_u8[SLOTS] = {};
-  float* d_zc_f32[SLOTS] = {};
+  // RING slots: the caller may be RING - 1 frames ahead of the setup kernel that has started last.  With three, frame n was handed over
+  // when setup n - 2 started and reached HBM 55-60 us later (host copy, submission, 35-45 us of copy engine) -- after setup n - 1 had
+  // looked for it, so it was rarely converted one step ahead (rmdk::MatcherArgs::ahead); with four it always is.
+  static constexpr int RING = 4;
+  unsigned char* h_zc_u8[RING] = {};
+  float* h_zc_f32[RING] = {};
+  unsigned char* d_zc_u8[RING] = {};
+  float* d_zc_f32[RING] = {};
   unsigned int* h_seq = nullptr;            // pinned, one block per slot: the frame number the copy stream writes into d_zc_flag
-  unsigned int* d_zc_flag = nullptr;        // device: number of the last frame whose staging copy has completed
+  unsigned int* d_zc_flag = nullptr;        // device, one block per ring slot: number of the last frame whose copy into that slot's staging buffer has completed
+  unsigned int* h_submitted = nullptr;      // pinned: [0] / [1] number of the newest 8-bit / float frame that is complete in the ring (one step ahead)
+  unsigned int* d_ahead = nullptr;          // device: the words of rmdk::MatcherArgs::ahead
   unsigned int* h_progress = nullptr;       // pinned: [0] number of the ingested frame whose setup kernel has started, [1] error bits
   unsigned long long zc_number = 0;         // ingested frames so far (the device sees the low 32 bits and compares modulo 2^32)
   int opt_fused_ingest = 1;                 // RMD_HIP_FUSED_INGEST=0 switches back to the copy-stream pipeline (A/B)
@@ -426,6 +469,8 @@ struct PendingIngest {
   rmdk::IngestArgs common;
   const unsigned int* u8 = nullptr;
   const float* f32 = nullptr;
+  const void* next_src = nullptr;  // one step ahead: the next frame's place in the ring and its plane
+  float* next_dst = nullptr;
 };
 
 int seeds_launch_update(rmd_hip_seeds* s, const PendingIngest* ingest = nullptr) {
@@ -483,6 +528,7 @@ int seeds_launch_update(rmd_hip_seeds* s, const PendingIngest* ingest = nullptr)
           B.seq[0].ingest_dst = const_cast<float*>(P.cur);
           B.seq[0].ingest_map1 = ingest->u8 ? s->d_undist_map1 : nullptr;  // null without lens undistortion
           B.seq[0].ingest_map2 = ingest->u8 ? s->d_undist_map2 : nullptr;
+          B.seq[0].next_src = ingest->next_src; B.seq[0].next_dst = ingest->next_dst;
         }
         HIP_TRY((rmdk::launch_seed_pipeline_compact<SIDE, 1>(B, 1, s->matcher_ws, s->stream, s->num_cus, s->opt_unit_target, ingest ? &ingest->common : nullptr)));
         s->P_pending = P;
@@ -681,13 +727,15 @@ static int seeds_destroy_impl(rmd_hip_seeds* s) {
     fprintf(stderr, "[rmd_hip ingest] %.0f frames: wait for slot %.2f us, host copy %.2f us, submit %.2f us per frame; longest wait %.0f us, %lu waits gave up after 2 ms\n",
             s->ingest_us[3], s->ingest_us[0] / s->ingest_us[3], s->ingest_us[1] / s->ingest_us[3], s->ingest_us[2] / s->ingest_us[3], g_progress_max_wait_us,
             g_progress_timeouts);
-  for (int k = 0; k < rmd_hip_seeds::SLOTS; ++k) {
-    if (s->h_u8[k]) (void)hipHostFree(s->h_u8[k]);
-    if (s->h_f32[k]) (void)hipHostFree(s->h_f32[k]);
+  for (int k = 0; k < rmd_hip_seeds::RING; ++k) {
     if (s->h_zc_u8[k]) (void)hipHostFree(s->h_zc_u8[k]);
     if (s->h_zc_f32[k]) (void)hipHostFree(s->h_zc_f32[k]);
     if (s->d_zc_u8[k]) (void)hipFree(s->d_zc_u8[k]);
     if (s->d_zc_f32[k]) (void)hipFree(s->d_zc_f32[k]);
+  }
+  for (int k = 0; k < rmd_hip_seeds::SLOTS; ++k) {
+    if (s->h_u8[k]) (void)hipHostFree(s->h_u8[k]);
+    if (s->h_f32[k]) (void)hipHostFree(s->h_f32[k]);
     if (s->d_u8[k]) (void)hipFree(s->d_u8[k]);
     if (s->staged[k]) (void)hipEventDestroy(s->staged[k]);
     if (s->frame_done[k]) (void)hipEventDestroy(s->frame_done[k]);
@@ -712,6 +760,8 @@ static int seeds_destroy_impl(rmd_hip_seeds* s) {
   if (s->h_progress) (void)hipHostFree(s->h_progress);
   if (s->h_seq) (void)hipHostFree(s->h_seq);
   if (s->d_zc_flag) (void)hipFree(s->d_zc_flag);
+  if (s->h_submitted) (void)hipHostFree(s->h_submitted);
+  if (s->d_ahead) (void)hipFree(s->d_ahead);
   if (s->stream && !s->batch) (void)hipStreamDestroy(s->stream);
   delete s;
   return RMD_HIP_OK;
@@ -863,9 +913,13 @@ static int ingest_init(rmd_hip_seeds* s) {
   if (const char* e = getenv("RMD_HIP_FUSED_INGEST")) s->opt_fused_ingest = e[0] != '0';
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_progress), 64, hipHostMallocMapped));
   s->h_progress[0] = s->h_progress[1] = 0u;
-  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_seq), rmd_hip_seeds::SLOTS * FLAG_SLOT_WORDS * sizeof(unsigned int), hipHostMallocDefault));
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_flag), FLAG_ALLOC_BYTES));
-  HIP_TRY(hipMemset(s->d_zc_flag, 0, FLAG_ALLOC_BYTES));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_seq), rmd_hip_seeds::RING * FLAG_SLOT_WORDS * sizeof(unsigned int), hipHostMallocDefault));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_flag), rmd_hip_seeds::RING * FLAG_ALLOC_BYTES));  // one flag block per ring slot
+  HIP_TRY(hipMemset(s->d_zc_flag, 0, rmd_hip_seeds::RING * FLAG_ALLOC_BYTES));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_submitted), 64, hipHostMallocMapped));
+  s->h_submitted[0] = s->h_submitted[1] = 0u;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_ahead), 64));
+  HIP_TRY(hipMemset(s->d_ahead, 0, 64));
   HIP_TRY(hipStreamSynchronize(nullptr));
   const rmd_hip_image& im = s->planes[RMD_HIP_PLANE_CURR_IMG];
   s->cur_planes[0] = im.data;
@@ -1103,42 +1157,88 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
   const double t_a = s->ingest_profile ? host_now_us() : 0.0;
   const unsigned long long n64 = ++s->zc_number;
   const unsigned int n = static_cast<unsigned int>(n64);
-  const int k = static_cast<int>(n64 % rmd_hip_seeds::SLOTS);
-  if (n64 > static_cast<unsigned long long>(rmd_hip_seeds::SLOTS)) TRY(wait_for_progress(s->h_progress, n - rmd_hip_seeds::SLOTS + 1u, s->stream));
+  const int k = static_cast<int>(n64 % rmd_hip_seeds::RING);
+  if (n64 > static_cast<unsigned long long>(rmd_hip_seeds::RING)) TRY(wait_for_progress(s->h_progress, n - rmd_hip_seeds::RING + 1u, s->stream));
   const double t_b = s->ingest_profile ? host_now_us() : 0.0;
   PendingIngest in;
+  bool in_place = false;
+  // every ring slot has its own arrival flag (the setup kernel of frame n asks for frame n's; its verdict for frame n + 1 reads that one's)
+  unsigned int* slot_flag = s->d_zc_flag + static_cast<size_t>(k) * (FLAG_ALLOC_BYTES / sizeof(unsigned int));
+  void* stage_src = nullptr; void* stage_dst = nullptr; size_t stage_bytes = 0;
   if (host_gray) {
     const size_t bytes = static_cast<size_t>(s->u8_pitch) * s->height;
-    if (!s->h_zc_u8[k]) {
-      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_zc_u8[k]), bytes, hipHostMallocDefault));
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_u8[k]), bytes));
+    for (int q = 0; q < rmd_hip_seeds::RING; ++q) {  // (all slots at once: the search kernel is told where the NEXT frame will be)
+      if (s->h_zc_u8[q]) continue;
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_zc_u8[q]), bytes + 16, hipHostMallocDefault));
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_u8[q]), bytes));
     }
     if (s->u8_pitch == s->width) host_copy(s->h_zc_u8[k], host_gray, bytes);
     else
       for (int y = 0; y < s->height; ++y)
         memcpy(s->h_zc_u8[k] + static_cast<size_t>(y) * s->u8_pitch, host_gray + static_cast<size_t>(y) * s->width, s->width);
-    HIP_TRY(hipMemcpyAsync(s->d_zc_u8[k], s->h_zc_u8[k], bytes, hipMemcpyHostToDevice, s->copy_stream));
-    in.u8 = reinterpret_cast<const unsigned int*>(s->d_zc_u8[k]);
+    in_place = frame_in_place(false, s->d_undist_map1 != nullptr);
+    if (in_place) {
+      void* dev = nullptr;
+      HIP_TRY(hipHostGetDevicePointer(&dev, s->h_zc_u8[k], 0));
+      in.u8 = static_cast<const unsigned int*>(dev);
+    } else {
+      stage_src = s->h_zc_u8[k]; stage_dst = s->d_zc_u8[k]; stage_bytes = bytes;
+      in.u8 = reinterpret_cast<const unsigned int*>(s->d_zc_u8[k]);
+    }
     in.common.kind = 1;
     in.common.pitch = s->u8_pitch;
   } else {
     const size_t bytes = static_cast<size_t>(s->width) * s->height * sizeof(float);
-    if (!s->h_zc_f32[k]) {
-      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_zc_f32[k]), bytes, hipHostMallocDefault));
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_f32[k]), bytes));
+    for (int q = 0; q < rmd_hip_seeds::RING; ++q) {
+      if (s->h_zc_f32[q]) continue;
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_zc_f32[q]), bytes + 16, hipHostMallocDefault));
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_f32[q]), bytes));
     }
     host_copy(s->h_zc_f32[k], host_f32, bytes);
-    HIP_TRY(hipMemcpyAsync(s->d_zc_f32[k], s->h_zc_f32[k], bytes, hipMemcpyHostToDevice, s->copy_stream));
-    in.f32 = s->d_zc_f32[k];
+    in_place = frame_in_place(false, false);
+    if (in_place) {
+      void* dev = nullptr;
+      HIP_TRY(hipHostGetDevicePointer(&dev, s->h_zc_f32[k], 0));
+      in.f32 = static_cast<const float*>(dev);
+    } else {
+      stage_src = s->h_zc_f32[k]; stage_dst = s->d_zc_f32[k]; stage_bytes = bytes;
+      in.f32 = s->d_zc_f32[k];
+    }
     in.common.kind = 2;
   }
-  const size_t fw = flag_words(s->h_progress, n);
-  fill_flag_block(s->h_seq + k * FLAG_SLOT_WORDS, n, fw);  // behind the frame on the same stream: when the kernel sees n, the frame is in HBM
-  HIP_TRY(hipMemcpyAsync(s->d_zc_flag, s->h_seq + k * FLAG_SLOT_WORDS, fw * sizeof(unsigned int), hipMemcpyHostToDevice, s->copy_stream));
-  in.common.flag = s->d_zc_flag;
+  const bool ahead = frame_ahead(host_gray && s->d_undist_map1 != nullptr);
+  if (in_place) {
+    in.common.flag = nullptr;  // the setup kernel reads the pinned buffer itself: it is complete before the kernel is launched
+  } else {
+    HIP_TRY(hipMemcpyAsync(stage_dst, stage_src, stage_bytes, hipMemcpyHostToDevice, s->copy_stream));
+    const size_t fw = flag_words(s->h_progress, n);
+    fill_flag_block(s->h_seq + k * FLAG_SLOT_WORDS, n, fw);  // behind the frame on the same stream: when the kernel sees n, the frame is in HBM
+    HIP_TRY(hipMemcpyAsync(slot_flag, s->h_seq + k * FLAG_SLOT_WORDS, fw * sizeof(unsigned int), hipMemcpyHostToDevice, s->copy_stream));
+    in.common.flag = slot_flag;
+  }
+  int plane = 0;  // one plane is enough: setup k writes it after search k - 1 has run (same stream)
+  if (ahead) {  // ... unless the previous update's search kernel brings the frame in: frame n lives in plane n % 2
+    const int kind = host_gray ? 0 : 1, k_next = static_cast<int>((n64 + 1) % rmd_hip_seeds::RING);
+    void* dev = nullptr;
+    if (in_place) {
+      __atomic_store_n(&s->h_submitted[kind], n, __ATOMIC_RELEASE);  // frame n is complete in the ring
+      HIP_TRY(hipHostGetDevicePointer(&dev, s->h_submitted, 0));
+      in.common.submitted = static_cast<const unsigned int*>(dev) + kind;
+      HIP_TRY(hipHostGetDevicePointer(&dev, host_gray ? static_cast<void*>(s->h_zc_u8[k_next]) : static_cast<void*>(s->h_zc_f32[k_next]), 0));
+      in.next_src = dev;
+    } else {
+      in.common.submitted = s->d_zc_flag + static_cast<size_t>(k_next) * (FLAG_ALLOC_BYTES / sizeof(unsigned int));  // the arrival flag of the next frame's slot
+      in.next_src = host_gray ? static_cast<const void*>(s->d_zc_u8[k_next]) : static_cast<const void*>(s->d_zc_f32[k_next]);
+    }
+    in.common.ahead = s->d_ahead;
+    static const int ahead_wgs = [] { const char* e = getenv("RMD_HIP_AHEAD_WGS"); return e ? atoi(e) : AHEAD_WGS; }();  // (A/B)
+    in.common.ahead_wgs = ahead_wgs;
+    plane = static_cast<int>(n64 & 1ull);
+    in.next_dst = static_cast<float*>(s->cur_planes[plane ^ 1]);
+  }
   const double t_c = s->ingest_profile ? host_now_us() : 0.0;
   rmd_hip_image& im = s->planes[RMD_HIP_PLANE_CURR_IMG];
-  im.data = s->cur_planes[0];  // one plane is enough: setup k writes it after search k - 1 has run (same stream)
+  im.data = s->cur_planes[plane];
   void* dev_progress = nullptr;
   HIP_TRY(hipHostGetDevicePointer(&dev_progress, s->h_progress, 0));
   in.common.progress = static_cast<unsigned int*>(dev_progress);
@@ -1662,7 +1762,7 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
       if (b->h_stage[q]) (void)hipHostFree(b->h_stage[q]);
       if (b->d_stage[q]) (void)hipFree(b->d_stage[q]);
       b->h_stage[q] = nullptr; b->d_stage[q] = nullptr;
-      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_stage[q]), need, hipHostMallocDefault));
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_stage[q]), need + 16, hipHostMallocDefault));
       HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_stage[q]), need));
     }
     b->stage_bytes = need;
@@ -1683,17 +1783,26 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
     last = i;
   }
   if (n_segs) CopyPool::instance().copy_many(segs, n_segs, frame_bytes);  // the frames of the step, spread over the copy threads
-  const size_t off = static_cast<size_t>(first) * frame_bytes, len = static_cast<size_t>(last - first + 1) * frame_bytes;
-  HIP_TRY(hipMemcpyAsync(b->d_stage[k] + off, b->h_stage[k] + off, len, hipMemcpyHostToDevice, b->copy_stream));
-  size_t fw = 1;
-  for (int g = 0; g < b->n_groups; ++g)
-    if (b->groups[g].last_step != 0 && flag_words(b->groups[g].h_progress, static_cast<unsigned int>(b->groups[g].last_step) + 1u) != 1) fw = FLAG_WORDS;
-  fill_flag_block(b->h_seq + k * FLAG_SLOT_WORDS, n, fw);  // behind the frames on the same stream: when the kernel sees n, they are in HBM
-  HIP_TRY(hipMemcpyAsync(b->d_flag, b->h_seq + k * FLAG_SLOT_WORDS, fw * sizeof(unsigned int), hipMemcpyHostToDevice, b->copy_stream));
+  const bool in_place = frame_in_place(true, false);
+  const unsigned char* frames_dev = b->d_stage[k];
   rmdk::IngestArgs in;
+  if (in_place) {  // the setup kernels read the pinned block themselves
+    void* dev = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dev, b->h_stage[k], 0));
+    frames_dev = static_cast<const unsigned char*>(dev);
+    in.flag = nullptr;
+  } else {
+    const size_t off = static_cast<size_t>(first) * frame_bytes, len = static_cast<size_t>(last - first + 1) * frame_bytes;
+    HIP_TRY(hipMemcpyAsync(b->d_stage[k] + off, b->h_stage[k] + off, len, hipMemcpyHostToDevice, b->copy_stream));
+    size_t fw = 1;
+    for (int g = 0; g < b->n_groups; ++g)
+      if (b->groups[g].last_step != 0 && flag_words(b->groups[g].h_progress, static_cast<unsigned int>(b->groups[g].last_step) + 1u) != 1) fw = FLAG_WORDS;
+    fill_flag_block(b->h_seq + k * FLAG_SLOT_WORDS, n, fw);  // behind the frames on the same stream: when the kernel sees n, they are in HBM
+    HIP_TRY(hipMemcpyAsync(b->d_flag, b->h_seq + k * FLAG_SLOT_WORDS, fw * sizeof(unsigned int), hipMemcpyHostToDevice, b->copy_stream));
+    in.flag = b->d_flag;
+  }
   in.kind = gray ? 1 : 2;
   in.pitch = u8_pitch;
-  in.flag = b->d_flag;
   in.number = n;
   for (int i = 0; i < b->n; ++i) {
     if (!((active >> i) & 1u)) continue;
@@ -1706,7 +1815,7 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
     rmd_hip_batch::Group& G = b->groups[g];
     if ((active >> G.first) & ((1u << G.n) - 1u)) { G.slot_step[k] = n64; G.last_step = n64; }
   }
-  return batch_launch(b, active, &in, b->d_stage[k], frame_bytes);
+  return batch_launch(b, active, &in, frames_dev, frame_bytes);
 }
 
 }  // namespace

@@ -40,6 +40,8 @@ constexpr int FR_TRACE_FRAMES = 256, FR_TRACE_WORDS = 8;  // per workgroup: star
 // ---- agent-scope accessors (global address space, sc1) ---------------------------------------------------------------
 RMDK_D unsigned int ld_agent(const unsigned int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 RMDK_D unsigned long long ld_agent(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+RMDK_D unsigned int ld_system(const unsigned int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+RMDK_D unsigned long long ld_system(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 RMDK_D void st_agent(unsigned int* p, unsigned int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 RMDK_D void st_agent(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 RMDK_D void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -376,8 +378,81 @@ RMDK_D int frame_prefix_and_window(const SeedParams& P, FrameSmem<SIDE>& S, int 
 // The unit list is built without a planning step: a tile reserves its units in the list of its shard (tile % 16) with one
 // returning atomic on the shard's counter; the unit size comes from the PREVIOUS frame's total work (the counters of three
 // consecutive frames rotate).  The search kernel reads the sixteen counts and walks the shards' lists as one list.
+// A frame in pinned HOST memory converted into a current-image plane by workgroup `part` of `parts`: plain 16-byte loads over the host
+// link (pinned host memory is mapped uncached: every load fetches; 8-byte system-scope atomic loads reached 10 GB/s, these reach the
+// link's 50).  kind 1: 8-bit rows of `pitch` bytes, x (1/255) like Depthmap::inputImage's convertTo(CV_32F, 1.0f / 255.0f)
+// (depthmap.cpp:105); kind 2: w x h floats, unpadded.  The buffer is padded to a multiple of 16 bytes.
+RMDK_D void ingest_in_place(int kind, int pitch, const void* src_v, float* __restrict__ dst, int w, int h, int stride, int part, int parts, int tid) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4* src = static_cast<const u32x4*>(src_v);
+  if (kind == 1) {
+    const int total_bytes = pitch * h, requests = (total_bytes + 15) >> 4;
+    for (int d = part * TILE_PIX + tid; d < requests; d += parts * TILE_PIX) {
+      const u32x4 v = __builtin_nontemporal_load(src + d);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {  // four pixels per dword; rows are a multiple of 4 bytes, so a dword never straddles two rows
+        const int byte = d * 16 + q * 4;
+        if (byte >= total_bytes) break;
+        const int row = byte / pitch, x4 = byte - row * pitch;
+        const unsigned int u = v[q];
+        float* out = dst + static_cast<size_t>(row) * stride + x4;
+        const float f0 = static_cast<float>(u & 0xffu) * (1.0f / 255.0f), f1 = static_cast<float>((u >> 8) & 0xffu) * (1.0f / 255.0f);
+        const float f2 = static_cast<float>((u >> 16) & 0xffu) * (1.0f / 255.0f), f3 = static_cast<float>(u >> 24) * (1.0f / 255.0f);
+        if (x4 + 3 < w) *reinterpret_cast<float4*>(out) = make_float4(f0, f1, f2, f3);  // plane rows and x4 are multiples of 16 bytes
+        else {
+          if (x4 < w) out[0] = f0;
+          if (x4 + 1 < w) out[1] = f1;
+          if (x4 + 2 < w) out[2] = f2;
+        }
+      }
+    }
+  } else {
+    const int total = w * h, requests = (total + 3) >> 2;
+    for (int d = part * TILE_PIX + tid; d < requests; d += parts * TILE_PIX) {
+      const u32x4 v = __builtin_nontemporal_load(src + d);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = d * 4 + q;
+        if (e >= total) break;
+        const int row = e / w;
+        dst[static_cast<size_t>(row) * stride + (e - row * w)] = __uint_as_float(v[q]);
+      }
+    }
+  }
+}
+
+// A staged frame (MatcherArgs::ingest_kind) converted into a current-image plane by workgroup `part` of `parts`, for the search kernel's
+// bringers: the copy had completed before an EARLIER kernel saw its flag, so plain loads will do.
+RMDK_D void ingest_staged(int kind, int pitch, const void* src_v, float* __restrict__ dst, int w, int h, int stride, int part, int parts, int tid) {
+  if (kind == 1) {
+    const unsigned int* src = static_cast<const unsigned int*>(src_v);
+    const int per_row = pitch >> 2, total = per_row * h;
+    for (int d = part * TILE_PIX + tid; d < total; d += parts * TILE_PIX) {
+      const unsigned int u = src[d];
+      const int row = d / per_row, x4 = (d - row * per_row) * 4;
+      float* out = dst + static_cast<size_t>(row) * stride + x4;
+      const float f0 = static_cast<float>(u & 0xffu) * (1.0f / 255.0f), f1 = static_cast<float>((u >> 8) & 0xffu) * (1.0f / 255.0f);
+      const float f2 = static_cast<float>((u >> 16) & 0xffu) * (1.0f / 255.0f), f3 = static_cast<float>(u >> 24) * (1.0f / 255.0f);
+      if (x4 + 3 < w) *reinterpret_cast<float4*>(out) = make_float4(f0, f1, f2, f3);
+      else {
+        if (x4 < w) out[0] = f0;
+        if (x4 + 1 < w) out[1] = f1;
+        if (x4 + 2 < w) out[2] = f2;
+      }
+    }
+  } else {
+    const float* src = static_cast<const float*>(src_v);
+    const int total = w * h;
+    for (int d = part * TILE_PIX + tid; d < total; d += parts * TILE_PIX) {
+      const int row = d / w;
+      dst[static_cast<size_t>(row) * stride + (d - row * w)] = src[d];
+    }
+  }
+}
+
 constexpr int INGEST_WGS = 128;  // workgroups (per sequence) that bring a host frame into the current-image plane (the only ones that may wait)
 constexpr int INGEST_WGS_REMAP = 512;  // with lens undistortion (two dependent round trips per pixel): a quarter of the chip's wave slots at most
+constexpr int INGEST_WGS_IN_PLACE = 256;  // frames read in place from pinned host memory: enough requests in flight to cover the host link's latency
 
 template <int SIDE, int NSEQ>
 __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<NSEQ> B, MatcherArgs M, int target_units) {
@@ -412,12 +487,24 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
     if (iw >= M.ingest_wgs) return;
     // step numbers are compared modulo 2^32 (a live system never stops counting): "behind" = the signed difference is negative
     auto behind = [&]() { return static_cast<int>(__hip_atomic_load(M.ingest_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - M.ingest_number) < 0; };
-    if (behind()) {
+    // No flag: the frame is read IN PLACE from the pinned host buffer the caller's frame was copied into before this kernel was
+    // launched (ingest_in_place: 16 bytes per lane and request over the host link; a 640x480 8-bit frame is one round trip of 75
+    // workgroups plus 6 us of link time) -- no copy engine, no staging in HBM, nothing to wait for.
+    const bool in_place = M.ingest_flag == nullptr;
+    if (NSEQ == 1 && M.ahead) {  // one step ahead (see MatcherArgs): the verdict for the next frame, and whether this one has been brought in already
+      if (iw == 0 && tid == 0) {
+        const unsigned int next = M.ingest_number + 1u;
+        // (the word says: handed over -- a pinned host word, frames read in place -- or arrived in HBM -- the arrival flag of its ring slot)
+        __hip_atomic_store(M.ahead, static_cast<int>(ld_system(M.submitted) - next) >= 0 ? next : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (ld_agent(M.ahead + 2) == M.ingest_number) return;
+    }
+    if (!in_place && behind()) {
       unsigned int spins = 0u;
       while (behind() && ++spins < (1u << 18)) __builtin_amdgcn_s_sleep(16);
       if (behind() && tid == 0) __hip_atomic_store(M.progress + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // nothing below is read before the flag has been seen (once per workgroup)
+    if (!in_place) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // nothing below is read before the flag has been seen (once per workgroup)
     if (M.ingest_kind == 1 && Q.ingest_map1) {  // cv::remap through the undistortion maps first (depthmap.cpp:99), destination pixels four at a time per lane
       const unsigned char* src = reinterpret_cast<const unsigned char*>(Q.ingest_u8);
       const int total = P.w * P.h, step = M.ingest_wgs * TILE_PIX;
@@ -440,6 +527,9 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
           });
         }
       }
+    } else if (in_place) {
+      ingest_in_place(M.ingest_kind, M.ingest_pitch, M.ingest_kind == 1 ? static_cast<const void*>(Q.ingest_u8) : static_cast<const void*>(Q.ingest_f32),
+                      Q.ingest_dst, P.w, P.h, P.stride, iw, M.ingest_wgs, tid);
     } else if (M.ingest_kind == 1) {  // x (1/255): Depthmap::inputImage's convertTo(CV_32F, 1.0f / 255.0f), depthmap.cpp:105 -- one fp32 multiply per pixel
       const int per_row = M.ingest_pitch >> 2, total = per_row * P.h;
       for (int d = iw * TILE_PIX + tid; d < total; d += M.ingest_wgs * TILE_PIX) {
@@ -649,7 +739,25 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
   const SeqArgs* Qp = NSEQ == 1 ? &B.seq[0] : seq_table();  // the sequence of the tile in LDS (one sequence: the named argument, see the setup kernel)
   size_t so = 0;                    // ... and where its seeds start in the workspace planes
   unsigned long long* const trace0 = NSEQ == 1 ? B.seq[0].P.trace : nullptr;  // diagnostics (single sequences only)
-  unsigned long long* const tr = trace0 && static_cast<int>(blockIdx.x) < M.n_tiles ? trace0 + static_cast<size_t>(blockIdx.x) * FR_TRACE_WORDS : nullptr;
+  // One step ahead (MatcherArgs::ahead): the first ahead_wgs workgroups -- dispatched first, so they never queue behind the persistent
+  // ones -- bring the next host frame into the other current-image plane if the setup kernel found it in the ring, and leave.
+  if (NSEQ == 1 && blockIdx.x < static_cast<unsigned int>(M.ahead_wgs)) {
+    const unsigned int next = M.ingest_number + 1u;
+    if (ld_agent(M.ahead) != next) return;
+    const SeedParams& P = B.seq[0].P;
+    if (M.ingest_flag == nullptr) ingest_in_place(M.ingest_kind, M.ingest_pitch, B.seq[0].next_src, B.seq[0].next_dst, P.w, P.h, P.stride, static_cast<int>(blockIdx.x), M.ahead_wgs, tid);
+    else ingest_staged(M.ingest_kind, M.ingest_pitch, B.seq[0].next_src, B.seq[0].next_dst, P.w, P.h, P.stride, static_cast<int>(blockIdx.x), M.ahead_wgs, tid);
+    // The last one to finish publishes the frame.  Plane and number are read by the NEXT kernels only, and a kernel's stores are all
+    // visible to the kernels behind it on the stream: no fence here (an agent-scope fence writes back and invalidates the L2 the
+    // searching workgroups live on -- a hundred of them made every update 20 us longer).
+    if (tid == 0 && __hip_atomic_fetch_add(M.ahead + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == static_cast<unsigned int>(M.ahead_wgs) - 1u) {
+      __hip_atomic_store(M.ahead + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(M.ahead + 2, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  const unsigned int wg_id = blockIdx.x - static_cast<unsigned int>(M.ahead_wgs), n_wg = gridDim.x - static_cast<unsigned int>(M.ahead_wgs);
+  unsigned long long* const tr = trace0 && static_cast<int>(wg_id) < M.n_tiles ? trace0 + static_cast<size_t>(wg_id) * FR_TRACE_WORDS : nullptr;
   if (tr && tid == 0) tr[0] = wall_clock64();
 #ifdef RMD_PROFILE_ROUNDS
   if (tid < 8) S.prof[tid] = 0ull;
@@ -657,7 +765,7 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
   // The LAST workgroup (it has no unit of its own on all but the heaviest frames) adds up the per-tile counts of seeds the setup kernel
   // found CONVERGED and mirrors them, stamped with this update's number, to pinned host memory: getConvergedCount() after an update
   // needs no device synchronisation and no kernel of its own (seed_matrix.cu:195-198, depthmap_node.cpp:142-153).
-  if (M.conv_out && blockIdx.x == gridDim.x - 1) {
+  if (M.conv_out && wg_id == n_wg - 1) {
     for (int q = 0; q < (NSEQ == 1 ? 1 : M.n_seq); ++q) {
       if (NSEQ > 1 && !seq_table()[q].active) continue;
       int c = 0;
@@ -685,16 +793,16 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
     for (int q = 1; q < UNIT_SHARDS; ++q) sh_first = g >= shard_first[q] ? shard_first[q] : sh_first;
     return M.units[static_cast<size_t>(sh) * M.shard_cap + (g - sh_first)];
   };
-  // Unit blockIdx.x is ours for free.  When there are more units than workgroups the rest is handed out by sixteen counters (workgroup
-  // b draws from counter b % 16, which deals the units gridDim + b % 16 + 16 k: one counter word for a thousand workgroups serialises
+  // Unit wg_id is ours for free.  When there are more units than workgroups the rest is handed out by sixteen counters (workgroup
+  // b draws from counter b % 16, which deals the units n_wg + b % 16 + 16 k: one counter word for a thousand workgroups serialises
   // their returning atomics for 12 us), and the NEXT unit is claimed and its entry fetched while the current one is being searched: the
   // atomic is issued before the tile's descriptors are requested, the entry -- by an LDS-direct load, it never occupies registers
   // across the NCC block -- once they have arrived; both are consumed after the rounds.
-  const bool handout = n_units > gridDim.x;
+  const bool handout = n_units > n_wg;
   const bool prefetch = (M.search_flags & SEARCH_PREFETCH) != 0, sharded = (M.search_flags & SEARCH_SHARDED_HANDOUT) != 0;
-  const unsigned int cls = sharded ? blockIdx.x & (UNIT_SHARDS - 1) : 0u;
+  const unsigned int cls = sharded ? wg_id & (UNIT_SHARDS - 1) : 0u;
   const unsigned int cls_step = sharded ? UNIT_SHARDS : 1u;
-  unsigned int u = blockIdx.x;
+  unsigned int u = wg_id;
   int tile = 0, first = 0;
   unsigned int box0 = 0u, box1 = 0u;
   bool boxed = false;
@@ -761,7 +869,7 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
       if (tr && tid == 0 && n_done == 0) tr[1] = wall_clock64();
     }
     if (handout && prefetch && tid == 0) {
-      const unsigned int u_next = gridDim.x + cls + cls_step * nxt_k;
+      const unsigned int u_next = n_wg + cls + cls_step * nxt_k;
       S.bcast[0] = u_next;
       if (u_next < n_units) {
         int sh = 0;
@@ -778,7 +886,7 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
     ++n_done; n_items += static_cast<unsigned int>(min(first + unit_items, total) - first);
     if (!handout) break;  // light frame: every unit had its own workgroup, nothing to hand out
     if (!prefetch && tid == 0) {  // (A/B: claim and fetch the next unit only now)
-      const unsigned int u_next = gridDim.x + cls + cls_step * atomicAdd(&M.handout[cls * HANDOUT_STRIDE], 1u);
+      const unsigned int u_next = n_wg + cls + cls_step * atomicAdd(&M.handout[cls * HANDOUT_STRIDE], 1u);
       S.bcast[0] = u_next;
       if (u_next < n_units) {
         const uint4 e = entry_of(u_next);
@@ -825,6 +933,7 @@ inline hipError_t launch_seed_pipeline_compact(const BatchArgs<NSEQ>& B, int n_s
   if (ingest && ingest->kind) {
     M.ingest_kind = ingest->kind; M.ingest_pitch = ingest->pitch;
     M.ingest_flag = ingest->flag; M.progress = ingest->progress; M.ingest_number = ingest->number;
+    if (NSEQ == 1 && ingest->ahead) { M.ahead_wgs = ingest->ahead_wgs; M.submitted = ingest->submitted; M.ahead = ingest->ahead; }
   }
   auto search = seed_search_compact_kernel<SIDE, NSEQ>;
   constexpr int KIND = NSEQ == 1 ? 0 : 1;
@@ -845,13 +954,15 @@ inline hipError_t launch_seed_pipeline_compact(const BatchArgs<NSEQ>& B, int n_s
     bool remap = false;
     for (int q = 0; q < n_seq; ++q) remap = remap || (M.ingest_kind == 1 && B.seq[q].ingest_map1);
     const long long dwords = M.ingest_kind == 1 && !remap ? static_cast<long long>(M.ingest_pitch >> 2) * P0.h : static_cast<long long>(P0.w) * P0.h;
-    const long long want = (dwords + TILE_PIX - 1) / TILE_PIX, cap = remap ? INGEST_WGS_REMAP : INGEST_WGS;
+    const bool in_place = M.ingest_flag == nullptr;  // 16 bytes per lane and request
+    const long long requests = in_place ? (dwords + 3) / 4 : dwords;
+    const long long want = (requests + TILE_PIX - 1) / TILE_PIX, cap = remap ? INGEST_WGS_REMAP : in_place ? INGEST_WGS_IN_PLACE : INGEST_WGS;
     M.ingest_wgs = static_cast<int>(want < cap ? want : cap);
     tiles.y += static_cast<unsigned int>((M.ingest_wgs + ws.tiles_x - 1) / ws.tiles_x);
   }
   const int target_units = resident * target_mult;
   hipLaunchKernelGGL((seed_setup_compact_kernel<SIDE, NSEQ>), tiles, dim3(TILE_PIX), 0, stream, B, M, target_units);
-  hipLaunchKernelGGL(search, dim3(resident), dim3(TILE_PIX), sizeof(Smem), stream, B, M);
+  hipLaunchKernelGGL(search, dim3(resident + M.ahead_wgs), dim3(TILE_PIX), sizeof(Smem), stream, B, M);
   ++ws.frame;
   return hipGetLastError();
 }

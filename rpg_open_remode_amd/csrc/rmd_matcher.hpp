@@ -169,6 +169,15 @@ struct MatcherArgs {
   unsigned int* progress;          // pinned host words: [0] <- ingest_number when this setup starts (everything before it has
                                    // completed: the host may reuse that step's buffers), [1] |= 1 if the flag never came
   unsigned int ingest_number;
+  // Host frames ONE STEP AHEAD (single sequences, frames read in place from the pinned ring): the caller copies frame n + 1 into the ring
+  // and publishes its number in `submitted` while the device is still busy with frame n or n - 1.  The setup kernel of frame n looks at
+  // `submitted` once (one lane) and writes its verdict to ahead[0]; if frame n + 1 is there, the first `ahead_wgs` workgroups of frame n's
+  // SEARCH kernel -- which leaves most of the chip idle on all but the heaviest frames -- bring it into the other current-image plane
+  // and set ahead[2] = n + 1, and the ingest workgroups of setup n + 1 find nothing left to do.  Nobody ever waits: a frame that was
+  // not there in time is read in place by its own setup kernel, as without this.
+  int ahead_wgs;
+  const unsigned int* submitted;   // the word that tells whether frame n + 1 is there: frames read in place: a pinned host word, number of the newest frame of this kind that is complete in the ring; staged frames: the arrival flag of frame n + 1's ring slot
+  unsigned int* ahead;             // device words: [0] frame to bring in during this update's search kernel or 0, [1] bringers done, [2] newest frame brought in ahead
 };
 
 // One sequence of a launch: the reference's mvs::DeviceData of that SeedMatrix for this frame plus what the deferred finalisation
@@ -183,6 +192,8 @@ struct SeqArgs {
   float* ingest_dst;               // its current-image plane, row stride P.stride
   const short2* ingest_map1;       // lens undistortion of 8-bit frames (Depthmap::initUndistortionMap): source pixel per destination pixel
   const unsigned short* ingest_map2;  // ... and its 5-bit fractions; null = frames are used as they come
+  const void* next_src;            // one step ahead (MatcherArgs::ahead): where the NEXT frame of this kind will be in the pinned ring ...
+  float* next_dst;                 // ... and the current-image plane it goes to
 };
 
 // The sequences of one launch, passed BY VALUE as the kernels' FIRST argument.  The kernels never name the parameter: indexing a
@@ -199,9 +210,12 @@ RMDK_D const SeqArgs* seq_table() { return (const SeqArgs*)__builtin_amdgcn_kern
 struct IngestArgs {
   int kind = 0;       // 1: 8-bit, 2: float
   int pitch = 0;
-  const unsigned int* flag = nullptr;
+  const unsigned int* flag = nullptr;  // null: the frame is read in place from pinned host memory
   unsigned int* progress = nullptr;
   unsigned int number = 0;
+  int ahead_wgs = 0;  // see MatcherArgs::ahead
+  const unsigned int* submitted = nullptr;
+  unsigned int* ahead = nullptr;
 };
 
 // Timeline probe of one workgroup (diagnostics): record `slot` of the frame's trace slice gets the workgroup's start and
@@ -486,6 +500,7 @@ inline MatcherArgs matcher_args(const MatcherWorkspace& ws) {
   M.shard_cap = ws.shard_cap;
   M.trace = nullptr;
   M.ingest_kind = 0; M.ingest_pitch = 0; M.ingest_wgs = 0; M.ingest_flag = nullptr; M.progress = nullptr; M.ingest_number = 0u;
+  M.ahead_wgs = 0; M.submitted = nullptr; M.ahead = nullptr;
   return M;
 }
 
