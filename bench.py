@@ -44,6 +44,9 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector
 # MI355X_MICROARCH.md: a wave64 VALU instruction issues in 2 cycles on a SIMD-32; 256 CUs x 4 SIMDs x 2.4 GHz / 2
 VALU_PEAK_GINST_S = 256 * 4 * 2.4 / 2.0
+# What pure fp32 instruction streams SUSTAIN on this part at four waves per SIMD (tools/ubench/valu_rate.hip, profiles/r03_lds_ceiling.txt):
+# v_fma_f32 834-852, v_add_f32 / v_mul_f32 917-968, v_mov_b32 1052 G wave-instructions/s.  The NCC block is 1/4 fma, 3/4 add / sub / mul.
+VALU_SUSTAINED_GINST_S = 0.25 * 843.0 + 0.75 * 940.0
 FUSED_BYTES_PER_PIXEL = 52  # fused check+match+update, compulsory traffic (R 32 + W 20)
 TV_BYTES_PER_PIXEL_ITER = 40
 NCC_FLOP_PER_TAP = 14       # 3 FMA + 1 bilinear fetch per tap
@@ -120,6 +123,10 @@ def valu_roofline(avg_launch_s, counters, n_sequences=1):
     achieved = n / avg_launch_s / 1e9
     return {"bound": "valu", "kernel": "seed_update", "achieved": round(achieved, 1), "peak": round(VALU_PEAK_GINST_S, 1),
             "unit": "G wave-instructions/s", "frac": round(achieved / VALU_PEAK_GINST_S, 4),
+            "sustained_peak": round(VALU_SUSTAINED_GINST_S, 1), "frac_of_sustained": round(achieved / VALU_SUSTAINED_GINST_S, 4),
+            "sustained_peak_note": "what pure fp32 fma / add / mul streams reach on this part at four waves per SIMD, weighted by the NCC block's mix "
+                                   "(tools/ubench/valu_rate.hip); the search kernel on the heaviest updates issues at 2.88 cycles per instruction "
+                                   "against 2.95 for a pure v_fma_f32 stream (profiles/r03_lds_ceiling.txt)",
             "wave_instructions_per_launch": int(n), "source": "profiles/traffic.json (rocprofv3 --pmc SQ_INSTS_VALU, whole passes, same kernel sources)"}
 
 

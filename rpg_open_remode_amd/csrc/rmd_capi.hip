@@ -252,7 +252,8 @@ constexpr size_t FLAG_SLOT_WORDS = FLAG_WORDS < 16 ? 16 : FLAG_WORDS;  // pinned
 // streams of one level, two of them share a hardware queue and their kernels serialise -- a handle's copy stream behind its compute
 // stream (measured: 3300 instead of 4630 Mpix/s with host frames), or the two stream groups of a batch behind each other (93 instead of
 // 59 us per step for two sequences).  Streams of different levels never share a queue.  level 0: compute (normal priority), 1: a
-// batch's second stream group (high), 2: copy streams (low: they carry copy-engine commands and a 4-byte flag write).
+// batch's second stream group (high), 2: copy streams and a batch's third stream group (low; a batch reads its host frames in place and
+// leaves its copy stream idle).
 static hipError_t create_stream(hipStream_t* out, int level) {
   int least = 0, greatest = 0;
   if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest)
@@ -345,9 +346,10 @@ struct rmd_hip_seeds {
 struct rmd_hip_batch {
   int n = 0, device = 0, num_cus = 256;
   rmd_hip_seeds* members[rmdk::MAX_BATCH] = {};
-  // The members are stepped in up to two GROUPS, each with its own stream and update workspace: one launch pair per group and step,
-  // the two pairs issued back to back on the two streams.  While one group's setup kernel runs its latency chain, or its search is down
-  // to its last units, the other group's kernels fill the chip (2 x 2 sequences: 12 400 Mpix/s against 10 800 for one group of 4).
+  // The members are stepped in up to three GROUPS, each with its own stream (one per priority level, see create_stream) and update
+  // workspace: one launch pair per group and step, the pairs issued back to back on their streams.  While one group's setup kernel runs
+  // its latency chain, or its search is down to its last units, the other groups' kernels fill the chip (four sequences: one group
+  // 10 800 Mpix/s, two 11 940, three 12 460; a fourth group would share a hardware-queue pool with the first: 8 860).
   struct Group {
     hipStream_t stream = nullptr;
     rmdk::MatcherWorkspace ws;
@@ -357,7 +359,7 @@ struct rmd_hip_batch {
     unsigned long long last_step = 0;       // ... and of its last launch altogether
     hipEvent_t ev = nullptr;                // fork / join of the region timer
   };
-  static constexpr int MAX_GROUPS = 2;
+  static constexpr int MAX_GROUPS = 4;
   int n_groups = 0;
   Group groups[MAX_GROUPS];
   hipStream_t copy_stream = nullptr;
@@ -373,7 +375,11 @@ struct rmd_hip_batch {
   int opt_timing = 0, opt_unit_target = 1;
   hipEvent_t region_start = nullptr, region_stop = nullptr;
   long region_updates = 0;
-  Group& group_of(int member) { return groups[(n_groups > 1 && member >= groups[1].first) ? 1 : 0]; }
+  Group& group_of(int member) {
+    int g = 0;
+    while (g + 1 < n_groups && member >= groups[g + 1].first) ++g;
+    return groups[g];
+  }
 };
 
 namespace {
@@ -1861,16 +1867,20 @@ int rmd_hip_batch_create(int n, int width, int height, float fx, float fy, float
   if (!b) return fail(RMD_HIP_ERR_RUNTIME, "batch_create: out of host memory");
   (void)hipGetDevice(&b->device);
   auto bail = [&](int rc) { rmd_hip_batch_destroy(b); return rc; };
-  int want_groups = n >= 2 ? 2 : 1;
-  if (const char* e = getenv("RMD_HIP_BATCH_GROUPS")) want_groups = atoi(e) >= 2 && n >= 2 ? 2 : 1;  // (A/B)
+  int want_groups = n >= 3 ? 3 : n;  // measured (profiles/r03_batch_ab.txt): three groups beat two by 3-9 %, a fourth shares a hardware-queue pool and loses 25 %
+  if (const char* e = getenv("RMD_HIP_BATCH_GROUPS")) want_groups = atoi(e);  // (A/B)
+  if (want_groups < 1) want_groups = 1;
+  if (want_groups > rmd_hip_batch::MAX_GROUPS) want_groups = rmd_hip_batch::MAX_GROUPS;
+  if (want_groups > n) want_groups = n;
   b->n_groups = want_groups;
   b->opt_unit_target = 1;  // (2x / 3x as many, smaller units: +4 % with one group of 4, nothing with two groups)
   const size_t pitch = (static_cast<size_t>(width) * 4 + 255) / 256 * 256;  // as image_alloc lays the members' planes out
   for (int g = 0; g < b->n_groups; ++g) {
     rmd_hip_batch::Group& G = b->groups[g];
-    G.first = g == 0 ? 0 : (n + 1) / 2;
-    G.n = b->n_groups == 1 ? n : (g == 0 ? (n + 1) / 2 : n / 2);
-    if (create_stream(&G.stream, g) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: hipStreamCreate failed"));
+    G.first = g == 0 ? 0 : b->groups[g - 1].first + b->groups[g - 1].n;
+    G.n = n / b->n_groups + (g < n % b->n_groups ? 1 : 0);  // the larger groups first
+    // (one priority level each, see create_stream; a fourth group shares the first one's pool)
+    if (create_stream(&G.stream, g % 3) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: hipStreamCreate failed"));
     if (G.ws.allocate(width, height, static_cast<int>(pitch / 4), G.n) != 0) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: update workspace"));
     if (hipHostMalloc(reinterpret_cast<void**>(&G.h_progress), 64, hipHostMallocMapped) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: progress words"));
     G.h_progress[0] = G.h_progress[1] = 0u;

@@ -16,19 +16,31 @@ if [[ $PARTS == *sizes* ]]; then
 fi
 if [[ $PARTS == *host* ]]; then
   echo "== frames handed over in host memory (tools/h2d_rate.py)"
-  RMD_HIP_INGEST_PROFILE=1 python tools/h2d_rate.py > "$SUM/${TAG}_h2d.txt" 2>&1; cat "$SUM/${TAG}_h2d.txt"
+  { echo "# default: a single sequence stages its frames with the copy engine and converts them one step ahead; with the host-side time per frame"
+    RMD_HIP_INGEST_PROFILE=1 python tools/h2d_rate.py 2>&1
+    for m in staged inplace inplace_ahead; do
+      echo "# RMD_HIP_HOST_FRAMES=$m"; RMD_HIP_HOST_FRAMES=$m python tools/h2d_rate.py 2>&1 | tail -6 | head -3
+    done
+    echo "# batches of 4 / 8, 8-bit host frames: default (read in place) and RMD_HIP_HOST_FRAMES=staged"
+    python tools/batch_bench.py --b 4,8 --u8 --passes 2 2>&1 | grep flags
+    RMD_HIP_HOST_FRAMES=staged python tools/batch_bench.py --b 4,8 --u8 --passes 2 2>&1 | grep flags
+    echo "# tools/ubench/copy_rate: one 640x480 float / 8-bit frame from pinned memory, copy engine vs a kernel reading the host link"
+    tools/ubench/copy_rate; tools/ubench/copy_rate 307200
+  } > "$SUM/${TAG}_h2d.txt" 2>&1; cat "$SUM/${TAG}_h2d.txt"
 fi
 if [[ $PARTS == *batch* ]]; then
   echo "== batched mode: A/B of the stream groups and of the search loop's switches (same scene for every member)"
-  { echo "# python tools/batch_bench.py --same-scene (two stream groups, default)"; python tools/batch_bench.py --b 1,2,3,4,6,8 --same-scene --passes 2 2>&1 | grep flags
+  { echo "# python tools/batch_bench.py --same-scene (default: up to three stream groups)"; python tools/batch_bench.py --b 1,2,3,4,6,8 --same-scene --passes 2 2>&1 | grep flags
     echo "# RMD_HIP_BATCH_GROUPS=1 (one launch pair for all members)"; RMD_HIP_BATCH_GROUPS=1 python tools/batch_bench.py --b 2,4,8 --same-scene --passes 2 2>&1 | grep flags
+    echo "# RMD_HIP_BATCH_GROUPS=2"; RMD_HIP_BATCH_GROUPS=2 python tools/batch_bench.py --b 3,4,6,8 --same-scene --passes 2 2>&1 | grep flags
+    echo "# RMD_HIP_BATCH_GROUPS=4 (the fourth group shares a hardware-queue pool with the first)"; RMD_HIP_BATCH_GROUPS=4 python tools/batch_bench.py --b 4,8 --same-scene --passes 2 2>&1 | grep flags
     echo "# search-loop switches (RMD_HIP_OPT_SEARCH_FLAGS: 1 prefetch the next unit, 2 sixteen hand-out counters, 4 tile box with the unit)"; python tools/batch_bench.py --b 1,4 --same-scene --passes 2 --flags 6,0,4,2,7 2>&1 | grep flags
     echo "# stream-level alternative: S independent batches on S streams / host threads (tools/multi_batch.py)"; python tools/multi_batch.py --configs 1x4,2x2,4x1,1x8,2x4 2>&1 | tail -5
   } > "$SUM/${TAG}_batch_ab.txt" 2>&1; cat "$SUM/${TAG}_batch_ab.txt"
 fi
 if [[ $PARTS == *live* ]]; then
   echo "== live use (node state machine)"
-  python tools/live_bench.py > "$SUM/${TAG}_live.txt" 2>&1; tail -2 "$SUM/${TAG}_live.txt"
+  python tools/live_bench.py --breakdown > "$SUM/${TAG}_live.txt" 2>&1; tail -12 "$SUM/${TAG}_live.txt"
 fi
 if [[ $PARTS == *ref* ]]; then
   echo "== the reference's own programs on the library"
