@@ -321,6 +321,7 @@ struct rmd_hip_seeds {
   unsigned int* d_zc_flag = nullptr;        // device, one block per ring slot: number of the last frame whose copy into that slot's staging buffer has completed
   unsigned int* h_submitted = nullptr;      // pinned: [0] / [1] number of the newest 8-bit / float frame that is complete in the ring (one step ahead)
   unsigned int* d_ahead = nullptr;          // device: the words of rmdk::MatcherArgs::ahead
+  int pack_backoff = 0, pack_backoff_len = 15;  // float frames that are not 8-bit levels: the next pack_backoff_len frames are not examined (pack_float_rows_u8)
   unsigned int* h_progress = nullptr;       // pinned: [0] number of the ingested frame whose setup kernel has started, [1] error bits
   unsigned long long zc_number = 0;         // ingested frames so far (the device sees the low 32 bits and compares modulo 2^32)
   int opt_fused_ingest = 1;                 // RMD_HIP_FUSED_INGEST=0 switches back to the copy-stream pipeline (A/B)
@@ -373,6 +374,7 @@ struct rmd_hip_batch {
   unsigned int* d_flag = nullptr;
   unsigned long long step_number = 0;
   int opt_timing = 0, opt_unit_target = 1;
+  int pack_backoff = 0;
   hipEvent_t region_start = nullptr, region_stop = nullptr;
   long region_updates = 0;
   Group& group_of(int member) {
@@ -476,6 +478,7 @@ struct PendingIngest {
   const unsigned int* u8 = nullptr;
   const float* f32 = nullptr;
   const void* next_src = nullptr;  // one step ahead: the next frame's place in the ring and its plane
+  bool no_remap = false;           // a float frame that travels as bytes: never through the undistortion maps
   float* next_dst = nullptr;
 };
 
@@ -532,8 +535,8 @@ int seeds_launch_update(rmd_hip_seeds* s, const PendingIngest* ingest = nullptr)
         if (ingest) {
           B.seq[0].ingest_u8 = ingest->u8; B.seq[0].ingest_f32 = ingest->f32;
           B.seq[0].ingest_dst = const_cast<float*>(P.cur);
-          B.seq[0].ingest_map1 = ingest->u8 ? s->d_undist_map1 : nullptr;  // null without lens undistortion
-          B.seq[0].ingest_map2 = ingest->u8 ? s->d_undist_map2 : nullptr;
+          B.seq[0].ingest_map1 = ingest->u8 && !ingest->no_remap ? s->d_undist_map1 : nullptr;  // null without lens undistortion
+          B.seq[0].ingest_map2 = ingest->u8 && !ingest->no_remap ? s->d_undist_map2 : nullptr;
           B.seq[0].next_src = ingest->next_src; B.seq[0].next_dst = ingest->next_dst;
         }
         HIP_TRY((rmdk::launch_seed_pipeline_compact<SIDE, 1>(B, 1, s->matcher_ws, s->stream, s->num_cus, s->opt_unit_target, ingest ? &ingest->common : nullptr)));
@@ -917,11 +920,12 @@ static int ingest_init(rmd_hip_seeds* s) {
   s->ingest_profile = getenv("RMD_HIP_INGEST_PROFILE") != nullptr;
   if (const char* e = getenv("RMD_HIP_INGEST_HOST_WAIT")) s->ingest_host_wait = e[0] == '1';
   if (const char* e = getenv("RMD_HIP_FUSED_INGEST")) s->opt_fused_ingest = e[0] != '0';
+  if (const char* e = getenv("RMD_HIP_PACK_BACKOFF")) s->pack_backoff_len = atoi(e);  // (tests: 0 examines every float frame)
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_progress), 64, hipHostMallocMapped));
   s->h_progress[0] = s->h_progress[1] = 0u;
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_seq), rmd_hip_seeds::RING * FLAG_SLOT_WORDS * sizeof(unsigned int), hipHostMallocDefault));
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_flag), rmd_hip_seeds::RING * FLAG_ALLOC_BYTES));  // one flag block per ring slot
-  HIP_TRY(hipMemset(s->d_zc_flag, 0, rmd_hip_seeds::RING * FLAG_ALLOC_BYTES));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_flag), 2 * rmd_hip_seeds::RING * FLAG_ALLOC_BYTES));  // one flag block per ring slot and kind of frame
+  HIP_TRY(hipMemset(s->d_zc_flag, 0, 2 * rmd_hip_seeds::RING * FLAG_ALLOC_BYTES));
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_submitted), 64, hipHostMallocMapped));
   s->h_submitted[0] = s->h_submitted[1] = 0u;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_ahead), 64));
@@ -969,6 +973,37 @@ static inline void cpu_relax() {  // a polite spin, whatever the host architectu
 // not the GPU, the bound of update(float*) -- the reference's own signature (seed_matrix.cu:120-128).  Frames of 256 KB and more are
 // split across a few persistent helper threads (created at the first such copy, parked on a condition variable in between).
 namespace {
+// Float frames whose every pixel is an 8-bit level -- what the reference's own host path produces: Depthmap::inputImage converts the
+// 8-bit camera image with convertTo(CV_32F, 1.0f / 255.0f) and hands the floats to SeedMatrix::update (depthmap.cpp:105, 75-77) -- travel to
+// the device as bytes: a quarter of the copy-engine time, which is what bounds float frames (1.2 MB at the engine's 23 GB/s take longer than
+// the update).  The device multiplies by the same 1.0f / 255.0f, and a row is only accepted if that product has the caller's BIT PATTERN in
+// every pixel, so the current image is the caller's image bit for bit.  Rows [y0, y1) of a w-wide image; false at the first other pixel.
+#if defined(__HIP_DEVICE_COMPILE__) || !defined(__x86_64__)
+#define RMD_HOST_SIMD_CLONES
+#else
+#define RMD_HOST_SIMD_CLONES __attribute__((target_clones("avx2", "default")))  // (host pass only: an AVX2 body where the CPU has it)
+#endif
+RMD_HOST_SIMD_CLONES static bool pack_float_rows_u8(const float* src, unsigned char* dst, int w, int pitch, int y0, int y1) {
+  for (int y = y0; y < y1; ++y) {
+    const float* in = src + static_cast<size_t>(y) * w;
+    unsigned char* out = dst + static_cast<size_t>(y) * pitch;
+    unsigned int bad = 0u;
+    for (int x = 0; x < w; ++x) {
+      const float f = in[x];
+      const float c = f >= 0.0f && f <= 1.0f ? f : 2.0f;  // (NaN, negative and large values fail the comparison below)
+      const int u = static_cast<int>(c * 255.0f + 0.5f);
+      const float back = static_cast<float>(u) * (1.0f / 255.0f);
+      unsigned int fb, bb;
+      memcpy(&fb, &f, 4);
+      memcpy(&bb, &back, 4);
+      bad |= fb ^ bb;
+      out[x] = static_cast<unsigned char>(u);
+    }
+    if (bad) return false;
+  }
+  return true;
+}
+
 class CopyPool {
  public:
   static CopyPool& instance() {
@@ -989,6 +1024,21 @@ class CopyPool {
     for (int i = n_workers_; i < n; i += n_workers_ + 1) memcpy(segs[i].dst, segs[i].src, bytes);  // the caller's share
     wait();
     segs_ = nullptr; n_segs_ = 0;
+  }
+  // pack_float_rows_u8 over the rows of one frame, split over the participants; true if every row was accepted
+  bool pack(const float* src, unsigned char* dst, int w, int h, int pitch) {
+    if (!pack_float_rows_u8(src, dst, w, pitch, h / 2, h / 2 + 1)) return false;  // an image of other floats is turned down before anybody is woken
+    if (n_workers_ == 0 || static_cast<size_t>(w) * h * sizeof(float) < kMinBytes) return pack_float_rows_u8(src, dst, w, pitch, 0, h);
+    std::lock_guard<std::mutex> one_copy_at_a_time(call_mutex_);
+    const int parts = n_workers_ + 1, rows = (h + parts - 1) / parts;
+    pack_src_ = src; pack_dst_ = dst; pack_w_ = w; pack_h_ = h; pack_pitch_ = pitch; pack_rows_ = rows;
+    __atomic_store_n(&pack_ok_, 1, __ATOMIC_RELAXED);
+    post();
+    const int y0 = n_workers_ * rows;  // the caller takes the last part
+    if (y0 < h && !pack_float_rows_u8(src, dst, w, pitch, y0, h)) __atomic_store_n(&pack_ok_, 0, __ATOMIC_RELAXED);
+    wait();
+    pack_src_ = nullptr;
+    return __atomic_load_n(&pack_ok_, __ATOMIC_ACQUIRE) != 0;
   }
   void copy(void* dst, const void* src, size_t bytes) {
     const int parts = n_workers_ + 1;
@@ -1057,7 +1107,10 @@ class CopyPool {
       }
       if (__atomic_load_n(&stop_, __ATOMIC_ACQUIRE)) return;
       seen = __atomic_load_n(&generation_, __ATOMIC_ACQUIRE);
-      if (segs_) {
+      if (pack_src_) {
+        const int y0 = index * pack_rows_, y1 = y0 + pack_rows_ < pack_h_ ? y0 + pack_rows_ : pack_h_;
+        if (y0 < y1 && !pack_float_rows_u8(pack_src_, pack_dst_, pack_w_, pack_pitch_, y0, y1)) __atomic_store_n(&pack_ok_, 0, __ATOMIC_RELAXED);
+      } else if (segs_) {
         for (int i = index; i < n_segs_; i += n_workers_ + 1) memcpy(segs_[i].dst, segs_[i].src, bytes_);
       } else {
         const size_t off = static_cast<size_t>(index) * chunk_;
@@ -1077,8 +1130,15 @@ class CopyPool {
   const Segment* segs_ = nullptr;
   int n_segs_ = 0;
   size_t bytes_ = 0, chunk_ = 0;
+  const float* pack_src_ = nullptr; unsigned char* pack_dst_ = nullptr;
+  int pack_w_ = 0, pack_h_ = 0, pack_pitch_ = 0, pack_rows_ = 0, pack_ok_ = 1;
   int pending_ = 0;
 };
+// (A/B: RMD_HIP_FLOAT_AS_BYTES=0 sends every float frame as floats)
+static bool float_frames_as_bytes() {
+  static const bool on = [] { const char* e = getenv("RMD_HIP_FLOAT_AS_BYTES"); return !(e && e[0] == '0'); }();
+  return on;
+}
 }  // namespace
 static inline void host_copy(void* dst, const void* src, size_t bytes) { CopyPool::instance().copy(dst, src, bytes); }
 
@@ -1168,21 +1228,41 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
   const double t_b = s->ingest_profile ? host_now_us() : 0.0;
   PendingIngest in;
   bool in_place = false;
-  // every ring slot has its own arrival flag (the setup kernel of frame n asks for frame n's; its verdict for frame n + 1 reads that one's)
-  unsigned int* slot_flag = s->d_zc_flag + static_cast<size_t>(k) * (FLAG_ALLOC_BYTES / sizeof(unsigned int));
+  // every ring slot has its own arrival flag, one per kind of frame (8-bit / float: they use different staging buffers): the setup kernel
+  // of frame n asks for frame n's; its verdict for frame n + 1 reads the flag of that slot for ITS kind, which a frame of the other kind never sets
+  auto flag_of = [&](int kind, int slot) { return s->d_zc_flag + (static_cast<size_t>(kind) * rmd_hip_seeds::RING + slot) * (FLAG_ALLOC_BYTES / sizeof(unsigned int)); };
   void* stage_src = nullptr; void* stage_dst = nullptr; size_t stage_bytes = 0;
-  if (host_gray) {
+  auto ensure_u8_ring = [&]() -> int {
     const size_t bytes = static_cast<size_t>(s->u8_pitch) * s->height;
     for (int q = 0; q < rmd_hip_seeds::RING; ++q) {  // (all slots at once: the search kernel is told where the NEXT frame will be)
       if (s->h_zc_u8[q]) continue;
       HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_zc_u8[q]), bytes + 16, hipHostMallocDefault));
       HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_u8[q]), bytes));
     }
-    if (s->u8_pitch == s->width) host_copy(s->h_zc_u8[k], host_gray, bytes);
+    return RMD_HIP_OK;
+  };
+  // a float frame of 8-bit levels goes the 8-bit way from here on, never through the undistortion maps (pack_float_rows_u8)
+  bool packed = false;
+  if (!host_gray && float_frames_as_bytes()) {
+    if (s->pack_backoff > 0) --s->pack_backoff;
+    else {
+      TRY(ensure_u8_ring());
+      packed = CopyPool::instance().pack(host_f32, s->h_zc_u8[k], s->width, s->height, s->u8_pitch);
+      if (!packed) s->pack_backoff = s->pack_backoff_len;
+    }
+  }
+  const bool as_u8 = host_gray != nullptr || packed;
+  const bool remap = host_gray != nullptr && s->d_undist_map1 != nullptr;
+  in.no_remap = packed;
+  if (as_u8) {
+    const size_t bytes = static_cast<size_t>(s->u8_pitch) * s->height;
+    TRY(ensure_u8_ring());
+    if (packed) {
+    } else if (s->u8_pitch == s->width) host_copy(s->h_zc_u8[k], host_gray, bytes);
     else
       for (int y = 0; y < s->height; ++y)
         memcpy(s->h_zc_u8[k] + static_cast<size_t>(y) * s->u8_pitch, host_gray + static_cast<size_t>(y) * s->width, s->width);
-    in_place = frame_in_place(false, s->d_undist_map1 != nullptr);
+    in_place = frame_in_place(false, remap);
     if (in_place) {
       void* dev = nullptr;
       HIP_TRY(hipHostGetDevicePointer(&dev, s->h_zc_u8[k], 0));
@@ -1212,29 +1292,30 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
     }
     in.common.kind = 2;
   }
-  const bool ahead = frame_ahead(host_gray && s->d_undist_map1 != nullptr);
+  const bool ahead = frame_ahead(remap);
   if (in_place) {
     in.common.flag = nullptr;  // the setup kernel reads the pinned buffer itself: it is complete before the kernel is launched
   } else {
     HIP_TRY(hipMemcpyAsync(stage_dst, stage_src, stage_bytes, hipMemcpyHostToDevice, s->copy_stream));
     const size_t fw = flag_words(s->h_progress, n);
     fill_flag_block(s->h_seq + k * FLAG_SLOT_WORDS, n, fw);  // behind the frame on the same stream: when the kernel sees n, the frame is in HBM
+    unsigned int* slot_flag = flag_of(as_u8 ? 0 : 1, k);
     HIP_TRY(hipMemcpyAsync(slot_flag, s->h_seq + k * FLAG_SLOT_WORDS, fw * sizeof(unsigned int), hipMemcpyHostToDevice, s->copy_stream));
     in.common.flag = slot_flag;
   }
   int plane = 0;  // one plane is enough: setup k writes it after search k - 1 has run (same stream)
   if (ahead) {  // ... unless the previous update's search kernel brings the frame in: frame n lives in plane n % 2
-    const int kind = host_gray ? 0 : 1, k_next = static_cast<int>((n64 + 1) % rmd_hip_seeds::RING);
+    const int kind = as_u8 ? 0 : 1, k_next = static_cast<int>((n64 + 1) % rmd_hip_seeds::RING);
     void* dev = nullptr;
     if (in_place) {
       __atomic_store_n(&s->h_submitted[kind], n, __ATOMIC_RELEASE);  // frame n is complete in the ring
       HIP_TRY(hipHostGetDevicePointer(&dev, s->h_submitted, 0));
       in.common.submitted = static_cast<const unsigned int*>(dev) + kind;
-      HIP_TRY(hipHostGetDevicePointer(&dev, host_gray ? static_cast<void*>(s->h_zc_u8[k_next]) : static_cast<void*>(s->h_zc_f32[k_next]), 0));
+      HIP_TRY(hipHostGetDevicePointer(&dev, as_u8 ? static_cast<void*>(s->h_zc_u8[k_next]) : static_cast<void*>(s->h_zc_f32[k_next]), 0));
       in.next_src = dev;
     } else {
-      in.common.submitted = s->d_zc_flag + static_cast<size_t>(k_next) * (FLAG_ALLOC_BYTES / sizeof(unsigned int));  // the arrival flag of the next frame's slot
-      in.next_src = host_gray ? static_cast<const void*>(s->d_zc_u8[k_next]) : static_cast<const void*>(s->d_zc_f32[k_next]);
+      in.common.submitted = flag_of(kind, k_next);  // the arrival flag of the next frame's slot, for this kind
+      in.next_src = as_u8 ? static_cast<const void*>(s->d_zc_u8[k_next]) : static_cast<const void*>(s->d_zc_f32[k_next]);
     }
     in.common.ahead = s->d_ahead;
     static const int ahead_wgs = [] { const char* e = getenv("RMD_HIP_AHEAD_WGS"); return e ? atoi(e) : AHEAD_WGS; }();  // (A/B)
@@ -1694,7 +1775,7 @@ int batch_launch(rmd_hip_batch* b, unsigned int active, const rmdk::IngestArgs* 
         const unsigned char* src = d_stage + static_cast<size_t>(G.first + j) * frame_bytes;
         if (ingest->kind == 1) {
           B.seq[j].ingest_u8 = reinterpret_cast<const unsigned int*>(src);
-          B.seq[j].ingest_map1 = m->d_undist_map1;
+          B.seq[j].ingest_map1 = ingest->no_remap ? nullptr : m->d_undist_map1;
           B.seq[j].ingest_map2 = m->d_undist_map2;
         } else {
           B.seq[j].ingest_f32 = reinterpret_cast<const float*>(src);
@@ -1739,7 +1820,8 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
   TRY(batch_bind_device(b));
   const rmd_hip_seeds* m0 = b->members[0];
   const int u8_pitch = (m0->width + 3) / 4 * 4;
-  const size_t frame_bytes = gray ? static_cast<size_t>(u8_pitch) * m0->height : static_cast<size_t>(m0->width) * m0->height * sizeof(float);
+  const size_t bytes_u8 = static_cast<size_t>(u8_pitch) * m0->height;
+  size_t frame_bytes = gray ? bytes_u8 : static_cast<size_t>(m0->width) * m0->height * sizeof(float);
   unsigned int active = 0;
   for (int i = 0; i < b->n; ++i) {
     if (!(gray ? static_cast<const void*>(gray[i]) : static_cast<const void*>(f32[i]))) continue;
@@ -1773,10 +1855,26 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
     }
     b->stage_bytes = need;
   }
+  // float frames of 8-bit levels travel as bytes (pack_float_rows_u8), if every frame of the step qualifies
+  bool packed = false;
+  if (!gray && float_frames_as_bytes() && b->pack_backoff > 0) --b->pack_backoff;
+  else if (!gray && float_frames_as_bytes()) {
+    packed = true;
+    for (int i = 0; i < b->n && packed; ++i)
+      if ((active >> i) & 1u) packed = CopyPool::instance().pack(f32[i], b->h_stage[k] + static_cast<size_t>(i) * bytes_u8, m0->width, m0->height, u8_pitch);
+    if (packed) frame_bytes = bytes_u8;
+    else b->pack_backoff = 15;
+  }
+  const bool as_u8 = gray != nullptr || packed;
+  bool any_maps = false;
+  for (int i = 0; i < b->n; ++i) any_maps = any_maps || (gray && ((active >> i) & 1u) && b->members[i]->d_undist_map1);
   int first = -1, last = -1, n_segs = 0;
   CopyPool::Segment segs[rmdk::MAX_BATCH];
   for (int i = 0; i < b->n; ++i) {
     if (!((active >> i) & 1u)) continue;
+    if (first < 0) first = i;
+    last = i;
+    if (packed) continue;
     unsigned char* dst = b->h_stage[k] + static_cast<size_t>(i) * frame_bytes;
     if (gray && u8_pitch != m0->width) {
       for (int y = 0; y < m0->height; ++y) memcpy(dst + static_cast<size_t>(y) * u8_pitch, gray[i] + static_cast<size_t>(y) * m0->width, m0->width);
@@ -1785,11 +1883,9 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
       segs[n_segs].src = gray ? static_cast<const void*>(gray[i]) : static_cast<const void*>(f32[i]);
       ++n_segs;
     }
-    if (first < 0) first = i;
-    last = i;
   }
   if (n_segs) CopyPool::instance().copy_many(segs, n_segs, frame_bytes);  // the frames of the step, spread over the copy threads
-  const bool in_place = frame_in_place(true, false);
+  const bool in_place = frame_in_place(true, any_maps);  // (the remap gathers single bytes: staged)
   const unsigned char* frames_dev = b->d_stage[k];
   rmdk::IngestArgs in;
   if (in_place) {  // the setup kernels read the pinned block themselves
@@ -1807,9 +1903,10 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
     HIP_TRY(hipMemcpyAsync(b->d_flag, b->h_seq + k * FLAG_SLOT_WORDS, fw * sizeof(unsigned int), hipMemcpyHostToDevice, b->copy_stream));
     in.flag = b->d_flag;
   }
-  in.kind = gray ? 1 : 2;
+  in.kind = as_u8 ? 1 : 2;
   in.pitch = u8_pitch;
   in.number = n;
+  in.no_remap = packed;
   for (int i = 0; i < b->n; ++i) {
     if (!((active >> i) & 1u)) continue;
     rmd_hip_seeds* m = b->members[i];

@@ -213,6 +213,7 @@ struct IngestArgs {
   const unsigned int* flag = nullptr;  // null: the frame is read in place from pinned host memory
   unsigned int* progress = nullptr;
   unsigned int number = 0;
+  bool no_remap = false;  // 8-bit frames that must not go through the lens-undistortion maps (float frames that travel as bytes)
   int ahead_wgs = 0;  // see MatcherArgs::ahead
   const unsigned int* submitted = nullptr;
   unsigned int* ahead = nullptr;

@@ -558,3 +558,51 @@ def test_host_frames_arriving_on_an_idle_device(size):
     assert_states_equal(want, u8.state(), "8-bit host frames")
     assert_states_equal(want, f32.state(), "float host frames")
     assert time.perf_counter() - t0 < 5.0  # a wait that ran into its bound would take far longer
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(101, 67, 5), (640, 480, 9)])
+def test_float_frames_of_8bit_levels_travel_as_bytes_and_mix_with_other_floats(size):
+    """update(float*) examines the frame: 8-bit levels (what the reference's host path produces) are sent as bytes, anything else as floats
+    -- NaN, -0.0, values outside [0, 1] and levels that are one ulp off included.  The kinds alternate here without a pause, so frames
+    of one kind are converted one step ahead while the other kind's staging buffers and arrival flags are in use; the current image and the
+    state must equal those of the resident-frame path bit for bit after every kind of frame."""
+    w, h, side = size
+    n = 14
+    seq = sequence(w, h, n)
+    cam = api.PinholeCamera(*seq.K)
+    rng = np.random.default_rng(5)
+    frames = []
+    for k in range(n):
+        im = seq.images[k].copy()
+        kind = k % 4
+        if kind == 1:      # not levels: every pixel scaled
+            im = (im * np.float32(0.999)).astype(np.float32)
+        elif kind == 2:    # levels but for a handful of awkward pixels
+            ys, xs = rng.integers(0, h, 6), rng.integers(0, w, 6)
+            im[ys[0], xs[0]] = np.float32(-0.0)
+            im[ys[1], xs[1]] = np.nextafter(im[ys[1], xs[1]], np.float32(2.0))
+            im[ys[2], xs[2]] = np.float32(1.5)
+            im[ys[3], xs[3]] = np.float32(-0.25)
+            im[ys[4], xs[4]] = np.float32(np.nan)
+        frames.append(np.ascontiguousarray(im))
+    import os
+    os.environ["RMD_HIP_PACK_BACKOFF"] = "0"  # examine every float frame (read when a handle sees its first host frame)
+    try:
+        host, res = (api.SeedMatrix(w, h, cam, patch_side=side) for _ in range(2))
+        host.setReferenceImage(frames[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    finally:
+        del os.environ["RMD_HIP_PACK_BACKOFF"]
+    planes = []
+    for im in frames:
+        d = api.DeviceImage(w, h, np.float32)
+        d.setDevData(im)
+        planes.append(d)
+    res.setReferenceImageDevice(planes[0].data, planes[0].stride, seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    for k in range(1, n):
+        host.update(frames[k], seq.T_curr_world[k])
+        res.updateDevice(planes[k].data, planes[k].stride, seq.T_curr_world[k])
+        if k in (3, 6, 13):  # after a frame of bytes, of awkward floats, of scaled floats
+            got = host.download(api.PLANE_CURR_IMG)
+            assert np.array_equal(got.view(np.uint32), frames[k].view(np.uint32)), f"current image after frame {k}"
+    assert_states_equal(res.state(), host.state(), "float host frames of mixed kinds")
