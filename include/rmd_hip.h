@@ -104,8 +104,11 @@ int rmd_hip_seeds_destroy(rmd_hip_seeds_t* s);
 int rmd_hip_seeds_set_reference(rmd_hip_seeds_t* s, const float* host_img, const float* T_curr_world, float min_depth,
                                 float max_depth);
 /* update :120-158 (check -> epipolar match -> triangulate + fuse).  host_img (contiguous W x H floats, pageable memory is fine) has
- * been copied when the call returns, like the reference's synchronous cudaMemcpy2D (:128); the device work is in flight (up to three
- * frames inside the library), the next synchronising call (download, converged count, denoise, sync) waits for it. */
+ * been copied when the call returns, like the reference's synchronous cudaMemcpy2D (:128); the device work is in flight (up to four
+ * frames inside the library), the next synchronising call (download, converged count, denoise, sync) waits for it.  A frame whose every
+ * pixel has the bit pattern of (float)k * (1.0f / 255.0f), k = 0..255 -- what Depthmap::inputImage hands over (depthmap.cpp:105) --
+ * is sent to the device as bytes and multiplied there by the same constant: the current image is the caller's image bit for bit either
+ * way, the byte form just costs a quarter of the transfer. */
 int rmd_hip_seeds_update(rmd_hip_seeds_t* s, const float* host_img, const float* T_curr_world);
 /* same two calls for a frame that is already resident in device memory (row stride in elements).
  * set_reference_device copies the frame into the handle's own plane.  update_device reads the caller's buffer IN

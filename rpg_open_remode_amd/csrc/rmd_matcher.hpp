@@ -157,26 +157,28 @@ struct MatcherArgs {
   int housekeeper;           // the first sequence of the launch that has a frame: tile 0 of it resets the counters of the next launch
   int search_flags;          // SEARCH_* (rmd_frame.hpp)
   unsigned long long* trace;  // this frame's slice of the timeline buffer, may be null (round-1 pipeline, see trace_record)
-  // Frame ingest for frames handed over in host memory: a copy engine brings the frames of all sequences of the launch as they are
-  // into staging buffers in HBM and then writes the step's number into `ingest_flag`, both on the copy stream, with NO ordering
-  // against the compute stream; a few extra workgroups of the setup kernel wait for the flag themselves (it has normally been set
-  // long before) and convert the staged frames into the current-image planes, which only the search kernel -- the next launch --
-  // reads.  The staged frames and their destinations are per sequence (SeqArgs).  ingest_kind 0: the frames are resident already.
-  int ingest_kind;                 // 1: staged 8-bit rows of ingest_pitch bytes (a multiple of 4), four pixels per dword; 2: staged float rows of P.w elements, unpadded
+  // Frame ingest for frames handed over in host memory, two forms (rmd_capi.hip chooses).  STAGED: a copy engine brings the frames of all
+  // sequences of the launch as they are into staging buffers in HBM and then writes the step's number into `ingest_flag`, both on the
+  // copy stream, with NO ordering against the compute stream; a few extra workgroups of the setup kernel wait for the flag themselves
+  // (it has normally been set long before) and convert the staged frames into the current-image planes, which only the search kernel
+  // -- the next launch -- reads.  IN PLACE (ingest_flag == null): those workgroups read the frames straight from the pinned host
+  // buffers over the host link (ingest_in_place); the buffers were complete before the kernel was launched, nothing to wait for.
+  // The frames and their destinations are per sequence (SeqArgs).  ingest_kind 0: the frames are resident already.
+  int ingest_kind;                 // 1: 8-bit rows of ingest_pitch bytes (a multiple of 4), four pixels per dword; 2: float rows of P.w elements, unpadded
   int ingest_pitch;
   int ingest_wgs;                  // workgroups below the tile grid (per sequence) that do the conversion
-  const unsigned int* ingest_flag; // device word: number of the last step whose staging copy has completed
+  const unsigned int* ingest_flag; // device word: number of the last step whose staging copy (into this step's buffers) has completed; null: in place
   unsigned int* progress;          // pinned host words: [0] <- ingest_number when this setup starts (everything before it has
                                    // completed: the host may reuse that step's buffers), [1] |= 1 if the flag never came
   unsigned int ingest_number;
-  // Host frames ONE STEP AHEAD (single sequences, frames read in place from the pinned ring): the caller copies frame n + 1 into the ring
-  // and publishes its number in `submitted` while the device is still busy with frame n or n - 1.  The setup kernel of frame n looks at
-  // `submitted` once (one lane) and writes its verdict to ahead[0]; if frame n + 1 is there, the first `ahead_wgs` workgroups of frame n's
-  // SEARCH kernel -- which leaves most of the chip idle on all but the heaviest frames -- bring it into the other current-image plane
-  // and set ahead[2] = n + 1, and the ingest workgroups of setup n + 1 find nothing left to do.  Nobody ever waits: a frame that was
-  // not there in time is read in place by its own setup kernel, as without this.
+  // Host frames ONE STEP AHEAD (single sequences): the caller hands frame n + 1 over while the device is still busy with frame n or
+  // n - 1.  One lane of the setup kernel of frame n looks at `submitted` -- has frame n + 1 arrived in its staging buffer (staged) /
+  // been put into the pinned ring (in place)? -- and writes its verdict to ahead[0]; if it is there, the first `ahead_wgs` workgroups of
+  // frame n's SEARCH kernel, which leaves most of the chip idle on all but the heaviest frames, convert it into the other current-image
+  // plane and set ahead[2] = n + 1, and the ingest workgroups of setup n + 1 find nothing left to do.  Nobody waits for a frame on this
+  // path: one that was not there in time is handled by its own setup kernel as without it.
   int ahead_wgs;
-  const unsigned int* submitted;   // the word that tells whether frame n + 1 is there: frames read in place: a pinned host word, number of the newest frame of this kind that is complete in the ring; staged frames: the arrival flag of frame n + 1's ring slot
+  const unsigned int* submitted;   // staged: the arrival flag of frame n + 1's staging buffer; in place: a pinned host word, the newest frame of this kind that is complete in the ring
   unsigned int* ahead;             // device words: [0] frame to bring in during this update's search kernel or 0, [1] bringers done, [2] newest frame brought in ahead
 };
 
@@ -409,6 +411,10 @@ RMDK_D void ncc_sums_regular(const float* __restrict__ base, int rt_stride, cons
 // the filter / accumulate work on row r, and scheduling barriers keep the compiler from sinking the reads back to their first
 // use (left alone it issues every read a few instructions before an s_waitcnt: ~60 exposed LDS latencies per evaluation, which
 // is most of a round's time when a wave has its SIMD to itself, i.e. on every frame but the first twenty).
+// With four waves per SIMD the block is bound by VALU issue, not by the LDS: builds that leave out 28 % or 72 % of its LDS reads run
+// the heaviest updates in the same time (+-1 %), and the kernel issues one VALU instruction per 2.9 cycles and SIMD there, the rate of a
+// pure v_fma_f32 stream on this part (profiles/r03_lds_ceiling.txt).  Keeping the two product sums as a register pair for v_pk_add_f32
+// (4.3 cycles against 2 x 2.7) was tried: the compiler needs 168 VGPRs and scratch for it -- a third of the occupancy.
 template <int SIDE>
 RMDK_D void ncc_sums_lds_pipelined(const float* __restrict__ base, int stride, const float (&ax)[SIDE], const float (&ay)[SIDE],
                                    const float* __restrict__ ref_patch, int ref_stride, float& sum_img, float& sum_img_sq,
