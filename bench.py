@@ -89,14 +89,38 @@ def resolve_workload(args):
     return w, h, frames, tv_iters
 
 
+def _code_only(text):
+    """C++ source without comments and with white space collapsed: what a compiler sees"""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == '"' or c == "'":  # string / character literal: copied as it is
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c)
+            i += 1
+    return " ".join("".join(out).split())
+
+
 def kernel_source_sha256():
-    """hash of the device code of librmd_hip.so (the kernel headers; the host orchestration in rmd_capi.hip is not part of it):
-    committed counter files (profiles/traffic.json) carry the hash of the sources they were measured on, and a figure derived from
-    them is refused when the kernels have changed since"""
+    """hash of the device code of librmd_hip.so (the kernel headers; the host orchestration in rmd_capi.hip is not part of it), comments
+    and white space left out: committed counter files (profiles/traffic.json) carry the hash of the sources they were measured on, and a
+    figure derived from them is refused when the kernels have changed since -- editing a comment does not change a kernel"""
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "rpg_open_remode_amd", "csrc", "*.hpp")) + glob.glob(os.path.join(ROOT, "rpg_open_remode_amd", "csrc", "*.h"))):
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        h.update(_code_only(open(f, "r", encoding="utf-8", errors="replace").read()).encode())
     return h.hexdigest()
 
 

@@ -414,7 +414,9 @@ RMDK_D void ncc_sums_regular(const float* __restrict__ base, int rt_stride, cons
 // With four waves per SIMD the block is bound by VALU issue, not by the LDS: builds that leave out 28 % or 72 % of its LDS reads run
 // the heaviest updates in the same time (+-1 %), and the kernel issues one VALU instruction per 2.9 cycles and SIMD there, the rate of a
 // pure v_fma_f32 stream on this part (profiles/r03_lds_ceiling.txt).  Keeping the two product sums as a register pair for v_pk_add_f32
-// (4.3 cycles against 2 x 2.7) was tried: the compiler needs 168 VGPRs and scratch for it -- a third of the occupancy.
+// (4.3 cycles against 2 x 2.7 in isolation) was tried: as a vector-typed expression the optimiser sinks the chain of packed adds below the
+// last row with all 81 products alive (168 VGPRs + scratch); pinned by volatile inline assembly it costs 125 VGPRs, is bit-identical and
+// gains nothing on the heaviest updates (490 -> 494 us for a batch of 8); pairs of columns through the vertical filter cost 114 extra moves.
 template <int SIDE>
 RMDK_D void ncc_sums_lds_pipelined(const float* __restrict__ base, int stride, const float (&ax)[SIDE], const float (&ay)[SIDE],
                                    const float* __restrict__ ref_patch, int ref_stride, float& sum_img, float& sum_img_sq,

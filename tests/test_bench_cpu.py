@@ -117,3 +117,13 @@ def test_two_rank_launch_path_of_bench_py(launcher):
     assert out["rendezvous"] == "ok" and out["n_gpus"] == 2 and out["control_plane"] == "gloo"
     assert out["max_elapsed_s"] == pytest.approx(0.002) and out["total_units"] == 3.0
     assert [r[2] for r in out["per_rank"]] == [0.0, 1.0]  # LOCAL_RANK of each rank, in rank order
+
+
+def test_kernel_source_hash_ignores_comments_and_white_space_only():
+    b, _ = _bench([])
+    a = 'int f(int x) { // add one\n  return x + 1; /* here */ }\nconst char* s = "// not a comment";\n'
+    same = 'int f(int x) {\n\n   return x + 1;   }   // something else entirely\nconst char* s = "// not a comment";'
+    other = 'int f(int x) { return x + 2; }\nconst char* s = "// not a comment";'
+    assert b._code_only(a) == b._code_only(same)
+    assert b._code_only(a) != b._code_only(other)
+    assert '"// not a comment"' in b._code_only(a)
