@@ -996,7 +996,7 @@ RMD_HOST_SIMD_CLONES static bool pack_float_rows_u8(const float* src, unsigned c
       unsigned int fb, bb;
       memcpy(&fb, &f, 4);
       memcpy(&bb, &back, 4);
-      bad |= fb ^ bb;
+      bad |= (fb ^ bb) | static_cast<unsigned int>(u >> 8);  // (u > 255: the stand-in for values outside [0, 1])
       out[x] = static_cast<unsigned char>(u);
     }
     if (bad) return false;
