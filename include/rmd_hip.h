@@ -259,6 +259,10 @@ int rmd_hip_reduce_count_eq_i32_raw(const int* dev_data, size_t stride_elems, si
 
 /* ---- self test: the VALU (DPP) wave reductions / scans of the kernels against their shuffle forms; *mismatching_lanes must be 0 */
 int rmd_hip_selftest_wave_primitives(int* mismatching_lanes);
+/* ---- self test (host only, no device needed): the examination that lets a float frame of 8-bit levels travel as bytes (see
+ * rmd_hip_seeds_update).  *all_levels = 1 and `bytes` (height rows of `pitch` bytes) filled if every pixel of the W x H float image has the
+ * bit pattern of (float)k * (1.0f / 255.0f), else 0 (bytes then unspecified). */
+int rmd_hip_selftest_pack_float_frame(const float* host_img, int width, int height, int pitch, unsigned char* bytes, int* all_levels);
 
 /* ---- arithmetic-contract self test (device side of csrc/rmd_math.h) ---------------------- */
 /* op: 0 expf, 1 sinf, 2 acosf, 3 rsqrtf, 4 sqrtf, 5 x/y, 6 lerp(t=x, a=y, b=z); n host floats in, n out */

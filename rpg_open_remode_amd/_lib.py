@@ -90,6 +90,7 @@ SIGNATURES = {
     "rmd_hip_reduce_sum_i32_raw": (_i, [_p, _sz, _sz, _sz, _c.POINTER(_i)]),
     "rmd_hip_reduce_count_eq_i32_raw": (_i, [_p, _sz, _sz, _sz, _i, _c.POINTER(_sz)]),
     "rmd_hip_selftest_wave_primitives": (_i, [_c.POINTER(_i)]),
+    "rmd_hip_selftest_pack_float_frame": (_i, [_c.c_void_p, _i, _i, _i, _c.c_void_p, _c.POINTER(_i)]),
     "rmd_hip_math_eval": (_i, [_i, _p, _p, _p, _p, _sz]),
 }
 

@@ -29,7 +29,7 @@
 #include "ab/rmd_frame_one_launch.hpp"
 #endif
 
-#define RMD_HIP_VERSION_NUMBER 300
+#define RMD_HIP_VERSION_NUMBER 310
 
 
 namespace {
@@ -2427,6 +2427,14 @@ int rmd_hip_reduce_count_eq_i32_raw(const int* dev_data, size_t stride_elems, si
   unsigned long long r = 0;
   TRY(reduce_u64_dev(true, dev_data, stride_elems, width, height, value, &r));
   *count = static_cast<size_t>(r);
+  return RMD_HIP_OK;
+}
+
+// ---- self test of the float-frame examination (host code, the same entry the update path uses) ----
+int rmd_hip_selftest_pack_float_frame(const float* host_img, int width, int height, int pitch, unsigned char* bytes, int* all_levels) {
+  if (!host_img || !bytes || !all_levels || width <= 0 || height <= 0 || pitch < width)
+    return fail(RMD_HIP_ERR_INVALID_ARG, "selftest_pack_float_frame: bad argument");
+  *all_levels = CopyPool::instance().pack(host_img, bytes, width, height, pitch) ? 1 : 0;
   return RMD_HIP_OK;
 }
 

@@ -77,3 +77,39 @@ def test_wave_primitives_selftest():
     bad = ctypes.c_int(-1)
     _lib.check(_lib.lib().rmd_hip_selftest_wave_primitives(ctypes.byref(bad)))
     assert bad.value == 0
+
+
+@pytest.mark.parametrize("wh", [(640, 480), (101, 67), (7, 3)])
+def test_float_frames_of_8bit_levels_are_recognised_on_the_host(wh):
+    """host logic of update(float*): a frame travels as bytes only if EVERY pixel has the bit pattern of (float)k * (1.0f / 255.0f)
+    (depthmap.cpp:105); the bytes are the k.  No device involved."""
+    import ctypes
+    import numpy as np
+    from rpg_open_remode_amd import _lib
+    w, h = wh
+    pitch = (w + 3) // 4 * 4
+    rng = np.random.default_rng(w * 31 + h)
+    gray = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    gray.flat[:256 if w * h >= 256 else w * h] = np.arange(256, dtype=np.uint8)[:min(256, w * h)]  # every level at least once
+    levels = (gray.astype(np.float32) * np.float32(1.0 / 255.0)).astype(np.float32)
+
+    def pack(img):
+        img = np.ascontiguousarray(img, np.float32)
+        out = np.zeros((h, pitch), np.uint8)
+        ok = ctypes.c_int(-1)
+        _lib.check(_lib.lib().rmd_hip_selftest_pack_float_frame(img.ctypes.data, w, h, pitch, out.ctypes.data, ctypes.byref(ok)))
+        return ok.value, out[:, :w]
+
+    ok, got = pack(levels)
+    assert ok == 1 and np.array_equal(got, gray)
+    y, x = h // 3, w // 2
+    for bad in (np.float32(np.nan), np.float32(-0.0), np.float32(1.5), np.float32(2.0), np.float32(-0.25), np.float32(np.inf),
+                np.nextafter(levels[y, x], np.float32(2.0)), np.nextafter(np.float32(0.5), np.float32(0.0)), np.float32(1e-40)):
+        img = levels.copy()
+        img[y, x] = bad
+        assert pack(img)[0] == 0, f"a frame with the pixel {bad!r} was taken for 8-bit levels"
+    for pos in ((0, 0), (h - 1, w - 1), (h // 2, 0)):  # the examination looks at the middle row first and splits the rest: every part must see its pixels
+        img = levels.copy()
+        img[pos] = np.float32(0.1234)
+        assert pack(img)[0] == 0
+    assert pack((levels * np.float32(0.999)).astype(np.float32))[0] == 0
