@@ -402,7 +402,8 @@ def main():
                     for k in range(1, F):
                         s.update(fimgs[k], poses[k])
                 floats = dict(rate(pass_float), path="rmd_hip_seeds_update: float frames in pageable host memory, the reference's own signature "
-                              "(seed_matrix.cu:120-128); the host copy of the frame into the pinned ring is split across a few host threads")
+                              "(seed_matrix.cu:120-128), frames as the reference's host path produces them (convertTo(CV_32F, 1.0f / 255.0f), depthmap.cpp:105): the library "
+                              "finds every pixel to be an 8-bit level, bit pattern by bit pattern, and sends the bytes (DESIGN.md 4.6); the examination is split across a few host threads")
                 del fimgs
 
             # updates 1..20 of a pass: every seed is live and searches its full range (the heaviest twentieth of the job)
