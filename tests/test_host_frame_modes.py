@@ -1,0 +1,65 @@
+"""Every way a host frame can reach the current image (RMD_HIP_HOST_FRAMES, read once per process, hence one child process per mode;
+DESIGN.md 4.6) gives the state of the resident-frame path bit for bit: single sequences with 8-bit frames, float frames of 8-bit
+levels (sent as bytes) and other float frames, and a batch of three with 8-bit frames."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from rpg_open_remode_amd import api, synth
+w, h, side, n = 320, 240, 7, 12
+seq = synth.Sequence(w, h, n, 0)
+cam = api.PinholeCamera(*seq.K)
+other = [(im * np.float32(0.999)).astype(np.float32) for im in seq.images]
+
+def planes_of(images):
+    out = []
+    for im in images:
+        d = api.DeviceImage(w, h, np.float32); d.setDevData(im); out.append(d)
+    return out
+
+def run(kind):
+    s = api.SeedMatrix(w, h, cam, patch_side=side)
+    if kind == "resident" or kind == "resident-other":
+        pl = planes_of(seq.images if kind == "resident" else other)
+        s.setReferenceImageDevice(pl[0].data, pl[0].stride, seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+        for k in range(1, n): s.updateDevice(pl[k].data, pl[k].stride, seq.T_curr_world[k])
+    elif kind == "u8":
+        s.setReferenceImageU8(seq.gray[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+        for k in range(1, n): s.updateU8(seq.gray[k], seq.T_curr_world[k])
+    else:
+        src = seq.images if kind == "f32" else other
+        s.setReferenceImage(src[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+        for k in range(1, n): s.update(src[k], seq.T_curr_world[k])
+    st = s.state()
+    return [np.ascontiguousarray(st[p]).view(np.uint32).copy() for p in sorted(st)]
+
+def same(a, b):
+    return all(np.array_equal(x, y) for x, y in zip(a, b))
+
+want, want_other = run("resident"), run("resident-other")
+assert same(want, run("u8")), "8-bit host frames"
+assert same(want, run("f32")), "float host frames of 8-bit levels"
+assert same(want_other, run("f32-other")), "other float host frames"
+b = api.SeedMatrixBatch(3, w, h, cam, patch_side=side)
+for m in b.members: m.setReferenceImageU8(seq.gray[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+for k in range(1, n): b.updateU8([seq.gray[k]] * 3, [seq.T_curr_world[k]] * 3)
+for i in range(3):
+    st = b[i].state()
+    assert same(want, [np.ascontiguousarray(st[p]).view(np.uint32).copy() for p in sorted(st)]), f"batch member {i}"
+print("MODES-OK")
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["staged", "staged_ahead", "inplace", "inplace_ahead"])
+def test_every_host_frame_mode_equals_the_resident_path(mode):
+    env = dict(os.environ, RMD_HIP_HOST_FRAMES=mode, RMD_HIP_PACK_BACKOFF="0")
+    res = subprocess.run([sys.executable, "-c", CHILD, ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert res.returncode == 0 and "MODES-OK" in res.stdout, res.stdout[-2000:]
