@@ -63,3 +63,42 @@ def test_every_host_frame_mode_equals_the_resident_path(mode):
     env = dict(os.environ, RMD_HIP_HOST_FRAMES=mode, RMD_HIP_PACK_BACKOFF="0")
     res = subprocess.run([sys.executable, "-c", CHILD, ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert res.returncode == 0 and "MODES-OK" in res.stdout, res.stdout[-2000:]
+
+
+GROUPS_CHILD = r'''
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from rpg_open_remode_amd import api, synth
+w, h, side, n, B = 256, 192, 5, 10, 5
+seqs = [synth.Sequence(w, h, n, s) for s in range(B)]
+cam = api.PinholeCamera(*seqs[0].K)
+def bits(st): return [np.ascontiguousarray(st[p]).view(np.uint32).copy() for p in sorted(st)]
+alone = []
+for q in seqs:
+    s = api.SeedMatrix(w, h, cam, patch_side=side)
+    s.setReferenceImage(q.images[0], q.T_curr_world[0], q.min_depth, q.max_depth)
+    for k in range(1, n): s.update(q.images[k], q.T_curr_world[k])
+    alone.append(bits(s.state()))
+b = api.SeedMatrixBatch(B, w, h, cam, patch_side=side)
+for m, q in zip(b.members, seqs): m.setReferenceImage(q.images[0], q.T_curr_world[0], q.min_depth, q.max_depth)
+for k in range(1, n):
+    frames = [q.gray[k] for q in seqs]
+    if k == 4: frames[2] = None  # member 2 sits step 4 out ...
+    b.updateU8(frames, [q.T_curr_world[k] for q in seqs])
+    if k == 4:  # ... and catches up on its own
+        b.updateU8([None, None, seqs[2].gray[4], None, None], [q.T_curr_world[4] for q in seqs])
+for i in range(B):
+    got = bits(b[i].state())
+    assert all(np.array_equal(x, y) for x, y in zip(alone[i], got)), f"member {i}"
+print("GROUPS-OK")
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("groups", [1, 2, 4])
+def test_batch_with_other_numbers_of_stream_groups(groups):
+    """RMD_HIP_BATCH_GROUPS (A/B switch; default three groups, tests/test_batch.py): five different scenes stepped together, one member sitting
+    a step out and catching up alone, equal the sequences stepped on their own bit for bit"""
+    env = dict(os.environ, RMD_HIP_BATCH_GROUPS=str(groups))
+    res = subprocess.run([sys.executable, "-c", GROUPS_CHILD, ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert res.returncode == 0 and "GROUPS-OK" in res.stdout, res.stdout[-2000:]
