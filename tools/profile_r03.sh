@@ -10,12 +10,6 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 SUM=$ROOT/gpurun_out/summary_$TAG
 mkdir -p "$OUT" "$SUM"
 : > "$OUT/commands.txt"
-if [[ $PARTS == *bench* ]]; then
-  echo "== plain default run"
-  timeout 900 python bench.py > "$SUM/${TAG}_bench_default.json" 2> "$OUT/bench_default.err"; tail -c 400 "$SUM/${TAG}_bench_default.json"; echo
-  echo "== as the driver runs it (--steps 20 --warmup 5)"
-  timeout 900 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 --no-extras > "$SUM/${TAG}_bench_steps20.json" 2> "$OUT/bench_steps20.err"
-fi
 cd /tmp
 ONE="--steps 1 --warmup 0 --cpu-seconds 0 --no-extras"
 if [[ $PARTS == *trace* ]]; then
@@ -47,4 +41,13 @@ fi
 cd "$ROOT"
 python tools/summarize_rocprof.py "$OUT" "$SUM" "$TAG" > /dev/null
 python tools/make_traffic.py "$OUT" "$SUM/${TAG}_traffic.json" || true
+# the bench lines come LAST: bench.py takes its instruction counts from profiles/traffic.json and refuses counts of other kernel sources, so the
+# counts of this very run are installed (in the box's copy of the repository; copy them into profiles/ at home as well) before it is started
+if [[ $PARTS == *pmc* && -s "$SUM/${TAG}_traffic.json" ]]; then cp "$SUM/${TAG}_traffic.json" "$ROOT/profiles/traffic.json"; fi
+if [[ $PARTS == *bench* ]]; then
+  echo "== plain default run"
+  timeout 900 python bench.py > "$SUM/${TAG}_bench_default.json" 2> "$OUT/bench_default.err"; tail -c 400 "$SUM/${TAG}_bench_default.json"; echo
+  echo "== as the driver runs it (--steps 20 --warmup 5)"
+  timeout 900 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 --no-extras > "$SUM/${TAG}_bench_steps20.json" 2> "$OUT/bench_steps20.err"
+fi
 ls -la "$SUM"
