@@ -25,6 +25,7 @@ class Publisher:
         self.on_depthmap, self.on_pointcloud, self.on_convergence = on_depthmap, on_pointcloud, on_convergence
         self.verbose = verbose
         self.pc_ = np.zeros((0, 4), np.float32)  # the reference never clears its cloud: every publication appends (publisher.cpp:83)
+        self._pc_store = np.zeros((0, 4), np.float32)  # what pc_ is a view of: grown by doubling, so that appending does not copy the whole cloud every time
 
     def publishDepthmap(self):
         if self.on_depthmap:
@@ -35,7 +36,13 @@ class Publisher:
     def publishPointCloud(self):
         pts = self.depthmap_.downloadPointCloud(denoised=True)
         if len(pts):
-            self.pc_ = np.concatenate([self.pc_, pts], axis=0)
+            n0, n1 = len(self.pc_), len(self.pc_) + len(pts)
+            if self.pc_.base is not self._pc_store or n1 > len(self._pc_store):  # (a caller may have replaced pc_: start from what it holds)
+                store = np.empty((max(2 * n1, 1 << 16), 4), np.float32)
+                store[:n0] = self.pc_
+                self._pc_store = store
+            self._pc_store[n0:n1] = pts
+            self.pc_ = self._pc_store[:n1]
         if len(self.pc_):
             if self.on_pointcloud:
                 self.on_pointcloud(self.pc_)
