@@ -340,6 +340,9 @@ def main():
         hip_denoised = den.denoise(seeds.getMu(), seeds.getSigmaSq(), seeds.getA(), seeds.getB(), TV_LAMBDA, tv_iters, download=True)
         denoise_wall_ms = (time.perf_counter() - td) * 1e3
         tv_ms, tv_launches = den.timing()
+        # the state the TIMED handle ended in (after its last complete pass of 8-bit host frames, or resident frames with --resident): what
+        # parity_vs_glibc_reference compares with the reference's run over the same sequence
+        timed_state = {p: seeds.download(p) for p in range(5)} if (args.cpu_seconds > 0 and world == 1 and F <= 500 and not args.no_extras) else None
 
         counters = load_counters(os.path.join(ROOT, "profiles", "traffic.json")) if headline else None
         fresh = bool(counters) and counters.get("kernel_source_sha256") == kernel_source_sha256()
@@ -501,10 +504,14 @@ def main():
                     if kind == "reference":
                         sys.path.insert(0, os.path.join(ROOT, "tests"))
                         import glibc_parity
-                        hip_state = {p: s2.download(p) for p in range(5)}
                         full = ref_den is not None and n_cpu == F - 1
+                        # the whole sequence fitted the CPU budget: the planes of the handle that ran the TIMED region are compared (and its
+                        # denoised map); a CPU run that was cut short is compared with a second handle stopped at the same update
+                        hip_state = timed_state if (full and timed_state is not None) else {p: s2.download(p) for p in range(5)}
                         glibc = glibc_parity.compare(ref_state, hip_state, ref_den if full else None, hip_denoised if full else None)
                         glibc["after_updates"] = n_cpu
+                        glibc["hip_side"] = ("the handle of the timed region after its last pass (frame source as timed), planes and TV-L1 map" if full and timed_state is not None
+                                             else "a second handle stopped after the same number of updates (frames resident in HBM)")
                         glibc["reference"] = ("the reference's seed_matrix.cu / depthmap_denoiser.cu compiled unmodified for the host against glibc's libm "
                                               "(Oracle A); the HIP path equals that build with expf/sinf/acosf from csrc/rmd_math.h bit for bit")
                         glibc["asserted_in"] = "tests/test_parity_glibc.py"

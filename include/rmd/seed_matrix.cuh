@@ -70,6 +70,13 @@ class SeedMatrix {
     return d;
   }
 
+  // Extension (not in the reference class): the coloured convergence map of Publisher::publishConvergenceMap (publisher.cpp:112-147) on the
+  // device -- gray reference image as BGR, blue = 255 where CONVERGED, red = 255 where DIVERGED; W x H x 3 bytes, packed (the data of a
+  // cv::Mat CV_8UC3): a 3-byte-per-pixel download instead of downloadConvergence + a host loop.
+  void downloadConvergenceBGR8(unsigned char* host_bgr) const {
+    detail::throw_on_error(rmd_hip_seeds_convergence_bgr8(handle_, host_bgr), "SeedMatrix: downloadConvergenceBGR8 failed");
+  }
+
   // Extension (not in the reference class): the loop of Publisher::publishPointCloud (publisher.cpp:54-104) on the device.
   // World-frame (x, y, z, intensity) of every CONVERGED seed, row-major pixel order; `depth` = NULL uses the seeds' own mu,
   // otherwise e.g. DepthmapDenoiser::resultHandle().  Returns the number of converged seeds; at most `capacity` points are written.

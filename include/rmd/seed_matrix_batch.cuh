@@ -19,12 +19,20 @@ class SeedMatrixBatch {
     detail::throw_on_error(rmd_hip_batch_create(static_cast<int>(n), static_cast<int>(width), static_cast<int>(height), cam.fx, cam.fy, cam.cx, cam.cy,
                                                 RMD_CORR_PATCH_SIDE, RMD_MAX_EXTENT_EPIPOLAR_SEARCH, &handle_),
                            "SeedMatrixBatch: unable to create");
-    for (size_t i = 0; i < n; ++i) {
-      rmd_hip_seeds_t* m = NULL;
-      detail::throw_on_error(rmd_hip_batch_member(handle_, static_cast<int>(i), &m), "SeedMatrixBatch: member");
-      members_.push_back(new SeedMatrix(m));
+    try {  // (the destructor does not run for a partly constructed object: release what exists so far, then rethrow)
+      for (size_t i = 0; i < n; ++i) {
+        rmd_hip_seeds_t* m = NULL;
+        detail::throw_on_error(rmd_hip_batch_member(handle_, static_cast<int>(i), &m), "SeedMatrixBatch: member");
+        members_.push_back(new SeedMatrix(m));
+      }
+      poses_.resize(12 * n);
+    } catch (...) {
+      for (size_t i = 0; i < members_.size(); ++i) delete members_[i];
+      members_.clear();
+      rmd_hip_batch_destroy(handle_);
+      handle_ = NULL;
+      throw;
     }
-    poses_.resize(12 * n);
   }
   ~SeedMatrixBatch() {
     for (size_t i = 0; i < members_.size(); ++i) delete members_[i];

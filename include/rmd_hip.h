@@ -155,6 +155,10 @@ int rmd_hip_seeds_undistortion_map(const rmd_hip_seeds_t* s, short* map1_xy, uns
  * depth: an f32 W x H device image (e.g. rmd_hip_denoiser_result) or NULL for the seeds' own mu.  out_xyzi: `capacity` points
  * of 4 floats.  *n_points = number of converged seeds; if it exceeds `capacity` only the first `capacity` points are written. */
 int rmd_hip_seeds_point_cloud(rmd_hip_seeds_t* s, const rmd_hip_image_t* depth, float* out_xyzi, size_t capacity, size_t* n_points);
+/* The coloured convergence map of Publisher::publishConvergenceMap (publisher.cpp:112-147) on the device: the 8-bit reference image as
+ * B = G = R (cv::cvtColor GRAY2BGR), blue = 255 where the seed is CONVERGED, red = 255 where it is DIVERGED.  host_bgr: W x H x 3 bytes,
+ * packed (what cv::Mat CV_8UC3 / sensor_msgs BGR8 hold).  Replaces downloadConvergence (4 B/pixel) + a host loop by a 3 B/pixel download. */
+int rmd_hip_seeds_convergence_bgr8(rmd_hip_seeds_t* s, unsigned char* host_bgr);
 int rmd_hip_seeds_dist_from_ref(const rmd_hip_seeds_t* s, float* dist);
 /* blocks until all work queued by this handle has finished */
 int rmd_hip_seeds_sync(const rmd_hip_seeds_t* s);
@@ -177,6 +181,9 @@ int rmd_hip_seeds_sync(const rmd_hip_seeds_t* s);
 #define RMD_HIP_OPT_SEARCH_FLAGS 8  /* tile pipeline, A/B switches of the search kernel's unit loop (default 6): 1 = claim and fetch the next
                                       unit while the current one is searched, 2 = sixteen hand-out counters instead of one, 4 = use the tile's sample
                                       box that the setup kernel sends along with the unit */
+#define RMD_HIP_OPT_INJECT_FAULT 9  /* test hook: 1 = the arrival flag of the NEXT host frame that travels through a staging buffer is withheld once; that
+                                      update's bounded in-kernel wait (about 0.1 s) runs out, the next synchronising call reports RMD_HIP_ERR_RUNTIME
+                                      once, and the handle is usable again from the next setReferenceImage on (tests/test_full_speed.py) */
 int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value);
 /* kernels of the seed path, for rmd_hip_seeds_timing */
 #define RMD_HIP_STAGE_SEED_INIT 0

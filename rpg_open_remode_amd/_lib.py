@@ -52,6 +52,7 @@ SIGNATURES = {
     "rmd_hip_seeds_upload": (_i, [_p, _i, _p]),
     "rmd_hip_seeds_plane": (_i, [_p, _i, _pp]),
     "rmd_hip_seeds_converged_count": (_i, [_p, _c.POINTER(_sz)]),
+    "rmd_hip_seeds_convergence_bgr8": (_i, [_p, _p]),
     "rmd_hip_seeds_dist_from_ref": (_i, [_p, _c.POINTER(_f)]),
     "rmd_hip_seeds_sync": (_i, [_p]),
     "rmd_hip_seeds_set_option": (_i, [_p, _i, _i]),

@@ -30,6 +30,7 @@ PLANE_MU, PLANE_SIGMA_SQ, PLANE_A, PLANE_B, PLANE_CONVERGENCE = 0, 1, 2, 3, 4
 PLANE_SUM_TEMPL, PLANE_CONST_TEMPL_DENOM, PLANE_EPIPOLAR_MATCHES, PLANE_REF_IMG, PLANE_CURR_IMG = 5, 6, 7, 8, 9
 KIND_F32, KIND_I32, KIND_F32X2 = 0, 1, 2
 OPT_MATCHER, OPT_TIMING, OPT_COLLECT_STATS, OPT_WINDOW, OPT_LAZY_FINALIZE, OPT_LOCAL_MAX, OPT_UNIT_ROUNDS, OPT_UNIT_TARGET, OPT_SEARCH_FLAGS = 0, 1, 2, 3, 4, 5, 6, 7, 8
+OPT_INJECT_FAULT = 9  # test hook, see include/rmd_hip.h
 MATCHER_PIXEL, MATCHER_PIPELINE = 0, 3
 MATCHER_PIPELINE_R01, MATCHER_FRAME = 1, 2  # retired variants: A/B builds of the library only (tools/ab_make.sh)
 STAGE_SEED_INIT, STAGE_UPDATE, STAGE_COUNT = 0, 1, 2
@@ -121,7 +122,7 @@ def _as_pose(T):
     if isinstance(T, SE3):
         T = T.data
     if type(T) is np.ndarray and T.dtype == np.float32 and T.size == 12 and T.flags.c_contiguous:
-        return T  # (the per-frame calls of a streaming host: no temporary)
+        return T.reshape(12)  # a view (the per-frame calls of a streaming host: no temporary)
     return np.ascontiguousarray(T, np.float32).reshape(12)
 
 
@@ -237,19 +238,27 @@ class ImageReducer:
 class SeedMatrix:
     def __init__(self, width, height, cam, patch_side=5, max_extent=100, _member_of=None, _ptr=None):
         self.width, self.height, self.patch_side = int(width), int(height), int(patch_side)
-        self._batch = _member_of  # a member of a SeedMatrixBatch is owned (and kept alive) by the batch
+        self._batch = _member_of  # a member of a SeedMatrixBatch is owned by the batch; this wrapper keeps the batch alive
         if _member_of is not None:
-            self.ptr = _ptr
+            self._handle = _ptr
             return
         h = ctypes.c_void_p()
         check(_lib.lib().rmd_hip_seeds_create(self.width, self.height, cam.fx, cam.fy, cam.cx, cam.cy, int(patch_side),
                                               int(max_extent), ctypes.byref(h)))
-        self.ptr = h.value
+        self._handle = h.value
+
+    @property
+    def ptr(self):
+        """the rmd_hip_seeds_t* of this object.  A batch member's handle dies with its batch (rmd_hip_batch_destroy releases the members): a
+        wrapper that outlives an explicit SeedMatrixBatch.close() raises instead of handing a dangling pointer to the library."""
+        if self._batch is not None and not self._batch.ptr:
+            raise RmdHipError(_lib.ERR_INVALID_ARG, "this SeedMatrix was a member of a batch that has been closed")
+        return self._handle
 
     def close(self):
-        if getattr(self, "ptr", None) and self._batch is None:
-            _lib.lib().rmd_hip_seeds_destroy(self.ptr)
-        self.ptr = None
+        if getattr(self, "_handle", None) and self._batch is None:
+            _lib.lib().rmd_hip_seeds_destroy(self._handle)
+        self._handle = None
 
     def __del__(self):
         try:
@@ -365,6 +374,14 @@ class SeedMatrix:
         n = ctypes.c_size_t()
         check(_lib.lib().rmd_hip_seeds_point_cloud(self.ptr, depth.ptr if depth is not None else None, out.ctypes.data, cap, ctypes.byref(n)))
         return out[:int(n.value)].copy()
+
+    def convergenceBGR8(self, out=None):
+        """The coloured convergence map of Publisher::publishConvergenceMap (publisher.cpp:112-147), computed on the device: (H, W, 3)
+        uint8, the reference image as gray BGR with blue = 255 where CONVERGED, red = 255 where DIVERGED."""
+        if out is None:
+            out = np.empty((self.height, self.width, 3), np.uint8)
+        check(_lib.lib().rmd_hip_seeds_convergence_bgr8(self.ptr, _ptr(out)))
+        return out
 
     def getDistFromRef(self):
         out = ctypes.c_float()
@@ -620,6 +637,11 @@ class Depthmap:
         return self.seeds_.pointCloud(self.denoiser_.result() if denoised else None)
     def getReferenceImage(self): return self.ref_img_8uc1_
     def getConvergedCount(self): return self.seeds_.getConvergedCount()
+
+    def convergenceBGR8(self):
+        """what Publisher::publishConvergenceMap builds from getConvergenceMap() and getReferenceImage() (publisher.cpp:112-147), on the
+        device (no int32 download, no host loop)"""
+        return self.seeds_.convergenceBGR8()
 
     def getConvergedPercentage(self):  # depthmap.cpp:152-156
         return float(np.float32(self.getConvergedCount()) / np.float32(self.width_ * self.height_) * np.float32(100.0))

@@ -319,12 +319,14 @@ struct rmd_hip_seeds {
   float* d_zc_f32[RING] = {};
   unsigned int* h_seq = nullptr;            // pinned, one block per slot: the frame number the copy stream writes into d_zc_flag
   unsigned int* d_zc_flag = nullptr;        // device, one block per ring slot: number of the last frame whose copy into that slot's staging buffer has completed
-  unsigned int* h_submitted = nullptr;      // pinned: [0] / [1] number of the newest 8-bit / float frame that is complete in the ring (one step ahead)
+  unsigned int* h_submitted = nullptr;      // pinned, [kind * RING + slot]: number of the newest 8-bit (kind 0) / float (kind 1) frame that is complete in that ring slot (frames read in place, one step ahead)
   unsigned int* d_ahead = nullptr;          // device: the words of rmdk::MatcherArgs::ahead
   int pack_backoff = 0, pack_backoff_len = 15;  // float frames that are not 8-bit levels: the next pack_backoff_len frames are not examined (pack_float_rows_u8)
   unsigned int* h_progress = nullptr;       // pinned: [0] number of the ingested frame whose setup kernel has started, [1] error bits
   unsigned long long zc_number = 0;         // ingested frames so far (the device sees the low 32 bits and compares modulo 2^32)
   int opt_fused_ingest = 1;                 // RMD_HIP_FUSED_INGEST=0 switches back to the copy-stream pipeline (A/B)
+  bool ingest_ready = false;                // ingest_init has run
+  bool inject_withhold_flag = false;        // test hook (RMD_HIP_OPT_INJECT_FAULT): the arrival flag of the next staged host frame is not sent
   double ingest_us[4] = {0, 0, 0, 0};  // diagnostics (RMD_HIP_INGEST_PROFILE): host time waiting for a slot, copying, submitting; frames
   bool ingest_profile = false, ingest_host_wait = false;
   StageTimer timers[RMD_HIP_NUM_SEED_STAGES];
@@ -335,6 +337,8 @@ struct rmd_hip_seeds {
   unsigned short* d_undist_map2 = nullptr;  // ... and its 5-bit fractions; null = frames are used as they come
   std::vector<short> h_undist_map1;
   std::vector<unsigned short> h_undist_map2;
+  unsigned char* d_bgr = nullptr;       // coloured convergence map (allocated at the first request): W x H x 3 bytes on the device ...
+  unsigned char* h_bgr = nullptr;       // ... and their pinned landing buffer
   unsigned int* d_pc_counts = nullptr;  // point cloud (allocated at the first request): per-block counts / offsets, [n_blocks] = total
   float4* d_pc_points = nullptr;        // W x H points
   rmdk::MatcherWorkspace matcher_ws;
@@ -762,6 +766,8 @@ static int seeds_destroy_impl(rmd_hip_seeds* s) {
 #endif
   if (s->d_undist_map1) (void)hipFree(s->d_undist_map1);
   if (s->d_undist_map2) (void)hipFree(s->d_undist_map2);
+  if (s->d_bgr) (void)hipFree(s->d_bgr);
+  if (s->h_bgr) (void)hipHostFree(s->h_bgr);
   if (s->d_pc_counts) (void)hipFree(s->d_pc_counts);
   if (s->d_pc_points) (void)hipFree(s->d_pc_points);
   if (s->d_scalars) (void)hipFree(s->d_scalars);
@@ -852,7 +858,9 @@ static int seeds_create_impl(int width, int height, float fx, float fy, float cx
   int lds = 0;
   if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, s->device) == hipSuccess && lds > 0) s->mws->lds_bytes = lds;
   if (hipDeviceSynchronize() != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: device synchronisation failed"));  // all fills done
-  if (ingest_init(s) != RMD_HIP_OK) return bail(RMD_HIP_ERR_RUNTIME);  // the copy stream is created right next to the compute stream
+  // the copy stream is created right next to the compute stream.  A batch member's updates go through the BATCH's staging buffers and
+  // progress words: it gets its own (the staging slots of set_reference*) lazily, at its first host reference frame (ingest_reference)
+  if (!batch && ingest_init(s) != RMD_HIP_OK) return bail(RMD_HIP_ERR_RUNTIME);
   *out = s;
   return RMD_HIP_OK;
 }
@@ -881,6 +889,7 @@ int rmd_hip_seeds_set_reference_device(rmd_hip_seeds_t* s, const float* dev_img,
 
 int rmd_hip_seeds_update(rmd_hip_seeds_t* s, const float* host_img, const float* T_curr_world) {
   if (!s || !host_img || !T_curr_world) return fail(RMD_HIP_ERR_INVALID_ARG, "update: null argument");
+  if (s->batch) return fail(RMD_HIP_ERR_INVALID_ARG, "update: this SeedMatrix is a member of a batch; its updates are issued with rmd_hip_batch_update*");
   if (!s->has_reference) return fail(RMD_HIP_ERR_NOT_READY, "update: setReferenceImage has not been called");
   TRY(seeds_bind_device(s));
   // the frame is copied into pinned memory here (the caller's buffer is free on return, as after the reference's blocking
@@ -890,6 +899,7 @@ int rmd_hip_seeds_update(rmd_hip_seeds_t* s, const float* host_img, const float*
 
 int rmd_hip_seeds_update_device(rmd_hip_seeds_t* s, const float* dev_img, size_t stride_elems, const float* T_curr_world) {
   if (!s || !dev_img || !T_curr_world) return fail(RMD_HIP_ERR_INVALID_ARG, "update_device: null argument");
+  if (s->batch) return fail(RMD_HIP_ERR_INVALID_ARG, "update_device: this SeedMatrix is a member of a batch; its updates are issued with rmd_hip_batch_update*");
   if (!s->has_reference) return fail(RMD_HIP_ERR_NOT_READY, "update_device: setReferenceImage has not been called");
   if (stride_elems < static_cast<size_t>(s->width)) return fail(RMD_HIP_ERR_INVALID_ARG, "update_device: stride < width");
   TRY(seeds_bind_device(s));
@@ -915,19 +925,32 @@ int rmd_hip_seeds_update_device(rmd_hip_seeds_t* s, const float* dev_img, size_t
 //   compute   wait until the slot's plane is staged -> this frame's kernels -> mark the slot's plane free
 //     The current image rotates through SLOTS planes; planes[CURR_IMG] always names the one of the latest frame.
 static int ingest_init(rmd_hip_seeds* s) {
-  if (s->h_progress) return RMD_HIP_OK;
+  if (s->ingest_ready) return RMD_HIP_OK;
   if (!s->copy_stream) HIP_TRY(create_stream(&s->copy_stream, 2));  // (a batch member uses the batch's)
   s->ingest_profile = getenv("RMD_HIP_INGEST_PROFILE") != nullptr;
   if (const char* e = getenv("RMD_HIP_INGEST_HOST_WAIT")) s->ingest_host_wait = e[0] == '1';
   if (const char* e = getenv("RMD_HIP_FUSED_INGEST")) s->opt_fused_ingest = e[0] != '0';
   if (const char* e = getenv("RMD_HIP_PACK_BACKOFF")) s->pack_backoff_len = atoi(e);  // (tests: 0 examines every float frame)
+  s->ingest_ready = true;
+  if (s->batch) {  // a member only ever stages REFERENCE frames (ingest_frame: pinned slot -> plane on the copy stream): events, nothing else
+    s->cur_planes[0] = s->planes[RMD_HIP_PLANE_CURR_IMG].data;
+    s->u8_pitch = (s->width + 3) / 4 * 4;
+    for (int k = 0; k < rmd_hip_seeds::SLOTS; ++k) {
+      HIP_TRY(hipEventCreateWithFlags(&s->staged[k], hipEventDisableTiming | hipEventReleaseToDevice));
+      HIP_TRY(hipEventCreateWithFlags(&s->frame_done[k], hipEventDisableTiming | hipEventReleaseToDevice));
+      HIP_TRY(hipEventRecord(s->staged[k], s->copy_stream));
+      HIP_TRY(hipEventRecord(s->frame_done[k], s->stream));
+    }
+    return RMD_HIP_OK;
+  }
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_progress), 64, hipHostMallocMapped));
   s->h_progress[0] = s->h_progress[1] = 0u;
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_seq), rmd_hip_seeds::RING * FLAG_SLOT_WORDS * sizeof(unsigned int), hipHostMallocDefault));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_flag), 2 * rmd_hip_seeds::RING * FLAG_ALLOC_BYTES));  // one flag block per ring slot and kind of frame
   HIP_TRY(hipMemset(s->d_zc_flag, 0, 2 * rmd_hip_seeds::RING * FLAG_ALLOC_BYTES));
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_submitted), 64, hipHostMallocMapped));
-  s->h_submitted[0] = s->h_submitted[1] = 0u;
+  static_assert(2 * rmd_hip_seeds::RING * sizeof(unsigned int) <= 64, "h_submitted");
+  for (int q = 0; q < 2 * rmd_hip_seeds::RING; ++q) s->h_submitted[q] = 0u;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_ahead), 64));
   HIP_TRY(hipMemset(s->d_ahead, 0, 64));
   HIP_TRY(hipStreamSynchronize(nullptr));
@@ -1058,8 +1081,11 @@ class CopyPool {
  private:
   void post() {
     __atomic_store_n(&pending_, n_workers_, __ATOMIC_RELAXED);
-    __atomic_fetch_add(&generation_, 1ull, __ATOMIC_RELEASE);  // publishes the job to the helpers that are polling
-    if (__atomic_load_n(&parked_, __ATOMIC_ACQUIRE) != 0) {    // ... and wakes those that went to sleep
+    // generation_ / parked_ form a store-buffering (Dekker) handshake -- the poster bumps generation_ then reads parked_, a helper bumps
+    // parked_ then reads generation_ --: both sides must be sequentially consistent or each may miss the other (helper asleep, caller
+    // spinning in wait() for ever); release / acquire alone only happens to work where locked RMWs are full fences
+    __atomic_fetch_add(&generation_, 1ull, __ATOMIC_SEQ_CST);  // publishes the job to the helpers that are polling
+    if (__atomic_load_n(&parked_, __ATOMIC_SEQ_CST) != 0) {    // ... and wakes those that went to sleep
       std::lock_guard<std::mutex> lk(m_);
       cv_.notify_all();
     }
@@ -1100,9 +1126,9 @@ class CopyPool {
         cpu_relax();
         if ((++spins & 63u) == 0u && host_now_us() - t0 > kPollUs) {
           std::unique_lock<std::mutex> lk(m_);
-          __atomic_fetch_add(&parked_, 1, __ATOMIC_ACQ_REL);
-          cv_.wait(lk, [&] { return __atomic_load_n(&stop_, __ATOMIC_ACQUIRE) || __atomic_load_n(&generation_, __ATOMIC_ACQUIRE) != seen; });
-          __atomic_fetch_sub(&parked_, 1, __ATOMIC_ACQ_REL);
+          __atomic_fetch_add(&parked_, 1, __ATOMIC_SEQ_CST);
+          cv_.wait(lk, [&] { return __atomic_load_n(&stop_, __ATOMIC_ACQUIRE) || __atomic_load_n(&generation_, __ATOMIC_SEQ_CST) != seen; });
+          __atomic_fetch_sub(&parked_, 1, __ATOMIC_SEQ_CST);
         }
       }
       if (__atomic_load_n(&stop_, __ATOMIC_ACQUIRE)) return;
@@ -1300,7 +1326,8 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
     const size_t fw = flag_words(s->h_progress, n);
     fill_flag_block(s->h_seq + k * FLAG_SLOT_WORDS, n, fw);  // behind the frame on the same stream: when the kernel sees n, the frame is in HBM
     unsigned int* slot_flag = flag_of(as_u8 ? 0 : 1, k);
-    HIP_TRY(hipMemcpyAsync(slot_flag, s->h_seq + k * FLAG_SLOT_WORDS, fw * sizeof(unsigned int), hipMemcpyHostToDevice, s->copy_stream));
+    if (s->inject_withhold_flag) s->inject_withhold_flag = false;  // fault injection: the frame arrives, its flag never does -> the kernel's bounded wait runs out
+    else HIP_TRY(hipMemcpyAsync(slot_flag, s->h_seq + k * FLAG_SLOT_WORDS, fw * sizeof(unsigned int), hipMemcpyHostToDevice, s->copy_stream));
     in.common.flag = slot_flag;
   }
   int plane = 0;  // one plane is enough: setup k writes it after search k - 1 has run (same stream)
@@ -1308,9 +1335,12 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
     const int kind = as_u8 ? 0 : 1, k_next = static_cast<int>((n64 + 1) % rmd_hip_seeds::RING);
     void* dev = nullptr;
     if (in_place) {
-      __atomic_store_n(&s->h_submitted[kind], n, __ATOMIC_RELEASE);  // frame n is complete in the ring
+      // frame n is complete in ITS slot, for ITS kind: the verdict of setup n - 1 read this very word, and setup n's verdict for frame n + 1
+      // reads the word of slot k_next for this kind -- which a frame of the other kind, or a frame two steps ahead, never sets (one word
+      // per kind for the whole ring let setup n take "frame n + 2 of this kind is there" for "frame n + 1 is", and convert stale bytes)
+      __atomic_store_n(&s->h_submitted[kind * rmd_hip_seeds::RING + k], n, __ATOMIC_RELEASE);
       HIP_TRY(hipHostGetDevicePointer(&dev, s->h_submitted, 0));
-      in.common.submitted = static_cast<const unsigned int*>(dev) + kind;
+      in.common.submitted = static_cast<const unsigned int*>(dev) + kind * rmd_hip_seeds::RING + k_next;
       HIP_TRY(hipHostGetDevicePointer(&dev, as_u8 ? static_cast<void*>(s->h_zc_u8[k_next]) : static_cast<void*>(s->h_zc_f32[k_next]), 0));
       in.next_src = dev;
     } else {
@@ -1375,6 +1405,7 @@ int rmd_hip_seeds_set_reference_u8(rmd_hip_seeds_t* s, const unsigned char* host
 
 int rmd_hip_seeds_update_u8(rmd_hip_seeds_t* s, const unsigned char* host_gray, const float* T_curr_world) {
   if (!s || !host_gray || !T_curr_world) return fail(RMD_HIP_ERR_INVALID_ARG, "update_u8: null argument");
+  if (s->batch) return fail(RMD_HIP_ERR_INVALID_ARG, "update_u8: this SeedMatrix is a member of a batch; its updates are issued with rmd_hip_batch_update*");
   if (!s->has_reference) return fail(RMD_HIP_ERR_NOT_READY, "update_u8: setReferenceImage has not been called");
   TRY(seeds_bind_device(s));
   return ingest_current(s, host_gray, nullptr, T_curr_world);
@@ -1560,6 +1591,28 @@ int rmd_hip_seeds_point_cloud(rmd_hip_seeds_t* s, const rmd_hip_image_t* depth, 
   return RMD_HIP_OK;
 }
 
+int rmd_hip_seeds_convergence_bgr8(rmd_hip_seeds_t* s, unsigned char* host_bgr) {
+  if (!s || !host_bgr) return fail(RMD_HIP_ERR_INVALID_ARG, "convergence_bgr8: null argument");
+  if (!s->has_reference) return fail(RMD_HIP_ERR_NOT_READY, "convergence_bgr8: no reference image set");
+  TRY(seeds_bind_device(s));
+  // No flush of the deferred finalisation: it only ever turns UPDATE into NO_MATCH, and neither has a colour (publisher.cpp:124-134);
+  // CONVERGED / DIVERGED were settled by the update's seed_check.  Stream order puts the kernel behind the update.
+  const size_t bytes = static_cast<size_t>(s->width) * s->height * 3;
+  if (!s->d_bgr) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_bgr), (bytes + 15) & ~static_cast<size_t>(15)));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_bgr), bytes));
+  }
+  const long long groups = (static_cast<long long>(s->width) * s->height + 3) / 4;
+  hipLaunchKernelGGL(rmdk::convergence_bgr8_kernel, dim3(static_cast<unsigned int>((groups + 255) / 256)), dim3(256), 0, s->stream, s->P.ref, s->P.conv, s->width,
+                     s->height, s->P.stride, s->d_bgr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(s->h_bgr, s->d_bgr, bytes, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  TRY(ingest_error_check(s->batch ? s->batch->group_of(s->batch_index).h_progress : s->h_progress));
+  memcpy(host_bgr, s->h_bgr, bytes);
+  return RMD_HIP_OK;
+}
+
 int rmd_hip_seeds_dist_from_ref(const rmd_hip_seeds_t* s, float* dist) {
   if (!s || !dist) return fail(RMD_HIP_ERR_INVALID_ARG, "dist_from_ref: null argument");
   *dist = s->dist_from_ref;
@@ -1574,6 +1627,12 @@ int rmd_hip_seeds_sync(const rmd_hip_seeds_t* s) {
 
 int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value) {
   if (!s) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: null handle");
+  // a batch member's updates are launched by the batch (batch_launch), which knows nothing of per-member statistics, per-update event
+  // pairs, eager finalisation or unit targets: accepting such a setting and then ignoring it would leave last_stats / timing stale
+  if (s->batch && ((option == RMD_HIP_OPT_COLLECT_STATS && value != 0) || (option == RMD_HIP_OPT_TIMING && value != 0) ||
+                   (option == RMD_HIP_OPT_LAZY_FINALIZE && value == 0) || option == RMD_HIP_OPT_UNIT_TARGET || option == RMD_HIP_OPT_SEARCH_FLAGS))
+    return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: option %d has no effect on a member of a batch (rmd_hip_batch_set_option sets the batch's timing, unit "
+                                         "target and search flags)", option);
   switch (option) {
     case RMD_HIP_OPT_MATCHER:
 #ifdef RMD_AB_MATCHERS
@@ -1619,6 +1678,11 @@ int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value) {
       return RMD_HIP_OK;
     case RMD_HIP_OPT_LAZY_FINALIZE:
       s->opt_lazy = value != 0;
+      return RMD_HIP_OK;
+    case RMD_HIP_OPT_INJECT_FAULT:
+      if (value != 0 && value != 1) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: fault %d (1 = withhold the arrival flag of the next staged host frame)", value);
+      if (s->batch) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: fault injection is for plain SeedMatrix handles");
+      s->inject_withhold_flag = value == 1;
       return RMD_HIP_OK;
     case RMD_HIP_OPT_WINDOW:
       if (value < 0 || value > 2) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: window %d", value);

@@ -459,6 +459,40 @@ __global__ __launch_bounds__(PC_BLOCK) void pc_write_kernel(PointCloudParams P, 
 }
 
 // ------------------------------------------------------------------------------------------
+// The coloured convergence map of Publisher::publishConvergenceMap (src/publisher.cpp:112-147): cv::cvtColor(ref_img, GRAY2BGR), then
+// channel 0 (blue) = 255 where the seed has CONVERGED, channel 2 (red) = 255 where it has DIVERGED -- a host loop over two images in the
+// reference, after a W x H x int32 download.  Here: 1 + 4 bytes in, 3 bytes out per pixel, and only the 3 cross the bus.  The 8-bit
+// reference image comes back from the float plane the path works on (rint(v * 255) is exact for v = k * (1/255)f, like pc_write_kernel).
+// Four pixels per lane: twelve output bytes = three dwords (rows of the packed W x 3 output need not be dword-aligned: the output is
+// addressed as ONE array of W * H * 3 bytes, groups of four pixels counted over the whole image, the last group may be short).
+__global__ __launch_bounds__(256) void convergence_bgr8_kernel(const float* __restrict__ ref, const int* __restrict__ conv, int w, int h, int stride,
+                                                               unsigned char* __restrict__ out) {
+  const long long n = static_cast<long long>(w) * h;
+  const long long p0 = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) * 4;
+  if (p0 >= n) return;
+  unsigned int b[12];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const long long p = p0 + q < n ? p0 + q : n - 1;
+    const int y = static_cast<int>(p / w), x = static_cast<int>(p - static_cast<long long>(y) * w);
+    const size_t i = static_cast<size_t>(y) * stride + x;
+    const unsigned int g = static_cast<unsigned int>(rintf(ref[i] * 255.0f)) & 0xffu;
+    const int st = conv[i];
+    b[3 * q] = st == ST_CONVERGED ? 255u : g;
+    b[3 * q + 1] = g;
+    b[3 * q + 2] = st == ST_DIVERGED ? 255u : g;
+  }
+  if (p0 + 3 < n) {
+    unsigned int* o = reinterpret_cast<unsigned int*>(out + p0 * 3);  // p0 * 3 is a multiple of 12
+    o[0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+    o[1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+    o[2] = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+  } else {
+    for (long long k = 0; k < (n - p0) * 3; ++k) out[p0 * 3 + k] = static_cast<unsigned char>(b[k]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // TV-L1 denoiser.
 struct TvParams {
   int w, h;

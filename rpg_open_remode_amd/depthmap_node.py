@@ -54,10 +54,15 @@ class Publisher:
         self.publishPointCloud()
 
     def publishConvergenceMap(self):
-        conv = self.depthmap_.getConvergenceMap()
-        colored = np.repeat(self.depthmap_.getReferenceImage()[:, :, None], 3, axis=2)  # CV_GRAY2BGR
-        colored[..., 0][conv == api.ConvergenceStates.CONVERGED] = 255
-        colored[..., 2][conv == api.ConvergenceStates.DIVERGED] = 255
+        """publisher.cpp:112-147.  The library's Depthmap colours the map on the device (rmd_hip_seeds_convergence_bgr8: 3 bytes per pixel
+        cross the bus); any other object with rmd::Depthmap's interface (the CPU tests drive the oracle) gets the reference's host loop."""
+        if hasattr(self.depthmap_, "convergenceBGR8"):
+            colored = self.depthmap_.convergenceBGR8()
+        else:
+            conv = self.depthmap_.getConvergenceMap()
+            colored = np.repeat(self.depthmap_.getReferenceImage()[:, :, None], 3, axis=2)  # CV_GRAY2BGR
+            colored[..., 0][conv == api.ConvergenceStates.CONVERGED] = 255
+            colored[..., 2][conv == api.ConvergenceStates.DIVERGED] = 255
         if self.on_convergence:
             self.on_convergence(colored)
         if self.verbose:
@@ -123,5 +128,6 @@ class DepthmapNode:
         self.publisher_.publishDepthmapAndPointCloud()
 
     def publishConvergenceMap(self):  # :175-182
-        self.depthmap_.downloadConvergenceMap()
+        if not hasattr(self.depthmap_, "convergenceBGR8"):  # (the device colouring reads the convergence plane where it lives)
+            self.depthmap_.downloadConvergenceMap()
         self.publisher_.publishConvergenceMap()

@@ -3,9 +3,35 @@ libm, oracle/_ref/libremode_ref_s<side>.so) -- the figures behind north_star's "
 masks bit-exact".  The HIP path is bit-identical to the reference built with the shared expf/sinf/acosf of csrc/rmd_math.h (A'); A
 and A' differ in the last ulp of those three functions, and the depth filter amplifies a last-ulp difference wherever two NCC
 candidates are nearly tied.  Test infrastructure: used by tests/test_parity_glibc.py (asserted bounds) and by bench.py (reported)."""
+import ctypes
+import platform
+
 import numpy as np
 
 CONVERGED = 1
+PINNED_GLIBC = "2.35"  # csrc/rmd_math.h restates the expf / sinf / acosf of THIS glibc (x86-64, the FMA ifunc variants)
+
+
+def libc_version():
+    """version string of the C library the oracle's libm calls resolve to (None if it is not glibc)"""
+    try:
+        f = ctypes.CDLL(None).gnu_get_libc_version
+        f.restype = ctypes.c_char_p
+        return f().decode()
+    except Exception:
+        return None
+
+
+def require_pinned_glibc():
+    """The "== the reference linked against the system's libm" claims hold where the system's libm IS the one csrc/rmd_math.h restates:
+    glibc 2.35 on x86-64 (2.41+ ships the correctly rounded CORE-MATH acosf / expf, other architectures other ifunc variants).  Elsewhere
+    the comparison is skipped WITH this explanation instead of failing without one; Oracle A with the shared math (ref_rmd) and
+    Oracle B remain the bit-exact checkers there."""
+    import pytest
+    v, m = libc_version(), platform.machine()
+    if v != PINNED_GLIBC or m != "x86_64":
+        pytest.skip(f"needs glibc {PINNED_GLIBC} on x86_64 (this box: glibc {v}, {m}): csrc/rmd_math.h restates that library's expf / sinf / acosf "
+                    f"operation for operation; against another libm the reference build differs in the last ulp of those functions")
 
 
 def compare(ref_state, hip_state, ref_denoised=None, hip_denoised=None, tol=1e-4):

@@ -2,7 +2,7 @@
 
 The oracle (Oracle B, oracle/remode_oracle.cpp) is fast enough to follow the GPU frame by frame even at these sizes, so
 the bar stays BIT-EXACT on every plane; on top of that the two independent device implementations (per-pixel baseline
-kernel, matcher 0, and the load-balanced pipeline, matcher 1) are compared with each other over longer runs, and the
+kernel, matcher 0, and the load-balanced two-launch pipeline, matcher 3) are compared with each other over longer runs, and the
 denoiser's temporally blocked kernel against its one-iteration-per-launch form.
 """
 import os
@@ -106,9 +106,13 @@ class LazySequence:
         return g, np.ascontiguousarray(self.synth.invert_pose(T).astype(np.float32).reshape(12))
 
 
-def _long_run(w, h, n_frames, oracle_updates, compare_every, what):
+def _long_run(w, h, n_frames, oracle_updates, compare_every, what, deep=()):
     """Pipeline (default matcher, 8-bit frames through the ingest path) against the per-pixel kernel over the whole configured
-    length, against the oracle on the first updates (where every seed is live and the searches are longest)."""
+    length, against the oracle on the first updates (where every seed is live and the searches are longest) and again DEEP into the
+    sequence: at every update k0 of `deep` a fresh Oracle B is started from the pipeline's state planes at k0 (mu, sigma_sq, a, b: all
+    the state there is -- the convergence plane is recomputed by every update's seed_check) and follows the next three updates, where
+    most seeds have converged and the work lists are sparse.  (The epipolar-match plane keeps values of EARLIER frames for seeds that
+    found no match since: it is compared by the per-pixel kernel, which has seen those frames; the restarted oracle has not.)"""
     seq = LazySequence(w, h, n_frames)
     cam = api.PinholeCamera(*seq.K)
     hip, base = api.SeedMatrix(w, h, cam, patch_side=9), api.SeedMatrix(w, h, cam, patch_side=9)
@@ -121,6 +125,7 @@ def _long_run(w, h, n_frames, oracle_updates, compare_every, what):
     orc.set_reference(img0, T0, seq.min_depth, seq.max_depth)
     hip.setOption(api.OPT_COLLECT_STATS, 1)
     max_steps_per_seed = 0.0
+    deep_orc, deep_until = None, 0
     for k in range(1, n_frames):
         g, T = seq.frame(k)
         img = synth_float(g)
@@ -136,6 +141,19 @@ def _long_run(w, h, n_frames, oracle_updates, compare_every, what):
                 hip.setOption(api.OPT_COLLECT_STATS, 0)
         elif k % compare_every == 0 or k == n_frames - 1:
             assert_states_equal(base.state(), hip.state(), f"{what}: pipeline vs per-pixel kernel after {k} updates")
+        if k in deep:
+            st = hip.state()
+            deep_orc = O.Seeds(O.OracleLib("port", 9), w, h, seq.K)
+            deep_orc.set_reference(img0, T0, seq.min_depth, seq.max_depth)
+            for p in range(4):
+                deep_orc.upload(p, st[p])
+            deep_until = k + 3
+        elif deep_orc is not None:
+            deep_orc.update(img, T)
+            assert_states_equal(deep_orc.state(), hip.state(), f"{what} update {k} vs an oracle restarted from the state at {deep_until - 3}", planes=range(7))
+            assert hip.getConvergedCount() == deep_orc.converged_count()
+            if k == deep_until:
+                deep_orc = None
     assert hip.getConvergedCount() == base.getConvergedCount()
     return seq, hip, max_steps_per_seed
 
@@ -148,7 +166,7 @@ def synth_float(gray):
 def test_config2_1280x960_500_frames():
     """configs[2] as configured: 1280x960, 500 frames, side 9; the early searches are capped at
     RMD_MAX_EXTENT_EPIPOLAR_SEARCH (143 steps): LDS window sizing."""
-    seq, hip, max_steps_per_seed = _long_run(1280, 960, 500, oracle_updates=6, compare_every=83, what="1280x960")
+    seq, hip, max_steps_per_seed = _long_run(1280, 960, 500, oracle_updates=6, compare_every=83, what="1280x960", deep=(120, 250, 450))
     assert max_steps_per_seed > 30.0, max_steps_per_seed
     assert hip.getConvergedCount() > 0.5 * 1280 * 960
 
@@ -156,7 +174,7 @@ def test_config2_1280x960_500_frames():
 def test_config5_1080p_1000_frames_and_tvl1_500():
     """configs[4] as configured: 1920x1080, 1000 frames, side 9, then denoise(0.5, 500): the blocked TV-L1 kernel against the
     one-iteration-per-launch kernel over all 500 iterations and against the oracle."""
-    seq, hip, _ = _long_run(1920, 1080, 1000, oracle_updates=4, compare_every=199, what="1080p")
+    seq, hip, _ = _long_run(1920, 1080, 1000, oracle_updates=4, compare_every=199, what="1080p", deep=(300, 500, 900))
     outs = []
     for ipl in (0, 1):
         den = api.DepthmapDenoiser(1920, 1080)

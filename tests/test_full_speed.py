@@ -1,0 +1,177 @@
+"""The host-frame paths are timing-dependent BY DESIGN (a ring of pinned slots, arrival flags, frames converted one step ahead inside the
+previous search kernel, link reads in batches: DESIGN.md 4.6), so they are checked where the timing is the benchmark's: 640x480, 200
+frames, patch side 9, every frame handed over at FULL SPEED -- no observer between updates, the host runs ahead of the device as far as
+the ring lets it -- against the same sequence with the frames resident in HBM (no ring, no flags; itself pinned to the oracles and to the
+reference's own kernels by test_full_size.py / test_parity_glibc.py), every state plane, bit for bit:
+
+  * a batch of 8 (scenes 0..7, three stream groups, frames read in place over the host link) and eight stand-alone handles;
+  * one sequence in each RMD_HIP_HOST_FRAMES mode (one child process per mode: the switch is read once), 8-bit frames, float frames of
+    8-bit levels (sent as bytes), and the three kinds of frame alternating;
+  * the error path of a staging copy that never arrives (fault injection: RMD_HIP_OPT_INJECT_FAULT).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracles as O
+from common import assert_states_equal, sequence
+from rpg_open_remode_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H, F, SIDE = 640, 480, 200, 9
+
+
+def _render(scene):
+    """8-bit frames and poses only (eight scenes of float frames would be 2 GB of host memory)"""
+    K = synth.intrinsics(W, H)
+    gray, poses, rng0 = [], [], None
+    for k in range(F):
+        T = synth.pose(k, scene)
+        g, rng = synth.render(W, H, T, scene, want_range=(k == 0), K=K)
+        if k == 0:
+            rng0 = rng
+        gray.append(g)
+        poses.append(np.ascontiguousarray(synth.invert_pose(T).astype(np.float32).reshape(12)))
+    return {"K": K, "gray": gray, "poses": poses, "min": float(rng0.min()), "max": float(rng0.max())}
+
+
+def _bits(st):
+    return [np.ascontiguousarray(st[p]).view(np.uint32).copy() for p in sorted(st)]
+
+
+def _resident_run(sc):
+    """the reference run of one scene: frames resident in HBM, read in place"""
+    s = api.SeedMatrix(W, H, api.PinholeCamera(*sc["K"]), patch_side=SIDE)
+    dev = []
+    for g in sc["gray"]:
+        d = api.DeviceImage(W, H, np.float32)
+        d.setDevData(synth.to_float_image(g))
+        dev.append(d)
+    s.setReferenceImageDevice(dev[0].data, dev[0].stride, sc["poses"][0], sc["min"], sc["max"])
+    for k in range(1, F):
+        s.updateDevice(dev[k].data, dev[k].stride, sc["poses"][k])
+    out = _bits(s.state()), s.getConvergedCount()
+    s.close()
+    return out
+
+
+def test_batch_of_8_and_standalone_vga_200_host_frames_at_full_speed():
+    scenes = [_render(sc) for sc in range(8)]
+    want = [_resident_run(sc) for sc in scenes]
+    assert all(n > 0.5 * W * H for _, n in want), "the benchmark scenes converge for most seeds"
+    names = ["mu", "sigma_sq", "a", "b", "convergence", "sum_templ", "const_templ_denom", "epipolar_matches"]
+    # eight stand-alone handles, 8-bit host frames (default: staging ring + conversion one step ahead), nothing between the updates
+    for i, sc in enumerate(scenes):
+        s = api.SeedMatrix(W, H, api.PinholeCamera(*sc["K"]), patch_side=SIDE)
+        for rep in range(2):  # the second pass finds the ring warm and the host further ahead
+            s.setReferenceImageU8(sc["gray"][0], sc["poses"][0], sc["min"], sc["max"])
+            for k in range(1, F):
+                s.updateU8(sc["gray"][k], sc["poses"][k])
+            got = _bits(s.state())
+            bad = {names[p]: int(np.count_nonzero(want[i][0][p] != got[p])) for p in range(8) if not np.array_equal(want[i][0][p], got[p])}
+            assert not bad, f"scene {i} alone, pass {rep}, 8-bit host frames at full speed: {bad}"
+            assert s.getConvergedCount() == want[i][1]
+        s.close()
+    # the batch of 8: one launch pair per stream group and step, frames read in place from one pinned block
+    b = api.SeedMatrixBatch(8, W, H, api.PinholeCamera(*scenes[0]["K"]), patch_side=SIDE)
+    for rep in range(2):
+        for i, sc in enumerate(scenes):
+            b[i].setReferenceImageU8(sc["gray"][0], sc["poses"][0], sc["min"], sc["max"])
+        for k in range(1, F):
+            b.updateU8([sc["gray"][k] for sc in scenes], [sc["poses"][k] for sc in scenes])
+        for i in range(8):
+            got = _bits(b[i].state())
+            bad = {names[p]: int(np.count_nonzero(want[i][0][p] != got[p])) for p in range(8) if not np.array_equal(want[i][0][p], got[p])}
+            assert not bad, f"batch of 8, member {i}, pass {rep}, 8-bit host frames at full speed: {bad}"
+            assert b[i].getConvergedCount() == want[i][1]
+    b.close()
+
+
+MODE_CHILD = r'''
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from rpg_open_remode_amd import api, synth
+W, H, F, SIDE = 640, 480, 200, 9
+seq = synth.Sequence(W, H, F, 0)
+cam = api.PinholeCamera(*seq.K)
+other = {k: (seq.images[k] * np.float32(0.999)).astype(np.float32) for k in range(F) if k % 3 == 2}
+
+def bits(st): return [np.ascontiguousarray(st[p]).view(np.uint32).copy() for p in sorted(st)]
+def same(a, b): return all(np.array_equal(x, y) for x, y in zip(a, b))
+
+def resident(content):
+    s = api.SeedMatrix(W, H, cam, patch_side=SIDE)
+    d = api.DeviceImage(W, H, np.float32)
+    d.setDevData(content(0))
+    s.setReferenceImageDevice(d.data, d.stride, seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    for k in range(1, F):
+        d2 = api.DeviceImage(W, H, np.float32)
+        d2.setDevData(content(k))
+        s.updateDevice(d2.data, d2.stride, seq.T_curr_world[k])
+        s.sync()
+        d = d2
+    return bits(s.state())
+
+plain = lambda k: seq.images[k]
+mixed = lambda k: other[k] if (k % 3 == 2 and k > 0) else seq.images[k]
+want_plain, want_mixed = resident(plain), resident(mixed)
+
+def host(kind_of_frame):
+    """all F - 1 updates at full speed: kind_of_frame(k) in 'u8' (8-bit), 'f32' (float: levels travel as bytes, others as floats)"""
+    s = api.SeedMatrix(W, H, cam, patch_side=SIDE)
+    out = []
+    for rep in range(2):
+        s.setReferenceImage(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+        for k in range(1, F):
+            kind, img = kind_of_frame(k)
+            (s.updateU8 if kind == "u8" else s.update)(img, seq.T_curr_world[k])
+        out.append(bits(s.state()))
+    return out
+
+for rep, got in enumerate(host(lambda k: ("u8", seq.gray[k]))):
+    assert same(want_plain, got), f"8-bit host frames at full speed, pass {rep}"
+for rep, got in enumerate(host(lambda k: ("f32", seq.images[k]))):
+    assert same(want_plain, got), f"float host frames of 8-bit levels at full speed, pass {rep}"
+# the three kinds alternating: 8-bit, float of 8-bit levels (sent as bytes), other floats (sent as floats)
+for rep, got in enumerate(host(lambda k: ("u8", seq.gray[k]) if k % 3 == 0 else ("f32", seq.images[k]) if k % 3 == 1 else ("f32", other[k]))):
+    assert same(want_mixed, got), f"alternating kinds of host frame at full speed, pass {rep}"
+print("FULL-SPEED-MODES-OK")
+'''
+
+
+@pytest.mark.parametrize("mode", ["staged", "staged_ahead", "inplace", "inplace_ahead"])
+def test_single_sequence_vga_200_in_every_host_frame_mode_at_full_speed(mode):
+    env = dict(os.environ, RMD_HIP_HOST_FRAMES=mode, RMD_HIP_PACK_BACKOFF="0")
+    res = subprocess.run([sys.executable, "-c", MODE_CHILD, ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert res.returncode == 0 and "FULL-SPEED-MODES-OK" in res.stdout, res.stdout[-3000:]
+
+
+def test_a_staging_copy_that_never_arrives_is_reported_once_and_the_handle_recovers():
+    """fault injection (RMD_HIP_OPT_INJECT_FAULT): the arrival flag of one staged frame is withheld; the ingest workgroups of that update
+    give up after their bounded wait (about 0.1 s), the next synchronising call reports the error ONCE, and from the next setReferenceImage on
+    the handle is as good as new (rmd_frame.hpp: the bounded spin; rmd_capi.hip: ingest_error_check)"""
+    seq = sequence(192, 144, 10)
+    s = api.SeedMatrix(seq.width, seq.height, api.PinholeCamera(*seq.K), patch_side=5)
+    s.setReferenceImageU8(seq.gray[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    for k in range(1, 4):
+        s.updateU8(seq.gray[k], seq.T_curr_world[k])
+    s.sync()
+    s.setOption(api.OPT_INJECT_FAULT, 1)
+    s.updateU8(seq.gray[4], seq.T_curr_world[4])  # its flag never arrives
+    with pytest.raises(api.RmdHipError, match="staging copy"):
+        s.sync()
+    s.sync()  # reported once, then cleared
+    s.updateU8(seq.gray[5], seq.T_curr_world[5])  # (the state is declared invalid until the next reference frame; the call itself works)
+    s.sync()
+    orc = O.Seeds(O.OracleLib("port", 5), seq.width, seq.height, seq.K)
+    s.setReferenceImageU8(seq.gray[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    orc.set_reference(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    for k in range(1, 10):
+        s.updateU8(seq.gray[k], seq.T_curr_world[k])
+        orc.update(seq.images[k], seq.T_curr_world[k])
+    assert_states_equal(orc.state(), s.state(), "after the injected fault and a new reference frame")
+    assert s.getConvergedCount() == orc.converged_count()

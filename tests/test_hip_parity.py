@@ -337,7 +337,7 @@ def test_denoiser_bit_exact_large_image_geometry(iters_per_launch):
 
 def test_denoiser_after_sequence_matches_oracle_and_reference_kernel():
     seq = sequence(160, 120, 25)
-    hip, orc = _compare_run(seq, 5, 1, 24, check_every=24)
+    hip, orc = _compare_run(seq, 5, 3, 24, check_every=24)  # the production pipeline (matcher 3)
     d = api.DepthmapDenoiser(seq.width, seq.height)
     d.setLargeSigmaSq(seq.max_depth - seq.min_depth)
     got = d.denoise(hip.getMu(), hip.getSigmaSq(), hip.getA(), hip.getB(), 0.5, 60)
@@ -526,6 +526,43 @@ def test_point_cloud_ragged_size_and_intensity_round_trip():
     got = s.pointCloud()
     assert O.count_mismatch(want, got) == 0
     assert set(np.unique(got[:, 3]).astype(int)) == set(range(256))
+
+
+def _publisher_colouring(ref_u8, conv):
+    """Publisher::publishConvergenceMap (publisher.cpp:112-147): cv::cvtColor(ref_img, GRAY2BGR), then [0] = 255 for CONVERGED, [2] = 255 for
+    DIVERGED.  (The reference's own publisher.cpp, compiled unmodified, is compared with the node in test_reference_host_sources.py.)"""
+    out = np.repeat(ref_u8[:, :, None], 3, axis=2)
+    out[..., 0][conv == api.ConvergenceStates.CONVERGED] = 255
+    out[..., 2][conv == api.ConvergenceStates.DIVERGED] = 255
+    return out
+
+
+@pytest.mark.parametrize("wh", [(101, 67), (203, 131), (640, 480), (33, 19)])
+def test_convergence_colouring_on_the_device_equals_the_publisher_loop(wh):
+    """rmd_hip_seeds_convergence_bgr8: every state present (adversarial planes: CONVERGED, DIVERGED, UPDATE, NO_MATCH, BORDER), every 8-bit
+    level as reference intensity, widths that are not multiples of four (the packed W x 3 rows are not dword-aligned), with the update's
+    finalisation still deferred and after an observer has forced it"""
+    w, h = wh
+    seq = sequence(w, h, 4)
+    s = api.SeedMatrix(w, h, api.PinholeCamera(*seq.K), patch_side=3)
+    with pytest.raises(api.RmdHipError):
+        s.convergenceBGR8()  # no reference yet
+    ramp = ((np.arange(w * h) * 7) % 256).astype(np.uint8).reshape(h, w)
+    s.setReferenceImageU8(ramp, seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    st = random_state(w, h, seq, np.random.default_rng(99), 3)
+    for p in range(4):
+        s.upload(p, st[p])
+    s.updateU8(seq.gray[1], seq.T_curr_world[1])
+    got_deferred = s.convergenceBGR8()  # the finalisation of this update is still pending: UPDATE / NO_MATCH have no colour either way
+    conv = s.downloadConvergence()      # (forces it)
+    got = s.convergenceBGR8()
+    want = _publisher_colouring(ramp, conv)
+    assert got.shape == (h, w, 3) and got.dtype == np.uint8
+    assert np.array_equal(want, got) and np.array_equal(want, got_deferred)
+    if w * h > 2000:
+        assert (conv == api.ConvergenceStates.CONVERGED).any() and (conv == api.ConvergenceStates.DIVERGED).any()
+    s.updateU8(seq.gray[2], seq.T_curr_world[2])
+    assert np.array_equal(_publisher_colouring(ramp, s.downloadConvergence()), s.convergenceBGR8())
 
 
 @pytest.mark.gpu

@@ -18,6 +18,8 @@ def _eval(fn, xs):
 def test_transcendentals_equal_the_host_libm_on_a_strided_sample_of_all_floats():
     """every 1021st float (4.2 million arguments per function, all exponents, both signs, NaNs and infinities included); the full
     run (`oracle/libm_exhaustive 1`, ~30 s on 8 cores) was 0 differences of 3 x 2^32 on glibc 2.35 / x86-64 with FMA"""
+    import glibc_parity
+    glibc_parity.require_pinned_glibc()
     exe = os.path.join(O.ORACLE_DIR, "libm_exhaustive")
     if not os.path.exists(exe):
         import pytest

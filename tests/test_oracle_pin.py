@@ -207,6 +207,8 @@ def test_reference_with_system_libm_equals_reference_with_shared_math(side):
     bit-identical to the UNMODIFIED reference as it builds on this host.  (Until round 3 the shared functions were correctly
     rounded fp64 evaluations, <= 1 ulp from glibc's, and 199 updates amplified that to an RMSE of 3.6e-4 m at 640x480,
     profiles/r03_parity_glibc.txt.)"""
+    import glibc_parity
+    glibc_parity.require_pinned_glibc()
     seq = sequence(160, 120, 31)
     _, ref = _run("ref", side, seq, 30)
     _, port = _run("ref_rmd", side, seq, 30)

@@ -25,6 +25,7 @@ def _more_oracle_threads():
 
 
 def test_config1_equals_the_untouched_reference():
+    glibc_parity.require_pinned_glibc()
     if not O.available("ref", 9):
         pytest.skip("oracle/_ref not present")
     seq = sequence(640, 480, 200)

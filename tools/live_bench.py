@@ -41,7 +41,7 @@ if a.breakdown:
     timed(dm, "downloadDenoisedDepthmap", "TV-L1 denoise + download")
     timed(dm, "downloadConvergenceMap", "convergence map download")
     timed(dm, "downloadPointCloud", "point cloud (device compaction + download)")
-    timed(node.publisher_, "publishConvergenceMap", "convergence map colouring on the host (numpy)")
+    timed(node.publisher_, "publishConvergenceMap", "coloured convergence map (device kernel + 3 B/pixel download)")
     timed(node.publisher_, "publishPointCloud", "point cloud publication incl. the growing host-side concatenation")
 for rep in range(2):  # ONE node, two passes over the sequence: the first pays for every buffer the library allocates on first use
     node.state_ = State.TAKE_REFERENCE_FRAME
