@@ -108,11 +108,14 @@ def header_functions():
 def lib():
     global _LIB
     if _LIB is None:
-        if not os.path.exists(LIB_PATH):
+        # RMD_HIP_LIB: another build of the SAME library (A/B variants under build_ab/, tools/ab_make.sh) -- a measurement switch, not a
+        # fallback: the file must exist and export every symbol of the header like the product build
+        path = os.environ.get("RMD_HIP_LIB") or LIB_PATH
+        if not os.path.exists(path):
             raise RuntimeError(
-                f"{LIB_PATH} not found: the HIP extension has not been built "
+                f"{path} not found: the HIP extension has not been built "
                 "(run `python -m rpg_open_remode_amd.build`); there is no CPU fallback")
-        L = ctypes.CDLL(LIB_PATH)
+        L = ctypes.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args

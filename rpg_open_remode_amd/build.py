@@ -53,8 +53,9 @@ def hipcc_path():
     raise RuntimeError("hipcc not found")
 
 
-def build_hip(force=False, verbose=False, extra_flags=()):
-    out = os.path.join(HERE, "librmd_hip.so")
+def build_hip(force=False, verbose=False, extra_flags=(), out=None):
+    """out: another file name (A/B variants, tools/ab_make.sh; selected at run time with RMD_HIP_LIB); default: the product library"""
+    out = out or os.path.join(HERE, "librmd_hip.so")
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h"))]
     srcs.append(os.path.join(ROOT, "include", "rmd_hip.h"))
     if force or _newer(out, srcs):

@@ -444,8 +444,14 @@ RMDK_D void ncc_sums_lds_pipelined(const float* __restrict__ base, int stride, c
         const float img = rmd_lerp(by, hprev[k], hcur[k]);
         const float templ = tm[cur][k];
         sum_img += img;
+#ifdef RMD_EXPERIMENT_FMA  // diagnostics build (tools/ab_make.sh fma -DRMD_EXPERIMENT_FMA): what a contracted arithmetic contract would gain -- the
+                           // reference's own nvcc build contracts these two (CMakeLists.txt:25); NOT the product's arithmetic, results differ
+        sum_img_sq = __builtin_fmaf(img, img, sum_img_sq);
+        sum_img_templ = __builtin_fmaf(img, templ, sum_img_templ);
+#else
         sum_img_sq += img * img;
         sum_img_templ += img * templ;
+#endif
       }
     }
 #pragma unroll

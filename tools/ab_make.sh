@@ -7,7 +7,6 @@ mkdir -p build_ab
 python - <<PY
 import os, shutil
 from rpg_open_remode_amd import build
-out = build.build_hip(force=True, extra_flags="$2".split())
-shutil.copy(out, os.path.join("build_ab", "librmd_hip_$1.so"))
+out = build.build_hip(force=True, extra_flags="$2".split(), out=os.path.join("build_ab", "librmd_hip_$1.so"))
 PY
 echo "built build_ab/librmd_hip_$1.so"

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Per-update work of the benchmark sequence (live seeds, search steps visited, NCC evaluations): one pass with the diagnostics counters on.
+usage: python tools/frame_stats.py out.json [--size WxH] [--frames F]"""
+import argparse, json, os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from rpg_open_remode_amd import api, synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("out"); ap.add_argument("--size", default="640x480"); ap.add_argument("--frames", type=int, default=200); ap.add_argument("--side", type=int, default=9)
+a = ap.parse_args()
+W, H = (int(v) for v in a.size.split("x"))
+K = synth.intrinsics(W, H)
+s = api.SeedMatrix(W, H, api.PinholeCamera(*K), patch_side=a.side)
+s.setOption(api.OPT_COLLECT_STATS, 1)
+out = {"live": [], "steps": [], "evals": []}
+for k in range(a.frames):
+    T = synth.pose(k, 0)
+    g, rng = synth.render(W, H, T, 0, want_range=(k == 0), K=K)
+    Tcw = np.ascontiguousarray(synth.invert_pose(T).astype(np.float32).reshape(12))
+    if k == 0:
+        s.setReferenceImageU8(g, Tcw, float(rng.min()), float(rng.max()))
+        continue
+    s.updateU8(g, Tcw)
+    st = s.lastStats()
+    out["live"].append(st["live_seeds"]); out["steps"].append(st["steps"]); out["evals"].append(st["ncc_evals"])
+json.dump(out, open(a.out, "w"))
+print(f"{a.frames - 1} updates: mean live seeds {np.mean(out['live']):.0f}, mean NCC evaluations {np.mean(out['evals']):.0f}")
