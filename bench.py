@@ -75,6 +75,8 @@ def parse():
     ap.add_argument("--resident", action="store_true", help="timed region with the frames already resident in HBM (rmd_hip_seeds_update_device) instead "
                     "of 8-bit frames from host memory; the line says so")
     ap.add_argument("--batch", default="2,4,8", help="batch sizes of the batched_per_gpu section (empty: skip it)")
+    ap.add_argument("--batch-per-gpu", type=int, default=1, help="B independent sequences per rank, stepped as ONE batch (rmd_hip_batch_*): rank r runs scenes "
+                    "r*B .. r*B+B-1; the headline stays whole-job pixels / max elapsed.  Default 1: one sequence per GPU (the driver's BENCH / SCALE lines)")
     ap.add_argument("--dist", action="store_true", help="create the torch.distributed (RCCL) group even for a single rank")
     ap.add_argument("--no-extras", action="store_true", help="the timed region and the denoise only (profiling runs)")
     ap.add_argument("--rendezvous-only", action="store_true", help="launch-path check, no measurement: join the process group (gloo when "
@@ -131,7 +133,10 @@ def load_counters(path):
         return None
 
 
-def valu_roofline(avg_launch_s, counters, n_sequences=1):
+NCC_VALU_PER_WAVE_EVALUATION = {9: 851}  # VALU instructions of one NCC evaluation of 64 lanes (the filter + accumulate block), by patch side
+
+
+def valu_roofline(avg_launch_s, counters, n_sequences=1, ncc_evals_per_update=None):
     """The roof that actually binds the seed update: VALU issue.  Wave-instruction counts per update() come from
     the committed PMC pass over the same complete passes (profiles/traffic.json, SQ_INSTS_VALU) -- accepted only if that file was
     measured on the kernel sources of this build --, the launch time from this run."""
@@ -145,7 +150,14 @@ def valu_roofline(avg_launch_s, counters, n_sequences=1):
     except Exception:
         return None
     achieved = n / avg_launch_s / 1e9
-    return {"bound": "valu", "kernel": "seed_update", "achieved": round(achieved, 1), "peak": round(VALU_PEAK_GINST_S, 1),
+    useful = None
+    if ncc_evals_per_update and SIDE in NCC_VALU_PER_WAVE_EVALUATION:
+        # how much of what the chip issues is the arithmetic the reference prescribes: NCC evaluations / 64 lanes x the block's instruction count
+        # over ALL VALU wave-instructions of the update (setup + search; the rest is unit set-up, item decode, window staging, the fused
+        # finalisation, partly filled waves)
+        useful = round(float(ncc_evals_per_update) / 64.0 * NCC_VALU_PER_WAVE_EVALUATION[SIDE] * n_sequences / n, 4)
+    return {"bound": "valu", "kernel": "seed_update", "achieved": round(achieved, 1), "peak": round(VALU_PEAK_GINST_S, 1), "useful_valu_frac": useful,
+            "per_kernel": {k: int(v) for k, v in counters["valu_wave_instructions_per_update"].items()},
             "unit": "G wave-instructions/s", "frac": round(achieved / VALU_PEAK_GINST_S, 4),
             "sustained_peak": round(VALU_SUSTAINED_GINST_S, 1), "frac_of_sustained": round(achieved / VALU_SUSTAINED_GINST_S, 4),
             "sustained_peak_note": "what pure fp32 fma / add / mul streams reach on this part at four waves per SIMD, weighted by the NCC block's mix "
@@ -205,6 +217,24 @@ def cpu_reference_run(frame_fn, width, height, K, n_frames, side, min_depth, max
     return out, n, state, den, kind
 
 
+def scenes_of_rank(rank, batch_per_gpu):
+    """the independent sequences (scene / trajectory seeds) rank `rank` runs: B consecutive ones, stepped together as one batch"""
+    return [rank * batch_per_gpu + i for i in range(batch_per_gpu)]
+
+
+class BatchAsSeeds:
+    """the few SeedMatrix methods the timed region uses, on a SeedMatrixBatch (--batch-per-gpu)"""
+
+    def __init__(self, bm):
+        self.bm = bm
+
+    def sync(self): self.bm.sync()
+    def setOption(self, option, value): self.bm.setOption(option, value)
+    def timingReset(self): self.bm.timingReset()
+    def timing(self, stage): return self.bm.timing()  # (device ms of the region, steps in it)
+    def getConvergedCount(self): return sum(self.bm[i].getConvergedCount() for i in range(self.bm.n))
+
+
 def main():
     args = parse()
     W, H, F, tv_iters = resolve_workload(args)
@@ -225,11 +255,13 @@ def main():
         # the control plane of a --gpus N launch and nothing else (tests/test_bench_cpu.py runs it under torch.distributed.run
         # with two ranks on the CPU): same barrier / gather / rank-0-prints sequence as the measurement below
         batch.barrier()
-        max_e, total_u, per_rank = batch.gather_throughput(0.001 * (rank + 1), float(rank + 1), None, extra=(float(local_rank), 0.0))
+        Bq = max(1, args.batch_per_gpu)
+        max_e, total_u, per_rank = batch.gather_throughput(0.001 * (rank + 1), float(rank + 1), None, extra=(float(local_rank), 0.0, float(Bq)))
         batch.barrier()
         if rank == 0:
             print(json.dumps({"rendezvous": "ok", "n_gpus": world, "control_plane": batch.backend_name(), "max_elapsed_s": max_e,
-                              "total_units": total_u, "per_rank": [list(r) for r in per_rank]}), flush=True)
+                              "total_units": total_u, "per_rank": [list(r) for r in per_rank], "batch_per_gpu": Bq,
+                              "scenes_of_rank": [scenes_of_rank(r, Bq) for r in range(world)]}), flush=True)
         import torch.distributed as dist
         if dist.is_initialized():
             dist.destroy_process_group()
@@ -264,8 +296,13 @@ def main():
                 dev.append(d)
         return {"gray": gray, "poses": poses, "dev": dev, "min": float(rng0.min()), "max": float(rng0.max())}
 
+    B = max(1, args.batch_per_gpu)
+    if B > api.MAX_BATCH:
+        raise SystemExit(f"--batch-per-gpu {B}: a batch holds at most {api.MAX_BATCH} sequences")
+    my_scenes = scenes_of_rank(rank, B)
     t_render = time.perf_counter()
-    seq = render_scene(rank, True)
+    seq = render_scene(my_scenes[0], True)
+    batch_scenes = [seq] + [render_scene(sc, args.resident) for sc in my_scenes[1:]]
     render_s = time.perf_counter() - t_render
     gray, poses, frames = seq["gray"], seq["poses"], seq["dev"]
     min_depth, max_depth = seq["min"], seq["max"]
@@ -290,6 +327,24 @@ def main():
             s.updateU8(gray[k], poses[k])
 
     run_pass = pass_resident if args.resident else pass_u8
+    bm = None
+    if B > 1:  # the rank's B sequences as ONE batch: one setup + one search launch per stream group and step
+        bm = api.SeedMatrixBatch(B, W, H, api.PinholeCamera(*K), patch_side=SIDE)
+        bm.setOption(api.OPT_UNIT_TARGET, args.unit_target)
+
+        def run_pass(_s, n_updates=None):
+            sc = batch_scenes
+            for i in range(B):
+                if args.resident:
+                    bm[i].setReferenceImageDevice(sc[i]["dev"][0].data, sc[i]["dev"][0].stride, sc[i]["poses"][0], sc[i]["min"], sc[i]["max"])
+                else:
+                    bm[i].setReferenceImageU8(sc[i]["gray"][0], sc[i]["poses"][0], sc[i]["min"], sc[i]["max"])
+            for k in range(1, (F if n_updates is None else n_updates + 1)):
+                p = [sc[i]["poses"][k] for i in range(B)]
+                if args.resident:
+                    bm.updateDevice([sc[i]["dev"][k].data for i in range(B)], [sc[i]["dev"][k].stride for i in range(B)], p)
+                else:
+                    bm.updateU8([sc[i]["gray"][k] for i in range(B)], p)
 
     def timed(s, one_pass, passes):
         """(wall seconds, device ms of the region, update() calls in it) of `passes` complete passes"""
@@ -305,7 +360,7 @@ def main():
         s.setOption(api.OPT_TIMING, 0)
         return dt, ms, n
 
-    seeds = new_seeds()
+    seeds = BatchAsSeeds(bm) if bm is not None else new_seeds()
     for _ in range(args.warmup):  # W untimed passes (clocks, code objects, allocator, staging buffers)
         run_pass(seeds)
     seeds.sync()
@@ -324,42 +379,50 @@ def main():
     kernel_ms, kernel_updates = seeds.timing(api.STAGE_UPDATE)  # device time of the region / update() calls in it
     seeds.setOption(api.OPT_TIMING, 0)
     converged = seeds.getConvergedCount()
-    n_updates = (F - 1) * args.steps
-    units = float(W * H * n_updates)
-    max_elapsed, total_units, per_rank = batch.gather_throughput(elapsed, units, device, extra=(float(n_updates), float(converged)))
+    n_updates = (F - 1) * args.steps          # update() calls of ONE sequence; a batch steps B sequences per call
+    units = float(W * H * n_updates * B)
+    max_elapsed, total_units, per_rank = batch.gather_throughput(elapsed, units, device, extra=(float(n_updates * B), float(converged), float(B)))
 
     # ---- the rest is reporting on rank 0; other ranks idle at the final barrier
     result = None
     if rank == 0:
         # denoiser of the config (reported beside the metric, not inside it)
-        den = api.DepthmapDenoiser(W, H)
-        den.setLargeSigmaSq(max_depth - min_depth)
-        den.setOption(api.DENOISE_OPT_TIMING, 1)
-        den.denoise(seeds.getMu(), seeds.getSigmaSq(), seeds.getA(), seeds.getB(), TV_LAMBDA, 10, download=True)  # warm
-        td = time.perf_counter()
-        hip_denoised = den.denoise(seeds.getMu(), seeds.getSigmaSq(), seeds.getA(), seeds.getB(), TV_LAMBDA, tv_iters, download=True)
-        denoise_wall_ms = (time.perf_counter() - td) * 1e3
-        tv_ms, tv_launches = den.timing()
+        if bm is not None:  # the B depth maps of the batch in one launch sequence (rmd_hip_batch_denoise)
+            ranges = [sc["max"] - sc["min"] for sc in batch_scenes]
+            bm.denoise(ranges, TV_LAMBDA, 10)  # warm
+            td = time.perf_counter()
+            hip_denoised = bm.denoise(ranges, TV_LAMBDA, tv_iters)[0]
+            denoise_wall_ms = (time.perf_counter() - td) * 1e3
+            tv_ms, tv_launches = bm.denoiseTiming()
+        else:
+            den = api.DepthmapDenoiser(W, H)
+            den.setLargeSigmaSq(max_depth - min_depth)
+            den.setOption(api.DENOISE_OPT_TIMING, 1)
+            den.denoise(seeds.getMu(), seeds.getSigmaSq(), seeds.getA(), seeds.getB(), TV_LAMBDA, 10, download=True)  # warm
+            td = time.perf_counter()
+            hip_denoised = den.denoise(seeds.getMu(), seeds.getSigmaSq(), seeds.getA(), seeds.getB(), TV_LAMBDA, tv_iters, download=True)
+            denoise_wall_ms = (time.perf_counter() - td) * 1e3
+            tv_ms, tv_launches = den.timing()
         # the state the TIMED handle ended in (after its last complete pass of 8-bit host frames, or resident frames with --resident): what
         # parity_vs_glibc_reference compares with the reference's run over the same sequence
-        timed_state = {p: seeds.download(p) for p in range(5)} if (args.cpu_seconds > 0 and world == 1 and F <= 500 and not args.no_extras) else None
+        timed_state = {p: seeds.download(p) for p in range(5)} if (args.cpu_seconds > 0 and world == 1 and F <= 500 and not args.no_extras and bm is None) else None
 
         counters = load_counters(os.path.join(ROOT, "profiles", "traffic.json")) if headline else None
         fresh = bool(counters) and counters.get("kernel_source_sha256") == kernel_source_sha256()
         avg_kernel_s = kernel_ms / max(kernel_updates, 1) / 1e3
-        achieved = FUSED_BYTES_PER_PIXEL * W * H / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+        achieved = FUSED_BYTES_PER_PIXEL * W * H * B / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0  # (a batch step updates B sequences)
         roofline = {"bound": "hbm", "kernel": "seed_update (fused seed_check+epipolar_match+triangulation+seed_update)",
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5),
                     "traffic": counters.get("seed_update_bytes_per_launch") if fresh else None,
                     "avg_launch_us": round(avg_kernel_s * 1e6, 2), "launches": kernel_updates,
-                    "algorithmic_bytes_per_launch": FUSED_BYTES_PER_PIXEL * W * H,
+                    "algorithmic_bytes_per_launch": FUSED_BYTES_PER_PIXEL * W * H * B, "sequences_per_launch": B,
                     "note": "device time of the timed region (one HIP event pair on the kernels' stream, seed_init of each pass "
                             "included) / update() calls; epipolar_match is VALU/LDS-bound (hundreds of flop per compulsory "
                             "byte), see roofline_valu / roofline_flops and DESIGN.md"}
         tv_avg_s = tv_ms / max(tv_launches, 1) / 1e3
         tv_iters_per_launch = tv_iters / max(tv_launches, 1)
-        tv_achieved = TV_BYTES_PER_PIXEL_ITER * W * H * tv_iters_per_launch / tv_avg_s / 1e9 if tv_avg_s > 0 else 0.0
+        tv_achieved = TV_BYTES_PER_PIXEL_ITER * W * H * B * tv_iters_per_launch / tv_avg_s / 1e9 if tv_avg_s > 0 else 0.0
         tv_traffic = None
         if fresh:
             tv_traffic = (counters.get("tv_bytes_per_launch") or {}).get(f"{W}x{H}")
@@ -367,11 +430,11 @@ def main():
                        "unit": "GB/s", "frac": round(tv_achieved / HBM_PEAK_GBS, 5), "traffic": tv_traffic,
                        "avg_launch_us": round(tv_avg_s * 1e6, 2), "launches": tv_launches,
                        "iterations_per_launch": round(tv_iters_per_launch, 2),
-                       "denoise_wall_ms": round(denoise_wall_ms, 3), "iterations": tv_iters}
+                       "denoise_wall_ms": round(denoise_wall_ms, 3), "iterations": tv_iters, "depth_maps_per_launch": B}
 
         search_stats, cpu, glibc, resident, floats, heavy, batched, other_path = None, None, None, None, None, None, None, None
         extra_passes = max(1, min(args.steps, 3))
-        if not args.no_extras:
+        if not args.no_extras and bm is None:
             # search statistics of the timed workload (separate pass over the same sequence, diagnostics counters on)
             s3 = new_seeds()
             s3.setOption(api.OPT_COLLECT_STATS, 1)
@@ -531,19 +594,21 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{label}: {W}x{H} synthetic over-table sequence; one step = setReferenceImage(frame 0) + update() on "
                                    f"frames 1..{F - 1} ({F - 1} updates); NCC patch side {SIDE} (half-patch 4), max epipolar extent "
-                                   f"100 px; one independent sequence per GPU; timed region = {args.steps} complete passes; frame source: {source}",
+                                   f"100 px; " + ("one independent sequence per GPU" if B == 1 else f"{B} independent sequences per GPU (scenes r*{B} .. r*{B}+{B - 1} on rank r) stepped "
+                                   f"together as one batch, one launch pair per stream group and step") + f"; timed region = {args.steps} complete passes; frame source: {source}",
+                       "batch_per_gpu": B,
                        "frames_per_pass": F, "updates_timed": n_updates, "frames_resident_in_hbm": bool(args.resident), "h2d_inclusive": not args.resident,
                        "matcher": {-1: "library default (two-launch tile pipeline)", 0: "per-pixel kernel", 1: "round-1 tile pipeline (A/B build)",
                                    2: "one-launch frame kernel (A/B build)", 3: "two-launch tile pipeline"}.get(args.matcher, str(args.matcher)),
                        "converged_seeds_at_end": converged, "mean_per_update": search_stats,
                        "us_per_update_wall": round(max_elapsed / n_updates * 1e6, 3), "host_render_s": round(render_s, 1)},
             "roofline": roofline,
-            "roofline_valu": valu_roofline(avg_kernel_s, counters) if headline else None,
+            "roofline_valu": valu_roofline(avg_kernel_s, counters, n_sequences=B, ncc_evals_per_update=search_stats["ncc_evals"] if search_stats else None) if headline else None,
             "roofline_flops": flops_roofline(avg_kernel_s, search_stats["ncc_evals"] if search_stats else None, SIDE),
             "roofline_denoiser": roofline_tv, "cpu_baseline": cpu,
             "resident": resident, "h2d_inclusive": other_path, "float_frames": floats, "heavy_prefix": heavy, "batched_per_gpu": batched,
             "parity": PARITY_NOTE, "parity_vs_glibc_reference": glibc,
-            "per_rank": [{"elapsed_s": round(r[0], 6), "mpix": r[1] / 1e6, "updates": int(r[2]), "converged": int(r[3])} for r in per_rank],
+            "per_rank": [{"elapsed_s": round(r[0], 6), "mpix": r[1] / 1e6, "updates": int(r[2]), "converged": int(r[3]), "sequences": int(r[4])} for r in per_rank],
         }
     batch.barrier(device)
     if rank == 0:

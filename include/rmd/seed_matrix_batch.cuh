@@ -56,6 +56,11 @@ class SeedMatrixBatch {
     return true;
   }
   void synchronize() { detail::throw_on_error(rmd_hip_batch_sync(handle_), "SeedMatrixBatch: synchronize failed"); }
+  // DepthmapDenoiser::denoise for every member in one launch sequence (depthmap_denoiser.cu:179-224 per member, bit for bit): depth_range[i]
+  // = what DepthmapDenoiser::setLargeSigmaSq gets for member i; host_denoised[i] = W x H floats or NULL
+  void denoise(const float* depth_range, float* const* host_denoised, float lambda, int iterations) {
+    detail::throw_on_error(rmd_hip_batch_denoise(handle_, depth_range, lambda, iterations, host_denoised), "SeedMatrixBatch: denoise failed");
+  }
   rmd_hip_batch_t* handle() const { return handle_; }
 
  private:

@@ -233,6 +233,16 @@ int rmd_hip_batch_set_option(rmd_hip_batch_t* b, int option, int value);
 int rmd_hip_batch_timing_reset(rmd_hip_batch_t* b);
 int rmd_hip_batch_timing(rmd_hip_batch_t* b, double* total_ms, long* steps);
 
+/* DepthmapDenoiser::denoise (depthmap_denoiser.cu:179-224) for EVERY member of the batch in one launch sequence (grid z = member: the B depth
+ * maps of a step share each launch instead of queueing B x 50 latency-bound launches one behind the other); per member the arithmetic and the
+ * result are those of a rmd_hip_denoiser_t on that member's planes, bit for bit.  depth_range: n floats (setLargeSigmaSq per member, :226-229);
+ * host_denoised: NULL, or n pointers to W x H floats (NULL entries: that member's map stays on the device).  Synchronises like denoise(). */
+int rmd_hip_batch_denoise(rmd_hip_batch_t* b, const float* depth_range, float lambda, int iterations, float* const* host_denoised);
+/* member `index`'s result of the last rmd_hip_batch_denoise, in device memory (a view, valid until the next one; e.g. for rmd_hip_seeds_point_cloud) */
+int rmd_hip_batch_denoise_result(const rmd_hip_batch_t* b, int index, const rmd_hip_image_t** view);
+/* device time of the iteration launches of the last rmd_hip_batch_denoise (one HIP event pair on its stream) and their number */
+int rmd_hip_batch_denoise_timing(const rmd_hip_batch_t* b, double* total_ms, long* launches);
+
 /* ---- rmd::DepthmapDenoiser (depthmap_denoiser.cu) --------------------------------------- */
 int rmd_hip_denoiser_create(int width, int height, rmd_hip_denoiser_t** out); /* ctor :143-169 */
 int rmd_hip_denoiser_destroy(rmd_hip_denoiser_t* d);

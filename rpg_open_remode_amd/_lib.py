@@ -76,6 +76,9 @@ SIGNATURES = {
     "rmd_hip_batch_set_option": (_i, [_p, _i, _i]),
     "rmd_hip_batch_timing_reset": (_i, [_p]),
     "rmd_hip_batch_timing": (_i, [_p, _c.POINTER(_c.c_double), _c.POINTER(_c.c_long)]),
+    "rmd_hip_batch_denoise": (_i, [_p, _p, _f, _i, _p]),
+    "rmd_hip_batch_denoise_result": (_i, [_p, _i, _pp]),
+    "rmd_hip_batch_denoise_timing": (_i, [_p, _c.POINTER(_c.c_double), _c.POINTER(_c.c_long)]),
     "rmd_hip_denoiser_create": (_i, [_i, _i, _pp]),
     "rmd_hip_denoiser_destroy": (_i, [_p]),
     "rmd_hip_denoiser_set_large_sigma_sq": (_i, [_p, _f]),

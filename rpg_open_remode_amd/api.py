@@ -31,6 +31,7 @@ PLANE_SUM_TEMPL, PLANE_CONST_TEMPL_DENOM, PLANE_EPIPOLAR_MATCHES, PLANE_REF_IMG,
 KIND_F32, KIND_I32, KIND_F32X2 = 0, 1, 2
 OPT_MATCHER, OPT_TIMING, OPT_COLLECT_STATS, OPT_WINDOW, OPT_LAZY_FINALIZE, OPT_LOCAL_MAX, OPT_UNIT_ROUNDS, OPT_UNIT_TARGET, OPT_SEARCH_FLAGS = 0, 1, 2, 3, 4, 5, 6, 7, 8
 OPT_INJECT_FAULT = 9  # test hook, see include/rmd_hip.h
+MAX_BATCH = 8  # sequences one SeedMatrixBatch can hold (rmdk::MAX_BATCH)
 MATCHER_PIXEL, MATCHER_PIPELINE = 0, 3
 MATCHER_PIPELINE_R01, MATCHER_FRAME = 1, 2  # retired variants: A/B builds of the library only (tools/ab_make.sh)
 STAGE_SEED_INIT, STAGE_UPDATE, STAGE_COUNT = 0, 1, 2
@@ -514,6 +515,27 @@ class SeedMatrixBatch:
 
     def update(self, float_frames, poses):
         return self._host(_lib.lib().rmd_hip_batch_update, float_frames, poses, np.float32)
+
+    def denoise(self, depth_ranges, lam, iterations, download=True):
+        """DepthmapDenoiser::denoise for every member in ONE launch sequence (rmd_hip_batch_denoise): depth_ranges[i] = max_depth - min_depth of
+        member i (setLargeSigmaSq).  Returns the n denoised maps (download=True) or None; denoiseResult(i) is member i's map on the device."""
+        dr = np.ascontiguousarray(depth_ranges, np.float32).reshape(self.n)
+        outs = [np.empty((self.height, self.width), np.float32) for _ in range(self.n)] if download else None
+        ptrs = (ctypes.c_void_p * self.n)(*[_ptr(o) for o in outs]) if download else None
+        check(_lib.lib().rmd_hip_batch_denoise(self.ptr, _ptr(dr), float(lam), int(iterations), ptrs))
+        return outs
+
+    def denoiseResult(self, i):
+        v = ctypes.c_void_p()
+        check(_lib.lib().rmd_hip_batch_denoise_result(self.ptr, int(i), ctypes.byref(v)))
+        img = DeviceImage(0, 0, _view=v.value)
+        img._keepalive = self
+        return img
+
+    def denoiseTiming(self):
+        ms, n = ctypes.c_double(), ctypes.c_long()
+        check(_lib.lib().rmd_hip_batch_denoise_timing(self.ptr, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
 
     def sync(self):
         check(_lib.lib().rmd_hip_batch_sync(self.ptr))

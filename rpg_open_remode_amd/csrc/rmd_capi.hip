@@ -381,6 +381,19 @@ struct rmd_hip_batch {
   int pack_backoff = 0;
   hipEvent_t region_start = nullptr, region_stop = nullptr;
   long region_updates = 0;
+  // TV-L1 for all members in one launch sequence (rmd_hip_batch_denoise), allocated at the first request: the denoiser's planes hold the
+  // members back to back (one tall image each: member z = rows [z * height, (z + 1) * height)), the members' input planes come from `table`
+  struct Denoise {
+    rmd_hip_image u[2], u_head[2], p[2], g;
+    unsigned long long* d_table = nullptr;   // rmdk::TV_MEMBER_WORDS words per member (device)
+    float* h_staging = nullptr;              // pinned, n x W x H
+    hipStream_t stream = nullptr;
+    rmd_hip_image result[rmdk::MAX_BATCH];   // views of the members' results of the last run
+    int result_index = 0;
+    double total_ms = 0.0;
+    long launches = 0;
+    bool ready = false;
+  } dn;
   Group& group_of(int member) {
     int g = 0;
     while (g + 1 < n_groups && member >= groups[g + 1].first) ++g;
@@ -2003,6 +2016,16 @@ int rmd_hip_batch_destroy(rmd_hip_batch_t* b) {
   }
   if (b->h_seq) (void)hipHostFree(b->h_seq);
   if (b->d_flag) (void)hipFree(b->d_flag);
+  {
+    rmd_hip_batch::Denoise& dn = b->dn;
+    if (dn.stream) (void)hipStreamSynchronize(dn.stream);
+    rmd_hip_image* all[] = {&dn.u[0], &dn.u[1], &dn.u_head[0], &dn.u_head[1], &dn.p[0], &dn.p[1], &dn.g};
+    for (auto* im : all)
+      if (im->owns && im->data) (void)hipFree(im->data);
+    if (dn.d_table) (void)hipFree(dn.d_table);
+    if (dn.h_staging) (void)hipHostFree(dn.h_staging);
+    if (dn.stream) (void)hipStreamDestroy(dn.stream);
+  }
   if (b->region_start) (void)hipEventDestroy(b->region_start);
   if (b->region_stop) (void)hipEventDestroy(b->region_stop);
   for (auto& G : b->groups) {
@@ -2169,6 +2192,70 @@ int rmd_hip_batch_timing(rmd_hip_batch_t* b, double* total_ms, long* steps) {
 
 }  // extern "C"
 
+
+namespace {
+
+// tv_prepare + `iterations` primal-dual iterations of TvParams P for `n_z` depth maps (grid z; 1 = the single denoiser, P.members null) on
+// `stream`, ping-ponging between the two sets of iterate planes; *result_index = the set that holds the result.  ev0 (may be null) is
+// recorded between the preparation and the first iteration.
+int tv_run(const rmdk::TvParams& P, float* const u[2], float* const uh[2], float2* const p[2], int n_z, int iterations, int opt_iters_per_launch, int opt_geometry,
+           hipStream_t stream, hipEvent_t ev0, int* result_index, long* launches) {
+  const unsigned int nz = static_cast<unsigned int>(n_z);
+  {
+    const dim3 block(64, 4), grid((P.w + 63) / 64, (P.h + 3) / 4, nz);
+    hipLaunchKernelGGL(rmdk::tv_prepare_kernel, grid, block, 0, stream, P, u[0], uh[0], p[0]);
+    HIP_TRY(hipGetLastError());
+  }
+  int cur_buf = 0;
+  if (ev0) HIP_TRY(hipEventRecord(ev0, stream));
+  long n_launches = 0;
+  if (opt_iters_per_launch == 1) {
+    const dim3 block(rmdk::TV_TX, rmdk::TV_TY);
+    const dim3 grid((P.w + rmdk::TV_TX - 1) / rmdk::TV_TX, (P.h + rmdk::TV_TY - 1) / rmdk::TV_TY, nz);
+    for (int it = 0; it < iterations; ++it) {
+      const int nxt = cur_buf ^ 1;
+      hipLaunchKernelGGL(rmdk::tv_iterate_kernel, grid, block, 0, stream, P, u[cur_buf], uh[cur_buf], p[cur_buf], u[nxt], uh[nxt], p[nxt]);
+      cur_buf = nxt;
+      ++n_launches;
+    }
+  } else {
+    // Temporally blocked kernel: tile geometry and blocking depth K by image size (K iterations per launch; the halo
+    // grows with K, so small tiles pay more redundant work per iteration, but a VGA launch is latency-bound: fewer, fatter
+    // launches win there).  opt_geometry (experiments): 0 = by size, 1..n = a fixed entry of the table below.
+    auto run = [&](auto geom, int kmax, auto kernel) {
+      using G = decltype(geom);
+      const int k = opt_iters_per_launch == 0 ? kmax : (opt_iters_per_launch < kmax ? opt_iters_per_launch : kmax);
+      const dim3 block(G::THREADS), grid((P.w + G::BX - 1) / G::BX, (P.h + G::BY - 1) / G::BY, nz);
+      for (int done = 0; done < iterations; done += k) {
+        const int now = iterations - done < k ? iterations - done : k;
+        const int nxt = cur_buf ^ 1;
+        hipLaunchKernelGGL(kernel, grid, block, 0, stream, P, u[cur_buf], uh[cur_buf], p[cur_buf], u[nxt], uh[nxt], p[nxt], now);
+        cur_buf = nxt;
+        ++n_launches;
+      }
+    };
+    // Measured (tools/denoise_sweep.py, MI355X): 16x16 tiles with K = 4 are the fastest at 640x480 (3.4 us per iteration, 50
+    // launches for 200 iterations, latency-bound) AND at 1920x1080 (11.5 us per iteration = 7.2 TB/s of algorithmic traffic);
+    // deeper blocking (K = 8) loses more to the redundant halo work than it saves in launches.
+    int geometry = opt_geometry;
+    if (geometry == 0) geometry = opt_iters_per_launch == 2 ? 1 : 4;
+    switch (geometry) {
+      case 1: run(rmdk::TvBlocked<32, 8, 2>(), 2, rmdk::tv_iterate_blocked_kernel<32, 8, 2>); break;
+      case 2: run(rmdk::TvBlocked<64, 16, 4>(), 4, rmdk::tv_iterate_blocked_kernel<64, 16, 4>); break;
+      case 3: run(rmdk::TvBlocked<32, 16, 4>(), 4, rmdk::tv_iterate_blocked_kernel<32, 16, 4>); break;
+      case 4: run(rmdk::TvBlocked<16, 16, 4>(), 4, rmdk::tv_iterate_blocked_kernel<16, 16, 4>); break;
+      case 5: run(rmdk::TvBlocked<16, 16, 8>(), 8, rmdk::tv_iterate_blocked_kernel<16, 16, 8>); break;
+      default: return fail(RMD_HIP_ERR_INVALID_ARG, "denoise: unknown geometry %d", geometry);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  *result_index = cur_buf;
+  *launches = n_launches;
+  return RMD_HIP_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 // ---- DepthmapDenoiser -----------------------------------------------------------------------
@@ -2283,67 +2370,19 @@ int rmd_hip_denoiser_denoise(rmd_hip_denoiser_t* d, const rmd_hip_image_t* mu, c
   P.g = static_cast<float*>(d->g.data);
   P.large_sigma_sq = d->large_sigma_sq;
   P.tau = d->tau; P.sigma = d->sigma; P.theta = d->theta; P.lambda = lambda;
+  P.members = nullptr; P.member_stride = 0; P.member_stride2 = 0;
 
-  {
-    const dim3 block(64, 4), grid((d->width + 63) / 64, (d->height + 3) / 4);
-    hipLaunchKernelGGL(rmdk::tv_prepare_kernel, grid, block, 0, d->stream, P, static_cast<float*>(d->u[0].data),
-                       static_cast<float*>(d->u_head[0].data), static_cast<float2*>(d->p[0].data));
-    HIP_TRY(hipGetLastError());
-  }
-  int cur_buf = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (d->opt_timing) {  // one event pair around the whole iteration loop (per-launch markers would serialise it)
     HIP_TRY(hipEventCreate(&ev0));
     HIP_TRY(hipEventCreate(&ev1));
-    HIP_TRY(hipEventRecord(ev0, d->stream));
   }
+  int cur_buf = 0;
   long n_launches = 0;
-  auto bufs = [&](int b) {
-    return std::make_tuple(static_cast<float*>(d->u[b].data), static_cast<float*>(d->u_head[b].data), static_cast<float2*>(d->p[b].data));
-  };
-  if (d->opt_iters_per_launch == 1) {
-    const dim3 block(rmdk::TV_TX, rmdk::TV_TY);
-    const dim3 grid((d->width + rmdk::TV_TX - 1) / rmdk::TV_TX, (d->height + rmdk::TV_TY - 1) / rmdk::TV_TY);
-    for (int it = 0; it < iterations; ++it) {
-      const int nxt = cur_buf ^ 1;
-      auto [ui, uhi, pi] = bufs(cur_buf);
-      auto [uo, uho, po] = bufs(nxt);
-      hipLaunchKernelGGL(rmdk::tv_iterate_kernel, grid, block, 0, d->stream, P, ui, uhi, pi, uo, uho, po);
-      cur_buf = nxt;
-      ++n_launches;
-    }
-  } else {
-    // Temporally blocked kernel: tile geometry and blocking depth K by image size (K iterations per launch; the halo
-    // grows with K, so small tiles pay more redundant work per iteration, but a VGA launch is latency-bound: fewer, fatter
-    // launches win there).  opt_geometry (experiments): 0 = by size, 1..n = a fixed entry of the table below.
-    auto run = [&](auto geom, int kmax, auto kernel) {
-      using G = decltype(geom);
-      const int k = d->opt_iters_per_launch == 0 ? kmax : (d->opt_iters_per_launch < kmax ? d->opt_iters_per_launch : kmax);
-      const dim3 block(G::THREADS), grid((d->width + G::BX - 1) / G::BX, (d->height + G::BY - 1) / G::BY);
-      for (int done = 0; done < iterations; done += k) {
-        const int now = iterations - done < k ? iterations - done : k;
-        const int nxt = cur_buf ^ 1;
-        auto [ui, uhi, pi] = bufs(cur_buf);
-        auto [uo, uho, po] = bufs(nxt);
-        hipLaunchKernelGGL(kernel, grid, block, 0, d->stream, P, ui, uhi, pi, uo, uho, po, now);
-        cur_buf = nxt;
-        ++n_launches;
-      }
-    };
-    // Measured (tools/denoise_sweep.py, MI355X): 16x16 tiles with K = 4 are the fastest at 640x480 (3.4 us per iteration, 50
-    // launches for 200 iterations, latency-bound) AND at 1920x1080 (11.5 us per iteration = 7.2 TB/s of algorithmic traffic);
-    // deeper blocking (K = 8) loses more to the redundant halo work than it saves in launches.
-    int geometry = d->opt_geometry;
-    if (geometry == 0) geometry = d->opt_iters_per_launch == 2 ? 1 : 4;
-    switch (geometry) {
-      case 1: run(rmdk::TvBlocked<32, 8, 2>(), 2, rmdk::tv_iterate_blocked_kernel<32, 8, 2>); break;
-      case 2: run(rmdk::TvBlocked<64, 16, 4>(), 4, rmdk::tv_iterate_blocked_kernel<64, 16, 4>); break;
-      case 3: run(rmdk::TvBlocked<32, 16, 4>(), 4, rmdk::tv_iterate_blocked_kernel<32, 16, 4>); break;
-      case 4: run(rmdk::TvBlocked<16, 16, 4>(), 4, rmdk::tv_iterate_blocked_kernel<16, 16, 4>); break;
-      case 5: run(rmdk::TvBlocked<16, 16, 8>(), 8, rmdk::tv_iterate_blocked_kernel<16, 16, 8>); break;
-      default: return fail(RMD_HIP_ERR_INVALID_ARG, "denoise: unknown geometry %d", geometry);
-    }
-  }
+  float* us[2] = {static_cast<float*>(d->u[0].data), static_cast<float*>(d->u[1].data)};
+  float* uhs[2] = {static_cast<float*>(d->u_head[0].data), static_cast<float*>(d->u_head[1].data)};
+  float2* ps[2] = {static_cast<float2*>(d->p[0].data), static_cast<float2*>(d->p[1].data)};
+  TRY(tv_run(P, us, uhs, ps, 1, iterations, d->opt_iters_per_launch, d->opt_geometry, d->stream, ev0, &cur_buf, &n_launches));
   HIP_TRY(hipGetLastError());
   if (d->opt_timing) HIP_TRY(hipEventRecord(ev1, d->stream));
   d->result_index = cur_buf;
@@ -2374,6 +2413,111 @@ int rmd_hip_denoiser_timing(const rmd_hip_denoiser_t* d, double* total_ms, long*
   if (!d) return fail(RMD_HIP_ERR_INVALID_ARG, "denoiser_timing: null handle");
   if (total_ms) *total_ms = d->timer.total_ms;
   if (launches) *launches = d->timer.launches;
+  return RMD_HIP_OK;
+}
+
+}  // extern "C"
+
+// ---- TV-L1 for every member of a batch in one launch sequence ---------------------------------
+// DepthmapDenoiser::denoise (depthmap_denoiser.cu:179-224) per member; what changes is the launch shape: at 640x480 one depth map is 50
+// launches of 1 200 workgroups, each bound by dispatch and load latency (14 us for 4 iterations), and the B maps of a batch cost B times
+// that when they are denoised one after the other.  With grid z = member the same 50 launches carry B x 1 200 workgroups.
+extern "C" {
+
+int rmd_hip_batch_denoise(rmd_hip_batch_t* b, const float* depth_range, float lambda, int iterations, float* const* host_denoised) {
+  if (!b || !depth_range) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_denoise: null argument");
+  if (iterations < 0) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_denoise: negative iteration count");
+  TRY(batch_bind_device(b));
+  const rmd_hip_seeds* m0 = b->members[0];
+  const int w = m0->width, h = m0->height, n = b->n;
+  rmd_hip_batch::Denoise& dn = b->dn;
+  if (!dn.ready) {
+    rmd_hip_image* f32[] = {&dn.u[0], &dn.u[1], &dn.u_head[0], &dn.u_head[1], &dn.g};
+    for (auto* im : f32) TRY(image_alloc(im, RMD_HIP_KIND_F32, w, h * n));
+    for (int k = 0; k < 2; ++k) TRY(image_alloc(&dn.p[k], RMD_HIP_KIND_F32X2, w, h * n));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dn.d_table), static_cast<size_t>(rmdk::MAX_BATCH) * rmdk::TV_MEMBER_WORDS * sizeof(unsigned long long)));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&dn.h_staging), static_cast<size_t>(n) * w * h * sizeof(float)));
+    HIP_TRY(hipStreamCreateWithFlags(&dn.stream, hipStreamNonBlocking));
+    HIP_TRY(hipDeviceSynchronize());
+    dn.ready = true;
+  }
+  // the members' state must be final and at rest: deferred finalisations, then every group's stream (the members' last kernels are left in flight)
+  for (int i = 0; i < n; ++i) TRY(seeds_flush(b->members[i]));
+  for (int g = 0; g < b->n_groups; ++g) HIP_TRY(hipStreamSynchronize(b->groups[g].stream));
+  for (int g = 0; g < b->n_groups; ++g) TRY(ingest_error_check(b->groups[g].h_progress));
+  HIP_TRY(hipStreamSynchronize(dn.stream));
+  unsigned long long table[rmdk::MAX_BATCH * rmdk::TV_MEMBER_WORDS] = {};
+  for (int i = 0; i < n; ++i) {
+    const rmd_hip_seeds* m = b->members[i];
+    const float large_sigma_sq = depth_range[i] * depth_range[i] / 72.0f;  // DepthmapDenoiser::setLargeSigmaSq, depthmap_denoiser.cu:226-229
+    unsigned int bits;
+    memcpy(&bits, &large_sigma_sq, 4);
+    unsigned long long* t = table + static_cast<size_t>(i) * rmdk::TV_MEMBER_WORDS;
+    t[0] = reinterpret_cast<unsigned long long>(m->P.mu); t[1] = reinterpret_cast<unsigned long long>(m->P.sigma_sq);
+    t[2] = reinterpret_cast<unsigned long long>(m->P.a); t[3] = reinterpret_cast<unsigned long long>(m->P.b);
+    t[4] = bits;
+  }
+  HIP_TRY(hipMemcpyAsync(dn.d_table, table, sizeof(table), hipMemcpyHostToDevice, dn.stream));
+  HIP_TRY(hipStreamSynchronize(dn.stream));  // (the source is on this function's stack)
+  rmdk::TvParams P;
+  P.w = w; P.h = h;
+  P.stride = static_cast<int>(dn.g.stride);
+  P.stride2 = static_cast<int>(dn.p[0].stride);
+  P.mu = nullptr; P.sigma_sq = nullptr; P.a = nullptr; P.b = nullptr;  // per member, from the table
+  P.in_stride = m0->P.stride;
+  P.g = static_cast<float*>(dn.g.data);
+  P.large_sigma_sq = 0.0f;
+  // denoise::DeviceData constructor, depthmap_denoiser.cu:124-141 (the constants of rmd_hip_denoiser_create)
+  const float L = sqrtf(8.0f);
+  P.tau = 0.02f; P.sigma = (1 / (L * L)) / P.tau; P.theta = 0.5f; P.lambda = lambda;
+  P.members = dn.d_table;
+  P.member_stride = dn.g.stride * static_cast<size_t>(h);
+  P.member_stride2 = dn.p[0].stride * static_cast<size_t>(h);
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  HIP_TRY(hipEventCreate(&ev0));
+  HIP_TRY(hipEventCreate(&ev1));
+  float* us[2] = {static_cast<float*>(dn.u[0].data), static_cast<float*>(dn.u[1].data)};
+  float* uhs[2] = {static_cast<float*>(dn.u_head[0].data), static_cast<float*>(dn.u_head[1].data)};
+  float2* ps[2] = {static_cast<float2*>(dn.p[0].data), static_cast<float2*>(dn.p[1].data)};
+  int cur_buf = 0;
+  long n_launches = 0;
+  const int rc = tv_run(P, us, uhs, ps, n, iterations, 0, 0, dn.stream, ev0, &cur_buf, &n_launches);
+  if (rc != RMD_HIP_OK) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); return rc; }
+  HIP_TRY(hipEventRecord(ev1, dn.stream));
+  dn.result_index = cur_buf;
+  const rmd_hip_image& r = dn.u[cur_buf];
+  const size_t row = static_cast<size_t>(w) * 4, plane = static_cast<size_t>(w) * h;
+  for (int i = 0; i < n; ++i) {
+    rmd_hip_image& v = dn.result[i];
+    v = rmd_hip_image();
+    v.kind = RMD_HIP_KIND_F32; v.width = w; v.height = h; v.device = b->device; v.pitch = r.pitch; v.stride = r.stride;
+    v.data = static_cast<char*>(r.data) + static_cast<size_t>(i) * h * r.pitch;
+    v.owns = false; v.owner_stream = dn.stream;
+    if (host_denoised && host_denoised[i])
+      HIP_TRY(hipMemcpy2DAsync(dn.h_staging + i * plane, row, v.data, v.pitch, row, h, hipMemcpyDeviceToHost, dn.stream));
+  }
+  HIP_TRY(hipStreamSynchronize(dn.stream));
+  for (int i = 0; i < n; ++i)
+    if (host_denoised && host_denoised[i]) memcpy(host_denoised[i], dn.h_staging + i * plane, plane * sizeof(float));
+  float ms = 0.0f;
+  if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) { dn.total_ms = ms; dn.launches = n_launches; }
+  (void)hipEventDestroy(ev0);
+  (void)hipEventDestroy(ev1);
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_batch_denoise_result(const rmd_hip_batch_t* b, int index, const rmd_hip_image_t** view) {
+  if (!b || !view) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_denoise_result: null argument");
+  if (index < 0 || index >= b->n) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_denoise_result: index %d outside [0, %d)", index, b->n);
+  if (!b->dn.ready || !b->dn.result[index].data) return fail(RMD_HIP_ERR_NOT_READY, "batch_denoise_result: rmd_hip_batch_denoise has not run");
+  *view = &b->dn.result[index];
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_batch_denoise_timing(const rmd_hip_batch_t* b, double* total_ms, long* launches) {
+  if (!b) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_denoise_timing: null handle");
+  if (total_ms) *total_ms = b->dn.total_ms;
+  if (launches) *launches = b->dn.launches;
   return RMD_HIP_OK;
 }
 

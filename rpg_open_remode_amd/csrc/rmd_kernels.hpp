@@ -506,11 +506,38 @@ struct TvParams {
   float* g;
   float large_sigma_sq;
   float tau, sigma, theta, lambda;
+  // Several depth maps of one size denoised by ONE launch sequence (rmd_hip_batch_denoise): grid z = member.  The denoiser's own planes
+  // (g, u, u_head, p) hold the members back to back, `member_stride` / `member_stride2` elements apart; the input planes belong to the
+  // members' SeedMatrix objects and come from a table in device memory, TV_MEMBER_WORDS 64-bit words per member: the addresses of mu,
+  // sigma_sq, a, b, then large_sigma_sq (the bits of the float in the low half).  null: one depth map, the fields above.
+  const unsigned long long* members;
+  size_t member_stride, member_stride2;
 };
+constexpr int TV_MEMBER_WORDS = 5;
+
+// the parameters and iterate planes of member blockIdx.z (no-op for a single depth map); the table is read through the scalar path
+// (nobody writes it while a denoise is in flight)
+RMDK_D void tv_select_member(TvParams& P) {
+  if (!P.members) return;
+  typedef const __attribute__((address_space(4))) unsigned long long* const_u64_ptr;
+  const const_u64_ptr t = (const_u64_ptr)(P.members) + static_cast<size_t>(blockIdx.z) * TV_MEMBER_WORDS;
+  P.mu = reinterpret_cast<const float*>(t[0]);
+  P.sigma_sq = reinterpret_cast<const float*>(t[1]);
+  P.a = reinterpret_cast<const float*>(t[2]);
+  P.b = reinterpret_cast<const float*>(t[3]);
+  P.large_sigma_sq = __uint_as_float(static_cast<unsigned int>(t[4]));
+  P.g += static_cast<size_t>(blockIdx.z) * P.member_stride;
+}
+template <typename T>
+RMDK_D T* tv_member_plane(const TvParams& P, T* plane, size_t member_stride) {
+  return P.members ? plane + static_cast<size_t>(blockIdx.z) * member_stride : plane;
+}
 
 // depthmap_denoiser.cu:45-59 (weights) fused with the re-initialisation at :215-217
 __global__ __launch_bounds__(256) void tv_prepare_kernel(TvParams P, float* __restrict__ u, float* __restrict__ u_head,
                                                          float2* __restrict__ p) {
+  tv_select_member(P);
+  u = tv_member_plane(P, u, P.member_stride); u_head = tv_member_plane(P, u_head, P.member_stride); p = tv_member_plane(P, p, P.member_stride2);
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x >= P.w || y >= P.h) return;
@@ -553,6 +580,9 @@ __global__ __launch_bounds__(TV_TX* TV_TY) void tv_iterate_kernel(TvParams P, co
                                                                   const float2* __restrict__ p_in, float* __restrict__ u_out,
                                                                   float* __restrict__ uh_out, float2* __restrict__ p_out) {
   __shared__ float2 sp[TV_TY + 1][TV_TX + 1];
+  tv_select_member(P);
+  u_in = tv_member_plane(P, u_in, P.member_stride); uh_in = tv_member_plane(P, uh_in, P.member_stride); p_in = tv_member_plane(P, p_in, P.member_stride2);
+  u_out = tv_member_plane(P, u_out, P.member_stride); uh_out = tv_member_plane(P, uh_out, P.member_stride); p_out = tv_member_plane(P, p_out, P.member_stride2);
   const int tx = threadIdx.x, ty = threadIdx.y;
   const int x0 = blockIdx.x * TV_TX, y0 = blockIdx.y * TV_TY;
   const int x = x0 + tx, y = y0 + ty;
@@ -609,6 +639,9 @@ __global__ __launch_bounds__(256) void tv_iterate_blocked_kernel(TvParams P, con
                                                                  float2* __restrict__ p_out, int iters) {
   using G = TvBlocked<BX_, BY_, KMAX>;
   __shared__ float su[G::EN], suh[G::EN], spx[G::EN], spy[G::EN], sg[G::EN], smu[G::EN];
+  tv_select_member(P);
+  u_in = tv_member_plane(P, u_in, P.member_stride); uh_in = tv_member_plane(P, uh_in, P.member_stride); p_in = tv_member_plane(P, p_in, P.member_stride2);
+  u_out = tv_member_plane(P, u_out, P.member_stride); uh_out = tv_member_plane(P, uh_out, P.member_stride); p_out = tv_member_plane(P, p_out, P.member_stride2);
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x * G::BX, y0 = blockIdx.y * G::BY;
   const int ex0 = max(x0 - iters, 0), ey0 = max(y0 - iters, 0);

@@ -140,3 +140,36 @@ def test_batch_with_denoiser_and_point_cloud():
         od.set_large_sigma_sq(seq.max_depth - seq.min_depth)
         assert O.planes_equal(od.denoise(orcs[i], 0.5, 30), got)
         assert len(b[i].pointCloud()) == b[i].getConvergedCount() == orcs[i].converged_count()
+
+
+@pytest.mark.parametrize("n", [1, 3, 8])
+def test_batch_denoise_equals_every_member_denoised_alone(n):
+    """rmd_hip_batch_denoise: TV-L1 for all members in one launch sequence (grid z = member) -- per member the oracle's result and the
+    stand-alone DepthmapDenoiser's, bit for bit, for iteration counts that are and are not multiples of the blocking depth, members with
+    different depth ranges (large_sigma_sq per member), and the device-resident results feed the point cloud"""
+    side = 5
+    seqs = [sequence(203, 131, 8, scene) for scene in range(n)]
+    b = _batch(seqs, side)
+    orcs = [_oracle(seq, side) for seq in seqs]
+    for k in range(1, 8):
+        b.updateU8([seq.gray[k] for seq in seqs], [seq.T_curr_world[k] for seq in seqs])
+        for o, seq in zip(orcs, seqs):
+            o.update(seq.images[k], seq.T_curr_world[k])
+    ranges = [(seq.max_depth - seq.min_depth) * (1.0 + 0.25 * i) for i, seq in enumerate(seqs)]
+    for lam, iters in ((0.5, 40), (0.3, 7), (0.5, 1), (0.5, 0)):
+        got = b.denoise(ranges, lam, iters)
+        ms, launches = b.denoiseTiming()
+        assert launches == (iters + 3) // 4
+        for i, seq in enumerate(seqs):
+            od = O.Denoiser(orcs[i].o, seq.width, seq.height)
+            od.set_large_sigma_sq(ranges[i])
+            want = od.denoise(orcs[i], lam, iters)
+            assert O.planes_equal(want, got[i]), f"batch of {n}, member {i}, lambda {lam}, {iters} iterations: {O.count_mismatch(want, got[i])} pixels differ"
+            den = api.DepthmapDenoiser(seq.width, seq.height)
+            den.setLargeSigmaSq(ranges[i])
+            alone = den.denoise(b[i].getMu(), b[i].getSigmaSq(), b[i].getA(), b[i].getB(), lam, iters)
+            assert O.planes_equal(alone, got[i])
+            if iters == 40:
+                assert O.count_mismatch(b[i].pointCloud(den.result()), b[i].pointCloud(b.denoiseResult(i))) == 0
+    assert b.denoise(ranges, 0.5, 5, download=False) is None
+    assert O.planes_equal(b.denoiseResult(n - 1).getDevData(), b.denoise(ranges, 0.5, 5)[n - 1])

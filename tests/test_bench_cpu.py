@@ -117,6 +117,36 @@ def test_two_rank_launch_path_of_bench_py(launcher):
     assert out["rendezvous"] == "ok" and out["n_gpus"] == 2 and out["control_plane"] == "gloo"
     assert out["max_elapsed_s"] == pytest.approx(0.002) and out["total_units"] == 3.0
     assert [r[2] for r in out["per_rank"]] == [0.0, 1.0]  # LOCAL_RANK of each rank, in rank order
+    assert out["batch_per_gpu"] == 1 and out["scenes_of_rank"] == [[0], [1]]
+
+
+def test_two_ranks_times_four_sequences_launch_path():
+    """--gpus 2 --batch-per-gpu 4 (N GPUs x B sequences, BASELINE configs[3] composed with the batched mode): rank r owns scenes 4r .. 4r+3, the
+    gathered record carries B for every rank"""
+    import subprocess
+    port = str(_free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", port,
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch-per-gpu", "4", "--steps", "1", "--warmup", "0", "--rendezvous-only"]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
+    assert out["batch_per_gpu"] == 4 and out["scenes_of_rank"] == [[0, 1, 2, 3], [4, 5, 6, 7]]
+    assert [r[4] for r in out["per_rank"]] == [4.0, 4.0]
+
+
+def test_scene_assignment_and_useful_valu_fraction():
+    b, a = _bench(["--batch-per-gpu", "8"])
+    assert a.batch_per_gpu == 8 and b.scenes_of_rank(0, 8) == list(range(8)) and b.scenes_of_rank(3, 2) == [6, 7] and b.scenes_of_rank(5, 1) == [5]
+    t = dict(json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))), kernel_source_sha256=b.kernel_source_sha256())
+    n = sum(t["valu_wave_instructions_per_update"].values())
+    r = b.valu_roofline(46e-6, t, ncc_evals_per_update=64.0 * 1000)
+    assert r["useful_valu_frac"] == round(1000 * 851 / n, 4) and set(r["per_kernel"]) == set(t["valu_wave_instructions_per_update"])
+    r8 = b.valu_roofline(8 * 46e-6, t, n_sequences=8, ncc_evals_per_update=64.0 * 1000)
+    assert r8["useful_valu_frac"] == r["useful_valu_frac"]
+    assert b.valu_roofline(46e-6, t)["useful_valu_frac"] is None
 
 
 def test_kernel_source_hash_ignores_comments_and_white_space_only():

@@ -88,6 +88,14 @@ def test_batch_of_8_and_standalone_vga_200_host_frames_at_full_speed():
             bad = {names[p]: int(np.count_nonzero(want[i][0][p] != got[p])) for p in range(8) if not np.array_equal(want[i][0][p], got[p])}
             assert not bad, f"batch of 8, member {i}, pass {rep}, 8-bit host frames at full speed: {bad}"
             assert b[i].getConvergedCount() == want[i][1]
+    # ... and TV-L1 (0.5, 200) of all eight maps in one launch sequence against each member denoised alone (configs[1]'s denoise, eight times)
+    ranges = [sc["max"] - sc["min"] for sc in scenes]
+    together = b.denoise(ranges, 0.5, 200)
+    for i in range(8):
+        den = api.DepthmapDenoiser(W, H)
+        den.setLargeSigmaSq(ranges[i])
+        alone = den.denoise(b[i].getMu(), b[i].getSigmaSq(), b[i].getA(), b[i].getB(), 0.5, 200)
+        assert O.planes_equal(alone, together[i]), f"TV-L1 of member {i}: batch vs alone"
     b.close()
 
 
