@@ -34,7 +34,8 @@ namespace rmdk {
 #endif
 constexpr int FR_WIN_CAP = 5632;  // texels of the LDS window (22 KB); any shape with (width | 1) * height <= FR_WIN_CAP
 constexpr int FR_UNIT_ROUNDS = 4, FR_UNIT_ITEMS = FR_UNIT_ROUNDS * TILE_PIX;
-enum : int { SEARCH_PREFETCH = 1, SEARCH_SHARDED_HANDOUT = 2, SEARCH_TILE_BOX = 4, SEARCH_FLAGS_DEFAULT = 6 };  // MatcherArgs::search_flags (A/B switches of the search kernel's unit loop)
+enum : int { SEARCH_FLAGS_DEFAULT = 6 };  // rounds 2-3 carried A/B switches of the search kernel's unit loop here (1: claim the next unit early -- measured, lost; 2: sixteen
+                                          // hand-out counters; 4: the tile's sample box travels with the unit); 2 | 4 is what the kernel does now, unconditionally
 constexpr int FR_TRACE_FRAMES = 256, FR_TRACE_WORDS = 8;  // per workgroup: start, setup done, own tile done, exit (10 ns ticks), work items, units searched
 
 // ---- agent-scope accessors (global address space, sc1) ---------------------------------------------------------------
@@ -78,14 +79,23 @@ RMDK_D float ncc_at_dyn(const SeedParams& P, F2 px, const float* __restrict__ wi
   int ix[SIDE], iy[SIDE];
   float ax[SIDE], ay[SIDE];
   bool reg_x = true, reg_y = true;
-  if (__all(axis_is_uniform<SIDE>(px.x) && axis_is_uniform<SIDE>(px.y))) {  // wave-uniform branch
-    const float fx = floorf(px.x), fy = floorf(px.y);
-    const float wx = px.x - fx, wy = px.y - fy;
-    ix[0] = static_cast<int>(fx) + OFFSET; iy[0] = static_cast<int>(fy) + OFFSET;
+  // wave-uniform branches, one per axis (a wave whose x positions straddle a power of two replays the roundings of x only)
+  if (__all(axis_is_uniform<SIDE>(px.x))) {
+    const float fx = floorf(px.x);
+    const float wx = px.x - fx;
+    ix[0] = static_cast<int>(fx) + OFFSET;
 #pragma unroll
-    for (int k = 0; k < SIDE; ++k) { ax[k] = wx; ay[k] = wy; }
+    for (int k = 0; k < SIDE; ++k) ax[k] = wx;
   } else {
     reg_x = axis_params<SIDE>(px.x, ix, ax);
+  }
+  if (__all(axis_is_uniform<SIDE>(px.y))) {
+    const float fy = floorf(px.y);
+    const float wy = px.y - fy;
+    iy[0] = static_cast<int>(fy) + OFFSET;
+#pragma unroll
+    for (int k = 0; k < SIDE; ++k) ay[k] = wy;
+  } else {
     reg_y = axis_params<SIDE>(px.y, iy, ay);
   }
   const bool regular = reg_x && reg_y;
@@ -165,29 +175,33 @@ struct FrameWindow {
   bool valid;          // staged and covering every sample of the tile in LDS
 };
 
-// Stage texels [x0, x1] x [y0, y1] of the current image (batches of independent loads: one memory round trip per 2048
-// texels).  No barrier.
+// Stage texels [x0, x1] x [y0, y1] of the current image into the LDS window, ROW-WISE: wave v takes rows v, v + 4, ... and its lanes the
+// columns (64 at a time); the row's base address and its place in the LDS are scalar arithmetic, a lane adds its column -- two vector
+// instructions per row and 64 texels where the element-wise form (a division of the element index by the run-time width per texel)
+// spent twenty-five, which made the staging of a light tile's window as expensive as its NCC evaluations.  Batches of 8 rows per lane
+// are in flight together.  No barrier.
 template <int SIDE>
 RMDK_D void frame_stage_window(const SeedParams& P, FrameSmem<SIDE>& S, int tid, const FrameWindow& W) {
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ww = W.x1 - W.x0 + 1, wh = W.y1 - W.y0 + 1;
-  const int n_el = ww * wh;
-  const float inv_ww = 1.0f / static_cast<float>(ww);
-  constexpr int BATCH = 8;
-  for (int e0 = tid; e0 < n_el; e0 += TILE_PIX * BATCH) {
-    float v[BATCH];
-    int dst[BATCH];
+  constexpr int BATCH = 8, WAVES = TILE_PIX / 64;
+  for (int c0 = 0; c0 < ww; c0 += 64) {  // (uniform: at most three column chunks, (ww | 1) * wh <= FR_WIN_CAP)
+    const int c = c0 + lane;
+    const bool in = c < ww;
+    for (int r0 = wave; r0 < wh; r0 += WAVES * BATCH) {
+      float v[BATCH];
 #pragma unroll
-    for (int q = 0; q < BATCH; ++q) {
-      const int e = e0 + q * TILE_PIX;
-      int r = static_cast<int>(static_cast<float>(e) * inv_ww);  // e / ww, fixed up below (e < 2^14)
-      int cc = e - r * ww;
-      if (cc < 0) { --r; cc += ww; } else if (cc >= ww) { ++r; cc -= ww; }
-      dst[q] = r * W.ws + cc;
-      v[q] = e < n_el ? P.cur[(W.y0 + r) * P.cur_stride + W.x0 + cc] : 0.0f;
+      for (int q = 0; q < BATCH; ++q) {
+        const int r = r0 + WAVES * q;  // uniform over the wave
+        const float* row = P.cur + static_cast<size_t>(W.y0 + min(r, wh - 1)) * P.cur_stride + W.x0;
+        v[q] = in ? row[c] : 0.0f;
+      }
+#pragma unroll
+      for (int q = 0; q < BATCH; ++q) {
+        const int r = r0 + WAVES * q;
+        if (in && r < wh) S.win[r * W.ws + c] = v[q];
+      }
     }
-#pragma unroll
-    for (int q = 0; q < BATCH; ++q)
-      if (e0 + q * TILE_PIX < n_el) S.win[dst[q]] = v[q];
   }
 }
 
@@ -621,7 +635,12 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
   }
   int state = ST_BORDER;
   if (in_image) {
-    state = seed_check(P, x, y, sigma_sq, a, b, SIDE);
+    // A seed that the PREVIOUS frame's check (the same lane, one launch ago: fuse_prev says nobody touched the planes in between) found
+    // BORDER / CONVERGED / DIVERGED keeps sigma_sq, a, b -- the finalisation only ever touches UPDATE seeds -- so the check, a pure function
+    // of those and of the pixel position, gives the same answer again: it is not re-evaluated (two IEEE divisions per lane; on the ~170
+    // light frames of the sequence four waves in five consist of such seeds only).
+    const bool settled = conv_old == ST_BORDER || conv_old == ST_CONVERGED || conv_old == ST_DIVERGED;
+    state = settled ? conv_old : seed_check(P, x, y, sigma_sq, a, b, SIDE);
     if (state != conv_old) P.conv[gi] = state;  // final for BORDER / CONVERGED / DIVERGED; UPDATE seeds are settled by the finalisation
   }
   if (P.trace) t_loaded = wall_clock64();
@@ -666,14 +685,18 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
     const unsigned long long s_evals = wave_sum_u64(static_cast<unsigned long long>(n_evals));
     if (lane == 0 && s_live) { atomicAdd(&P.stats[0], s_live); atomicAdd(&P.stats[1], s_steps); atomicAdd(&P.stats[2], s_evals); }
   }
-  const int tot = wave_reduce_i32<WaveAdd>(n_valid);
   // seeds that this frame's check found CONVERGED: what getConvergedCount() reports after this update (seed_matrix.cu:195-198 counts
   // the plane that seed_check has just rewritten; the matcher only ever turns UPDATE into NO_MATCH)
   const int n_conv = __popcll(__ballot(in_image && state == ST_CONVERGED));
-  // ... and the texel box of ALL samples of the tile: it travels with the tile's work units, so that the search kernel can request
-  // the tile's window of the current image together with the tile's descriptors (one memory round trip less per tile)
-  bx0 = wave_reduce_i32<WaveMin>(bx0); by0 = wave_reduce_i32<WaveMin>(by0);
-  bx1 = wave_reduce_i32<WaveMax>(bx1); by1 = wave_reduce_i32<WaveMax>(by1);
+  // the wave's work total, and the texel box of ALL samples of the tile: it travels with the tile's work units, so that the search kernel
+  // can request the tile's window of the current image together with the tile's descriptors (one memory round trip less per tile).  A
+  // wave without work skips the five reductions (sixty-five vector instructions: more than the rest of what such a wave executes).
+  int tot = 0;
+  if (__any(n_valid > 0)) {  // uniform over the wave: all 64 lanes take part in the DPP reductions
+    tot = wave_reduce_i32<WaveAdd>(n_valid);
+    bx0 = wave_reduce_i32<WaveMin>(bx0); by0 = wave_reduce_i32<WaveMin>(by0);
+    bx1 = wave_reduce_i32<WaveMax>(bx1); by1 = wave_reduce_i32<WaveMax>(by1);
+  }
   if (lane == 0) { red_i[wave] = tot; red_c[wave] = n_conv; red_b[wave][0] = bx0; red_b[wave][1] = by0; red_b[wave][2] = bx1; red_b[wave][3] = by1; }
   __syncthreads();
   const int total = red_i[0] + red_i[1] + red_i[2] + red_i[3];
@@ -719,6 +742,29 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
   if (tid == 0) M.tile_plan[tile_g] = static_cast<unsigned int>(total);
 }
 
+// The shards' unit lists read as ONE list: entry `g` lives in shard s with first[s] <= g < first[s + 1].  The sixteen counts were
+// written by the setup kernel -- the launch before this one -- and nobody writes them while this kernel runs: they are read through the
+// scalar path (constant address space) every time they are needed, sixteen words from the scalar cache, instead of being kept in
+// seventeen scalar registers across the whole kernel (which, with the kernel arguments, overflowed the scalar register file: 104
+// spills to vector-register lanes, two hundred v_writelane / v_readlane per workgroup -- executed by all 1 024 workgroups of every
+// launch, most of which have no unit on a light frame).
+typedef const __attribute__((address_space(4))) unsigned long long* const_u64_ptr;
+RMDK_D unsigned int unit_count(const_u64_ptr counts) {
+  unsigned int n = 0u;
+#pragma unroll
+  for (int q = 0; q < UNIT_SHARDS; ++q) n += static_cast<unsigned int>(counts[q]);
+  return n;
+}
+RMDK_D const uint4* unit_entry(const MatcherArgs& M, const_u64_ptr counts, unsigned int g) {  // g uniform: scalar arithmetic
+  unsigned int acc = 0u, sh = 0u, sh_first = 0u;
+#pragma unroll
+  for (int q = 0; q < UNIT_SHARDS - 1; ++q) {
+    acc += static_cast<unsigned int>(counts[q]);
+    if (g >= acc) { sh = static_cast<unsigned int>(q + 1); sh_first = acc; }
+  }
+  return M.units + static_cast<size_t>(sh) * M.shard_cap + (g - sh_first);
+}
+
 template <int SIDE, int NSEQ>
 __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_kernel(BatchArgs<NSEQ> B, MatcherArgs M) {
   using Smem = FrameSmem<SIDE>;
@@ -726,19 +772,6 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem& S = *reinterpret_cast<Smem*>(smem_raw);
   const int tid = threadIdx.x;
-  const int tx = tid & (TILE_W - 1), ty = tid >> 4;
-  // the shards' unit lists as one list: unit g lives in shard s with first[s] <= g < first[s + 1]
-  unsigned int shard_first[UNIT_SHARDS + 1];
-  shard_first[0] = 0u;
-#pragma unroll
-  for (int q = 0; q < UNIT_SHARDS; ++q) shard_first[q + 1] = shard_first[q] + static_cast<unsigned int>(M.shards_cur[q]);
-  const unsigned int n_units = shard_first[UNIT_SHARDS];
-  const int unit_items = static_cast<int>(M.queue[5]);
-  unsigned int n_fallback = 0, n_windows = 0, n_done = 0, n_items = 0;
-  int lds_tile = -1, x0 = 0, y0 = 0, total = 0;
-  const SeqArgs* Qp = NSEQ == 1 ? &B.seq[0] : seq_table();  // the sequence of the tile in LDS (one sequence: the named argument, see the setup kernel)
-  size_t so = 0;                    // ... and where its seeds start in the workspace planes
-  unsigned long long* const trace0 = NSEQ == 1 ? B.seq[0].P.trace : nullptr;  // diagnostics (single sequences only)
   // One step ahead (MatcherArgs::ahead): the first ahead_wgs workgroups -- dispatched first, so they never queue behind the persistent
   // ones -- bring the next host frame into the other current-image plane if the setup kernel found it in the ring, and leave.
   if (NSEQ == 1 && blockIdx.x < static_cast<unsigned int>(M.ahead_wgs)) {
@@ -757,11 +790,8 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
     return;
   }
   const unsigned int wg_id = blockIdx.x - static_cast<unsigned int>(M.ahead_wgs), n_wg = gridDim.x - static_cast<unsigned int>(M.ahead_wgs);
-  unsigned long long* const tr = trace0 && static_cast<int>(wg_id) < M.n_tiles ? trace0 + static_cast<size_t>(wg_id) * FR_TRACE_WORDS : nullptr;
-  if (tr && tid == 0) tr[0] = wall_clock64();
-#ifdef RMD_PROFILE_ROUNDS
-  if (tid < 8) S.prof[tid] = 0ull;
-#endif
+  const const_u64_ptr counts = (const_u64_ptr)(M.shards_cur);
+  const unsigned int n_units = unit_count(counts);
   // The LAST workgroup (it has no unit of its own on all but the heaviest frames) adds up the per-tile counts of seeds the setup kernel
   // found CONVERGED and mirrors them, stamped with this update's number, to pinned host memory: getConvergedCount() after an update
   // needs no device synchronisation and no kernel of its own (seed_matrix.cu:195-198, depthmap_node.cpp:142-153).
@@ -770,8 +800,7 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
       if (NSEQ > 1 && !seq_table()[q].active) continue;
       int c = 0;
       for (int t = tid; t < M.n_tiles; t += TILE_PIX) c += static_cast<int>(M.tile_conv[static_cast<size_t>(q) * M.n_tiles + t]);
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+      c = wave_reduce_i32<WaveAdd>(c);
       if ((tid & 63) == 0) S.red[tid >> 6][0] = c;
       __syncthreads();
       if (tid == 0) {
@@ -781,44 +810,39 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
       __syncthreads();
     }
   }
+  if (wg_id >= n_units) return;  // no unit for this workgroup: on a light frame most of the grid leaves here, a few dozen scalar instructions in
+  unsigned long long* const trace0 = NSEQ == 1 ? B.seq[0].P.trace : nullptr;  // diagnostics (single sequences only)
+  unsigned long long* const tr = trace0 && static_cast<int>(wg_id) < M.n_tiles ? trace0 + static_cast<size_t>(wg_id) * FR_TRACE_WORDS : nullptr;
+  if (tr && tid == 0) tr[0] = wall_clock64();
+#ifdef RMD_PROFILE_ROUNDS
+  if (tid < 8) S.prof[tid] = 0ull;
+#endif
+  const int tx = tid & (TILE_W - 1), ty = tid >> 4;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int unit_items = static_cast<int>(*(const __attribute__((address_space(4))) unsigned int*)(M.queue + 5));  // written by the setup kernel
+  unsigned int n_fallback = 0, n_windows = 0, n_done = 0, n_items = 0;
+  int lds_tile = -1, x0 = 0, y0 = 0, total = 0;
+  const SeqArgs* Qp = NSEQ == 1 ? &B.seq[0] : seq_table();  // the sequence of the tile in LDS (one sequence: the named argument, see the setup kernel)
+  size_t so = 0;                    // ... and where its seeds start in the workspace planes
   FrameWindow W;
   W.valid = false; W.x0 = W.y0 = 0; W.x1 = W.y1 = -1; W.ws = 1;
-  // unit g of the sixteen lists read as one list
-  auto entry_of = [&](unsigned int g) {
-    int sh = 0;
-#pragma unroll
-    for (int q = 1; q < UNIT_SHARDS; ++q) sh += g >= shard_first[q] ? 1 : 0;
-    unsigned int sh_first = 0u;
-#pragma unroll
-    for (int q = 1; q < UNIT_SHARDS; ++q) sh_first = g >= shard_first[q] ? shard_first[q] : sh_first;
-    return M.units[static_cast<size_t>(sh) * M.shard_cap + (g - sh_first)];
-  };
   // Unit wg_id is ours for free.  When there are more units than workgroups the rest is handed out by sixteen counters (workgroup
   // b draws from counter b % 16, which deals the units n_wg + b % 16 + 16 k: one counter word for a thousand workgroups serialises
-  // their returning atomics for 12 us), and the NEXT unit is claimed and its entry fetched while the current one is being searched: the
-  // atomic is issued before the tile's descriptors are requested, the entry -- by an LDS-direct load, it never occupies registers
-  // across the NCC block -- once they have arrived; both are consumed after the rounds.
+  // their returning atomics for 12 us).  Claiming the next unit while the current one is searched was measured and lost (a unit claimed
+  // one unit-time earlier is a unit the fastest workgroup cannot take, profiles/r03_batch_ab.txt).
   const bool handout = n_units > n_wg;
-  const bool prefetch = (M.search_flags & SEARCH_PREFETCH) != 0, sharded = (M.search_flags & SEARCH_SHARDED_HANDOUT) != 0;
-  const unsigned int cls = sharded ? wg_id & (UNIT_SHARDS - 1) : 0u;
-  const unsigned int cls_step = sharded ? UNIT_SHARDS : 1u;
+  const unsigned int cls = wg_id & (UNIT_SHARDS - 1);
   unsigned int u = wg_id;
-  int tile = 0, first = 0;
-  unsigned int box0 = 0u, box1 = 0u;
-  bool boxed = false;
-  auto take = [&](const uint4& e) {  // uniform over the workgroup: scalar registers
-    tile = __builtin_amdgcn_readfirstlane(static_cast<int>(e.x));
-    const unsigned int fy = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(e.y)));
-    first = static_cast<int>(fy & ~UNIT_TILE_BOX);
-    boxed = (fy & UNIT_TILE_BOX) != 0u && (M.search_flags & SEARCH_TILE_BOX) != 0;
-    box0 = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(e.z)));
-    box1 = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(e.w)));
-  };
-  if (u < n_units) take(entry_of(u));
   while (u < n_units) {
-    unsigned int nxt_k = 0u;
-    if (handout && prefetch && tid == 0) nxt_k = atomicAdd(&M.handout[cls * HANDOUT_STRIDE], 1u);
+    // the unit: (tile, first item | UNIT_TILE_BOX, the texel box of all samples of the tile) -- uniform over the workgroup: scalar registers
+    const uint4 e = *unit_entry(M, counts, u);
+    const int tile = __builtin_amdgcn_readfirstlane(static_cast<int>(e.x));
+    const unsigned int fy = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(e.y)));
+    const int first = static_cast<int>(fy & ~UNIT_TILE_BOX);
+    const bool boxed = (fy & UNIT_TILE_BOX) != 0u;
     if (tile != lds_tile) {
+      const unsigned int box0 = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(e.z)));
+      const unsigned int box1 = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(e.w)));
       if (lds_tile >= 0) {  // hand the previous tile's keys over
         const unsigned long long key = S.best[tid];
         if (key != 0ull) atomicMax(&M.best[so + static_cast<size_t>(y0 + ty) * Qp->P.stride + x0 + tx], key);
@@ -839,13 +863,17 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
       const unsigned int packed = M.packed[gm];  // first in-image step << 16 | number of in-image steps
       const float2 m = M.mean[gm], d = M.dir[gm];
       const float lf = M.lfirst[gm], st = P.sum_templ[gi], dn = P.denom[gi];
-      constexpr int REF_N = Smem::REF_H * Smem::REF_W, REF_PER = (REF_N + TILE_PIX - 1) / TILE_PIX;
-      float refv[REF_PER];
+      // the patch halo, row-wise like the window: wave v takes halo rows v, v + 4, ..., its first REF_W lanes the columns; the clamped
+      // column is computed once per lane, the clamped row is scalar
+      constexpr int REF_ROWS_PER_WAVE = (Smem::REF_H + 3) / 4;
+      static_assert(Smem::REF_W <= 64, "one halo row per wave instruction");
+      float refv[REF_ROWS_PER_WAVE];
+      const int ref_col = clampi(x0 - HALF + lane, 0, P.w - 1);
 #pragma unroll
-      for (int q = 0; q < REF_PER; ++q) {
-        const int i = min(tid + q * TILE_PIX, REF_N - 1);
-        const int ry = i / Smem::REF_W, rx = i - ry * Smem::REF_W;
-        refv[q] = P.ref[clampi(y0 - HALF + ry, 0, P.h - 1) * P.stride + clampi(x0 - HALF + rx, 0, P.w - 1)];
+      for (int q = 0; q < REF_ROWS_PER_WAVE; ++q) {
+        const int ry = min(wave + 4 * q, Smem::REF_H - 1);
+        const float* row = P.ref + static_cast<size_t>(clampi(y0 - HALF + ry, 0, P.h - 1)) * P.stride;
+        refv[q] = lane < Smem::REF_W ? row[ref_col] : 0.0f;
       }
       if (boxed) {
         W.x0 = static_cast<int>(box0 & 0xffffu); W.y0 = static_cast<int>(box0 >> 16);
@@ -862,41 +890,18 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
       S.packed[tid] = pk;
       S.best[tid] = 0ull;
 #pragma unroll
-      for (int q = 0; q < REF_PER; ++q)
-        if (tid + q * TILE_PIX < REF_N) S.ref[tid + q * TILE_PIX] = refv[q];
+      for (int q = 0; q < REF_ROWS_PER_WAVE; ++q)
+        if (lane < Smem::REF_W && wave + 4 * q < Smem::REF_H) S.ref[(wave + 4 * q) * Smem::REF_W + lane] = refv[q];
       total = boxed ? frame_prefix<SIDE>(S, tid) : frame_prefix_and_window<SIDE>(P, S, tid, W);  // barriers inside
       lds_tile = tile;
       if (tr && tid == 0 && n_done == 0) tr[1] = wall_clock64();
     }
-    if (handout && prefetch && tid == 0) {
-      const unsigned int u_next = n_wg + cls + cls_step * nxt_k;
-      S.bcast[0] = u_next;
-      if (u_next < n_units) {
-        int sh = 0;
-#pragma unroll
-        for (int q = 1; q < UNIT_SHARDS; ++q) sh += u_next >= shard_first[q] ? 1 : 0;
-        unsigned int sh_first = 0u;
-#pragma unroll
-        for (int q = 1; q < UNIT_SHARDS; ++q) sh_first = u_next >= shard_first[q] ? shard_first[q] : sh_first;
-        const uint4* src = M.units + static_cast<size_t>(sh) * M.shard_cap + (u_next - sh_first);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(S.bcast + 4), 16, 0, 0);
-      }
-    }
     frame_search<SIDE>(Qp->P, S, tid, first, min(first + unit_items, total), W, n_fallback, n_windows);  // ends with a barrier
     ++n_done; n_items += static_cast<unsigned int>(min(first + unit_items, total) - first);
     if (!handout) break;  // light frame: every unit had its own workgroup, nothing to hand out
-    if (!prefetch && tid == 0) {  // (A/B: claim and fetch the next unit only now)
-      const unsigned int u_next = n_wg + cls + cls_step * atomicAdd(&M.handout[cls * HANDOUT_STRIDE], 1u);
-      S.bcast[0] = u_next;
-      if (u_next < n_units) {
-        const uint4 e = entry_of(u_next);
-        S.bcast[4] = e.x; S.bcast[5] = e.y; S.bcast[6] = e.z; S.bcast[7] = e.w;
-      }
-    }
-    drain_vmem();  // the LDS-direct load of the next entry has landed (it was issued before the rounds)
+    if (tid == 0) S.bcast[0] = n_wg + cls + UNIT_SHARDS * atomicAdd(&M.handout[cls * HANDOUT_STRIDE], 1u);
     __syncthreads();
     u = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(S.bcast[0])));
-    take(make_uint4(S.bcast[4], S.bcast[5], S.bcast[6], S.bcast[7]));
     __syncthreads();
   }
   if (lds_tile >= 0) {
