@@ -67,7 +67,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="budget of the cpu_baseline run (0 disables it and the glibc parity figures)")
     ap.add_argument("--matcher", type=int, default=-1, help="A/B: 0 per-pixel kernel, 3 tile pipeline (the library's default, used when the flag "
                     "is absent); 1 / 2 (retired variants) only with an A/B build of the library")
-    ap.add_argument("--unit-target", type=int, default=1, help="tile pipeline: work units aimed at per frame, in multiples of the resident search workgroups (experiments)")
+    ap.add_argument("--unit-target", type=int, default=0, help="tile pipeline: work units aimed at per frame, in multiples of the resident search workgroups (experiments; "
+                    "0 = the library's defaults: 2 for a single sequence, 1 for a batch)")
     ap.add_argument("--size", default=f"{WIDTH}x{HEIGHT}", help="frame size WxH; 640x480 with 200 frames is the headline metric")
     ap.add_argument("--frames", type=int, default=0, help="frames per pass incl. the reference (default: 200; 500 at 1280x960, "
                     "1000 at 1920x1080, as BASELINE.json configures them)")
@@ -311,7 +312,8 @@ def main():
         s = api.SeedMatrix(W, H, api.PinholeCamera(*K), patch_side=SIDE)
         if args.matcher >= 0:
             s.setOption(api.OPT_MATCHER, args.matcher)
-        s.setOption(api.OPT_UNIT_TARGET, args.unit_target)
+        if args.unit_target > 0:
+            s.setOption(api.OPT_UNIT_TARGET, args.unit_target)
         return s
 
     def pass_resident(s, n_updates=None):
@@ -330,7 +332,8 @@ def main():
     bm = None
     if B > 1:  # the rank's B sequences as ONE batch: one setup + one search launch per stream group and step
         bm = api.SeedMatrixBatch(B, W, H, api.PinholeCamera(*K), patch_side=SIDE)
-        bm.setOption(api.OPT_UNIT_TARGET, args.unit_target)
+        if args.unit_target > 0:
+            bm.setOption(api.OPT_UNIT_TARGET, args.unit_target)
 
         def run_pass(_s, n_updates=None):
             sc = batch_scenes
@@ -511,45 +514,46 @@ def main():
                                    "per step for all of them (rmd_hip_batch_update_*); aggregate Mpix/s over all B sequences; every member is bit-identical "
                                    "to the same sequence run alone (tests/test_batch.py)",
                            "host_render_s": round(time.perf_counter() - t_render, 1)}
-                for B in sizes:
-                    sc = [scenes[i] for i in range(B)]
-                    bm = api.SeedMatrixBatch(B, W, H, api.PinholeCamera(*K), patch_side=SIDE)
-                    bm.setOption(api.OPT_UNIT_TARGET, args.unit_target)
+                for Bq in sizes:
+                    sc = [scenes[i] for i in range(Bq)]
+                    bmq = api.SeedMatrixBatch(Bq, W, H, api.PinholeCamera(*K), patch_side=SIDE)
+                    if args.unit_target > 0:
+                        bmq.setOption(api.OPT_UNIT_TARGET, args.unit_target)
 
                     def bpass(use_u8):
-                        for i in range(B):
+                        for i in range(Bq):
                             if use_u8:
-                                bm[i].setReferenceImageU8(sc[i]["gray"][0], sc[i]["poses"][0], sc[i]["min"], sc[i]["max"])
+                                bmq[i].setReferenceImageU8(sc[i]["gray"][0], sc[i]["poses"][0], sc[i]["min"], sc[i]["max"])
                             else:
-                                bm[i].setReferenceImageDevice(sc[i]["dev"][0].data, sc[i]["dev"][0].stride, sc[i]["poses"][0], sc[i]["min"], sc[i]["max"])
+                                bmq[i].setReferenceImageDevice(sc[i]["dev"][0].data, sc[i]["dev"][0].stride, sc[i]["poses"][0], sc[i]["min"], sc[i]["max"])
                         for k in range(1, F):
-                            p = [sc[i]["poses"][k] for i in range(B)]
+                            p = [sc[i]["poses"][k] for i in range(Bq)]
                             if use_u8:
-                                bm.updateU8([sc[i]["gray"][k] for i in range(B)], p)
+                                bmq.updateU8([sc[i]["gray"][k] for i in range(Bq)], p)
                             else:
-                                bm.updateDevice([sc[i]["dev"][k].data for i in range(B)], [sc[i]["dev"][k].stride for i in range(B)], p)
+                                bmq.updateDevice([sc[i]["dev"][k].data for i in range(Bq)], [sc[i]["dev"][k].stride for i in range(Bq)], p)
                     entry = {}
                     for use_u8, name in ((False, "resident"), (True, "u8_host_frames")):
                         bpass(use_u8)
-                        bm.sync()
-                        bm.setOption(api.OPT_TIMING, 2)
-                        bm.timingReset()
+                        bmq.sync()
+                        bmq.setOption(api.OPT_TIMING, 2)
+                        bmq.timingReset()
                         tb = time.perf_counter()
                         for _ in range(extra_passes):
                             bpass(use_u8)
-                        bm.sync()
+                        bmq.sync()
                         dtb = time.perf_counter() - tb
-                        msb, nb = bm.timing()
-                        bm.setOption(api.OPT_TIMING, 0)
-                        entry[name] = {"value": round(W * H * (F - 1) * B * extra_passes / dtb / 1e6, 1), "unit": "Mpix/s",
+                        msb, nb = bmq.timing()
+                        bmq.setOption(api.OPT_TIMING, 0)
+                        entry[name] = {"value": round(W * H * (F - 1) * Bq * extra_passes / dtb / 1e6, 1), "unit": "Mpix/s",
                                        "us_per_step_wall": round(dtb / nb * 1e6, 2), "us_per_step_device": round(msb / nb * 1e3, 2),
-                                       "us_per_sequence_update": round(dtb / nb / B * 1e6, 2)}
-                    rv = valu_roofline(entry["resident"]["us_per_step_device"] / 1e6, counters, n_sequences=B)
+                                       "us_per_sequence_update": round(dtb / nb / Bq * 1e6, 2)}
+                    rv = valu_roofline(entry["resident"]["us_per_step_device"] / 1e6, counters, n_sequences=Bq)
                     if rv and not rv.get("stale"):
                         entry["roofline_valu_frac"] = rv["frac"]
-                    entry["converged_seeds_at_end"] = [bm[i].getConvergedCount() for i in range(B)]
-                    batched[f"B={B}"] = entry
-                    del bm
+                    entry["converged_seeds_at_end"] = [bmq[i].getConvergedCount() for i in range(Bq)]
+                    batched[f"B={Bq}"] = entry
+                    del bmq
 
             # CPU baseline = the untouched reference on the host cores; the same run gives the distance of the GPU result from it
             if args.cpu_seconds > 0 and world == 1 and F <= 500:

@@ -278,7 +278,9 @@ struct rmd_hip_seeds {
   hipStream_t stream = nullptr;
   unsigned long long* d_scalars = nullptr;  // [0] count result, [1..16] diagnostics
   unsigned long long* h_scalars = nullptr;  // pinned mirror
-  int opt_matcher = 3, opt_timing = 0, opt_stats = 0, opt_window = 0, opt_local_max = 0, opt_unit_rounds = 0, opt_unit_target = 1;
+  // (unit target 2: a single sequence's search is a latency chain with a tail; units of half the size shorten the tail now that a unit's staging is cheap:
+  // 45.4 -> 44.3 us per update, profiles/r04_unit_target.txt; a batch keeps 1, its tails are filled by the other stream groups)
+  int opt_matcher = 3, opt_timing = 0, opt_stats = 0, opt_window = 0, opt_local_max = 0, opt_unit_rounds = 0, opt_unit_target = 2;
   // a SeedMatrix that is a member of a batch (rmd_hip_batch_*) shares the batch's streams and update workspace: its update
   // kernels are launched by the batch, for all members at once; everything else (reference frames, observers) works per member
   struct rmd_hip_batch* batch = nullptr;

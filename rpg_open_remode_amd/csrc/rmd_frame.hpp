@@ -59,7 +59,7 @@ struct FrameSmem {
   int prefix[TILE_PIX + 1];
   unsigned int packed[TILE_PIX];   // state << 16 | first in-image step << 8 | number of in-image steps
   int red[4][12];
-  alignas(16) unsigned int bcast[8];  // [0] the workgroup's next unit, [4..7] its entry (written by an LDS-direct load)
+  alignas(16) unsigned int bcast[8];  // [0] the workgroup's next unit
 #ifdef RMD_PROFILE_ROUNDS
   unsigned long long prof[8];  // diagnostics build: [4] window policy, [5] staging, [6] rounds + barrier ticks; [0..3] per wave, ticks / count of rounds without (bits 0..23 / 56..63) and with (24..47 / 48..55) a fallback
 #endif
@@ -470,7 +470,7 @@ constexpr int INGEST_WGS_IN_PLACE = 256;  // frames read in place from pinned ho
 
 template <int SIDE, int NSEQ>
 __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<NSEQ> B, MatcherArgs M, int target_units) {
-  __shared__ int red_i[4], red_c[4], red_b[4][4];
+  __shared__ int red_i[4], red_c[4], red_l[4], red_b[4][4];
   __shared__ unsigned int s_base;
   constexpr int HALF = SIDE / 2;
   const int seq = NSEQ == 1 ? 0 : static_cast<int>(blockIdx.z);
@@ -571,8 +571,18 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
 #ifdef RMD_PROFILE_ROUNDS
   unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // fuse: start, triangulated, uncertainty, normpdf, end; segment done; run done
 #endif
+  const int tile = blockIdx.y * M.tiles_x + blockIdx.x;                      // within the sequence
+  const int tile_g = (NSEQ == 1 ? 0 : seq * M.n_tiles) + tile;               // within the launch
+  // A tile in which the previous frame's check left no seed in state UPDATE is DEAD until the next reference frame: BORDER / CONVERGED /
+  // DIVERGED are absorbing (nothing but the finalisation of an UPDATE seed ever changes sigma_sq, a, b), so every plane, the tile's CONVERGED
+  // count and its empty descriptors already hold what this launch would write.  Its workgroup leaves after one scalar load -- on the ~170
+  // light frames of the benchmark sequence that is four tiles in five, which used to fetch 44 bytes per pixel and run the check for nothing.
+  // (tile_live: written at the end of this kernel by the tile's own workgroup, read here one launch later; fuse_prev = nobody touched the
+  // planes in between.  The launch's housekeeping below must not depend on tile 0 being alive.)
+  const bool dead_tile = Q.fuse_prev && *(const __attribute__((address_space(4))) unsigned int*)(M.tile_live + tile_g) == 0u;
   // the seed's state: requested before anything else, so that the scalar-load chains below (kernel arguments, the previous frame's
   // counters) run while these are in flight
+  if (dead_tile && !(tile == 0 && seq == M.housekeeper)) return;  // (the keeper goes on: its loads are as harmless as they were)
   float mu = P.mu[gi], sigma_sq = P.sigma_sq[gi], a = P.a[gi], b = P.b[gi];
   // ... and, when the previous frame's finalisation runs here, what that needs: the state it left, its arg-max key, its search descriptor
   // (requested whether or not a finalisation is pending -- it nearly always is, and a conditional load costs a register shuffle and a
@@ -697,11 +707,10 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
     bx0 = wave_reduce_i32<WaveMin>(bx0); by0 = wave_reduce_i32<WaveMin>(by0);
     bx1 = wave_reduce_i32<WaveMax>(bx1); by1 = wave_reduce_i32<WaveMax>(by1);
   }
-  if (lane == 0) { red_i[wave] = tot; red_c[wave] = n_conv; red_b[wave][0] = bx0; red_b[wave][1] = by0; red_b[wave][2] = bx1; red_b[wave][3] = by1; }
+  const int n_live = __popcll(__ballot(live));
+  if (lane == 0) { red_i[wave] = tot; red_c[wave] = n_conv; red_l[wave] = n_live; red_b[wave][0] = bx0; red_b[wave][1] = by0; red_b[wave][2] = bx1; red_b[wave][3] = by1; }
   __syncthreads();
   const int total = red_i[0] + red_i[1] + red_i[2] + red_i[3];
-  const int tile = blockIdx.y * M.tiles_x + blockIdx.x;                      // within the sequence
-  const int tile_g = (NSEQ == 1 ? 0 : seq * M.n_tiles) + tile;               // within the launch
   const int unit_items = unit_rounds * TILE_PIX;
   // the launch's housekeeping falls to tile 0 of its first sequence that has a frame (M.housekeeper: a sequence that sits the step out
   // leaves at the top of the kernel)
@@ -710,6 +719,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
   if (keeper && tid < UNIT_SHARDS) M.handout[tid * HANDOUT_STRIDE] = 0u;  // the search kernel's hand-out counters
   if (keeper && tid == 0) M.queue[5] = static_cast<unsigned int>(unit_items);
   if (tid == 0) M.tile_conv[tile_g] = static_cast<unsigned int>(red_c[0] + red_c[1] + red_c[2] + red_c[3]);
+  if (tid == 0) M.tile_live[tile_g] = static_cast<unsigned int>(red_l[0] + red_l[1] + red_l[2] + red_l[3]);  // seeds in state UPDATE after this frame's check
 #ifdef RMD_PROFILE_ROUNDS
   if (P.trace && prof_t[0] != 0ull && prof_t[6] != 0ull) {  // any live lane that ran both the fusion and the set-up: phases of the setup chain, 10 ns ticks
     auto d = [](unsigned long long a, unsigned long long b) { return static_cast<unsigned long long>(b > a ? (b - a > 511 ? 511 : b - a) : 0); };
@@ -739,7 +749,6 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
                    boxed ? static_cast<unsigned int>(x0) | (static_cast<unsigned int>(y0) << 16) : 0u,
                    boxed ? static_cast<unsigned int>(x1) | (static_cast<unsigned int>(y1) << 16) : 0u);
   }
-  if (tid == 0) M.tile_plan[tile_g] = static_cast<unsigned int>(total);
 }
 
 // The shards' unit lists read as ONE list: entry `g` lives in shard s with first[s] <= g < first[s + 1].  The sixteen counts were
@@ -828,21 +837,26 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
   W.valid = false; W.x0 = W.y0 = 0; W.x1 = W.y1 = -1; W.ws = 1;
   // Unit wg_id is ours for free.  When there are more units than workgroups the rest is handed out by sixteen counters (workgroup
   // b draws from counter b % 16, which deals the units n_wg + b % 16 + 16 k: one counter word for a thousand workgroups serialises
-  // their returning atomics for 12 us).  Claiming the next unit while the current one is searched was measured and lost (a unit claimed
-  // one unit-time earlier is a unit the fastest workgroup cannot take, profiles/r03_batch_ab.txt).
+  // their returning atomics for 12 us).  Claiming the next unit while the current one is searched was measured twice and lost twice: throughout
+  // (round 3: a unit claimed one unit-time earlier is a unit the fastest workgroup cannot take, profiles/r03_batch_ab.txt) and only while two
+  // more units per workgroup were left, with the claimed entry fetched by a scalar load during the rounds (round 4: batch of 4 -3 %, batch
+  // of 8 -1 %, profiles/r04_early_claim_ab.txt) -- the two round trips it hides are not what a unit waits for.
   const bool handout = n_units > n_wg;
   const unsigned int cls = wg_id & (UNIT_SHARDS - 1);
+  // the unit entries were written by the setup kernel, the launch before this one: scalar loads (the address is uniform, the words land in
+  // scalar registers, nothing waits on the vector memory counter)
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(4))) u32x4* const_entry_ptr;
   unsigned int u = wg_id;
+  u32x4 e = *(const_entry_ptr)unit_entry(M, counts, u);
   while (u < n_units) {
     // the unit: (tile, first item | UNIT_TILE_BOX, the texel box of all samples of the tile) -- uniform over the workgroup: scalar registers
-    const uint4 e = *unit_entry(M, counts, u);
-    const int tile = __builtin_amdgcn_readfirstlane(static_cast<int>(e.x));
-    const unsigned int fy = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(e.y)));
+    const int tile = static_cast<int>(e.x);
+    const unsigned int fy = e.y;
     const int first = static_cast<int>(fy & ~UNIT_TILE_BOX);
     const bool boxed = (fy & UNIT_TILE_BOX) != 0u;
     if (tile != lds_tile) {
-      const unsigned int box0 = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(e.z)));
-      const unsigned int box1 = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(e.w)));
+      const unsigned int box0 = e.z, box1 = e.w;
       if (lds_tile >= 0) {  // hand the previous tile's keys over
         const unsigned long long key = S.best[tid];
         if (key != 0ull) atomicMax(&M.best[so + static_cast<size_t>(y0 + ty) * Qp->P.stride + x0 + tx], key);
@@ -892,7 +906,10 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
 #pragma unroll
       for (int q = 0; q < REF_ROWS_PER_WAVE; ++q)
         if (lane < Smem::REF_W && wave + 4 * q < Smem::REF_H) S.ref[(wave + 4 * q) * Smem::REF_W + lane] = refv[q];
-      total = boxed ? frame_prefix<SIDE>(S, tid) : frame_prefix_and_window<SIDE>(P, S, tid, W);  // barriers inside
+      // (a unit without the box flag belongs to a tile whose sample box the setup kernel found too large for the LDS window: the box is not
+      // computed a second time here -- frame_search cuts windows to the unit's own rounds)
+      if (!boxed) { W.valid = false; W.x0 = W.y0 = 0; W.x1 = W.y1 = -1; W.ws = 1; }
+      total = frame_prefix<SIDE>(S, tid);  // barriers inside
       lds_tile = tile;
       if (tr && tid == 0 && n_done == 0) tr[1] = wall_clock64();
     }
@@ -903,10 +920,16 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
     __syncthreads();
     u = static_cast<unsigned int>(__builtin_amdgcn_readfirstlane(static_cast<int>(S.bcast[0])));
     __syncthreads();
+    if (u < n_units) e = *(const_entry_ptr)unit_entry(M, counts, u);
   }
   if (lds_tile >= 0) {
     const unsigned long long key = S.best[tid];
     if (key != 0ull) atomicMax(&M.best[so + static_cast<size_t>(y0 + ty) * Qp->P.stride + x0 + tx], key);
+  }
+  if (NSEQ == 1 && B.seq[0].P.stats) {  // diagnostics (COLLECT_STATS = 1): evaluations that read their texels from L2 instead of the LDS window, units, windows staged in the search
+    const unsigned long long fb = wave_sum_u64(n_fallback);
+    if ((tid & 63) == 0 && fb) atomicAdd(&B.seq[0].P.stats[3], fb);
+    if (tid == 0) { atomicAdd(&B.seq[0].P.stats[4], static_cast<unsigned long long>(n_done)); atomicAdd(&B.seq[0].P.stats[5], static_cast<unsigned long long>(n_windows)); }
   }
   if (tr && tid < 64) {
     const unsigned long long fb = wave_sum_u64(n_fallback);  // the first wave's lanes only: a hint, not a count

@@ -56,7 +56,7 @@ struct MatcherWorkspace {
   unsigned int* d_packed = nullptr;      // per seed: first in-image step << 16 | number of in-image steps
   unsigned long long* d_best = nullptr;  // per seed: arg-max key
   TileInfo* d_tiles = nullptr;           // round-1 pipeline only (A/B builds)
-  unsigned int* d_tile_plan = nullptr;   // per tile: work items
+  unsigned int* d_tile_live = nullptr;   // per tile: seeds in state UPDATE after the last frame's check (0: the tile is dead until the next reference frame)
   unsigned int* d_tile_conv = nullptr;   // per tile: seeds that seed_check found CONVERGED in this frame
   uint4* d_units = nullptr;         // work units: (tile, first item | UNIT_TILE_BOX, the tile's sample box x0 | y0 << 16, x1 | y1 << 16)
   unsigned int* d_handout = nullptr;  // UNIT_SHARDS hand-out counters of the search kernel, HANDOUT_STRIDE words apart
@@ -94,7 +94,7 @@ struct MatcherWorkspace {
 #ifdef RMD_AB_MATCHERS
     if (hipMalloc(reinterpret_cast<void**>(&d_tiles), n_tiles_all * sizeof(TileInfo)) != hipSuccess) return -1;
 #endif
-    if (hipMalloc(reinterpret_cast<void**>(&d_tile_plan), n_tiles_all * sizeof(unsigned int)) != hipSuccess) return -1;
+    if (hipMalloc(reinterpret_cast<void**>(&d_tile_live), n_tiles_all * sizeof(unsigned int)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_tile_conv), n_tiles_all * sizeof(unsigned int)) != hipSuccess) return -1;
     shard_cap = static_cast<int>((n_tiles_all + UNIT_SHARDS - 1) / UNIT_SHARDS) * units_per_tile;  // tiles of a shard x units of a tile
     max_units = static_cast<int>(n_tiles_all + UNIT_SHARDS) * units_per_tile;
@@ -113,6 +113,7 @@ struct MatcherWorkspace {
     if (hipMemset(d_packed, 0, n * sizeof(unsigned int)) != hipSuccess) return -1;
     if (hipMemset(d_best, 0, n * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (hipMemset(d_tile_conv, 0, n_tiles_all * sizeof(unsigned int)) != hipSuccess) return -1;
+    if (hipMemset(d_tile_live, 0, n_tiles_all * sizeof(unsigned int)) != hipSuccess) return -1;
     if (hipMemset(d_queue, 0, 8 * sizeof(unsigned int)) != hipSuccess) return -1;
     return 0;
   }
@@ -120,12 +121,12 @@ struct MatcherWorkspace {
   size_t trace_slice_u64() const { return 2 * (static_cast<size_t>(tiles_x) * tiles_y + 1 + TRACE_MAX_SEARCH_WGS); }
   size_t wg_trace_slice_u64() const { return static_cast<size_t>(tiles_x) * tiles_y * 8; }  // FR_TRACE_WORDS per workgroup / tile
   void release() {
-    void* all[] = {d_mean, d_dir, d_lfirst, d_packed, d_best, d_tiles, d_tile_plan, d_tile_conv, d_units, d_handout, d_queue, d_shards, d_trace, d_wg_trace};
+    void* all[] = {d_mean, d_dir, d_lfirst, d_packed, d_best, d_tiles, d_tile_live, d_tile_conv, d_units, d_handout, d_queue, d_shards, d_trace, d_wg_trace};
     for (void* p : all)
       if (p) (void)hipFree(p);
     if (h_conv) (void)hipHostFree(h_conv);
     d_mean = d_dir = nullptr; d_lfirst = nullptr; d_packed = nullptr; d_best = nullptr;
-    d_tiles = nullptr; d_tile_plan = nullptr; d_tile_conv = nullptr; d_units = nullptr; d_handout = nullptr; d_queue = nullptr; d_shards = nullptr; d_trace = nullptr;
+    d_tiles = nullptr; d_tile_live = nullptr; d_tile_conv = nullptr; d_units = nullptr; d_handout = nullptr; d_queue = nullptr; d_shards = nullptr; d_trace = nullptr;
     d_wg_trace = nullptr; h_conv = nullptr; d_conv = nullptr;
   }
 };
@@ -139,7 +140,8 @@ struct MatcherArgs {
   unsigned long long* best;
   size_t seq_plane;          // elements per sequence in the five planes above
   TileInfo* tiles;
-  unsigned int* tile_plan;
+  unsigned int* tile_live;   // per tile: seeds in state UPDATE after the last frame's check (see seed_setup_compact_kernel)
+  unsigned int* tile_plan;   // A/B builds, round-1 pipeline: work items per tile (the same buffer: the two pipelines never run interleaved without a reset)
   unsigned int* tile_conv;
   uint4* units;
   unsigned int* handout;     // UNIT_SHARDS counters, HANDOUT_STRIDE words apart (zero at the search kernel's launch)
@@ -502,7 +504,7 @@ inline MatcherArgs matcher_args(const MatcherWorkspace& ws) {
   MatcherArgs M;
   M.mean = ws.d_mean; M.dir = ws.d_dir; M.lfirst = ws.d_lfirst; M.packed = ws.d_packed; M.best = ws.d_best;
   M.seq_plane = ws.seq_plane;
-  M.tiles = ws.d_tiles; M.tile_plan = ws.d_tile_plan; M.tile_conv = ws.d_tile_conv; M.units = ws.d_units; M.handout = ws.d_handout;
+  M.tiles = ws.d_tiles; M.tile_live = ws.d_tile_live; M.tile_plan = ws.d_tile_live; M.tile_conv = ws.d_tile_conv; M.units = ws.d_units; M.handout = ws.d_handout;
   M.tiles_x = ws.tiles_x; M.tiles_y = ws.tiles_y; M.n_tiles = ws.tiles_x * ws.tiles_y; M.n_seq = ws.n_seq;
   M.queue = ws.d_queue;
   M.shards_cur = ws.d_shards + (ws.frame % 3) * UNIT_SHARDS;
@@ -524,7 +526,7 @@ inline MatcherArgs matcher_args_of(const MatcherWorkspace& ws, int seq) {
   MatcherArgs M = matcher_args(ws);
   const size_t off = ws.seq_plane * static_cast<size_t>(seq);
   M.mean += off; M.dir += off; M.lfirst += off; M.packed += off; M.best += off;
-  M.tile_plan += static_cast<size_t>(seq) * M.n_tiles; M.tile_conv += static_cast<size_t>(seq) * M.n_tiles;
+  M.tile_live += static_cast<size_t>(seq) * M.n_tiles; M.tile_plan = M.tile_live; M.tile_conv += static_cast<size_t>(seq) * M.n_tiles;
   return M;
 }
 

@@ -9,7 +9,7 @@ from rpg_open_remode_amd import api, synth
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--b", default="1,8"); ap.add_argument("--size", default="640x480"); ap.add_argument("--reps", type=int, default=40)
-ap.add_argument("--side", type=int, default=9); ap.add_argument("--label", default="")
+ap.add_argument("--side", type=int, default=9); ap.add_argument("--label", default=""); ap.add_argument("--unit-target", type=int, default=1)
 a = ap.parse_args()
 W, H = (int(v) for v in a.size.split("x"))
 seq = synth.Sequence(W, H, 3, 0)
@@ -20,6 +20,7 @@ for k in range(2):
     dev.append(d)
 for n in (int(v) for v in a.b.split(",")):
     b = api.SeedMatrixBatch(n, W, H, api.PinholeCamera(*seq.K), patch_side=a.side)
+    b.setOption(api.OPT_UNIT_TARGET, a.unit_target)
     ts = []
     for rep in range(a.reps + 3):
         for i in range(n):

@@ -11,6 +11,7 @@ ap.add_argument("--size", default="640x480"); ap.add_argument("--frames", type=i
 ap.add_argument("--side", type=int, default=9)
 ap.add_argument("--show", default="1,5,20,60,100,150,199")
 ap.add_argument("--u8", action="store_true", help="frames handed over as 8-bit host images (ingest fused into the setup kernel)")
+ap.add_argument("--brief", action="store_true", help="one line for EVERY update, nothing else")
 a = ap.parse_args()
 W, H = (int(v) for v in a.size.split("x"))
 seq = synth.Sequence(W, H, a.frames)
@@ -36,6 +37,12 @@ print(f"{'frame':>5} | {'busy':>5} | 1st unit ready p50 {'p99':>6} | end p50 {'p
 for k in range(a.frames - 1):
     t_all = s.frameTraceDownload(k).astype(np.int64)
     t = t_all[t_all[:, 0] != 0]
+    if a.brief and len(t):
+        b = t[t[:, 5] > 0]
+        t0 = t[:, 0].min()
+        ex = b[:, 3] - t0
+        print(f"{k + 1:5d} | busy {len(b):5d} | end p50 {us(np.percentile(ex, 50)):6.1f} max {us(ex.max()):6.1f} | items {int(b[:, 4].sum()):8d} units {int(b[:, 5].sum()):6d} windows staged in the search {int((b[:, 7] >> 32).sum()):6d}")
+        continue
     if k + 1 not in show or len(t) == 0:
         continue
     t0 = t[:, 0].min()
