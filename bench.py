@@ -116,12 +116,15 @@ def _code_only(text):
     return " ".join("".join(out).split())
 
 
+KERNEL_SOURCES = ["rmd_device.hpp", "rmd_frame.hpp", "rmd_kernels.hpp", "rmd_matcher.hpp", "rmd_math.h"]  # the device code of librmd_hip.so (csrc/rmd_host.hpp and the .hip units are host code)
+
+
 def kernel_source_sha256():
     """hash of the device code of librmd_hip.so (the kernel headers; the host orchestration in rmd_capi.hip is not part of it), comments
     and white space left out: committed counter files (profiles/traffic.json) carry the hash of the sources they were measured on, and a
     figure derived from them is refused when the kernels have changed since -- editing a comment does not change a kernel"""
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "rpg_open_remode_amd", "csrc", "*.hpp")) + glob.glob(os.path.join(ROOT, "rpg_open_remode_amd", "csrc", "*.h"))):
+    for f in [os.path.join(ROOT, "rpg_open_remode_amd", "csrc", n) for n in KERNEL_SOURCES]:
         h.update(os.path.basename(f).encode())
         h.update(_code_only(open(f, "r", encoding="utf-8", errors="replace").read()).encode())
     return h.hexdigest()

@@ -72,6 +72,22 @@ typedef struct rmd_hip_seeds rmd_hip_seeds_t;
 typedef struct rmd_hip_denoiser rmd_hip_denoiser_t;
 typedef struct rmd_hip_batch rmd_hip_batch_t;
 
+/* ---- environment switches ---------------------------------------------------------------
+ * Every one is an A/B or diagnostics switch of the host side, read ONCE per process (function-local statics) or once per handle at its
+ * creation; none changes results (tests/test_host_frame_modes.py, tests/test_full_speed.py run the frame-path modes against the resident
+ * path bit for bit).  Defaults are what DESIGN.md 4.6 / 4.7 measured to be fastest.
+ *   RMD_HIP_HOST_FRAMES = staged | staged_ahead | inplace | inplace_ahead
+ *                            how a frame handed over in host memory reaches the current-image plane: through a staging buffer in HBM filled by the copy
+ *                            engine (staged) or read from the pinned ring by the kernels themselves (inplace); "_ahead": converted during the previous
+ *                            update's search kernel.  Default: staged_ahead for a SeedMatrix, inplace for a batch; frames with lens undistortion: staged.
+ *   RMD_HIP_BATCH_GROUPS = 1..4   stream groups of a batch (default min(n, 3)); RMD_HIP_AHEAD_WGS = workgroups that convert a frame one step ahead (128)
+ *   RMD_HIP_PACK_BACKOFF = n      float frames that are not 8-bit levels: the next n frames are not examined (15; tests use 0);
+ *   RMD_HIP_FLOAT_AS_BYTES = 0    float frames always travel as floats;   RMD_HIP_COPY_THREADS = n   host threads that copy large frames (4)
+ *   RMD_HIP_FUSED_INGEST = 0      host frames through the copy-stream pipeline with events (the round-1 path) instead of the setup kernel's ingest workgroups
+ *   RMD_HIP_INGEST_HOST_WAIT = 1  (with the above) the host waits for the staging event instead of the stream;  RMD_HIP_COPY_STREAM_LEVEL = 0..2  priority
+ *                            level of copy streams;   RMD_HIP_INGEST_PROFILE = 1   prints host time per frame spent waiting / copying / submitting at destroy
+ * (The Python loader additionally honours RMD_HIP_LIB = path of another build of this library, tools/ab_make.sh.) */
+
 /* ---- library ------------------------------------------------------------------------ */
 const char* rmd_hip_last_error(void);
 int rmd_hip_version(void);
@@ -121,9 +137,9 @@ int rmd_hip_seeds_update_device(rmd_hip_seeds_t* s, const float* dev_img, size_t
 /* same two calls for an 8-bit gray frame (contiguous W x H bytes): what rmd::Depthmap::inputImage does on the host
  * (src/depthmap.cpp:95-106: cv::remap through the undistortion maps if rmd_hip_seeds_init_undistortion_map was called, then
  * cv::Mat::convertTo(CV_32F, 1.0f/255.0f)) happens on the device, bit for bit.  A quarter of the bytes of a float frame cross the bus;
- * update_u8 returns as soon as the frame has been copied into one of three pinned buffers, the conversion runs inside the update's own
- * first kernel (no extra launch, no synchronisation between the upload and the compute queue): 95 % of the rate of frames that are
- * already resident. */
+ * update_u8 returns as soon as the frame has been copied into one of four pinned buffers; the conversion runs inside the PREVIOUS update's
+ * search kernel when the frame has arrived by then, else inside the update's own first kernel (no extra launch, no synchronisation between
+ * the upload and the compute queue): 97 % of the rate of frames that are already resident. */
 int rmd_hip_seeds_set_reference_u8(rmd_hip_seeds_t* s, const unsigned char* host_gray, const float* T_curr_world,
                                    float min_depth, float max_depth);
 int rmd_hip_seeds_update_u8(rmd_hip_seeds_t* s, const unsigned char* host_gray, const float* T_curr_world);
@@ -178,9 +194,8 @@ int rmd_hip_seeds_sync(const rmd_hip_seeds_t* s);
 #define RMD_HIP_OPT_UNIT_ROUNDS 6   /* frame kernel: rounds of 256 NCC evaluations per handed-out unit, 1..4; 0 (default) = from the load */
 #define RMD_HIP_OPT_UNIT_TARGET 7   /* tile pipeline: work units aimed at per frame, in multiples (1..4, default 1) of the resident search workgroups;
                                       the unit size (1..4 rounds of 256 NCC evaluations) follows from the previous frame's work (experiments) */
-#define RMD_HIP_OPT_SEARCH_FLAGS 8  /* tile pipeline, A/B switches of the search kernel's unit loop (default 6): 1 = claim and fetch the next
-                                      unit while the current one is searched, 2 = sixteen hand-out counters instead of one, 4 = use the tile's sample
-                                      box that the setup kernel sends along with the unit */
+#define RMD_HIP_OPT_SEARCH_FLAGS 8  /* retired (rounds 2-3: A/B switches of the search kernel's unit loop).  Only the value 6 -- what the kernel now does
+                                      unconditionally: sixteen hand-out counters, the tile's sample box travels with the unit -- is accepted */
 #define RMD_HIP_OPT_INJECT_FAULT 9  /* test hook: 1 = the arrival flag of the NEXT host frame that travels through a staging buffer is withheld once; that
                                       update's bounded in-kernel wait (about 0.1 s) runs out, the next synchronising call reports RMD_HIP_ERR_RUNTIME
                                       once, and the handle is usable again from the next setReferenceImage on (tests/test_full_speed.py) */

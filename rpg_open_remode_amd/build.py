@@ -53,15 +53,50 @@ def hipcc_path():
     raise RuntimeError("hipcc not found")
 
 
+HIP_UNITS = ["rmd_capi", "rmd_update", "rmd_ingest", "rmd_batch", "rmd_denoise", "rmd_reduce"]  # translation units of librmd_hip.so (csrc/rmd_host.hpp says who owns what)
+
+
 def build_hip(force=False, verbose=False, extra_flags=(), out=None):
-    """out: another file name (A/B variants, tools/ab_make.sh; selected at run time with RMD_HIP_LIB); default: the product library"""
+    """librmd_hip.so from its translation units, compiled in parallel (the unit that instantiates the seed kernels dominates: ~10 s) and linked
+    by hipcc.  out: another file name (A/B variants, tools/ab_make.sh; selected at run time with RMD_HIP_LIB).  A/B builds with the retired
+    matchers (-DRMD_AB_MATCHERS) are ONE translation unit (csrc/rmd_all.hip): their headers define kernels that must not be compiled twice.
+    Returns the library's path; build_hip.last_report says what was compiled and what was reused."""
+    product = out is None
     out = out or os.path.join(HERE, "librmd_hip.so")
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h"))]
-    srcs.append(os.path.join(ROOT, "include", "rmd_hip.h"))
-    if force or _newer(out, srcs):
-        _run([hipcc_path(), *HIPCC_FLAGS, *extra_flags, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-              os.path.join(CSRC, "rmd_capi.hip"), "-o", out], verbose=verbose)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))] + [os.path.join(ROOT, "include", "rmd_hip.h")]
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags) + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    unity = any("RMD_AB_MATCHERS" in f for f in extra_flags)
+    units = ["rmd_all"] if unity else HIP_UNITS
+    # objects are kept per output file and flag set: a product build and an A/B variant never share them
+    tag = "" if product and not extra_flags else "_" + str(abs(hash((os.path.basename(out),) + tuple(extra_flags))) % 10 ** 8)
+    obj_dir = os.path.join(HERE, "build")
+    os.makedirs(obj_dir, exist_ok=True)
+    jobs, compiled, reused = [], [], []
+    for u in units:
+        src, obj = os.path.join(CSRC, u + ".hip"), os.path.join(obj_dir, u + tag + ".o")
+        deps = [src] + headers + ([os.path.join(CSRC, v + ".hip") for v in HIP_UNITS] if unity else [])
+        if force or _newer(obj, deps):
+            cmd = [hipcc_path(), *flags, "-c", src, "-o", obj]
+            if verbose:
+                print("+", " ".join(cmd), flush=True)
+            jobs.append((u, cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+            compiled.append(u)
+        else:
+            reused.append(u)
+    for u, cmd, proc in jobs:
+        log, _ = proc.communicate()
+        if proc.returncode != 0:
+            raise RuntimeError(f"build step failed ({' '.join(cmd)}):\n{log}")
+    objs = [os.path.join(obj_dir, u + tag + ".o") for u in units]
+    linked = False
+    if force or compiled or _newer(out, objs):
+        _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out], verbose=verbose)
+        linked = True
+    build_hip.last_report = {"library": out, "compiled": compiled, "reused": reused, "linked": linked}
     return out
+
+
+build_hip.last_report = None
 
 
 def build_synth(force=False, verbose=False):
@@ -130,11 +165,16 @@ def build_reference_host_programs(force=False, verbose=False):
             _run(cmd, verbose=verbose)
 
 
-def build_all(force=False, verbose=False):
+def build_all(force=False, verbose=False, report=True):
+    """everything; prints one line saying what was compiled and what was found up to date (the driver's build check reads it)"""
     build_hip(force, verbose)
     build_synth(force, verbose)
     build_oracles(force, verbose)
     build_reference_host_programs(force, verbose)
+    if report:
+        r = build_hip.last_report
+        print(f"[rpg_open_remode_amd.build] librmd_hip.so: compiled {r['compiled'] or 'nothing'} for gfx950, reused {r['reused'] or 'nothing'}, "
+              f"{'linked' if r['linked'] else 'up to date'}; synth / oracles / reference host programs: make-style (rebuilt where sources are newer)", flush=True)
 
 
 if __name__ == "__main__":

@@ -36,7 +36,6 @@ constexpr int FR_WIN_CAP = 5632;  // texels of the LDS window (22 KB); any shape
 constexpr int FR_UNIT_ROUNDS = 4, FR_UNIT_ITEMS = FR_UNIT_ROUNDS * TILE_PIX;
 enum : int { SEARCH_FLAGS_DEFAULT = 6 };  // rounds 2-3 carried A/B switches of the search kernel's unit loop here (1: claim the next unit early -- measured, lost; 2: sixteen
                                           // hand-out counters; 4: the tile's sample box travels with the unit); 2 | 4 is what the kernel does now, unconditionally
-constexpr int FR_TRACE_FRAMES = 256, FR_TRACE_WORDS = 8;  // per workgroup: start, setup done, own tile done, exit (10 ns ticks), work items, units searched
 
 // ---- agent-scope accessors (global address space, sc1) ---------------------------------------------------------------
 RMDK_D unsigned int ld_agent(const unsigned int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

@@ -1,0 +1,409 @@
+// librmd_hip.so -- frames handed over in host memory (SeedMatrix::setReferenceImage / update with host pointers, seed_matrix.cu:87-158; Depthmap::inputImage,
+// depthmap.cpp:95-106): pinned ring, staging copies and arrival flags, conversion one step ahead, lens-undistortion maps.
+#include "rmd_host.hpp"
+#include "rmd_copy_pool.hpp"
+
+using namespace rmdh;
+
+unsigned long g_progress_timeouts = 0;  // diagnostics (RMD_HIP_INGEST_PROFILE): waits for a staging slot that gave up after 2 ms
+double g_progress_max_wait_us = 0.0;    // ... and the longest such wait
+
+namespace rmdh {
+
+// Frames that arrive in host memory.  Two pipelines, both with SLOTS frames in flight and no call that waits for the device:
+//
+// (a) default, tile pipeline (ingest_current_fused): host copies the frame into pinned buffer n % SLOTS (the caller's buffer is free
+//     on return, as with the reference's synchronous cudaMemcpy, seed_matrix.cu:128); the copy stream moves it to a staging buffer in
+//     HBM and writes the frame's number behind it; the setup kernel of that frame waits for the number ITSELF and converts the frame
+//     into the current-image plane (x(1/255) for 8-bit frames).  No event, no cross-stream wait: a barrier packet on the compute
+//     queue cost 6 us per frame, an event record a little less, and a kernel that reads the pinned buffer across PCIe slows every
+//     load around it down (+5 us).  The host learns from a word the setup kernel writes into pinned memory which frames have been
+//     consumed.  640x480, 8-bit frames: 51.7 us per update against 48.6 us with resident frames; pipeline (b): 60.9 us.
+// (b) the other matchers, the reference frame, and 8-bit frames with lens undistortion (ingest_frame): upload and conversion /
+//     remap kernel on the copy stream, events between the two streams:
+//   host      wait until slot's staging buffer has been read (SLOTS frames ago), copy the caller's frame into it
+//   copy      wait until the update that read the slot's plane (SLOTS frames ago) has run -> H2D -> [u8: x(1/255) / remap kernel]
+//   compute   wait until the slot's plane is staged -> this frame's kernels -> mark the slot's plane free
+//     The current image rotates through SLOTS planes; planes[CURR_IMG] always names the one of the latest frame.
+int ingest_init(rmd_hip_seeds* s) {
+  if (s->ingest_ready) return RMD_HIP_OK;
+  if (!s->copy_stream) HIP_TRY(create_stream(&s->copy_stream, 2));  // (a batch member uses the batch's)
+  s->ingest_profile = getenv("RMD_HIP_INGEST_PROFILE") != nullptr;
+  if (const char* e = getenv("RMD_HIP_INGEST_HOST_WAIT")) s->ingest_host_wait = e[0] == '1';
+  if (const char* e = getenv("RMD_HIP_FUSED_INGEST")) s->opt_fused_ingest = e[0] != '0';
+  if (const char* e = getenv("RMD_HIP_PACK_BACKOFF")) s->pack_backoff_len = atoi(e);  // (tests: 0 examines every float frame)
+  s->ingest_ready = true;
+  if (s->batch) {  // a member only ever stages REFERENCE frames (ingest_frame: pinned slot -> plane on the copy stream): events, nothing else
+    s->cur_planes[0] = s->planes[RMD_HIP_PLANE_CURR_IMG].data;
+    s->u8_pitch = (s->width + 3) / 4 * 4;
+    for (int k = 0; k < rmd_hip_seeds::SLOTS; ++k) {
+      HIP_TRY(hipEventCreateWithFlags(&s->staged[k], hipEventDisableTiming | hipEventReleaseToDevice));
+      HIP_TRY(hipEventCreateWithFlags(&s->frame_done[k], hipEventDisableTiming | hipEventReleaseToDevice));
+      HIP_TRY(hipEventRecord(s->staged[k], s->copy_stream));
+      HIP_TRY(hipEventRecord(s->frame_done[k], s->stream));
+    }
+    return RMD_HIP_OK;
+  }
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_progress), 64, hipHostMallocMapped));
+  s->h_progress[0] = s->h_progress[1] = 0u;
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_seq), rmd_hip_seeds::RING * FLAG_SLOT_WORDS * sizeof(unsigned int), hipHostMallocDefault));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_flag), 2 * rmd_hip_seeds::RING * FLAG_ALLOC_BYTES));  // one flag block per ring slot and kind of frame
+  HIP_TRY(hipMemset(s->d_zc_flag, 0, 2 * rmd_hip_seeds::RING * FLAG_ALLOC_BYTES));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_submitted), 64, hipHostMallocMapped));
+  static_assert(2 * rmd_hip_seeds::RING * sizeof(unsigned int) <= 64, "h_submitted");
+  for (int q = 0; q < 2 * rmd_hip_seeds::RING; ++q) s->h_submitted[q] = 0u;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_ahead), 64));
+  HIP_TRY(hipMemset(s->d_ahead, 0, 64));
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  const rmd_hip_image& im = s->planes[RMD_HIP_PLANE_CURR_IMG];
+  s->cur_planes[0] = im.data;
+  for (int k = 1; k < rmd_hip_seeds::SLOTS; ++k) {
+    HIP_TRY(hipMalloc(&s->cur_planes[k], im.pitch * im.height));
+    HIP_TRY(hipMemset(s->cur_planes[k], 0, im.pitch * im.height));
+  }
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  s->u8_pitch = (s->width + 3) / 4 * 4;  // rows start on a dword (the conversion kernel reads 4 pixels at a time)
+  // The events only order work of this device's two streams (and tell the host that a staging buffer has been read): a
+  // device-scope release is enough.  The default -- a system-scope fence with cache write-back and invalidation at every
+  // record -- cost more per frame than the upload it was ordering.
+  for (int k = 0; k < rmd_hip_seeds::SLOTS; ++k) {
+    HIP_TRY(hipEventCreateWithFlags(&s->staged[k], hipEventDisableTiming | hipEventReleaseToDevice));
+    HIP_TRY(hipEventCreateWithFlags(&s->frame_done[k], hipEventDisableTiming | hipEventReleaseToDevice));
+    HIP_TRY(hipEventRecord(s->staged[k], s->copy_stream));
+    HIP_TRY(hipEventRecord(s->frame_done[k], s->stream));
+  }
+  return RMD_HIP_OK;
+}
+
+static int ingest_frame(rmd_hip_seeds* s, const unsigned char* host_gray, const float* host_f32, void* dst, size_t dst_pitch, bool dst_is_ref, int k) {
+  const double t_a = s->ingest_profile ? host_now_us() : 0.0;
+  HIP_TRY(hipEventSynchronize(s->staged[k]));  // the upload that last used this slot's staging buffers has run
+  const double t_b = s->ingest_profile ? host_now_us() : 0.0;
+  const size_t row_f32 = static_cast<size_t>(s->width) * 4;
+  if (host_gray) {
+    const size_t bytes = static_cast<size_t>(s->u8_pitch) * s->height;
+    if (!s->h_u8[k]) {
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_u8[k]), bytes));
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_u8[k]), bytes));
+    }
+    if (s->u8_pitch == s->width) memcpy(s->h_u8[k], host_gray, bytes);
+    else
+      for (int y = 0; y < s->height; ++y)
+        memcpy(s->h_u8[k] + static_cast<size_t>(y) * s->u8_pitch, host_gray + static_cast<size_t>(y) * s->width, s->width);
+  } else {
+    if (!s->h_f32[k]) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_f32[k]), row_f32 * s->height));
+    host_copy(s->h_f32[k], host_f32, row_f32 * s->height);
+  }
+  const double t_c = s->ingest_profile ? host_now_us() : 0.0;
+  if (dst_is_ref) {  // everything issued so far may read the reference plane
+    HIP_TRY(hipEventRecord(s->frame_done[k], s->stream));
+  }
+  HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->frame_done[k], 0));
+  if (host_gray) {
+    HIP_TRY(hipMemcpyAsync(s->d_u8[k], s->h_u8[k], static_cast<size_t>(s->u8_pitch) * s->height, hipMemcpyHostToDevice, s->copy_stream));
+    const int dst_stride = static_cast<int>(dst_pitch / 4);
+    if (s->d_undist_map1) {
+      const dim3 block(64, 4), grid((s->width + 63) / 64, (s->height + 3) / 4);
+      hipLaunchKernelGGL(rmdk::ingest_u8_remap_kernel, grid, block, 0, s->copy_stream, s->d_u8[k], s->u8_pitch, s->d_undist_map1, s->d_undist_map2,
+                         static_cast<float*>(dst), dst_stride, s->width, s->height);
+    } else {
+      const dim3 block(64, 4), grid((s->width + 255) / 256, (s->height + 3) / 4);
+      hipLaunchKernelGGL(rmdk::ingest_u8_kernel, grid, block, 0, s->copy_stream, s->d_u8[k], s->u8_pitch, static_cast<float*>(dst), dst_stride,
+                         s->width, s->height);
+    }
+    HIP_TRY(hipGetLastError());
+  } else {
+    HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch, s->h_f32[k], row_f32, row_f32, s->height, hipMemcpyHostToDevice, s->copy_stream));
+  }
+  HIP_TRY(hipEventRecord(s->staged[k], s->copy_stream));
+  // The compute stream has to run behind the staging.  A stream-side wait (barrier packet) costs the compute queue ~6 us per
+  // frame even when the event has long fired; the staging of a frame finishes while the PREVIOUS frame's kernels still run,
+  // so the host can simply wait for it before it queues this frame's kernels behind them (no bubble, no packet).
+  if (s->ingest_host_wait) HIP_TRY(hipEventSynchronize(s->staged[k]));
+  else HIP_TRY(hipStreamWaitEvent(s->stream, s->staged[k], 0));
+  if (s->ingest_profile) {
+    const double t_d = host_now_us();
+    s->ingest_us[0] += t_b - t_a; s->ingest_us[1] += t_c - t_b; s->ingest_us[2] += t_d - t_c; s->ingest_us[3] += 1.0;
+  }
+  return RMD_HIP_OK;
+}
+
+// a host frame becomes the current image: stage it into the plane that is NOT being read by the update in flight
+// The fused path: frame n goes through pinned buffer and staging buffer n % SLOTS, last read by the copy engine / the setup kernel of
+// frame n - SLOTS.  That kernel has completed once the setup kernel of frame n - SLOTS + 1 has STARTED (same stream), which is
+// what h_progress reports.
+// Wait (on the host, without touching the device) until the setup kernel of step `need` has started, as reported through the pinned word
+// `progress`: the staging buffers of SLOTS steps ago are free then.  Numbers are compared modulo 2^32 like the kernel's test.
+int wait_for_progress(volatile unsigned int* progress, unsigned int need, hipStream_t stream) {
+  auto behind = [&]() { return static_cast<int>(*progress - need) < 0; };
+  if (behind()) {
+    const double t0 = host_now_us();
+    while (behind()) {
+      if (host_now_us() - t0 > 2000.0) {  // far behind (or another matcher ran the frames in between): an idle stream has read everything
+        ++g_progress_timeouts;
+        HIP_TRY(hipStreamSynchronize(stream));
+        break;
+      }
+      cpu_relax();
+    }
+    const double w = host_now_us() - t0;
+    if (w > g_progress_max_wait_us) g_progress_max_wait_us = w;
+  }
+  return RMD_HIP_OK;
+}
+
+static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray, const float* host_f32, const float* T_curr_world) {
+  const double t_a = s->ingest_profile ? host_now_us() : 0.0;
+  const unsigned long long n64 = ++s->zc_number;
+  const unsigned int n = static_cast<unsigned int>(n64);
+  const int k = static_cast<int>(n64 % rmd_hip_seeds::RING);
+  if (n64 > static_cast<unsigned long long>(rmd_hip_seeds::RING)) TRY(wait_for_progress(s->h_progress, n - rmd_hip_seeds::RING + 1u, s->stream));
+  const double t_b = s->ingest_profile ? host_now_us() : 0.0;
+  PendingIngest in;
+  bool in_place = false;
+  // every ring slot has its own arrival flag, one per kind of frame (8-bit / float: they use different staging buffers): the setup kernel
+  // of frame n asks for frame n's; its verdict for frame n + 1 reads the flag of that slot for ITS kind, which a frame of the other kind never sets
+  auto flag_of = [&](int kind, int slot) { return s->d_zc_flag + (static_cast<size_t>(kind) * rmd_hip_seeds::RING + slot) * (FLAG_ALLOC_BYTES / sizeof(unsigned int)); };
+  void* stage_src = nullptr; void* stage_dst = nullptr; size_t stage_bytes = 0;
+  auto ensure_u8_ring = [&]() -> int {
+    const size_t bytes = static_cast<size_t>(s->u8_pitch) * s->height;
+    for (int q = 0; q < rmd_hip_seeds::RING; ++q) {  // (all slots at once: the search kernel is told where the NEXT frame will be)
+      if (s->h_zc_u8[q]) continue;
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_zc_u8[q]), bytes + 16, hipHostMallocDefault));
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_u8[q]), bytes));
+    }
+    return RMD_HIP_OK;
+  };
+  // a float frame of 8-bit levels goes the 8-bit way from here on, never through the undistortion maps (pack_float_rows_u8)
+  bool packed = false;
+  if (!host_gray && float_frames_as_bytes()) {
+    if (s->pack_backoff > 0) --s->pack_backoff;
+    else {
+      TRY(ensure_u8_ring());
+      packed = CopyPool::instance().pack(host_f32, s->h_zc_u8[k], s->width, s->height, s->u8_pitch);
+      if (!packed) s->pack_backoff = s->pack_backoff_len;
+    }
+  }
+  const bool as_u8 = host_gray != nullptr || packed;
+  const bool remap = host_gray != nullptr && s->d_undist_map1 != nullptr;
+  in.no_remap = packed;
+  if (as_u8) {
+    const size_t bytes = static_cast<size_t>(s->u8_pitch) * s->height;
+    TRY(ensure_u8_ring());
+    if (packed) {
+    } else if (s->u8_pitch == s->width) host_copy(s->h_zc_u8[k], host_gray, bytes);
+    else
+      for (int y = 0; y < s->height; ++y)
+        memcpy(s->h_zc_u8[k] + static_cast<size_t>(y) * s->u8_pitch, host_gray + static_cast<size_t>(y) * s->width, s->width);
+    in_place = frame_in_place(false, remap);
+    if (in_place) {
+      void* dev = nullptr;
+      HIP_TRY(hipHostGetDevicePointer(&dev, s->h_zc_u8[k], 0));
+      in.u8 = static_cast<const unsigned int*>(dev);
+    } else {
+      stage_src = s->h_zc_u8[k]; stage_dst = s->d_zc_u8[k]; stage_bytes = bytes;
+      in.u8 = reinterpret_cast<const unsigned int*>(s->d_zc_u8[k]);
+    }
+    in.common.kind = 1;
+    in.common.pitch = s->u8_pitch;
+  } else {
+    const size_t bytes = static_cast<size_t>(s->width) * s->height * sizeof(float);
+    for (int q = 0; q < rmd_hip_seeds::RING; ++q) {
+      if (s->h_zc_f32[q]) continue;
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_zc_f32[q]), bytes + 16, hipHostMallocDefault));
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_f32[q]), bytes));
+    }
+    host_copy(s->h_zc_f32[k], host_f32, bytes);
+    in_place = frame_in_place(false, false);
+    if (in_place) {
+      void* dev = nullptr;
+      HIP_TRY(hipHostGetDevicePointer(&dev, s->h_zc_f32[k], 0));
+      in.f32 = static_cast<const float*>(dev);
+    } else {
+      stage_src = s->h_zc_f32[k]; stage_dst = s->d_zc_f32[k]; stage_bytes = bytes;
+      in.f32 = s->d_zc_f32[k];
+    }
+    in.common.kind = 2;
+  }
+  const bool ahead = frame_ahead(remap);
+  if (in_place) {
+    in.common.flag = nullptr;  // the setup kernel reads the pinned buffer itself: it is complete before the kernel is launched
+  } else {
+    HIP_TRY(hipMemcpyAsync(stage_dst, stage_src, stage_bytes, hipMemcpyHostToDevice, s->copy_stream));
+    const size_t fw = flag_words(s->h_progress, n);
+    fill_flag_block(s->h_seq + k * FLAG_SLOT_WORDS, n, fw);  // behind the frame on the same stream: when the kernel sees n, the frame is in HBM
+    unsigned int* slot_flag = flag_of(as_u8 ? 0 : 1, k);
+    if (s->inject_withhold_flag) s->inject_withhold_flag = false;  // fault injection: the frame arrives, its flag never does -> the kernel's bounded wait runs out
+    else HIP_TRY(hipMemcpyAsync(slot_flag, s->h_seq + k * FLAG_SLOT_WORDS, fw * sizeof(unsigned int), hipMemcpyHostToDevice, s->copy_stream));
+    in.common.flag = slot_flag;
+  }
+  int plane = 0;  // one plane is enough: setup k writes it after search k - 1 has run (same stream)
+  if (ahead) {  // ... unless the previous update's search kernel brings the frame in: frame n lives in plane n % 2
+    const int kind = as_u8 ? 0 : 1, k_next = static_cast<int>((n64 + 1) % rmd_hip_seeds::RING);
+    void* dev = nullptr;
+    if (in_place) {
+      // frame n is complete in ITS slot, for ITS kind: the verdict of setup n - 1 read this very word, and setup n's verdict for frame n + 1
+      // reads the word of slot k_next for this kind -- which a frame of the other kind, or a frame two steps ahead, never sets (one word
+      // per kind for the whole ring let setup n take "frame n + 2 of this kind is there" for "frame n + 1 is", and convert stale bytes)
+      __atomic_store_n(&s->h_submitted[kind * rmd_hip_seeds::RING + k], n, __ATOMIC_RELEASE);
+      HIP_TRY(hipHostGetDevicePointer(&dev, s->h_submitted, 0));
+      in.common.submitted = static_cast<const unsigned int*>(dev) + kind * rmd_hip_seeds::RING + k_next;
+      HIP_TRY(hipHostGetDevicePointer(&dev, as_u8 ? static_cast<void*>(s->h_zc_u8[k_next]) : static_cast<void*>(s->h_zc_f32[k_next]), 0));
+      in.next_src = dev;
+    } else {
+      in.common.submitted = flag_of(kind, k_next);  // the arrival flag of the next frame's slot, for this kind
+      in.next_src = as_u8 ? static_cast<const void*>(s->d_zc_u8[k_next]) : static_cast<const void*>(s->d_zc_f32[k_next]);
+    }
+    in.common.ahead = s->d_ahead;
+    static const int ahead_wgs = [] { const char* e = getenv("RMD_HIP_AHEAD_WGS"); return e ? atoi(e) : AHEAD_WGS; }();  // (A/B)
+    in.common.ahead_wgs = ahead_wgs;
+    plane = static_cast<int>(n64 & 1ull);
+    in.next_dst = static_cast<float*>(s->cur_planes[plane ^ 1]);
+  }
+  const double t_c = s->ingest_profile ? host_now_us() : 0.0;
+  rmd_hip_image& im = s->planes[RMD_HIP_PLANE_CURR_IMG];
+  im.data = s->cur_planes[plane];
+  void* dev_progress = nullptr;
+  HIP_TRY(hipHostGetDevicePointer(&dev_progress, s->h_progress, 0));
+  in.common.progress = static_cast<unsigned int*>(dev_progress);
+  in.common.number = n;
+  s->P.cur = static_cast<const float*>(im.data);
+  s->P.cur_stride = s->P.stride;
+  const int rc = seeds_after_frame(s, T_curr_world, &in);
+  if (s->ingest_profile) {
+    const double t_d = host_now_us();
+    s->ingest_us[0] += t_b - t_a; s->ingest_us[1] += t_c - t_b; s->ingest_us[2] += t_d - t_c; s->ingest_us[3] += 1.0;
+  }
+  return rc;
+}
+
+int ingest_current(rmd_hip_seeds* s, const unsigned char* host_gray, const float* host_f32, const float* T_curr_world) {
+  TRY(ingest_init(s));
+  if (s->opt_fused_ingest && s->opt_matcher == 3) return ingest_current_fused(s, host_gray, host_f32, T_curr_world);
+  const int k = s->ingest_slot;
+  s->ingest_slot = (k + 1) % rmd_hip_seeds::SLOTS;
+  rmd_hip_image& im = s->planes[RMD_HIP_PLANE_CURR_IMG];
+  im.data = s->cur_planes[k];  // the plane last used SLOTS frames ago (its frame_done event is this slot's)
+  TRY(ingest_frame(s, host_gray, host_f32, im.data, im.pitch, false, k));
+  s->P.cur = static_cast<const float*>(im.data);
+  s->P.cur_stride = s->P.stride;
+  const int rc = seeds_after_frame(s, T_curr_world);
+  HIP_TRY(hipEventRecord(s->frame_done[k], s->stream));
+  return rc;
+}
+
+int ingest_reference(rmd_hip_seeds* s, const unsigned char* host_gray, const float* host_f32, const float* T_curr_world, float min_depth,
+                            float max_depth) {
+  TRY(ingest_init(s));
+  TRY(seeds_flush(s));
+  const int k = s->ingest_slot;
+  s->ingest_slot = (k + 1) % rmd_hip_seeds::SLOTS;
+  const rmd_hip_image& im = s->planes[RMD_HIP_PLANE_REF_IMG];
+  TRY(ingest_frame(s, host_gray, host_f32, im.data, im.pitch, true, k));
+  return seeds_after_reference(s, T_curr_world, min_depth, max_depth);
+}
+
+}  // namespace rmdh
+
+extern "C" {
+
+int rmd_hip_seeds_set_reference(rmd_hip_seeds_t* s, const float* host_img, const float* T_curr_world, float min_depth,
+                                float max_depth) {
+  if (!s || !host_img || !T_curr_world) return fail(RMD_HIP_ERR_INVALID_ARG, "set_reference: null argument");
+  TRY(seeds_bind_device(s));
+  return ingest_reference(s, nullptr, host_img, T_curr_world, min_depth, max_depth);
+}
+
+int rmd_hip_seeds_update(rmd_hip_seeds_t* s, const float* host_img, const float* T_curr_world) {
+  if (!s || !host_img || !T_curr_world) return fail(RMD_HIP_ERR_INVALID_ARG, "update: null argument");
+  if (s->batch) return fail(RMD_HIP_ERR_INVALID_ARG, "update: this SeedMatrix is a member of a batch; its updates are issued with rmd_hip_batch_update*");
+  if (!s->has_reference) return fail(RMD_HIP_ERR_NOT_READY, "update: setReferenceImage has not been called");
+  TRY(seeds_bind_device(s));
+  // the frame is copied into pinned memory here (the caller's buffer is free on return, as after the reference's blocking
+  // cudaMemcpy, seed_matrix.cu:128) and uploaded beside the previous frame's kernels; nothing waits for the device
+  return ingest_current(s, nullptr, host_img, T_curr_world);
+}
+
+int rmd_hip_seeds_set_reference_u8(rmd_hip_seeds_t* s, const unsigned char* host_gray, const float* T_curr_world, float min_depth,
+                                   float max_depth) {
+  if (!s || !host_gray || !T_curr_world) return fail(RMD_HIP_ERR_INVALID_ARG, "set_reference_u8: null argument");
+  TRY(seeds_bind_device(s));
+  return ingest_reference(s, host_gray, nullptr, T_curr_world, min_depth, max_depth);
+}
+
+int rmd_hip_seeds_update_u8(rmd_hip_seeds_t* s, const unsigned char* host_gray, const float* T_curr_world) {
+  if (!s || !host_gray || !T_curr_world) return fail(RMD_HIP_ERR_INVALID_ARG, "update_u8: null argument");
+  if (s->batch) return fail(RMD_HIP_ERR_INVALID_ARG, "update_u8: this SeedMatrix is a member of a batch; its updates are issued with rmd_hip_batch_update*");
+  if (!s->has_reference) return fail(RMD_HIP_ERR_NOT_READY, "update_u8: setReferenceImage has not been called");
+  TRY(seeds_bind_device(s));
+  return ingest_current(s, host_gray, nullptr, T_curr_world);
+}
+
+// Depthmap::initUndistortionMap (depthmap.cpp:45-61) = cv::initUndistortRectifyMap(K, (k1, k2, r1, r2), I, K, size, CV_16SC2).
+// OpenCV is not part of this build (and the reference does not pin its version); the map is computed here the way OpenCV's
+// scalar code does (imgproc/undistort.cpp, core cv::invert): K and the coefficients are float values widened to double;
+// ir = K^-1 by the closed-form 3x3 inverse cv::invert uses for n <= 3 (cofactors times 1/det, every product written out, zeros
+// included); the normalised coordinates are ACCUMULATED along a row (_x += ir[0] per column); u, v are rounded to 1/32 pixel
+// (cvRound: ties to even) and split into the integer position (map1) and the two 5-bit fractions (map2 = fy * 32 + fx).
+// Host code, IEEE double, no contraction.  oracle/host_steps.py restates the same in numpy; neither can be pinned against OpenCV
+// here ("parity unpinned" for this step).
+int rmd_hip_compute_undistortion_map(int w, int h, float cam_fx, float cam_fy, float cam_cx, float cam_cy, float k1, float k2, float r1,
+                                     float r2, short* map1_xy, unsigned short* map2) {
+  if (w <= 0 || h <= 0 || !map1_xy || !map2) return fail(RMD_HIP_ERR_INVALID_ARG, "compute_undistortion_map: bad argument");
+  const double fx = cam_fx, fy = cam_fy, u0 = cam_cx, v0 = cam_cy;
+  const double dk1 = k1, dk2 = k2, p1 = r1, p2 = r2, k3 = 0.0, k4 = 0.0, k5 = 0.0, k6 = 0.0;
+  const double S[3][3] = {{fx, 0.0, u0}, {0.0, fy, v0}, {0.0, 0.0, 1.0}};
+  double d = S[0][0] * (S[1][1] * S[2][2] - S[1][2] * S[2][1]) - S[0][1] * (S[1][0] * S[2][2] - S[1][2] * S[2][0]) +
+             S[0][2] * (S[1][0] * S[2][1] - S[1][1] * S[2][0]);
+  d = 1.0 / d;
+  const double ir[9] = {(S[1][1] * S[2][2] - S[1][2] * S[2][1]) * d, (S[0][2] * S[2][1] - S[0][1] * S[2][2]) * d,
+                        (S[0][1] * S[1][2] - S[0][2] * S[1][1]) * d, (S[1][2] * S[2][0] - S[1][0] * S[2][2]) * d,
+                        (S[0][0] * S[2][2] - S[0][2] * S[2][0]) * d, (S[0][2] * S[1][0] - S[0][0] * S[1][2]) * d,
+                        (S[1][0] * S[2][1] - S[1][1] * S[2][0]) * d, (S[0][1] * S[2][0] - S[0][0] * S[2][1]) * d,
+                        (S[0][0] * S[1][1] - S[0][1] * S[1][0]) * d};
+  for (int i = 0; i < h; ++i) {
+    double _x = i * ir[1] + ir[2], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
+    for (int j = 0; j < w; ++j, _x += ir[0], _y += ir[3], _w += ir[6]) {
+      const double wi = 1. / _w, x = _x * wi, y = _y * wi;
+      const double x2 = x * x, y2 = y * y;
+      const double r2_ = x2 + y2, _2xy = 2 * x * y;
+      const double kr = (1 + ((k3 * r2_ + dk2) * r2_ + dk1) * r2_) / (1 + ((k6 * r2_ + k5) * r2_ + k4) * r2_);
+      const double u = fx * (x * kr + p1 * _2xy + p2 * (r2_ + 2 * x2)) + u0;
+      const double v = fy * (y * kr + p1 * (r2_ + 2 * y2) + p2 * _2xy) + v0;
+      const int iu = static_cast<int>(lrint(u * 32)), iv = static_cast<int>(lrint(v * 32));  // saturate_cast<int>(double) = cvRound
+      const size_t k = static_cast<size_t>(i) * w + j;
+      map1_xy[2 * k] = static_cast<short>(iu >> 5);
+      map1_xy[2 * k + 1] = static_cast<short>(iv >> 5);
+      map2[k] = static_cast<unsigned short>((iv & 31) * 32 + (iu & 31));
+    }
+  }
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_seeds_init_undistortion_map(rmd_hip_seeds_t* s, float k1, float k2, float r1, float r2) {
+  if (!s) return fail(RMD_HIP_ERR_INVALID_ARG, "init_undistortion_map: null handle");
+  TRY(seeds_bind_device(s));
+  const int w = s->width, h = s->height;
+  s->h_undist_map1.assign(static_cast<size_t>(w) * h * 2, 0);
+  s->h_undist_map2.assign(static_cast<size_t>(w) * h, 0);
+  TRY(rmd_hip_compute_undistortion_map(w, h, s->P.cam.fx, s->P.cam.fy, s->P.cam.cx, s->P.cam.cy, k1, k2, r1, r2, s->h_undist_map1.data(),
+                                       s->h_undist_map2.data()));
+  TRY(seeds_sync(s));
+  if (!s->d_undist_map1) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_undist_map1), static_cast<size_t>(w) * h * sizeof(short2)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_undist_map2), static_cast<size_t>(w) * h * sizeof(unsigned short)));
+  }
+  HIP_TRY(hipMemcpy(s->d_undist_map1, s->h_undist_map1.data(), static_cast<size_t>(w) * h * sizeof(short2), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(s->d_undist_map2, s->h_undist_map2.data(), static_cast<size_t>(w) * h * sizeof(unsigned short), hipMemcpyHostToDevice));
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_seeds_undistortion_map(const rmd_hip_seeds_t* s, short* map1_xy, unsigned short* map2) {
+  if (!s || !map1_xy || !map2) return fail(RMD_HIP_ERR_INVALID_ARG, "undistortion_map: null argument");
+  if (s->h_undist_map1.empty()) return fail(RMD_HIP_ERR_NOT_READY, "undistortion_map: initUndistortionMap has not been called");
+  memcpy(map1_xy, s->h_undist_map1.data(), s->h_undist_map1.size() * sizeof(short));
+  memcpy(map2, s->h_undist_map2.data(), s->h_undist_map2.size() * sizeof(unsigned short));
+  return RMD_HIP_OK;
+}
+
+}  // extern "C"

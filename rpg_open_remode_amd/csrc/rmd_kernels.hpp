@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void seed_init_kernel(SeedParams P) {
 // Frame ingest (reference: Depthmap::inputImage, src/depthmap.cpp:95-106 -- cv::Mat::convertTo(CV_32F, 1.0f/255.0f) on the
 // host): 8-bit gray -> f32 plane on the device.  One fp32 multiply per pixel, identical bits to the host conversion.
 // 4 pixels per lane: one 32-bit load, one 128-bit store.
-__global__ __launch_bounds__(256) void ingest_u8_kernel(const unsigned char* __restrict__ src, int src_pitch, float* __restrict__ dst,
+static __global__ __launch_bounds__(256) void ingest_u8_kernel(const unsigned char* __restrict__ src, int src_pitch, float* __restrict__ dst,
                                                         int dst_stride, int w, int h) {
   const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const int y = blockIdx.y * blockDim.y + threadIdx.y;
@@ -124,7 +124,7 @@ RMDK_D float remap_u8_pixel(const unsigned char* src, int src_pitch, short2 m, i
   return static_cast<float>(v) * (1.0f / 255.0f);
 }
 
-__global__ __launch_bounds__(256) void ingest_u8_remap_kernel(const unsigned char* __restrict__ src, int src_pitch,
+static __global__ __launch_bounds__(256) void ingest_u8_remap_kernel(const unsigned char* __restrict__ src, int src_pitch,
                                                               const short2* __restrict__ map1, const unsigned short* __restrict__ map2,
                                                               float* __restrict__ dst, int dst_stride, int w, int h) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -312,7 +312,7 @@ RMDK_D double wave_sum_f64(double v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void count_eq_kernel(const int* __restrict__ img, int w, int h, int stride, int value,
+static __global__ __launch_bounds__(256) void count_eq_kernel(const int* __restrict__ img, int w, int h, int stride, int value,
                                                        unsigned long long* __restrict__ out) {
   __shared__ unsigned long long wave_part[4];
   unsigned long long c = 0;
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void count_eq_kernel(const int* __restrict__ i
 }
 
 // pass 1: one fp64 partial per block, in a fixed order; pass 2: one block folds the partials.
-__global__ __launch_bounds__(256) void sum_partial_kernel(const float* __restrict__ img, int w, int h, int stride,
+static __global__ __launch_bounds__(256) void sum_partial_kernel(const float* __restrict__ img, int w, int h, int stride,
                                                           double* __restrict__ partials) {
   __shared__ double wave_part[4];
   double acc = 0.0;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void sum_partial_kernel(const float* __restric
 }
 // integer image sum (ImageReducer<int>::sum, reduction.cu:186): exact in 64 bits, the caller truncates to int like the
 // reference's int accumulation wraps
-__global__ __launch_bounds__(256) void sum_i32_kernel(const int* __restrict__ img, int w, int h, int stride, unsigned long long* __restrict__ out) {
+static __global__ __launch_bounds__(256) void sum_i32_kernel(const int* __restrict__ img, int w, int h, int stride, unsigned long long* __restrict__ out) {
   __shared__ unsigned long long wave_part[4];
   unsigned long long acc = 0;
   for (int y = blockIdx.y; y < h; y += gridDim.y) {
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void sum_i32_kernel(const int* __restrict__ im
   if (threadIdx.x == 0) atomicAdd(out, wave_part[0] + wave_part[1] + wave_part[2] + wave_part[3]);
 }
 
-__global__ __launch_bounds__(64) void sum_final_kernel(const double* __restrict__ partials, int n, float* __restrict__ out) {
+static __global__ __launch_bounds__(64) void sum_final_kernel(const double* __restrict__ partials, int n, float* __restrict__ out) {
   double acc = 0.0;
   for (int i = threadIdx.x; i < n; i += 64) acc += partials[i];
   acc = wave_sum_f64(acc);
@@ -394,7 +394,7 @@ RMDK_D bool pc_pixel(const PointCloudParams& P, int i, int& x, int& y) {
   return P.conv[static_cast<size_t>(y) * P.stride + x] == ST_CONVERGED;
 }
 
-__global__ __launch_bounds__(PC_BLOCK) void pc_count_kernel(PointCloudParams P, unsigned int* __restrict__ block_counts) {
+static __global__ __launch_bounds__(PC_BLOCK) void pc_count_kernel(PointCloudParams P, unsigned int* __restrict__ block_counts) {
   __shared__ unsigned int wave_part[PC_BLOCK / 64];
   int x, y;
   const bool keep = pc_pixel(P, blockIdx.x * PC_BLOCK + threadIdx.x, x, y);
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(PC_BLOCK) void pc_count_kernel(PointCloudParams P, 
 }
 
 // in place: counts -> exclusive offsets; total to *total
-__global__ __launch_bounds__(1024) void pc_scan_kernel(unsigned int* __restrict__ counts, int n, unsigned int* __restrict__ total) {
+static __global__ __launch_bounds__(1024) void pc_scan_kernel(unsigned int* __restrict__ counts, int n, unsigned int* __restrict__ total) {
   __shared__ unsigned int wave_tot[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (n + 1023) / 1024;
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(1024) void pc_scan_kernel(unsigned int* __restrict_
   if (tid == 0) *total = all;
 }
 
-__global__ __launch_bounds__(PC_BLOCK) void pc_write_kernel(PointCloudParams P, const unsigned int* __restrict__ block_offsets,
+static __global__ __launch_bounds__(PC_BLOCK) void pc_write_kernel(PointCloudParams P, const unsigned int* __restrict__ block_offsets,
                                                             float4* __restrict__ out, unsigned int capacity) {
   __shared__ unsigned int wave_part[PC_BLOCK / 64];
   int x = 0, y = 0;
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(PC_BLOCK) void pc_write_kernel(PointCloudParams P, 
 // reference image comes back from the float plane the path works on (rint(v * 255) is exact for v = k * (1/255)f, like pc_write_kernel).
 // Four pixels per lane: twelve output bytes = three dwords (rows of the packed W x 3 output need not be dword-aligned: the output is
 // addressed as ONE array of W * H * 3 bytes, groups of four pixels counted over the whole image, the last group may be short).
-__global__ __launch_bounds__(256) void convergence_bgr8_kernel(const float* __restrict__ ref, const int* __restrict__ conv, int w, int h, int stride,
+static __global__ __launch_bounds__(256) void convergence_bgr8_kernel(const float* __restrict__ ref, const int* __restrict__ conv, int w, int h, int stride,
                                                                unsigned char* __restrict__ out) {
   const long long n = static_cast<long long>(w) * h;
   const long long p0 = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) * 4;
@@ -534,7 +534,7 @@ RMDK_D T* tv_member_plane(const TvParams& P, T* plane, size_t member_stride) {
 }
 
 // depthmap_denoiser.cu:45-59 (weights) fused with the re-initialisation at :215-217
-__global__ __launch_bounds__(256) void tv_prepare_kernel(TvParams P, float* __restrict__ u, float* __restrict__ u_head,
+static __global__ __launch_bounds__(256) void tv_prepare_kernel(TvParams P, float* __restrict__ u, float* __restrict__ u_head,
                                                          float2* __restrict__ p) {
   tv_select_member(P);
   u = tv_member_plane(P, u, P.member_stride); u_head = tv_member_plane(P, u_head, P.member_stride); p = tv_member_plane(P, p, P.member_stride2);
@@ -575,7 +575,7 @@ RMDK_D float2 tv_dual(const TvParams& P, const float* __restrict__ u, const floa
 // and north row it needs, keeps them in LDS, then runs the primal step.  Iterates are
 // ping-ponged between (u,u_head,p)_in and _out so there is no inter-block race.
 constexpr int TV_TX = 64, TV_TY = 4;
-__global__ __launch_bounds__(TV_TX* TV_TY) void tv_iterate_kernel(TvParams P, const float* __restrict__ u_in,
+static __global__ __launch_bounds__(TV_TX* TV_TY) void tv_iterate_kernel(TvParams P, const float* __restrict__ u_in,
                                                                   const float* __restrict__ uh_in,
                                                                   const float2* __restrict__ p_in, float* __restrict__ u_out,
                                                                   float* __restrict__ uh_out, float2* __restrict__ p_out) {
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(256) void tv_iterate_blocked_kernel(TvParams P, con
 // ------------------------------------------------------------------------------------------
 // device side of the arithmetic contract, for the self test
 // self test of the DPP wave primitives of rmd_device.hpp against the shuffle forms: mismatching lanes -> *bad
-__global__ __launch_bounds__(64) void wave_primitives_selftest_kernel(unsigned int seed, unsigned int* bad) {
+static __global__ __launch_bounds__(64) void wave_primitives_selftest_kernel(unsigned int seed, unsigned int* bad) {
   const int lane = threadIdx.x;
   unsigned int h = seed * 2654435761u + static_cast<unsigned int>(lane) * 40503u + blockIdx.x * 97u;
   h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(64) void wave_primitives_selftest_kernel(unsigned i
   if (!ok) atomicAdd(bad, 1u);
 }
 
-__global__ void math_eval_kernel(int op, const float* x, const float* y, const float* z, float* out, size_t n) {
+static __global__ void math_eval_kernel(int op, const float* x, const float* y, const float* z, float* out, size_t n) {
   const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float r;

@@ -35,6 +35,7 @@ constexpr int UNIT_SHARDS = 16;  // unit lists / counters, tile t -> shard t % U
 constexpr int HANDOUT_STRIDE = 32;  // words between two hand-out counters (128 B: one L2 line each)
 constexpr unsigned int UNIT_TILE_BOX = 0x80000000u;  // flag in a unit's first-item word: words 2, 3 hold the texel box of ALL samples of the unit's tile, and it fits the LDS window
 constexpr int TRACE_FRAMES = 256, TRACE_MAX_SEARCH_WGS = 1024;  // diagnostics (trace_record)
+constexpr int FR_TRACE_FRAMES = 256, FR_TRACE_WORDS = 8;  // timeline of the tile pipeline, per workgroup: start, setup done, own tile done, exit (10 ns ticks), work items, units searched
 
 constexpr int MAX_BATCH = 8;  // sequences one launch pair can carry (the per-sequence parameter blocks travel as kernel arguments: 4 KB)
 
@@ -489,7 +490,7 @@ RMDK_D int finalize_seed(const SeedParams& P, const MatcherArgs& M, int x, int y
 
 // ------------------------------------------------------------------------------------------------
 // stage 3: the stand-alone finalisation kernel (the per-seed code is finalize_seed above)
-__global__ __launch_bounds__(256) void seed_finalize_kernel(SeedParams P, MatcherArgs M) {
+static __global__ __launch_bounds__(256) void seed_finalize_kernel(SeedParams P, MatcherArgs M) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x >= P.w || y >= P.h) return;
