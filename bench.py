@@ -555,6 +555,17 @@ def main():
                     if rv and not rv.get("stale"):
                         entry["roofline_valu_frac"] = rv["frac"]
                     entry["converged_seeds_at_end"] = [bmq[i].getConvergedCount() for i in range(Bq)]
+                    # TV-L1 of the Bq depth maps in ONE launch sequence (rmd_hip_batch_denoise: grid z = member), device time of the iteration launches
+                    ranges_q = [sc[i]["max"] - sc[i]["min"] for i in range(Bq)]
+                    bmq.denoise(ranges_q, TV_LAMBDA, 8, download=False)
+                    tdq = time.perf_counter()
+                    bmq.denoise(ranges_q, TV_LAMBDA, tv_iters, download=False)
+                    dn_wall = (time.perf_counter() - tdq) * 1e3
+                    dn_ms, dn_launches = bmq.denoiseTiming()
+                    dn_bw = TV_BYTES_PER_PIXEL_ITER * W * H * Bq * tv_iters / (dn_ms / 1e3) / 1e9 if dn_ms > 0 else 0.0
+                    entry["denoise_all_members"] = {"iterations": tv_iters, "launches": dn_launches, "device_ms": round(dn_ms, 3), "wall_ms": round(dn_wall, 3),
+                                                    "ms_per_depth_map": round(dn_ms / Bq, 4), "achieved_GBs_algorithmic": round(dn_bw, 1),
+                                                    "frac_of_hbm_peak": round(dn_bw / HBM_PEAK_GBS, 4)}
                     batched[f"B={Bq}"] = entry
                     del bmq
 

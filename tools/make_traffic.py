@@ -43,7 +43,7 @@ def kernel_source_sha256():
 
 
 W, H, UPDATES = 640, 480, 199
-res = {"source": "rocprofv3 --pmc passes of `python bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-extras` (tools/profile_r03.sh): one complete pass "
+res = {"source": "rocprofv3 --pmc passes of `python bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-extras` (tools/profile_r04.sh): one complete pass "
                  "of configs[1] (setReferenceImage + 199 update() calls, 8-bit frames from host memory) followed by the TV-L1 denoise; sums over the pass "
                  "divided by 199",
        "kernel_source_sha256": kernel_source_sha256(),
