@@ -174,16 +174,29 @@ struct FrameWindow {
   bool valid;          // staged and covering every sample of the tile in LDS
 };
 
+// A sample box that does not fit the LDS window, cut down around its centre (the evaluations whose footprint falls outside read L2).  The cut
+// favours a shape the row-wise staging below fetches in two batches: at most 64 columns -- one column chunk, every lane of a row's load in
+// use -- by up to 86 rows when the box is tall, the full width (a few chunks of a few rows) when it is flat.
+RMDK_D void clamp_window(FrameWindow& W) {
+  const int ww = W.x1 - W.x0 + 1, wh = W.y1 - W.y0 + 1;
+  constexpr int FLAT = 43;  // rows: (128 | 1) * 43 <= FR_WIN_CAP
+  const int nw = wh > FLAT ? min(ww, 64) : min(ww, (FR_WIN_CAP / wh - 1) | 1);
+  const int nh = min(wh, FR_WIN_CAP / (nw | 1));
+  W.x0 += (ww - nw) / 2; W.x1 = W.x0 + nw - 1;
+  W.y0 += (wh - nh) / 2; W.y1 = W.y0 + nh - 1;
+}
+
 // Stage texels [x0, x1] x [y0, y1] of the current image into the LDS window, ROW-WISE: wave v takes rows v, v + 4, ... and its lanes the
 // columns (64 at a time); the row's base address and its place in the LDS are scalar arithmetic, a lane adds its column -- two vector
 // instructions per row and 64 texels where the element-wise form (a division of the element index by the run-time width per texel)
-// spent twenty-five, which made the staging of a light tile's window as expensive as its NCC evaluations.  Batches of 8 rows per lane
-// are in flight together.  No barrier.
+// spent twenty-five, which made the staging of a light tile's window as expensive as its NCC evaluations.  Batches of 12 rows per lane
+// are in flight together: a full window of 64 columns (86 rows, 22 per wave) is two memory round trips (with 8 per batch and the old
+// 73-column cut -- two column chunks, the second with nine lanes in use -- it was five, 7 us of a light unit's 23).  No barrier.
 template <int SIDE>
 RMDK_D void frame_stage_window(const SeedParams& P, FrameSmem<SIDE>& S, int tid, const FrameWindow& W) {
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ww = W.x1 - W.x0 + 1, wh = W.y1 - W.y0 + 1;
-  constexpr int BATCH = 8, WAVES = TILE_PIX / 64;
+  constexpr int BATCH = 12, WAVES = TILE_PIX / 64;
   for (int c0 = 0; c0 < ww; c0 += 64) {  // (uniform: at most three column chunks, (ww | 1) * wh <= FR_WIN_CAP)
     const int c = c0 + lane;
     const bool in = c < ww;
@@ -193,7 +206,7 @@ RMDK_D void frame_stage_window(const SeedParams& P, FrameSmem<SIDE>& S, int tid,
       for (int q = 0; q < BATCH; ++q) {
         const int r = r0 + WAVES * q;  // uniform over the wave
         const float* row = P.cur + static_cast<size_t>(W.y0 + min(r, wh - 1)) * P.cur_stride + W.x0;
-        v[q] = in ? row[c] : 0.0f;
+        v[q] = in ? row[c] : 0.0f;  // (rows past the end re-read the last row: skipping them by a scalar branch costs more in spilled scalars than it saves)
       }
 #pragma unroll
       for (int q = 0; q < BATCH; ++q) {
@@ -285,27 +298,25 @@ RMDK_D void frame_search(const SeedParams& P, FrameSmem<SIDE>& S, int tid, int k
       if (!window_fits(W.x0, W.y0, W.x1, W.y1)) {
         const int kb = min(k_end, k + FR_UNIT_ITEMS), kc = min(k_end, k + TILE_PIX);
         int bx0, by0, bx1, by1, cx0, cy0, cx1, cy1;
-        const bool four = kb < k_end;  // else the 4-round box IS the box that has just failed (units of <= 4 rounds: always)
+        // a box over the same items as the one that has just failed is not reduced again: the 4-round box when at most four rounds are left
+        // (units of the product pipeline: always), the one-round box when at most one is (most units of a light frame: one reduction pass and
+        // one barrier instead of two, 1 us of a unit's 2.3 us of window policy)
+        const bool four = kb < k_end, one = kc < kb;
         if (four) {
           seed_range_box<SIDE>(P, S, tid, my_n > 0 && my_first < kb && my_first + my_n > k, j0, min(kb - my_first, my_n) - 1, bx0, by0, bx1, by1);
           block_bbox<SIDE>(S, tid, bx0, by0, bx1, by1, 4);
         }
-        seed_range_box<SIDE>(P, S, tid, my_n > 0 && my_first < kc && my_first + my_n > k, j0, min(kc - my_first, my_n) - 1, cx0, cy0, cx1, cy1);
-        block_bbox<SIDE>(S, tid, cx0, cy0, cx1, cy1, 8);
-        __syncthreads();
+        if (one) {
+          seed_range_box<SIDE>(P, S, tid, my_n > 0 && my_first < kc && my_first + my_n > k, j0, min(kc - my_first, my_n) - 1, cx0, cy0, cx1, cy1);
+          block_bbox<SIDE>(S, tid, cx0, cy0, cx1, cy1, 8);
+        }
+        if (four || one) __syncthreads();
         if (four) block_bbox_read<SIDE>(S, W.x0, W.y0, W.x1, W.y1, 4);
         k1 = kb;
         if (!window_fits(W.x0, W.y0, W.x1, W.y1)) {
-          block_bbox_read<SIDE>(S, W.x0, W.y0, W.x1, W.y1, 8);
+          if (one) block_bbox_read<SIDE>(S, W.x0, W.y0, W.x1, W.y1, 8);
           k1 = kc;
-          if (!window_fits(W.x0, W.y0, W.x1, W.y1)) {  // clamp around the box's centre; the rest reads L2
-            const int ww = W.x1 - W.x0 + 1, wh = W.y1 - W.y0 + 1;
-            constexpr int SQ = 73;  // (73 | 1) * 75 <= FR_WIN_CAP
-            const int nw = ww > SQ ? (wh > SQ + 2 ? SQ : min(ww, (FR_WIN_CAP / wh - 1) | 1)) : ww;
-            const int nh = min(wh, FR_WIN_CAP / (nw | 1));
-            W.x0 += (ww - nw) / 2; W.x1 = W.x0 + nw - 1;
-            W.y0 += (wh - nh) / 2; W.y1 = W.y0 + nh - 1;
-          }
+          if (!window_fits(W.x0, W.y0, W.x1, W.y1)) clamp_window(W);  // cut down around the box's centre; the rest reads L2
         }
       }
       W.ws = (W.x1 - W.x0 + 1) | 1;

@@ -22,7 +22,7 @@ for k in range(F - 1):
     t_no, t_fb = (w & np.uint64(0xffffff)).astype(np.float64).sum() / 100, ((w >> np.uint64(24)) & np.uint64(0xffffff)).astype(np.float64).sum() / 100
     n_fb, n_no = ((w >> np.uint64(48)) & np.uint64(0xff)).sum(), ((w >> np.uint64(56)) & np.uint64(0xff)).sum()
     tot += (t_no, t_fb, n_no, n_fb)
-    if k + 1 in (4, 15, 25, 35, 60, 90, 105, 125, 150, 190):
+    if k + 1 in (4, 25, 35, 40, 60, 90, 100, 125, 160, 190):
         print(f"frame {k+1:3d}: {int(n_no):6d} rounds {t_no / max(n_no, 1):6.2f} us | {int(n_fb):5d} rounds {t_fb / max(n_fb, 1):6.2f} us")
         t0 = t[:, 0].min()
         ex = (t[:, 3] - t0).astype(np.float64) / 100
