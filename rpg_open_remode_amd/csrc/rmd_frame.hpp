@@ -785,7 +785,13 @@ RMDK_D const uint4* unit_entry(const MatcherArgs& M, const_u64_ptr counts, unsig
 }
 
 template <int SIDE, int NSEQ>
-__global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_kernel(BatchArgs<NSEQ> B, MatcherArgs M) {
+__global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_kernel(BatchArgs<NSEQ> B_by_value, MatcherArgs M_by_value) {
+  // Both argument blocks are read where they lie, in the kernel-argument segment (scalar loads at the point of use), not through the named
+  // parameters: named, every field the kernel uses anywhere is fetched at the top and kept in a scalar register across the whole persistent
+  // loop -- with the loop's own state more than the 104 there are, and every spilled one is a v_writelane / v_readlane pair somewhere hot.
+  (void)B_by_value; (void)M_by_value;
+  const SeqArgs* const Bq = seq_table();
+  const MatcherArgs& M = *reinterpret_cast<const MatcherArgs*>(reinterpret_cast<const char*>(seq_table()) + sizeof(BatchArgs<NSEQ>));
   using Smem = FrameSmem<SIDE>;
   constexpr int HALF = SIDE / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -796,9 +802,9 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
   if (NSEQ == 1 && blockIdx.x < static_cast<unsigned int>(M.ahead_wgs)) {
     const unsigned int next = M.ingest_number + 1u;
     if (ld_agent(M.ahead) != next) return;
-    const SeedParams& P = B.seq[0].P;
-    if (M.ingest_flag == nullptr) ingest_in_place(M.ingest_kind, M.ingest_pitch, B.seq[0].next_src, B.seq[0].next_dst, P.w, P.h, P.stride, static_cast<int>(blockIdx.x), M.ahead_wgs, tid);
-    else ingest_staged(M.ingest_kind, M.ingest_pitch, B.seq[0].next_src, B.seq[0].next_dst, P.w, P.h, P.stride, static_cast<int>(blockIdx.x), M.ahead_wgs, tid);
+    const SeedParams& P = Bq[0].P;
+    if (M.ingest_flag == nullptr) ingest_in_place(M.ingest_kind, M.ingest_pitch, Bq[0].next_src, Bq[0].next_dst, P.w, P.h, P.stride, static_cast<int>(blockIdx.x), M.ahead_wgs, tid);
+    else ingest_staged(M.ingest_kind, M.ingest_pitch, Bq[0].next_src, Bq[0].next_dst, P.w, P.h, P.stride, static_cast<int>(blockIdx.x), M.ahead_wgs, tid);
     // The last one to finish publishes the frame.  Plane and number are read by the NEXT kernels only, and a kernel's stores are all
     // visible to the kernels behind it on the stream: no fence here (an agent-scope fence writes back and invalidates the L2 the
     // searching workgroups live on -- a hundred of them made every update 20 us longer).
@@ -830,7 +836,7 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
     }
   }
   if (wg_id >= n_units) return;  // no unit for this workgroup: on a light frame most of the grid leaves here, a few dozen scalar instructions in
-  unsigned long long* const trace0 = NSEQ == 1 ? B.seq[0].P.trace : nullptr;  // diagnostics (single sequences only)
+  unsigned long long* const trace0 = NSEQ == 1 ? Bq[0].P.trace : nullptr;  // diagnostics (single sequences only)
   unsigned long long* const tr = trace0 && static_cast<int>(wg_id) < M.n_tiles ? trace0 + static_cast<size_t>(wg_id) * FR_TRACE_WORDS : nullptr;
   if (tr && tid == 0) tr[0] = wall_clock64();
 #ifdef RMD_PROFILE_ROUNDS
@@ -841,7 +847,7 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
   const int unit_items = static_cast<int>(*(const __attribute__((address_space(4))) unsigned int*)(M.queue + 5));  // written by the setup kernel
   unsigned int n_fallback = 0, n_windows = 0, n_done = 0, n_items = 0;
   int lds_tile = -1, x0 = 0, y0 = 0, total = 0;
-  const SeqArgs* Qp = NSEQ == 1 ? &B.seq[0] : seq_table();  // the sequence of the tile in LDS (one sequence: the named argument, see the setup kernel)
+  const SeqArgs* Qp = seq_table();  // the sequence of the tile in LDS (one sequence: the named argument, see the setup kernel)
   size_t so = 0;                    // ... and where its seeds start in the workspace planes
   FrameWindow W;
   W.valid = false; W.x0 = W.y0 = 0; W.x1 = W.y1 = -1; W.ws = 1;
@@ -936,10 +942,10 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
     const unsigned long long key = S.best[tid];
     if (key != 0ull) atomicMax(&M.best[so + static_cast<size_t>(y0 + ty) * Qp->P.stride + x0 + tx], key);
   }
-  if (NSEQ == 1 && B.seq[0].P.stats) {  // diagnostics (COLLECT_STATS = 1): evaluations that read their texels from L2 instead of the LDS window, units, windows staged in the search
+  if (NSEQ == 1 && Bq[0].P.stats) {  // diagnostics (COLLECT_STATS = 1): evaluations that read their texels from L2 instead of the LDS window, units, windows staged in the search
     const unsigned long long fb = wave_sum_u64(n_fallback);
-    if ((tid & 63) == 0 && fb) atomicAdd(&B.seq[0].P.stats[3], fb);
-    if (tid == 0) { atomicAdd(&B.seq[0].P.stats[4], static_cast<unsigned long long>(n_done)); atomicAdd(&B.seq[0].P.stats[5], static_cast<unsigned long long>(n_windows)); }
+    if ((tid & 63) == 0 && fb) atomicAdd(&Bq[0].P.stats[3], fb);
+    if (tid == 0) { atomicAdd(&Bq[0].P.stats[4], static_cast<unsigned long long>(n_done)); atomicAdd(&Bq[0].P.stats[5], static_cast<unsigned long long>(n_windows)); }
   }
   if (tr && tid < 64) {
     const unsigned long long fb = wave_sum_u64(n_fallback);  // the first wave's lanes only: a hint, not a count
