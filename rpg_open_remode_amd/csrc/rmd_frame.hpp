@@ -487,7 +487,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
   // one sequence: the named argument, which the compiler fetches with a few wide scalar loads at the top of the kernel; several: the
   // argument segment indexed by the sequence number (see BatchArgs), copied once so that its loads are issued here too and not one
   // by one where the values are used (every one of those was a scalar-cache round trip on this kernel's dependent chain)
-  const SeqArgs Q = NSEQ == 1 ? B.seq[0] : seq_table()[seq];
+  const SeqArgs Q = NSEQ == 1 ? B.seq[0] : seq_table()[seq];  // (a batch's block read by reference instead: +0.5 %, within the noise: profiles/r04_ab_setup_args.txt)
   const SeedParams& P = Q.P;
   if (NSEQ > 1 && !Q.active) return;  // this sequence has no frame in this launch
   const int tid = threadIdx.x;
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
   if (M.progress && wg == 0 && seq == M.housekeeper && tid == 0) __hip_atomic_store(M.progress, M.ingest_number, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   // (computed here, at the top, so that its scalar loads travel with the kernel arguments)
   // unit size: 1..4 rounds of 256 evaluations, from the previous frame's work (a frame differs little from the one before)
-  int unit_rounds = MAX_UNIT_ROUNDS;
+  int unit_rounds = MAX_UNIT_ROUNDS;  // (capped at 3 / 2 rounds -- a shorter tail on the heaviest updates, more staging --: update 1 +6 %, batch of 8 -2 % / -8 %: profiles/r04_ab_unit_cap.txt)
   if (M.shards_prev) {
     // the previous frame's counters are not written by anybody while this kernel runs: read them through the scalar path (constant
     // address space), which the compiler schedules with the kernel arguments at the top instead of as a vector-memory round trip
