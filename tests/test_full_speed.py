@@ -43,8 +43,13 @@ def _bits(st):
     return [np.ascontiguousarray(st[p]).view(np.uint32).copy() for p in sorted(st)]
 
 
-def _resident_run(sc):
-    """the reference run of one scene: frames resident in HBM, read in place"""
+ORACLE_CHECKPOINTS = (60, 120, 190)  # updates at which a fresh Oracle B is started from the resident run's state and follows three updates
+
+
+def _resident_run(sc, what):
+    """the reference run of one scene: frames resident in HBM, read in place -- itself checked against Oracle B deep into the sequence
+    (configs[3]: all eight scenes over their 200 frames): at each checkpoint a fresh oracle takes over the state planes (mu, sigma_sq, a, b:
+    all the state there is, the convergence plane is recomputed by every update's seed_check) and must agree on the next three updates"""
     s = api.SeedMatrix(W, H, api.PinholeCamera(*sc["K"]), patch_side=SIDE)
     dev = []
     for g in sc["gray"]:
@@ -52,8 +57,22 @@ def _resident_run(sc):
         d.setDevData(synth.to_float_image(g))
         dev.append(d)
     s.setReferenceImageDevice(dev[0].data, dev[0].stride, sc["poses"][0], sc["min"], sc["max"])
+    orc, until = None, 0
     for k in range(1, F):
         s.updateDevice(dev[k].data, dev[k].stride, sc["poses"][k])
+        if orc is not None:
+            orc.update(synth.to_float_image(sc["gray"][k]), sc["poses"][k])
+            assert_states_equal(orc.state(), s.state(), f"{what}, update {k} vs an oracle restarted from the state at {until - 3}", planes=range(7))
+            assert s.getConvergedCount() == orc.converged_count()
+            if k == until:
+                orc = None
+        if k in ORACLE_CHECKPOINTS:
+            st = s.state()
+            orc = O.Seeds(O.OracleLib("port", SIDE), W, H, sc["K"])
+            orc.set_reference(synth.to_float_image(sc["gray"][0]), sc["poses"][0], sc["min"], sc["max"])
+            for p in range(4):
+                orc.upload(p, st[p])
+            until = k + 3
     out = _bits(s.state()), s.getConvergedCount()
     s.close()
     return out
@@ -61,7 +80,7 @@ def _resident_run(sc):
 
 def test_batch_of_8_and_standalone_vga_200_host_frames_at_full_speed():
     scenes = [_render(sc) for sc in range(8)]
-    want = [_resident_run(sc) for sc in scenes]
+    want = [_resident_run(sc, f"scene {i}, frames resident") for i, sc in enumerate(scenes)]
     assert all(n > 0.5 * W * H for _, n in want), "the benchmark scenes converge for most seeds"
     names = ["mu", "sigma_sq", "a", "b", "convergence", "sum_templ", "const_templ_denom", "epipolar_matches"]
     # eight stand-alone handles, 8-bit host frames (default: staging ring + conversion one step ahead), nothing between the updates
