@@ -151,6 +151,8 @@ int rmd_hip_batch_destroy(rmd_hip_batch_t* b) {
     rmd_hip_image* all[] = {&dn.u[0], &dn.u[1], &dn.u_head[0], &dn.u_head[1], &dn.p[0], &dn.p[1], &dn.g};
     for (auto* im : all)
       if (im->owns && im->data) (void)hipFree(im->data);
+    if (dn.ev0) (void)hipEventDestroy(dn.ev0);
+    if (dn.ev1) (void)hipEventDestroy(dn.ev1);
     if (dn.d_table) (void)hipFree(dn.d_table);
     if (dn.h_staging) (void)hipHostFree(dn.h_staging);
     if (dn.stream) (void)hipStreamDestroy(dn.stream);
@@ -376,16 +378,16 @@ int rmd_hip_batch_denoise(rmd_hip_batch_t* b, const float* depth_range, float la
   P.members = dn.d_table;
   P.member_stride = dn.g.stride * static_cast<size_t>(h);
   P.member_stride2 = dn.p[0].stride * static_cast<size_t>(h);
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  HIP_TRY(hipEventCreate(&ev0));
-  HIP_TRY(hipEventCreate(&ev1));
+  if (!dn.ev0) HIP_TRY(hipEventCreate(&dn.ev0));  // (kept with the workspace: an error return below must not leak them)
+  if (!dn.ev1) HIP_TRY(hipEventCreate(&dn.ev1));
+  hipEvent_t ev0 = dn.ev0, ev1 = dn.ev1;
   float* us[2] = {static_cast<float*>(dn.u[0].data), static_cast<float*>(dn.u[1].data)};
   float* uhs[2] = {static_cast<float*>(dn.u_head[0].data), static_cast<float*>(dn.u_head[1].data)};
   float2* ps[2] = {static_cast<float2*>(dn.p[0].data), static_cast<float2*>(dn.p[1].data)};
   int cur_buf = 0;
   long n_launches = 0;
   const int rc = tv_run(P, us, uhs, ps, n, iterations, 0, 0, dn.stream, ev0, &cur_buf, &n_launches);
-  if (rc != RMD_HIP_OK) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); return rc; }
+  if (rc != RMD_HIP_OK) return rc;
   HIP_TRY(hipEventRecord(ev1, dn.stream));
   dn.result_index = cur_buf;
   const rmd_hip_image& r = dn.u[cur_buf];
@@ -404,8 +406,6 @@ int rmd_hip_batch_denoise(rmd_hip_batch_t* b, const float* depth_range, float la
     if (host_denoised && host_denoised[i]) memcpy(host_denoised[i], dn.h_staging + i * plane, plane * sizeof(float));
   float ms = 0.0f;
   if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) { dn.total_ms = ms; dn.launches = n_launches; }
-  (void)hipEventDestroy(ev0);
-  (void)hipEventDestroy(ev1);
   return RMD_HIP_OK;
 }
 

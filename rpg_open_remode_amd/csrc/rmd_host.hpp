@@ -361,6 +361,7 @@ struct rmd_hip_batch {
     unsigned long long* d_table = nullptr;   // rmdk::TV_MEMBER_WORDS words per member (device)
     float* h_staging = nullptr;              // pinned, n x W x H
     hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr; // around the iteration launches of a run
     rmd_hip_image result[rmdk::MAX_BATCH];   // views of the members' results of the last run
     int result_index = 0;
     double total_ms = 0.0;
