@@ -446,11 +446,14 @@ def main():
             s3.setOption(api.OPT_COLLECT_STATS, 1)
             s3.setReferenceImageDevice(frames[0].data, frames[0].stride, poses[0], min_depth, max_depth)
             tot = {"live_seeds": 0, "steps": 0, "ncc_evals": 0}
+            evals_first20 = 0
             for k in range(1, F):
                 s3.updateDevice(frames[k].data, frames[k].stride, poses[k])
                 st = s3.lastStats()
                 for key in tot:
                     tot[key] += st[key]
+                if k <= 20:
+                    evals_first20 += st["ncc_evals"]
             search_stats = {k: round(v / (F - 1), 1) for k, v in tot.items()}
             del s3
 
@@ -503,6 +506,8 @@ def main():
             if fresh and counters.get("valu_wave_instructions_first20_per_update"):
                 n_inst = float(sum(counters["valu_wave_instructions_first20_per_update"].values()))
                 heavy["valu_frac"] = round(n_inst / (hp_ms / max(hp_n, 1) / 1e3) / 1e9 / VALU_PEAK_GINST_S, 4)
+                if SIDE in NCC_VALU_PER_WAVE_EVALUATION and F > 20:
+                    heavy["useful_valu_frac"] = round(evals_first20 / 20.0 / 64.0 * NCC_VALU_PER_WAVE_EVALUATION[SIDE] / n_inst, 4)
             del s5
 
             # batched mode: B independent sequences (scenes 0..B-1) stepped by ONE launch pair per step (rmd_hip_batch_*)
@@ -554,6 +559,8 @@ def main():
                     rv = valu_roofline(entry["resident"]["us_per_step_device"] / 1e6, counters, n_sequences=Bq)
                     if rv and not rv.get("stale"):
                         entry["roofline_valu_frac"] = rv["frac"]
+                        # (the instruction counts are per sequence: a batch executes B times the single sequence's, the useful fraction is the same)
+                        entry["useful_valu_frac"] = valu_roofline(1.0, counters, ncc_evals_per_update=search_stats["ncc_evals"])["useful_valu_frac"] if search_stats else None
                     entry["converged_seeds_at_end"] = [bmq[i].getConvergedCount() for i in range(Bq)]
                     # TV-L1 of the Bq depth maps in ONE launch sequence (rmd_hip_batch_denoise: grid z = member), device time of the iteration launches
                     ranges_q = [sc[i]["max"] - sc[i]["min"] for i in range(Bq)]
