@@ -74,6 +74,8 @@ int rmd_hip_denoiser_destroy(rmd_hip_denoiser_t* d) {
   (void)hipSetDevice(d->device);
   if (d->stream) (void)hipStreamSynchronize(d->stream);
   d->timer.destroy();
+  if (d->ev0) (void)hipEventDestroy(d->ev0);
+  if (d->ev1) (void)hipEventDestroy(d->ev1);
   if (d->h_staging) (void)hipHostFree(d->h_staging);
   rmd_hip_image* all[] = {&d->u[0], &d->u[1], &d->u_head[0], &d->u_head[1], &d->p[0], &d->p[1], &d->g};
   for (auto* im : all)
@@ -184,8 +186,9 @@ int rmd_hip_denoiser_denoise(rmd_hip_denoiser_t* d, const rmd_hip_image_t* mu, c
 
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (d->opt_timing) {  // one event pair around the whole iteration loop (per-launch markers would serialise it)
-    HIP_TRY(hipEventCreate(&ev0));
-    HIP_TRY(hipEventCreate(&ev1));
+    if (!d->ev0) HIP_TRY(hipEventCreate(&d->ev0));
+    if (!d->ev1) HIP_TRY(hipEventCreate(&d->ev1));
+    ev0 = d->ev0; ev1 = d->ev1;
   }
   int cur_buf = 0;
   long n_launches = 0;
@@ -207,8 +210,6 @@ int rmd_hip_denoiser_denoise(rmd_hip_denoiser_t* d, const rmd_hip_image_t* mu, c
   if (d->opt_timing) {
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) { d->timer.total_ms = ms; d->timer.launches = n_launches; }
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
   }
   return RMD_HIP_OK;
 }

@@ -386,6 +386,7 @@ struct rmd_hip_denoiser {
   float* h_staging = nullptr;  // pinned, W x H: device -> pinned (async DMA) -> caller's pageable buffer
   int opt_timing = 0, opt_iters_per_launch = 0, opt_geometry = 0;
   rmdh::StageTimer timer;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;  // around the iteration loop when opt_timing is set; created at first use, destroyed with the handle
 };
 
 namespace rmdh {
