@@ -175,44 +175,47 @@ struct FrameWindow {
 };
 
 // A sample box that does not fit the LDS window, cut down around its centre (the evaluations whose footprint falls outside read L2).  The cut
-// favours a shape the row-wise staging below fetches in two batches: at most 64 columns -- one column chunk, every lane of a row's load in
-// use -- by up to 86 rows when the box is tall, the full width (a few chunks of a few rows) when it is flat.
+// favours a shape the row-wise staging below fetches with few instructions: at most 64 columns -- one column chunk, every lane of a row's
+// load in use -- by up to 86 rows when the box is tall, the full width (a few chunks of a few rows) when it is flat.
 RMDK_D void clamp_window(FrameWindow& W) {
   const int ww = W.x1 - W.x0 + 1, wh = W.y1 - W.y0 + 1;
   constexpr int FLAT = 43;  // rows: (128 | 1) * 43 <= FR_WIN_CAP
+#ifdef RMD_AB_SQUARE_CLAMP
+  const int nw = wh > FLAT ? min(ww, 73) : min(ww, (FR_WIN_CAP / wh - 1) | 1);
+#else
   const int nw = wh > FLAT ? min(ww, 64) : min(ww, (FR_WIN_CAP / wh - 1) | 1);
+#endif
   const int nh = min(wh, FR_WIN_CAP / (nw | 1));
   W.x0 += (ww - nw) / 2; W.x1 = W.x0 + nw - 1;
   W.y0 += (wh - nh) / 2; W.y1 = W.y0 + nh - 1;
 }
 
-// Stage texels [x0, x1] x [y0, y1] of the current image into the LDS window, ROW-WISE: wave v takes rows v, v + 4, ... and its lanes the
-// columns (64 at a time); the row's base address and its place in the LDS are scalar arithmetic, a lane adds its column -- two vector
-// instructions per row and 64 texels where the element-wise form (a division of the element index by the run-time width per texel)
-// spent twenty-five, which made the staging of a light tile's window as expensive as its NCC evaluations.  Batches of 12 rows per lane
-// are in flight together: a full window of 64 columns (86 rows, 22 per wave) is two memory round trips (with 8 per batch and the old
-// 73-column cut -- two column chunks, the second with nine lanes in use -- it was five, 7 us of a light unit's 23).  No barrier.
+// Stage texels [x0, x1] x [y0, y1] of the current image into the LDS window, ROW-WISE and LDS-DIRECT: wave v takes rows v, v + 4, ...; one
+// global_load_lds_dword per row and 64-column chunk brings 64 consecutive texels straight into the window (the instruction writes to a
+// wave-uniform LDS base + lane x 4 bytes: exactly a row of the window; lanes past the row's end are masked out), no vector register and
+// no ds_write in between -- so ALL rows of a wave are in flight together and the window arrives in ONE memory round trip whatever its
+// shape, six instructions per row (one of them on the vector ALU).  History: element-wise staging (a division of the element index by the
+// run-time width per texel: 25 vector instructions per texel row) -> row-wise through registers, 12 rows per lane in flight (a full
+// 64 x 86 window: two round trips, 4-7 us of an unboxed unit's 23) -> this: one sequence 43.4 -> 40.5 us per update, batch of 8 14 900 ->
+// 15 950 Mpix/s, the kernel 6 000 -> 5 100 instructions and 75 -> 40 spilled scalars (profiles/r04_ab_lds_direct_staging.txt).
+// No barrier; the loads are still in flight when this returns -- the workgroup barrier that precedes every read of the window waits for
+// them (vmcnt(0) is part of its release).
 template <int SIDE>
 RMDK_D void frame_stage_window(const SeedParams& P, FrameSmem<SIDE>& S, int tid, const FrameWindow& W) {
+  typedef const __attribute__((address_space(1))) float* gptr_t;
+  typedef __attribute__((address_space(3))) float* lptr_t;
+  constexpr int WAVES = TILE_PIX / 64;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ww = W.x1 - W.x0 + 1, wh = W.y1 - W.y0 + 1;
-  constexpr int BATCH = 12, WAVES = TILE_PIX / 64;
+  const size_t stride = static_cast<size_t>(P.cur_stride);
+  const float* const first = P.cur + static_cast<size_t>(W.y0 + wave) * stride + W.x0;  // this wave's first row
   for (int c0 = 0; c0 < ww; c0 += 64) {  // (uniform: at most three column chunks, (ww | 1) * wh <= FR_WIN_CAP)
     const int c = c0 + lane;
-    const bool in = c < ww;
-    for (int r0 = wave; r0 < wh; r0 += WAVES * BATCH) {
-      float v[BATCH];
-#pragma unroll
-      for (int q = 0; q < BATCH; ++q) {
-        const int r = r0 + WAVES * q;  // uniform over the wave
-        const float* row = P.cur + static_cast<size_t>(W.y0 + min(r, wh - 1)) * P.cur_stride + W.x0;
-        v[q] = in ? row[c] : 0.0f;  // (rows past the end re-read the last row: skipping them by a scalar branch costs more in spilled scalars than it saves)
-      }
-#pragma unroll
-      for (int q = 0; q < BATCH; ++q) {
-        const int r = r0 + WAVES * q;
-        if (in && r < wh) S.win[r * W.ws + c] = v[q];
-      }
+    if (c < ww) {
+      const float* src = first + c;
+      float* dst = S.win + wave * W.ws + c0;  // uniform over the wave
+      for (int r = wave; r < wh; r += WAVES, src += WAVES * stride, dst += WAVES * W.ws)
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 4, 0, 0);
     }
   }
 }
@@ -895,15 +898,15 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
       const float lf = M.lfirst[gm], st = P.sum_templ[gi], dn = P.denom[gi];
       // the patch halo, row-wise like the window: wave v takes halo rows v, v + 4, ..., its first REF_W lanes the columns; the clamped
       // column is computed once per lane, the clamped row is scalar
-      constexpr int REF_ROWS_PER_WAVE = (Smem::REF_H + 3) / 4;
       static_assert(Smem::REF_W <= 64, "one halo row per wave instruction");
-      float refv[REF_ROWS_PER_WAVE];
       const int ref_col = clampi(x0 - HALF + lane, 0, P.w - 1);
-#pragma unroll
-      for (int q = 0; q < REF_ROWS_PER_WAVE; ++q) {
-        const int ry = min(wave + 4 * q, Smem::REF_H - 1);
-        const float* row = P.ref + static_cast<size_t>(clampi(y0 - HALF + ry, 0, P.h - 1)) * P.stride;
-        refv[q] = lane < Smem::REF_W ? row[ref_col] : 0.0f;
+      if (lane < Smem::REF_W) {  // LDS-direct like the window (frame_stage_window): a row of the halo per instruction, nothing held in registers
+        typedef const __attribute__((address_space(1))) float* gptr_t;
+        typedef __attribute__((address_space(3))) float* lptr_t;
+        for (int ry = wave; ry < Smem::REF_H; ry += 4) {
+          const float* row = P.ref + static_cast<size_t>(clampi(y0 - HALF + ry, 0, P.h - 1)) * P.stride;
+          __builtin_amdgcn_global_load_lds((gptr_t)(row + ref_col), (lptr_t)(S.ref + ry * Smem::REF_W), 4, 0, 0);
+        }
       }
       if (boxed) {
         W.x0 = static_cast<int>(box0 & 0xffffu); W.y0 = static_cast<int>(box0 >> 16);
@@ -919,9 +922,6 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
       S.sum_templ[tid] = st; S.denom[tid] = dn;
       S.packed[tid] = pk;
       S.best[tid] = 0ull;
-#pragma unroll
-      for (int q = 0; q < REF_ROWS_PER_WAVE; ++q)
-        if (lane < Smem::REF_W && wave + 4 * q < Smem::REF_H) S.ref[(wave + 4 * q) * Smem::REF_W + lane] = refv[q];
       // (a unit without the box flag belongs to a tile whose sample box the setup kernel found too large for the LDS window: the box is not
       // computed a second time here -- frame_search cuts windows to the unit's own rounds)
       if (!boxed) { W.valid = false; W.x0 = W.y0 = 0; W.x1 = W.y1 = -1; W.ws = 1; }
