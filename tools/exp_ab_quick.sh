@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/$NAME; mkdir -p $OUT; : > $OUT/rates.txt
 for L in "$@"; do
   if [ $L = product ]; then unset RMD_HIP_LIB; else export RMD_HIP_LIB=$ROOT/build_ab/librmd_hip_$L.so; fi
   echo "== $L" >> $OUT/rates.txt
-  if [ $L != product ]; then
+  if [ $L != product ] && [ -z "${NO_PARITY:-}" ]; then
     timeout 600 python -m pytest tests/test_hip_parity.py tests/test_batch.py tests/test_golden_vga.py tests/test_host_frame_modes.py -m gpu -x -q 2>&1 | tail -2 >> $OUT/rates.txt
   fi
   python tools/first_update_bench.py --b 1,8 --label $L --unit-target 2 >> $OUT/rates.txt 2>&1
