@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): the round-4 measurement set.  Raw rocprofv3 output under gpurun_out/prof_<tag>/,
 # compact summaries (what gets committed under profiles/) under gpurun_out/summary_<tag>/.
-# usage: tools/profile_r04.sh <tag> [parts: bench,trace,pmc,tv1080]
+# usage: tools/profile_r04.sh <tag> [parts: bench,trace,restrace,pmc,tv1080]
 set -u
-TAG=${1:-r04}; PARTS=${2:-bench,trace,pmc,tv1080}
+TAG=${1:-r04}; PARTS=${2:-bench,trace,restrace,pmc,tv1080}
 export TMPDIR=/tmp
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
@@ -17,6 +17,15 @@ if [[ $PARTS == *trace* ]]; then
   printf 'trace\tpython bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-extras\n' >> "$OUT/commands.txt"
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python "$ROOT/bench.py" --steps 2 --warmup 1 --cpu-seconds 0 --no-extras > "$SUM/${TAG}_bench_under_trace.json" 2> "$OUT/trace.err"
   (cd "$ROOT" && python tools/trace_breakdown.py "$OUT" 199 398 > "$SUM/${TAG}_timed_pass_breakdown.txt"; cat "$SUM/${TAG}_timed_pass_breakdown.txt")
+fi
+if [[ $PARTS == *restrace* ]]; then
+  # the same passes with the frames resident in HBM: under the tracer the host thread (a frame copied into the pinned ring and two intercepted
+  # launches per update) is slower than the device, so the default command's setup kernels spend part of their time waiting for their frame
+  echo "== kernel trace, frames resident (2 timed passes after 1 warm-up pass)"
+  printf 'trace_resident\tpython bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-extras --resident\n' >> "$OUT/commands.txt"
+  mkdir -p "$OUT/res"
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/res/trace" -- python "$ROOT/bench.py" --steps 2 --warmup 1 --cpu-seconds 0 --no-extras --resident > "$SUM/${TAG}_bench_under_trace_resident.json" 2> "$OUT/res_trace.err"
+  (cd "$ROOT" && python tools/trace_breakdown.py "$OUT/res" 199 398 > "$SUM/${TAG}_timed_pass_breakdown_resident.txt"; cat "$SUM/${TAG}_timed_pass_breakdown_resident.txt")
 fi
 if [[ $PARTS == *pmc* ]]; then
   echo "== PMC pass 1 (instruction counts, one complete pass of the sequence + the denoise)"
