@@ -197,7 +197,8 @@ RMDK_D void clamp_window(FrameWindow& W) {
 // shape, six instructions per row (one of them on the vector ALU).  History: element-wise staging (a division of the element index by the
 // run-time width per texel: 25 vector instructions per texel row) -> row-wise through registers, 12 rows per lane in flight (a full
 // 64 x 86 window: two round trips, 4-7 us of an unboxed unit's 23) -> this: one sequence 43.4 -> 40.5 us per update, batch of 8 14 900 ->
-// 15 950 Mpix/s, the kernel 6 000 -> 5 100 instructions and 75 -> 40 spilled scalars (profiles/r04_ab_lds_direct_staging.txt).
+// 15 950 Mpix/s; with the patch halo staged the same way 40.0 us / 16 600, the kernel 6 000 -> 4 900 instructions (24.5 KB) and 75 -> 24 spilled
+// scalars (profiles/r04_ab_lds_direct_staging.txt; the budgets are checked by tests/test_kernel_budget.py).
 // No barrier; the loads are still in flight when this returns -- the workgroup barrier that precedes every read of the window waits for
 // them (vmcnt(0) is part of its release).
 template <int SIDE>
