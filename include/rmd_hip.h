@@ -199,6 +199,9 @@ int rmd_hip_seeds_sync(const rmd_hip_seeds_t* s);
 #define RMD_HIP_OPT_INJECT_FAULT 9  /* test hook: 1 = the arrival flag of the NEXT host frame that travels through a staging buffer is withheld once; that
                                       update's bounded in-kernel wait (about 0.1 s) runs out, the next synchronising call reports RMD_HIP_ERR_RUNTIME
                                       once, and the handle is usable again from the next setReferenceImage on (tests/test_full_speed.py) */
+#define RMD_HIP_OPT_PIPELINE 10  /* A/B builds of the library only (-DRMD_AB_PIPELINE; the product accepts 0): 1 = one launch per update for frames resident in HBM of a
+                                  * plain SeedMatrix -- the search of a frame rides on the next update()'s launch together with that frame's setup
+                                  * (csrc/ab/rmd_pipelined.hpp).  Bit-identical, measured slower than the two-launch pipeline, kept as a record. */
 int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value);
 /* kernels of the seed path, for rmd_hip_seeds_timing */
 #define RMD_HIP_STAGE_SEED_INIT 0

@@ -31,6 +31,7 @@ PLANE_SUM_TEMPL, PLANE_CONST_TEMPL_DENOM, PLANE_EPIPOLAR_MATCHES, PLANE_REF_IMG,
 KIND_F32, KIND_I32, KIND_F32X2 = 0, 1, 2
 OPT_MATCHER, OPT_TIMING, OPT_COLLECT_STATS, OPT_WINDOW, OPT_LAZY_FINALIZE, OPT_LOCAL_MAX, OPT_UNIT_ROUNDS, OPT_UNIT_TARGET, OPT_SEARCH_FLAGS = 0, 1, 2, 3, 4, 5, 6, 7, 8
 OPT_INJECT_FAULT = 9  # test hook, see include/rmd_hip.h
+OPT_PIPELINE = 10  # A/B builds only: one launch per update for resident frames (csrc/ab/rmd_pipelined.hpp), see include/rmd_hip.h
 MAX_BATCH = 8  # sequences one SeedMatrixBatch can hold (rmdk::MAX_BATCH)
 MATCHER_PIXEL, MATCHER_PIPELINE = 0, 3
 MATCHER_PIPELINE_R01, MATCHER_FRAME = 1, 2  # retired variants: A/B builds of the library only (tools/ab_make.sh)

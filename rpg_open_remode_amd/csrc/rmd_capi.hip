@@ -274,6 +274,7 @@ int rmdh::seeds_destroy_impl(rmd_hip_seeds* s) {
   if (s->region_stop) (void)hipEventDestroy(s->region_stop);
   for (auto& pl : s->planes)
     if (pl.owns && pl.data) (void)hipFree(pl.data);
+  pipe_release(s);
   s->matcher_ws.release();
 #ifdef RMD_AB_MATCHERS
   s->frame_ws.release();
@@ -321,6 +322,9 @@ int rmdh::seeds_create_impl(int width, int height, float fx, float fy, float cx,
   s->width = width; s->height = height; s->patch_side = patch_side;
   (void)hipGetDevice(&s->device);
   s->batch = batch; s->batch_index = seq;
+#ifdef RMD_AB_PIPELINE
+  if (!batch) { static const int pipeline = [] { const char* e = getenv("RMD_HIP_PIPELINE"); return e ? atoi(e) : 0; }(); s->opt_pipeline = pipeline != 0; }  // (the experiment without code changes)
+#endif
   rmd_hip_batch::Group* grp = batch ? &batch->group_of(seq) : nullptr;
   s->seq = batch ? seq - grp->first : 0;
   s->mws = batch ? &grp->ws : &s->matcher_ws;
@@ -555,7 +559,8 @@ int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value) {
   // a batch member's updates are launched by the batch (batch_launch), which knows nothing of per-member statistics, per-update event
   // pairs, eager finalisation or unit targets: accepting such a setting and then ignoring it would leave last_stats / timing stale
   if (s->batch && ((option == RMD_HIP_OPT_COLLECT_STATS && value != 0) || (option == RMD_HIP_OPT_TIMING && value != 0) ||
-                   (option == RMD_HIP_OPT_LAZY_FINALIZE && value == 0) || option == RMD_HIP_OPT_UNIT_TARGET || option == RMD_HIP_OPT_SEARCH_FLAGS))
+                   (option == RMD_HIP_OPT_LAZY_FINALIZE && value == 0) || option == RMD_HIP_OPT_UNIT_TARGET || option == RMD_HIP_OPT_SEARCH_FLAGS ||
+                   (option == RMD_HIP_OPT_PIPELINE && value != 0)))
     return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: option %d has no effect on a member of a batch (rmd_hip_batch_set_option sets the batch's timing, unit "
                                          "target and search flags)", option);
   switch (option) {
@@ -604,6 +609,16 @@ int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value) {
     case RMD_HIP_OPT_LAZY_FINALIZE:
       s->opt_lazy = value != 0;
       return RMD_HIP_OK;
+    case RMD_HIP_OPT_PIPELINE:  // experiment: one launch per update (csrc/ab/rmd_pipelined.hpp); resident frames of a plain SeedMatrix only
+#ifdef RMD_AB_PIPELINE
+      if (value != 0 && value != 1) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: pipeline %d (0 / 1)", value);
+      TRY(seeds_flush(s));
+      s->opt_pipeline = value;
+      return RMD_HIP_OK;
+#else
+      if (value != 0) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: the one-launch-per-update experiment exists in A/B builds of the library only (-DRMD_AB_PIPELINE)");
+      return RMD_HIP_OK;
+#endif
     case RMD_HIP_OPT_INJECT_FAULT:
       if (value != 0 && value != 1) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: fault %d (1 = withhold the arrival flag of the next staged host frame)", value);
       if (s->batch) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: fault injection is for plain SeedMatrix handles");

@@ -238,6 +238,7 @@ inline hipError_t create_stream(hipStream_t* out, int level) {
 extern unsigned long g_progress_timeouts;  // diagnostics (RMD_HIP_INGEST_PROFILE): waits for a staging slot that gave up after 2 ms
 extern double g_progress_max_wait_us;   // ... and the longest such wait
 
+namespace rmdk { struct PipeWorkspace; }
 // ---- rmd::SeedMatrix ------------------------------------------------------------------------
 struct rmd_hip_seeds {
   int width = 0, height = 0, patch_side = 5, device = 0, num_cus = 256;
@@ -267,6 +268,12 @@ struct rmd_hip_seeds {
   bool finalize_pending = false;
   rmdk::SeedParams P_pending;
   int opt_lazy = 1;
+  // EXPERIMENT, A/B builds only (-DRMD_AB_PIPELINE; RMD_HIP_OPT_PIPELINE, csrc/ab/rmd_pipelined.hpp): one launch per update -- the search of the newest frame stays pending until the
+  // next update() carries it (together with that frame's setup) or an observer forces it (rmdh::seeds_flush)
+  int opt_pipeline = 0;
+  bool search_pending = false;
+  rmdk::SeedParams P_search;                // the frame whose search is pending
+  rmdk::PipeWorkspace* pipe = nullptr;      // allocated at first use (rmd_update.hip)
   // 8-bit ingest: two pinned staging buffers + two device byte planes, used alternately so that the host-side copy of
   // frame k+1 overlaps the device work of frame k; an event per slot says when its H2D copy has been consumed
   static constexpr int SLOTS = 3;           // frames in flight between the host and the update kernels
@@ -429,6 +436,7 @@ int seeds_after_frame(rmd_hip_seeds* s, const float* T_curr_world, const Pending
 int seeds_create_impl(int width, int height, float fx, float fy, float cx, float cy, int patch_side, int max_extent, rmd_hip_batch* batch, int seq, rmd_hip_seeds** out);
 int seeds_destroy_impl(rmd_hip_seeds* s);
 // rmd_update.hip
+void pipe_release(rmd_hip_seeds* s);       // frees the buffers of the one-launch-per-update experiment (rmd_update.hip)
 int seeds_flush(rmd_hip_seeds* s);           // the deferred finalisation of this handle's last update, as a kernel of its own
 int seeds_launch_init(rmd_hip_seeds* s);
 int seeds_launch_update(rmd_hip_seeds* s, const PendingIngest* ingest = nullptr);

@@ -2,6 +2,9 @@
 // reference as seed_init_kernel + the two-launch pipeline of rmd_frame.hpp): launches for one SeedMatrix and for the stream groups of a batch.
 #include "rmd_host.hpp"
 #include "rmd_frame.hpp"
+#ifdef RMD_AB_PIPELINE
+#include "ab/rmd_pipelined.hpp"  // experiment, A/B builds only: one launch per update (measured and dropped)
+#endif
 
 namespace rmdh {
 
@@ -29,8 +32,35 @@ rmdk::SeqArgs seq_args_of(const rmd_hip_seeds* s, const rmdk::SeedParams& P) {
 }
 }  // namespace
 
+#ifdef RMD_AB_PIPELINE
+void pipe_release(rmd_hip_seeds* s) {
+  if (s->pipe) { s->pipe->release(); delete s->pipe; s->pipe = nullptr; }
+}
+
+// one-launch-per-update experiment: the pending search of the newest frame as a launch of its own; its finalisation is then pending like
+// that of any other update
+static int pipe_flush_search(rmd_hip_seeds* s) {
+  if (!s->search_pending) return RMD_HIP_OK;
+  s->search_pending = false;
+  rmdk::SeqArgs Qs;
+  memset(&Qs, 0, sizeof(Qs));
+  Qs.P = s->P_search; Qs.active = 1;
+  TRY(dispatch_side(s->patch_side, [&](auto side) {
+    HIP_TRY((rmdk::launch_pipe_search_only<decltype(side)::value>(Qs, s->matcher_ws, *s->pipe, s->stream, s->num_cus)));
+    return RMD_HIP_OK;
+  }));
+  s->P_pending = s->P_search;
+  s->finalize_pending = true;
+  return RMD_HIP_OK;
+}
+#else
+void pipe_release(rmd_hip_seeds*) {}
+static int pipe_flush_search(rmd_hip_seeds*) { return RMD_HIP_OK; }
+#endif
+
 // the deferred finalisation of this handle's last update, as a kernel of its own (an observer is about to look at the state)
 int seeds_flush(rmd_hip_seeds* s) {
+  TRY(pipe_flush_search(s));
   if (s->finalize_pending) {
     s->finalize_pending = false;
     HIP_TRY(rmdk::launch_seed_finalize(s->P_pending, *s->mws, s->stream, s->seq));
@@ -90,7 +120,31 @@ int seeds_launch_update(rmd_hip_seeds* s, const PendingIngest* ingest) {
         s->finalize_pending = true;
         if (!s->opt_lazy || s->opt_stats == 1) TRY(seeds_flush(s));
 #endif
+#ifdef RMD_AB_PIPELINE
+      } else if (s->opt_pipeline && !ingest && s->opt_stats == 0 && s->opt_lazy && !s->batch) {
+        // EXPERIMENT (csrc/rmd_pipelined.hpp): one launch per update -- this frame's setup (with the finalisation of the frame before) rides on
+        // the search of the frame before; its own search stays pending
+        if (!s->pipe) {
+          s->pipe = new (std::nothrow) rmdk::PipeWorkspace();
+          if (!s->pipe || s->pipe->allocate(s->matcher_ws) != 0) return fail(RMD_HIP_ERR_RUNTIME, "update: buffers of the one-launch pipeline");
+        }
+        if (!s->search_pending) {
+          const rmdk::SeqArgs Qn = seq_args_of(s, P);  // fuses the finalisation that is pending, if one is
+          HIP_TRY((rmdk::launch_pipe_setup<SIDE>(Qn, s->matcher_ws, *s->pipe, s->stream, s->num_cus, s->opt_unit_target)));
+        } else {
+          rmdk::SeqArgs Qs, Qn;
+          memset(&Qs, 0, sizeof(Qs)); memset(&Qn, 0, sizeof(Qn));
+          Qs.P = s->P_search; Qs.active = 1;
+          Qn.P = P; Qn.active = 1; Qn.fuse_prev = 1; Qn.T_ref_curr_prev = s->P_search.T_ref_curr;
+          HIP_TRY((rmdk::launch_pipe_search_setup<SIDE>(Qs, Qn, s->matcher_ws, *s->pipe, s->stream, s->num_cus, s->opt_unit_target)));
+        }
+        s->finalize_pending = false;
+        s->search_pending = true;
+        s->P_search = P;
+        s->async_count_valid = false;
+#endif
       } else {
+        TRY(pipe_flush_search(s));  // (A/B builds with the one-launch experiment: a frame of another kind, or the option has just been cleared)
         rmdk::SeedParams Pt = P;
         if (s->opt_stats == 2 && s->matcher_ws.d_wg_trace) {  // timeline probes of the setup tiles and the search workgroups
           Pt.trace = s->matcher_ws.d_wg_trace + static_cast<size_t>(s->trace_frame % rmdk::FR_TRACE_FRAMES) * s->matcher_ws.wg_trace_slice_u64();
