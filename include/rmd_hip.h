@@ -72,21 +72,26 @@ typedef struct rmd_hip_seeds rmd_hip_seeds_t;
 typedef struct rmd_hip_denoiser rmd_hip_denoiser_t;
 typedef struct rmd_hip_batch rmd_hip_batch_t;
 
-/* ---- environment switches ---------------------------------------------------------------
- * Every one is an A/B or diagnostics switch of the host side, read ONCE per process (function-local statics) or once per handle at its
- * creation; none changes results (tests/test_host_frame_modes.py, tests/test_full_speed.py run the frame-path modes against the resident
- * path bit for bit).  Defaults are what DESIGN.md 4.6 / 4.7 measured to be fastest.
- *   RMD_HIP_HOST_FRAMES = staged | staged_ahead | inplace | inplace_ahead
- *                            how a frame handed over in host memory reaches the current-image plane: through a staging buffer in HBM filled by the copy
- *                            engine (staged) or read from the pinned ring by the kernels themselves (inplace); "_ahead": converted during the previous
- *                            update's search kernel.  Default: staged_ahead for a SeedMatrix, inplace for a batch; frames with lens undistortion: staged.
- *   RMD_HIP_BATCH_GROUPS = 1..4   stream groups of a batch (default min(n, 3)); RMD_HIP_AHEAD_WGS = workgroups that convert a frame one step ahead (128)
- *   RMD_HIP_PACK_BACKOFF = n      float frames that are not 8-bit levels: the next n frames are not examined (15; tests use 0);
- *   RMD_HIP_FLOAT_AS_BYTES = 0    float frames always travel as floats;   RMD_HIP_COPY_THREADS = n   host threads that copy large frames (4)
- *   RMD_HIP_FUSED_INGEST = 0      host frames through the copy-stream pipeline with events (the round-1 path) instead of the setup kernel's ingest workgroups
- *   RMD_HIP_INGEST_HOST_WAIT = 1  (with the above) the host waits for the staging event instead of the stream;  RMD_HIP_COPY_STREAM_LEVEL = 0..2  priority
- *                            level of copy streams;   RMD_HIP_INGEST_PROFILE = 1   prints host time per frame spent waiting / copying / submitting at destroy
- * (The Python loader additionally honours RMD_HIP_LIB = path of another build of this library, tools/ab_make.sh.) */
+/* ---- process-wide settings of the host side ------------------------------------------------
+ * A/B and diagnostics switches; none changes results (tests/test_host_frame_modes.py, tests/test_full_speed.py run the frame-path modes
+ * against the resident path bit for bit).  Defaults are what was measured to be fastest.  A handle picks the values
+ * up when it is created.  The environment is read in ONE place (rmdh::tunables(), csrc/rmd_capi.hip), once, at the library's first
+ * use: RMD_HIP_<NAME> = value presets tunable <NAME>.  (The Python loader additionally honours RMD_HIP_LIB = path of another build of
+ * this library, tools/ab_make.sh.) */
+#define RMD_HIP_TUNE_HOST_FRAMES 0    /* how a frame handed over in host memory reaches the current-image plane: 0 staged (a copy engine fills a staging
+                                         buffer in HBM), 1 staged_ahead (... and the frame is converted during the previous update's search kernel), 2 inplace
+                                         (the kernels read the pinned ring themselves), 3 inplace_ahead; -1 (default) = staged_ahead for a SeedMatrix,
+                                         inplace for a batch; frames with lens undistortion are always staged.  Environment: the names or the numbers */
+#define RMD_HIP_TUNE_BATCH_GROUPS 1   /* stream groups of a batch, 1..4; 0 (default) = min(n, 3) */
+#define RMD_HIP_TUNE_AHEAD_WGS 2      /* workgroups that convert a host frame one step ahead (128) */
+#define RMD_HIP_TUNE_PACK_BACKOFF 3   /* after a float frame that is not made of 8-bit levels the next n frames are not examined (15; tests use 0) */
+#define RMD_HIP_TUNE_FLOAT_AS_BYTES 4 /* 1 (default): float frames of 8-bit levels travel as bytes; 0: always as floats */
+#define RMD_HIP_TUNE_COPY_THREADS 5   /* host threads that copy a large frame into the pinned ring, 1..16 (4); read when the first large frame arrives */
+#define RMD_HIP_TUNE_FUSED_INGEST 6   /* 1 (default): host frames are converted by the update's own kernels; 0: upload + conversion kernel on the copy stream */
+#define RMD_HIP_TUNE_INGEST_PROFILE 7 /* 1: a handle prints the host time per frame it spent waiting / copying / submitting when it is destroyed */
+#define RMD_HIP_NUM_TUNABLES 8
+int rmd_hip_set_tunable(int tunable, int value);
+int rmd_hip_get_tunable(int tunable, int* value);
 
 /* ---- library ------------------------------------------------------------------------ */
 const char* rmd_hip_last_error(void);
@@ -180,28 +185,19 @@ int rmd_hip_seeds_dist_from_ref(const rmd_hip_seeds_t* s, float* dist);
 int rmd_hip_seeds_sync(const rmd_hip_seeds_t* s);
 
 /* knobs (not in the reference) */
-#define RMD_HIP_OPT_MATCHER 0      /* 0 = per-pixel kernel (the reference's shape, A/B baseline), 3 = two-launch tile pipeline (default).  The retired
-                                      variants 1 (round-1 tile pipeline, 66 KB search window) and 2 (one-launch frame kernel) exist only in A/B builds
-                                      of the library (-DRMD_AB_MATCHERS, tools/ab_make.sh); elsewhere selecting them is an error */
+#define RMD_HIP_OPT_MATCHER 0      /* 0 = per-pixel kernel (the reference's shape: one lane per seed, every lane gathers its own texels; the A/B baseline the
+                                      full-size tests compare the tile pipeline with), 3 = two-launch tile pipeline (default) */
 #define RMD_HIP_OPT_TIMING 1       /* 1 = bracket every update with HIP events on the handle's stream; 2 = one event pair
                                       around everything between timing_reset and the timing query (no markers in between) */
 #define RMD_HIP_OPT_COLLECT_STATS 2 /* 1 = count live seeds / search steps / NCC evaluations per update;
                                       2 = in-kernel timeline probes instead (see rmd_hip_seeds_trace_download) */
-#define RMD_HIP_OPT_WINDOW 3       /* A/B builds, matcher 1 only: LDS window of its search kernel, 0 or 2 = large (133 x 104 texels), 1 = small (69 x 64) */
 #define RMD_HIP_OPT_LAZY_FINALIZE 4 /* 1 (default) = defer an update's last kernel and fuse it into the next update */
-#define RMD_HIP_OPT_LOCAL_MAX 5     /* frame kernel: work items a tile keeps to itself before it hands its search out through the
-                                      queue; 0 (default) = from the previous frame's load */
-#define RMD_HIP_OPT_UNIT_ROUNDS 6   /* frame kernel: rounds of 256 NCC evaluations per handed-out unit, 1..4; 0 (default) = from the load */
-#define RMD_HIP_OPT_UNIT_TARGET 7   /* tile pipeline: work units aimed at per frame, in multiples (1..4, default 1) of the resident search workgroups;
-                                      the unit size (1..4 rounds of 256 NCC evaluations) follows from the previous frame's work (experiments) */
-#define RMD_HIP_OPT_SEARCH_FLAGS 8  /* retired (rounds 2-3: A/B switches of the search kernel's unit loop).  Only the value 6 -- what the kernel now does
-                                      unconditionally: sixteen hand-out counters, the tile's sample box travels with the unit -- is accepted */
+#define RMD_HIP_OPT_UNIT_TARGET 7   /* tile pipeline: work units aimed at per frame, in multiples (1..4) of the resident search workgroups (default 2 for a
+                                      SeedMatrix, 1 for a batch); the unit size (1..4 rounds of 256 NCC evaluations) follows from the previous frame's work */
 #define RMD_HIP_OPT_INJECT_FAULT 9  /* test hook: 1 = the arrival flag of the NEXT host frame that travels through a staging buffer is withheld once; that
                                       update's bounded in-kernel wait (about 0.1 s) runs out, the next synchronising call reports RMD_HIP_ERR_RUNTIME
                                       once, and the handle is usable again from the next setReferenceImage on (tests/test_full_speed.py) */
-#define RMD_HIP_OPT_PIPELINE 10  /* A/B builds of the library only (-DRMD_AB_PIPELINE; the product accepts 0): 1 = one launch per update for frames resident in HBM of a
-                                  * plain SeedMatrix -- the search of a frame rides on the next update()'s launch together with that frame's setup
-                                  * (csrc/ab/rmd_pipelined.hpp).  Bit-identical, measured slower than the two-launch pipeline, kept as a record. */
+/* (option numbers 3, 5, 6, 8, 10 belonged to experiments that are no longer part of the library -- LAB.md -- and are rejected) */
 int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value);
 /* kernels of the seed path, for rmd_hip_seeds_timing */
 #define RMD_HIP_STAGE_SEED_INIT 0
@@ -213,10 +209,9 @@ int rmd_hip_seeds_timing(const rmd_hip_seeds_t* s, int stage, double* total_ms, 
 int rmd_hip_seeds_timing_reset(rmd_hip_seeds_t* s);
 /* out[0..2] = live seeds, epipolar steps visited, NCC evaluations of the last update (needs COLLECT_STATS) */
 int rmd_hip_seeds_last_stats(const rmd_hip_seeds_t* s, long long* out3);
-/* diagnostics of the last update (needs COLLECT_STATS = 1): [0..2] as last_stats; the tile pipeline fills nothing else (its
- * per-workgroup probes are the timeline, COLLECT_STATS = 2).  A/B builds, matcher 1: [3..5] NCC evaluations served from the LDS
- * window / regular global reads / per-sample reads, [6] max work items of a tile, [7..9] summed workgroup cycles in setup / staging /
- * search, [11] max workgroup cycles, [12] tiles with work, [13] search rounds, [14] max setup cycles, [15] max search cycles */
+/* diagnostics of the last update (needs COLLECT_STATS = 1): [0..2] as last_stats, [3] NCC evaluations that read their texels from L2 instead
+ * of the LDS window, [4] work units searched, [5] windows staged inside the search kernel; the rest is zero (per-workgroup probes are the
+ * timeline, COLLECT_STATS = 2) */
 int rmd_hip_seeds_last_diagnostics(const rmd_hip_seeds_t* s, long long* out16);
 /* timeline of update number `frame` (0 = first update after COLLECT_STATS was set to 2; the last 256 are kept), tile pipeline: 8 words
  * per 16x16 tile / search workgroup (row-major tiles; workgroup w of the search shares slot w): [0] search workgroup start, [1] its first unit

@@ -30,6 +30,8 @@ _pp = _c.POINTER(_c.c_void_p)
 SIGNATURES = {
     "rmd_hip_last_error": (_c.c_char_p, []),
     "rmd_hip_version": (_i, []),
+    "rmd_hip_set_tunable": (_i, [_i, _i]),
+    "rmd_hip_get_tunable": (_i, [_i, _c.POINTER(_i)]),
     "rmd_hip_device_count": (_i, [_c.POINTER(_i)]),
     "rmd_hip_set_device": (_i, [_i]),
     "rmd_hip_device_name": (_i, [_i, _c.c_char_p, _sz]),

@@ -29,12 +29,24 @@ __all__ = ["PinholeCamera", "SE3", "DeviceImage", "SeedMatrix", "SeedMatrixBatch
 PLANE_MU, PLANE_SIGMA_SQ, PLANE_A, PLANE_B, PLANE_CONVERGENCE = 0, 1, 2, 3, 4
 PLANE_SUM_TEMPL, PLANE_CONST_TEMPL_DENOM, PLANE_EPIPOLAR_MATCHES, PLANE_REF_IMG, PLANE_CURR_IMG = 5, 6, 7, 8, 9
 KIND_F32, KIND_I32, KIND_F32X2 = 0, 1, 2
-OPT_MATCHER, OPT_TIMING, OPT_COLLECT_STATS, OPT_WINDOW, OPT_LAZY_FINALIZE, OPT_LOCAL_MAX, OPT_UNIT_ROUNDS, OPT_UNIT_TARGET, OPT_SEARCH_FLAGS = 0, 1, 2, 3, 4, 5, 6, 7, 8
+OPT_MATCHER, OPT_TIMING, OPT_COLLECT_STATS, OPT_LAZY_FINALIZE, OPT_UNIT_TARGET = 0, 1, 2, 4, 7  # include/rmd_hip.h: RMD_HIP_OPT_*
 OPT_INJECT_FAULT = 9  # test hook, see include/rmd_hip.h
-OPT_PIPELINE = 10  # A/B builds only: one launch per update for resident frames (csrc/ab/rmd_pipelined.hpp), see include/rmd_hip.h
+# process-wide settings of the host side (include/rmd_hip.h: RMD_HIP_TUNE_*; the environment presets them: RMD_HIP_<NAME>)
+TUNE_HOST_FRAMES, TUNE_BATCH_GROUPS, TUNE_AHEAD_WGS, TUNE_PACK_BACKOFF, TUNE_FLOAT_AS_BYTES, TUNE_COPY_THREADS, TUNE_FUSED_INGEST, TUNE_INGEST_PROFILE = range(8)
+HOST_FRAMES_DEFAULT, HOST_FRAMES_STAGED, HOST_FRAMES_STAGED_AHEAD, HOST_FRAMES_INPLACE, HOST_FRAMES_INPLACE_AHEAD = -1, 0, 1, 2, 3
+
+
+def setTunable(tunable, value):
+    """rmd_hip_set_tunable: a process-wide setting of the host side; handles created afterwards pick it up"""
+    check(_lib.lib().rmd_hip_set_tunable(int(tunable), int(value)))
+
+
+def getTunable(tunable):
+    v = ctypes.c_int()
+    check(_lib.lib().rmd_hip_get_tunable(int(tunable), ctypes.byref(v)))
+    return v.value
 MAX_BATCH = 8  # sequences one SeedMatrixBatch can hold (rmdk::MAX_BATCH)
 MATCHER_PIXEL, MATCHER_PIPELINE = 0, 3
-MATCHER_PIPELINE_R01, MATCHER_FRAME = 1, 2  # retired variants: A/B builds of the library only (tools/ab_make.sh)
 STAGE_SEED_INIT, STAGE_UPDATE, STAGE_COUNT = 0, 1, 2
 DENOISE_OPT_TIMING, DENOISE_OPT_ITERS_PER_LAUNCH, DENOISE_OPT_GEOMETRY = 1, 2, 3
 

@@ -8,6 +8,7 @@
 
 Run as `python -m rpg_open_remode_amd.build` or through __graft_entry__.build().
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -53,28 +54,27 @@ def hipcc_path():
     raise RuntimeError("hipcc not found")
 
 
-HIP_UNITS = ["rmd_capi", "rmd_update", "rmd_ingest", "rmd_batch", "rmd_denoise", "rmd_reduce"]  # translation units of librmd_hip.so (csrc/rmd_host.hpp says who owns what)
+HIP_UNITS = ["rmd_capi", "rmd_update", "rmd_ingest", "rmd_batch", "rmd_denoise", "rmd_reduce", "rmd_publish"]  # translation units of librmd_hip.so (csrc/rmd_host.hpp says who owns what)
 
 
 def build_hip(force=False, verbose=False, extra_flags=(), out=None):
     """librmd_hip.so from its translation units, compiled in parallel (the unit that instantiates the seed kernels dominates: ~10 s) and linked
-    by hipcc.  out: another file name (A/B variants, tools/ab_make.sh; selected at run time with RMD_HIP_LIB).  A/B builds with the retired
-    matchers (-DRMD_AB_MATCHERS) are ONE translation unit (csrc/rmd_all.hip): their headers define kernels that must not be compiled twice.
+    by hipcc.  out: another file name (A/B variants, tools/ab_make.sh; selected at run time with RMD_HIP_LIB).
     Returns the library's path; build_hip.last_report says what was compiled and what was reused."""
     product = out is None
     out = out or os.path.join(HERE, "librmd_hip.so")
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))] + [os.path.join(ROOT, "include", "rmd_hip.h")]
     flags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags) + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
-    unity = any("RMD_AB_MATCHERS" in f for f in extra_flags)
-    units = ["rmd_all"] if unity else HIP_UNITS
-    # objects are kept per output file and flag set: a product build and an A/B variant never share them
-    tag = "" if product and not extra_flags else "_" + str(abs(hash((os.path.basename(out),) + tuple(extra_flags))) % 10 ** 8)
+    units = HIP_UNITS
+    # objects are kept per output file and flag set: a product build and an A/B variant never share them (a stable digest: Python's hash()
+    # of a string is salted per interpreter)
+    tag = "" if product and not extra_flags else "_" + hashlib.sha1(" ".join([os.path.basename(out), *extra_flags]).encode()).hexdigest()[:8]
     obj_dir = os.path.join(HERE, "build")
     os.makedirs(obj_dir, exist_ok=True)
     jobs, compiled, reused = [], [], []
     for u in units:
         src, obj = os.path.join(CSRC, u + ".hip"), os.path.join(obj_dir, u + tag + ".o")
-        deps = [src] + headers + ([os.path.join(CSRC, v + ".hip") for v in HIP_UNITS] if unity else [])
+        deps = [src] + headers
         if force or _newer(obj, deps):
             cmd = [hipcc_path(), *flags, "-c", src, "-o", obj]
             if verbose:

@@ -183,7 +183,7 @@ int rmd_hip_batch_create(int n, int width, int height, float fx, float fy, float
   (void)hipGetDevice(&b->device);
   auto bail = [&](int rc) { rmd_hip_batch_destroy(b); return rc; };
   int want_groups = n >= 3 ? 3 : n;  // measured (profiles/r03_batch_ab.txt): three groups beat two by 3-9 %, a fourth shares a hardware-queue pool and loses 25 %
-  if (const char* e = getenv("RMD_HIP_BATCH_GROUPS")) want_groups = atoi(e);  // (A/B)
+  if (tunables().v[RMD_HIP_TUNE_BATCH_GROUPS] > 0) want_groups = tunables().v[RMD_HIP_TUNE_BATCH_GROUPS];  // (A/B)
   if (want_groups < 1) want_groups = 1;
   if (want_groups > rmd_hip_batch::MAX_GROUPS) want_groups = rmd_hip_batch::MAX_GROUPS;
   if (want_groups > n) want_groups = n;
@@ -282,10 +282,6 @@ int rmd_hip_batch_set_option(rmd_hip_batch_t* b, int option, int value) {
       if (value < 1 || value > 4) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_set_option: unit target %d outside 1..4", value);
       b->opt_unit_target = value;
       return RMD_HIP_OK;
-    case RMD_HIP_OPT_SEARCH_FLAGS:
-      if (value != 6) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_set_option: search flags %d: retired switches, only 6 (what the kernel does) is accepted", value);
-      for (int g = 0; g < b->n_groups; ++g) b->groups[g].ws.search_flags = value;
-      return RMD_HIP_OK;
     default: return fail(RMD_HIP_ERR_INVALID_ARG, "batch_set_option: unknown option %d", option);
   }
 }
@@ -336,13 +332,19 @@ int rmd_hip_batch_denoise(rmd_hip_batch_t* b, const float* depth_range, float la
   const rmd_hip_seeds* m0 = b->members[0];
   const int w = m0->width, h = m0->height, n = b->n;
   rmd_hip_batch::Denoise& dn = b->dn;
-  if (!dn.ready) {
+  // a member that never got a reference frame holds no depth map (its planes are the zeros of its creation): an error like denoise() before
+  // setLargeSigmaSq(), not a map of the prior
+  for (int i = 0; i < n; ++i)
+    if (!b->members[i]->has_reference) return fail(RMD_HIP_ERR_NOT_READY, "batch_denoise: member %d has no reference image", i);
+  if (!dn.ready) {  // (a call that fails half-way allocates only what is still missing when it is repeated; batch_destroy releases whatever exists)
     rmd_hip_image* f32[] = {&dn.u[0], &dn.u[1], &dn.u_head[0], &dn.u_head[1], &dn.g};
-    for (auto* im : f32) TRY(image_alloc(im, RMD_HIP_KIND_F32, w, h * n));
-    for (int k = 0; k < 2; ++k) TRY(image_alloc(&dn.p[k], RMD_HIP_KIND_F32X2, w, h * n));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dn.d_table), static_cast<size_t>(rmdk::MAX_BATCH) * rmdk::TV_MEMBER_WORDS * sizeof(unsigned long long)));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&dn.h_staging), static_cast<size_t>(n) * w * h * sizeof(float)));
-    HIP_TRY(hipStreamCreateWithFlags(&dn.stream, hipStreamNonBlocking));
+    for (auto* im : f32)
+      if (!im->data) TRY(image_alloc(im, RMD_HIP_KIND_F32, w, h * n));
+    for (int k = 0; k < 2; ++k)
+      if (!dn.p[k].data) TRY(image_alloc(&dn.p[k], RMD_HIP_KIND_F32X2, w, h * n));
+    if (!dn.d_table) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dn.d_table), static_cast<size_t>(rmdk::MAX_BATCH) * rmdk::TV_MEMBER_WORDS * sizeof(unsigned long long)));
+    if (!dn.h_staging) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&dn.h_staging), static_cast<size_t>(n) * w * h * sizeof(float)));
+    if (!dn.stream) HIP_TRY(hipStreamCreateWithFlags(&dn.stream, hipStreamNonBlocking));
     HIP_TRY(hipDeviceSynchronize());
     dn.ready = true;
   }

@@ -23,6 +23,38 @@ int fail(int code, const char* fmt, ...) {
 }
 const char* last_error() { return g_last_error; }
 
+// The library's process-wide settings and THE ONE PLACE where it reads its environment (include/rmd_hip.h: RMD_HIP_TUNE_*): the
+// defaults come from RMD_HIP_<NAME>, once, at the first call; rmd_hip_set_tunable overrides them for handles created afterwards.
+Tunables& tunables() {
+  static Tunables T = [] {
+    Tunables t;
+    t.v[RMD_HIP_TUNE_HOST_FRAMES] = HOST_FRAMES_DEFAULT;
+    t.v[RMD_HIP_TUNE_BATCH_GROUPS] = 0;
+    t.v[RMD_HIP_TUNE_AHEAD_WGS] = AHEAD_WGS;
+    t.v[RMD_HIP_TUNE_PACK_BACKOFF] = 15;
+    t.v[RMD_HIP_TUNE_FLOAT_AS_BYTES] = 1;
+    t.v[RMD_HIP_TUNE_COPY_THREADS] = 4;
+    t.v[RMD_HIP_TUNE_FUSED_INGEST] = 1;
+    t.v[RMD_HIP_TUNE_INGEST_PROFILE] = 0;
+    static const char* const names[RMD_HIP_NUM_TUNABLES] = {"RMD_HIP_HOST_FRAMES", "RMD_HIP_BATCH_GROUPS", "RMD_HIP_AHEAD_WGS", "RMD_HIP_PACK_BACKOFF",
+                                                            "RMD_HIP_FLOAT_AS_BYTES", "RMD_HIP_COPY_THREADS", "RMD_HIP_FUSED_INGEST", "RMD_HIP_INGEST_PROFILE"};
+    for (int k = 0; k < RMD_HIP_NUM_TUNABLES; ++k) {
+      const char* e = getenv(names[k]);
+      if (!e || !e[0]) continue;
+      if (k == RMD_HIP_TUNE_HOST_FRAMES) {  // by name, or by number
+        static const char* const modes[4] = {"staged", "staged_ahead", "inplace", "inplace_ahead"};
+        for (int m = 0; m < 4; ++m)
+          if (!strcmp(e, modes[m])) t.v[k] = m;
+        if (e[0] >= '0' && e[0] <= '3' && !e[1]) t.v[k] = e[0] - '0';
+      } else {
+        t.v[k] = atoi(e);
+      }
+    }
+    return t;
+  }();
+  return T;
+}
+
 // wait until the owner of an image (if any) has settled it
 int image_settle(const rmd_hip_image* img) {
   ScopedDevice dev(img->device);  // the owner's stream belongs to the image's device, whatever the caller's current one is
@@ -64,19 +96,8 @@ int ingest_error_check(unsigned int* h_progress) {
 int seeds_sync(const rmd_hip_seeds* s) {
   rmd_hip_seeds* m = const_cast<rmd_hip_seeds*>(s);
   TRY(seeds_flush(m));
-#ifdef RMD_AB_MATCHERS
-  if (m->frame_ws.frame > 0) HIP_TRY(hipMemcpyAsync(m->frame_ws.h_error, m->frame_ws.d_error, sizeof(unsigned int), hipMemcpyDeviceToHost, s->stream));
-#endif
   HIP_TRY(hipStreamSynchronize(s->stream));
   TRY(ingest_error_check(m->batch ? m->batch->group_of(m->batch_index).h_progress : m->h_progress));
-#ifdef RMD_AB_MATCHERS
-  if (m->frame_ws.h_error && m->frame_ws.h_error[0] != 0u) {
-    const unsigned int bits = m->frame_ws.h_error[0];
-    m->frame_ws.h_error[0] = 0u;
-    (void)hipMemsetAsync(m->frame_ws.d_error, 0, sizeof(unsigned int), s->stream);
-    return fail(RMD_HIP_ERR_RUNTIME, "seed update: a bounded wait inside the frame kernel ran out (error bits 0x%x); results are invalid", bits);
-  }
-#endif
   for (auto& t : m->timers) t.drain();
   if (m->stats_pending) {
     for (int k = 0; k < 16; ++k) m->last_stats[k] = static_cast<long long>(m->h_scalars[1 + k]);
@@ -109,10 +130,6 @@ int seeds_after_reference(rmd_hip_seeds* s, const float* T_curr_world, float min
   s->async_count_valid = false;
   // the pipeline's load statistics (unit size from the previous frame's work) belong to the old sequence; in a batch the other
   // members' next frame simply starts from the largest unit size again
-#ifdef RMD_AB_MATCHERS
-  s->frame_ws.frame = 0;
-  HIP_TRY(hipMemsetAsync(s->frame_ws.d_ctl, 0, 3 * rmdk::FR_CTL_WORDS * sizeof(unsigned int), s->stream));
-#endif
   s->mws->frame = 0;
   HIP_TRY(hipMemsetAsync(s->mws->d_shards, 0, 3 * rmdk::UNIT_SHARDS * sizeof(unsigned long long), s->stream));
   s->has_reference = true;
@@ -141,6 +158,20 @@ extern "C" {
 
 const char* rmd_hip_last_error(void) { return g_last_error; }
 int rmd_hip_version(void) { return RMD_HIP_VERSION_NUMBER; }
+
+int rmd_hip_set_tunable(int tunable, int value) {
+  if (tunable < 0 || tunable >= RMD_HIP_NUM_TUNABLES) return fail(RMD_HIP_ERR_INVALID_ARG, "set_tunable: unknown tunable %d", tunable);
+  static const int lo[RMD_HIP_NUM_TUNABLES] = {-1, 0, 1, 0, 0, 1, 0, 0}, hi[RMD_HIP_NUM_TUNABLES] = {3, 4, 1024, 1 << 20, 1, 16, 1, 1};
+  if (value < lo[tunable] || value > hi[tunable])
+    return fail(RMD_HIP_ERR_INVALID_ARG, "set_tunable: value %d of tunable %d outside [%d, %d]", value, tunable, lo[tunable], hi[tunable]);
+  tunables().v[tunable] = value;
+  return RMD_HIP_OK;
+}
+int rmd_hip_get_tunable(int tunable, int* value) {
+  if (tunable < 0 || tunable >= RMD_HIP_NUM_TUNABLES || !value) return fail(RMD_HIP_ERR_INVALID_ARG, "get_tunable: bad argument");
+  *value = tunables().v[tunable];
+  return RMD_HIP_OK;
+}
 
 // ---- device selection (check_cuda_device.cu:23-117) -------------------------------------------
 int rmd_hip_device_count(int* count) {
@@ -274,11 +305,7 @@ int rmdh::seeds_destroy_impl(rmd_hip_seeds* s) {
   if (s->region_stop) (void)hipEventDestroy(s->region_stop);
   for (auto& pl : s->planes)
     if (pl.owns && pl.data) (void)hipFree(pl.data);
-  pipe_release(s);
   s->matcher_ws.release();
-#ifdef RMD_AB_MATCHERS
-  s->frame_ws.release();
-#endif
   if (s->d_undist_map1) (void)hipFree(s->d_undist_map1);
   if (s->d_undist_map2) (void)hipFree(s->d_undist_map2);
   if (s->d_bgr) (void)hipFree(s->d_bgr);
@@ -322,9 +349,6 @@ int rmdh::seeds_create_impl(int width, int height, float fx, float fy, float cx,
   s->width = width; s->height = height; s->patch_side = patch_side;
   (void)hipGetDevice(&s->device);
   s->batch = batch; s->batch_index = seq;
-#ifdef RMD_AB_PIPELINE
-  if (!batch) { static const int pipeline = [] { const char* e = getenv("RMD_HIP_PIPELINE"); return e ? atoi(e) : 0; }(); s->opt_pipeline = pipeline != 0; }  // (the experiment without code changes)
-#endif
   rmd_hip_batch::Group* grp = batch ? &batch->group_of(seq) : nullptr;
   s->seq = batch ? seq - grp->first : 0;
   s->mws = batch ? &grp->ws : &s->matcher_ws;
@@ -367,9 +391,6 @@ int rmdh::seeds_create_impl(int width, int height, float fx, float fy, float cx,
   if (!batch && s->matcher_ws.allocate(width, height, P.stride) != 0) return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: update workspace"));
   if (batch && (grp->ws.stride != P.stride || grp->ws.tiles_x != (width + rmdk::TILE_W - 1) / rmdk::TILE_W || grp->ws.tiles_y != (height + rmdk::TILE_H - 1) / rmdk::TILE_H))
     return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: the batch's workspace has another geometry"));
-#ifdef RMD_AB_MATCHERS
-  if (s->frame_ws.allocate(width, height, P.stride) != 0) return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: frame workspace"));
-#endif
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) s->num_cus = prop.multiProcessorCount;
   int lds = 0;
@@ -470,75 +491,13 @@ int rmd_hip_seeds_converged_count(const rmd_hip_seeds_t* s, size_t* count) {
   HIP_TRY(hipMemsetAsync(m->d_scalars, 0, sizeof(unsigned long long), m->stream));
   {
     ScopedStage st(m->opt_timing ? &m->timers[RMD_HIP_STAGE_COUNT] : nullptr, m->stream);
-    const dim3 block(256), grid((s->width + 255) / 256, s->height < 64 ? s->height : 64);
-    hipLaunchKernelGGL(rmdk::count_eq_kernel, grid, block, 0, m->stream,
-                       static_cast<const int*>(s->planes[RMD_HIP_PLANE_CONVERGENCE].data), s->width, s->height,
-                       s->P.stride, static_cast<int>(RMD_HIP_STATE_CONVERGED), m->d_scalars);
+    launch_count_eq(static_cast<const int*>(s->planes[RMD_HIP_PLANE_CONVERGENCE].data), s->width, s->height, s->P.stride,
+                    static_cast<int>(RMD_HIP_STATE_CONVERGED), m->d_scalars, m->stream);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipMemcpyAsync(m->h_scalars, m->d_scalars, sizeof(unsigned long long), hipMemcpyDeviceToHost, m->stream));
   TRY(seeds_sync(s));
   *count = static_cast<size_t>(m->h_scalars[0]);
-  return RMD_HIP_OK;
-}
-
-int rmd_hip_seeds_point_cloud(rmd_hip_seeds_t* s, const rmd_hip_image_t* depth, float* out_xyzi, size_t capacity, size_t* n_points) {
-  if (!s || !n_points || (!out_xyzi && capacity)) return fail(RMD_HIP_ERR_INVALID_ARG, "point_cloud: null argument");
-  if (!s->has_reference) return fail(RMD_HIP_ERR_NOT_READY, "point_cloud: no reference image set");
-  if (depth && (depth->kind != RMD_HIP_KIND_F32 || depth->width != s->width || depth->height != s->height))
-    return fail(RMD_HIP_ERR_INVALID_ARG, "point_cloud: depth must be an f32 %dx%d image", s->width, s->height);
-  TRY(seeds_bind_device(s));
-  TRY(seeds_flush(s));
-  if (depth && !(depth->owner_seeds == s) && (depth->owner_seeds || (depth->owner_stream && depth->owner_stream != s->stream)))
-    TRY(image_settle(depth));
-  const int n_pix = s->width * s->height;
-  const int n_blocks = (n_pix + rmdk::PC_BLOCK - 1) / rmdk::PC_BLOCK;
-  if (!s->d_pc_counts) {
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_pc_counts), (static_cast<size_t>(n_blocks) + 1) * sizeof(unsigned int)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_pc_points), static_cast<size_t>(n_pix) * sizeof(float4)));
-  }
-  rmdk::PointCloudParams P;
-  P.w = s->width; P.h = s->height;
-  P.stride = s->P.stride;
-  P.depth = depth ? static_cast<const float*>(depth->data) : s->P.mu;
-  P.depth_stride = depth ? static_cast<int>(depth->stride) : s->P.stride;
-  P.conv = s->P.conv;
-  P.ref = s->P.ref;
-  P.cam = s->P.cam;
-  P.T_world_ref = s->T_world_ref;
-  hipLaunchKernelGGL(rmdk::pc_count_kernel, dim3(n_blocks), dim3(rmdk::PC_BLOCK), 0, s->stream, P, s->d_pc_counts);
-  hipLaunchKernelGGL(rmdk::pc_scan_kernel, dim3(1), dim3(1024), 0, s->stream, s->d_pc_counts, n_blocks, s->d_pc_counts + n_blocks);
-  hipLaunchKernelGGL(rmdk::pc_write_kernel, dim3(n_blocks), dim3(rmdk::PC_BLOCK), 0, s->stream, P, s->d_pc_counts, s->d_pc_points,
-                     static_cast<unsigned int>(n_pix));
-  HIP_TRY(hipGetLastError());
-  unsigned int total = 0;
-  HIP_TRY(hipMemcpyAsync(&total, s->d_pc_counts + n_blocks, sizeof(total), hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
-  *n_points = total;
-  const size_t n_copy = total < capacity ? total : capacity;
-  if (n_copy) HIP_TRY(hipMemcpy(out_xyzi, s->d_pc_points, n_copy * sizeof(float4), hipMemcpyDeviceToHost));
-  return RMD_HIP_OK;
-}
-
-int rmd_hip_seeds_convergence_bgr8(rmd_hip_seeds_t* s, unsigned char* host_bgr) {
-  if (!s || !host_bgr) return fail(RMD_HIP_ERR_INVALID_ARG, "convergence_bgr8: null argument");
-  if (!s->has_reference) return fail(RMD_HIP_ERR_NOT_READY, "convergence_bgr8: no reference image set");
-  TRY(seeds_bind_device(s));
-  // No flush of the deferred finalisation: it only ever turns UPDATE into NO_MATCH, and neither has a colour (publisher.cpp:124-134);
-  // CONVERGED / DIVERGED were settled by the update's seed_check.  Stream order puts the kernel behind the update.
-  const size_t bytes = static_cast<size_t>(s->width) * s->height * 3;
-  if (!s->d_bgr) {
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_bgr), (bytes + 15) & ~static_cast<size_t>(15)));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_bgr), bytes));
-  }
-  const long long groups = (static_cast<long long>(s->width) * s->height + 3) / 4;
-  hipLaunchKernelGGL(rmdk::convergence_bgr8_kernel, dim3(static_cast<unsigned int>((groups + 255) / 256)), dim3(256), 0, s->stream, s->P.ref, s->P.conv, s->width,
-                     s->height, s->P.stride, s->d_bgr);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(s->h_bgr, s->d_bgr, bytes, hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
-  TRY(ingest_error_check(s->batch ? s->batch->group_of(s->batch_index).h_progress : s->h_progress));
-  memcpy(host_bgr, s->h_bgr, bytes);
   return RMD_HIP_OK;
 }
 
@@ -559,27 +518,17 @@ int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value) {
   // a batch member's updates are launched by the batch (batch_launch), which knows nothing of per-member statistics, per-update event
   // pairs, eager finalisation or unit targets: accepting such a setting and then ignoring it would leave last_stats / timing stale
   if (s->batch && ((option == RMD_HIP_OPT_COLLECT_STATS && value != 0) || (option == RMD_HIP_OPT_TIMING && value != 0) ||
-                   (option == RMD_HIP_OPT_LAZY_FINALIZE && value == 0) || option == RMD_HIP_OPT_UNIT_TARGET || option == RMD_HIP_OPT_SEARCH_FLAGS ||
-                   (option == RMD_HIP_OPT_PIPELINE && value != 0)))
-    return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: option %d has no effect on a member of a batch (rmd_hip_batch_set_option sets the batch's timing, unit "
-                                         "target and search flags)", option);
+                   (option == RMD_HIP_OPT_LAZY_FINALIZE && value == 0) || option == RMD_HIP_OPT_UNIT_TARGET))
+    return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: option %d has no effect on a member of a batch (rmd_hip_batch_set_option sets the batch's timing and unit "
+                                         "target)", option);
   switch (option) {
     case RMD_HIP_OPT_MATCHER:
-#ifdef RMD_AB_MATCHERS
-      if (value < 0 || value > 3) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: matcher %d", value);
-#else
       if (value != 0 && value != 3)
-        return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: matcher %d is not part of this build (0 = per-pixel kernel, 3 = tile pipeline; the retired "
-                                             "variants 1 and 2 exist in A/B builds only, tools/ab_make.sh)", value);
-#endif
+        return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: matcher %d (0 = per-pixel kernel, 3 = tile pipeline)", value);
       if (s->batch && value != 3) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: members of a batch use the tile pipeline");
       if (value != s->opt_matcher) {  // each matcher keeps its own per-frame state: settle the old one first
         TRY(seeds_bind_device(s));
         TRY(seeds_sync(s));
-#ifdef RMD_AB_MATCHERS
-        s->frame_ws.frame = 0;
-        HIP_TRY(hipMemsetAsync(s->frame_ws.d_ctl, 0, 3 * rmdk::FR_CTL_WORDS * sizeof(unsigned int), s->stream));
-#endif
         s->mws->frame = 0;
         HIP_TRY(hipMemsetAsync(s->mws->d_shards, 0, 3 * rmdk::UNIT_SHARDS * sizeof(unsigned long long), s->stream));
         s->async_count_valid = false;
@@ -590,18 +539,6 @@ int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value) {
       if (value < 1 || value > 4) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: unit target %d outside 1..4", value);
       s->opt_unit_target = value;
       return RMD_HIP_OK;
-    case RMD_HIP_OPT_SEARCH_FLAGS:
-      if (value != 6) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: search flags %d: retired switches, only 6 (what the kernel does) is accepted", value);
-      s->mws->search_flags = value;
-      return RMD_HIP_OK;
-    case RMD_HIP_OPT_LOCAL_MAX:
-      if (value < 0) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: local_max %d", value);
-      s->opt_local_max = value;
-      return RMD_HIP_OK;
-    case RMD_HIP_OPT_UNIT_ROUNDS:
-      if (value < 0 || value > 4) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: unit_rounds %d", value);
-      s->opt_unit_rounds = value;
-      return RMD_HIP_OK;
     case RMD_HIP_OPT_TIMING:
       if (value < 0 || value > 2) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: timing mode %d", value);
       s->opt_timing = value;
@@ -609,24 +546,10 @@ int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value) {
     case RMD_HIP_OPT_LAZY_FINALIZE:
       s->opt_lazy = value != 0;
       return RMD_HIP_OK;
-    case RMD_HIP_OPT_PIPELINE:  // experiment: one launch per update (csrc/ab/rmd_pipelined.hpp); resident frames of a plain SeedMatrix only
-#ifdef RMD_AB_PIPELINE
-      if (value != 0 && value != 1) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: pipeline %d (0 / 1)", value);
-      TRY(seeds_flush(s));
-      s->opt_pipeline = value;
-      return RMD_HIP_OK;
-#else
-      if (value != 0) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: the one-launch-per-update experiment exists in A/B builds of the library only (-DRMD_AB_PIPELINE)");
-      return RMD_HIP_OK;
-#endif
     case RMD_HIP_OPT_INJECT_FAULT:
       if (value != 0 && value != 1) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: fault %d (1 = withhold the arrival flag of the next staged host frame)", value);
       if (s->batch) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: fault injection is for plain SeedMatrix handles");
       s->inject_withhold_flag = value == 1;
-      return RMD_HIP_OK;
-    case RMD_HIP_OPT_WINDOW:
-      if (value < 0 || value > 2) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: window %d", value);
-      s->opt_window = value;
       return RMD_HIP_OK;
     case RMD_HIP_OPT_COLLECT_STATS:
       s->opt_stats = value == 2 ? 2 : (value != 0);
@@ -638,15 +561,6 @@ int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value) {
         if (!ws.d_wg_trace) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ws.d_wg_trace), wbytes));
         HIP_TRY(hipStreamSynchronize(s->stream));
         HIP_TRY(hipMemset(ws.d_wg_trace, 0, wbytes));
-#ifdef RMD_AB_MATCHERS
-        const size_t bytes = ws.trace_slice_u64() * rmdk::TRACE_FRAMES * sizeof(unsigned long long);
-        if (!ws.d_trace) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ws.d_trace), bytes));
-        rmdk::FrameWorkspace& fw = s->frame_ws;
-        const size_t fbytes = fw.trace_slice_u64() * rmdk::FR_TRACE_FRAMES * sizeof(unsigned long long);
-        if (!fw.d_trace) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&fw.d_trace), fbytes));
-        HIP_TRY(hipMemset(ws.d_trace, 0, bytes));
-        HIP_TRY(hipMemset(fw.d_trace, 0, fbytes));
-#endif
         HIP_TRY(hipDeviceSynchronize());
         s->trace_frame = 0;
       }
@@ -708,7 +622,7 @@ int rmd_hip_seeds_trace_download(rmd_hip_seeds_t* s, int frame, unsigned long lo
   if (!s || !out || !written) return fail(RMD_HIP_ERR_INVALID_ARG, "trace_download: null argument");
   const rmdk::MatcherWorkspace& ws = s->matcher_ws;
   if (!ws.d_wg_trace) return fail(RMD_HIP_ERR_NOT_READY, "trace_download: set RMD_HIP_OPT_COLLECT_STATS to 2 first");
-  if (frame < 0 || frame >= s->trace_frame || frame < s->trace_frame - rmdk::TRACE_FRAMES)
+  if (frame < 0 || frame >= s->trace_frame || frame < s->trace_frame - rmdk::FR_TRACE_FRAMES)
     return fail(RMD_HIP_ERR_INVALID_ARG, "trace_download: frame not in the buffer");
   if (s->opt_matcher == 3) {  // tile pipeline: FR_TRACE_WORDS words per tile / search workgroup
     const size_t fn = ws.wg_trace_slice_u64();
@@ -719,28 +633,7 @@ int rmd_hip_seeds_trace_download(rmd_hip_seeds_t* s, int frame, unsigned long lo
     *written = fn;
     return RMD_HIP_OK;
   }
-#ifdef RMD_AB_MATCHERS
-  if (s->opt_matcher == 2) {  // one-launch frame kernel: FR_TRACE_WORDS words per workgroup (256 front slots, then the tile grid)
-    const rmdk::FrameWorkspace& fw = s->frame_ws;
-    const size_t fn = fw.trace_slice_u64();
-    if (capacity < fn) return fail(RMD_HIP_ERR_INVALID_ARG, "trace_download: buffer too small (%zu words needed)", fn);
-    TRY(seeds_bind_device(s));
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    HIP_TRY(hipMemcpy(out, fw.d_trace + static_cast<size_t>(frame % rmdk::FR_TRACE_FRAMES) * fn, fn * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    *written = fn;
-    return RMD_HIP_OK;
-  }
-  const size_t n = ws.trace_slice_u64();
-  if (capacity < n) return fail(RMD_HIP_ERR_INVALID_ARG, "trace_download: buffer too small");
-  TRY(seeds_bind_device(s));
-  HIP_TRY(hipStreamSynchronize(s->stream));
-  HIP_TRY(hipMemcpy(out, ws.d_trace + static_cast<size_t>(frame % rmdk::TRACE_FRAMES) * n, n * sizeof(unsigned long long),
-                    hipMemcpyDeviceToHost));
-  *written = n;
-  return RMD_HIP_OK;
-#else
   return fail(RMD_HIP_ERR_INVALID_ARG, "trace_download: timeline probes exist for the tile pipeline (matcher 3) only in this build");
-#endif
 }
 
 }  // extern "C"

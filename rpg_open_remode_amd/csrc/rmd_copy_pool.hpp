@@ -112,8 +112,7 @@ class CopyPool {
   // the measurement box: one run in four lost 50 - 70 ms to a throttled thread (RMD_HIP_INGEST_PROFILE: "longest wait 58945 us").
   static constexpr double kPollUs = 0.0;
   CopyPool() {
-    int n = 3;
-    if (const char* e = getenv("RMD_HIP_COPY_THREADS")) n = atoi(e) - 1;
+    int n = tunables().v[RMD_HIP_TUNE_COPY_THREADS] - 1;  // (read when the pool is created: at the first large host frame)
     const unsigned hw = std::thread::hardware_concurrency();
     if (hw != 0 && static_cast<unsigned>(n + 1) > hw) n = static_cast<int>(hw) - 1;
     if (n < 0) n = 0;
@@ -173,11 +172,8 @@ class CopyPool {
   int pack_w_ = 0, pack_h_ = 0, pack_pitch_ = 0, pack_rows_ = 0, pack_ok_ = 1;
   int pending_ = 0;
 };
-// (A/B: RMD_HIP_FLOAT_AS_BYTES=0 sends every float frame as floats)
-inline bool float_frames_as_bytes() {
-  static const bool on = [] { const char* e = getenv("RMD_HIP_FLOAT_AS_BYTES"); return !(e && e[0] == '0'); }();
-  return on;
-}
+// (A/B: RMD_HIP_TUNE_FLOAT_AS_BYTES = 0 sends every float frame as floats)
+inline bool float_frames_as_bytes() { return tunables().v[RMD_HIP_TUNE_FLOAT_AS_BYTES] != 0; }
 inline void host_copy(void* dst, const void* src, size_t bytes) { CopyPool::instance().copy(dst, src, bytes); }
 }  // namespace rmdh
 

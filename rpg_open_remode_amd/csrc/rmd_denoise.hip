@@ -1,5 +1,6 @@
 // librmd_hip.so -- rmd::DepthmapDenoiser (depthmap_denoiser.cu:124-229): rmd_hip_denoiser_*, and the launch sequence shared with rmd_hip_batch_denoise.
 #include "rmd_host.hpp"
+#include "rmd_tv_kernels.hpp"
 
 using namespace rmdh;
 
@@ -48,9 +49,6 @@ int tv_run(const rmdk::TvParams& P, float* const u[2], float* const uh[2], float
     // launches for 200 iterations, latency-bound) AND at 1920x1080 (11.5 us per iteration = 7.2 TB/s of algorithmic traffic);
     // deeper blocking (K = 8) loses more to the redundant halo work than it saves in launches.
     int geometry = opt_geometry;
-#ifdef RMD_AB_TV_BATCH_GEOMETRY  // A/B builds: another tile geometry for several depth maps per launch
-    if (geometry == 0 && n_z > 1) geometry = RMD_AB_TV_BATCH_GEOMETRY;
-#endif
     if (geometry == 0) geometry = opt_iters_per_launch == 2 ? 1 : 4;
     switch (geometry) {
       case 1: run(rmdk::TvBlocked<32, 8, 2>(), 2, rmdk::tv_iterate_blocked_kernel<32, 8, 2>); break;
@@ -58,11 +56,6 @@ int tv_run(const rmdk::TvParams& P, float* const u[2], float* const uh[2], float
       case 3: run(rmdk::TvBlocked<32, 16, 4>(), 4, rmdk::tv_iterate_blocked_kernel<32, 16, 4>); break;
       case 4: run(rmdk::TvBlocked<16, 16, 4>(), 4, rmdk::tv_iterate_blocked_kernel<16, 16, 4>); break;
       case 5: run(rmdk::TvBlocked<16, 16, 8>(), 8, rmdk::tv_iterate_blocked_kernel<16, 16, 8>); break;
-#ifdef RMD_AB_TV_BATCH_GEOMETRY
-      case 6: run(rmdk::TvBlocked<32, 32, 4>(), 4, rmdk::tv_iterate_blocked_kernel<32, 32, 4>); break;
-      case 7: run(rmdk::TvBlocked<32, 16, 8>(), 8, rmdk::tv_iterate_blocked_kernel<32, 16, 8>); break;
-      case 8: run(rmdk::TvBlocked<32, 32, 8>(), 8, rmdk::tv_iterate_blocked_kernel<32, 32, 8>); break;
-#endif
       default: return fail(RMD_HIP_ERR_INVALID_ARG, "denoise: unknown geometry %d", geometry);
     }
   }

@@ -26,16 +26,13 @@
 #define RMD_FRAME_HPP
 
 #include "rmd_matcher.hpp"
+#include "rmd_lab.hpp"
 
 namespace rmdk {
 
-#ifndef FR_MIN_WAVES
-#define FR_MIN_WAVES 3
-#endif
+constexpr int FR_MIN_WAVES = 3;   // __launch_bounds__ of the search kernel (five workgroups per CU at 96 VGPRs: measured, slower -- LAB.md)
 constexpr int FR_WIN_CAP = 5632;  // texels of the LDS window (22 KB); any shape with (width | 1) * height <= FR_WIN_CAP
 constexpr int FR_UNIT_ROUNDS = 4, FR_UNIT_ITEMS = FR_UNIT_ROUNDS * TILE_PIX;
-enum : int { SEARCH_FLAGS_DEFAULT = 6 };  // rounds 2-3 carried A/B switches of the search kernel's unit loop here (1: claim the next unit early -- measured, lost; 2: sixteen
-                                          // hand-out counters; 4: the tile's sample box travels with the unit); 2 | 4 is what the kernel does now, unconditionally
 
 // ---- agent-scope accessors (global address space, sc1) ---------------------------------------------------------------
 RMDK_D unsigned int ld_agent(const unsigned int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -59,9 +56,7 @@ struct FrameSmem {
   unsigned int packed[TILE_PIX];   // state << 16 | first in-image step << 8 | number of in-image steps
   int red[4][12];
   alignas(16) unsigned int bcast[8];  // [0] the workgroup's next unit
-#ifdef RMD_PROFILE_ROUNDS
-  unsigned long long prof[8];  // diagnostics build: [4] window policy, [5] staging, [6] rounds + barrier ticks; [0..3] per wave, ticks / count of rounds without (bits 0..23 / 56..63) and with (24..47 / 48..55) a fallback
-#endif
+  LAB_PROF(unsigned long long prof[8];)  // lab builds (rmd_lab.hpp): per-phase ticks of the workgroup
 };
 
 // One NCC evaluation at px; the LDS window has a run-time row stride.  Two sources for the current-image samples, same
@@ -180,11 +175,7 @@ struct FrameWindow {
 RMDK_D void clamp_window(FrameWindow& W) {
   const int ww = W.x1 - W.x0 + 1, wh = W.y1 - W.y0 + 1;
   constexpr int FLAT = 43;  // rows: (128 | 1) * 43 <= FR_WIN_CAP
-#ifdef RMD_AB_SQUARE_CLAMP
-  const int nw = wh > FLAT ? min(ww, 73) : min(ww, (FR_WIN_CAP / wh - 1) | 1);
-#else
   const int nw = wh > FLAT ? min(ww, 64) : min(ww, (FR_WIN_CAP / wh - 1) | 1);
-#endif
   const int nh = min(wh, FR_WIN_CAP / (nw | 1));
   W.x0 += (ww - nw) / 2; W.x1 = W.x0 + nw - 1;
   W.y0 += (wh - nh) / 2; W.y1 = W.y0 + nh - 1;
@@ -199,8 +190,9 @@ RMDK_D void clamp_window(FrameWindow& W) {
 // 64 x 86 window: two round trips, 4-7 us of an unboxed unit's 23) -> this: one sequence 43.4 -> 40.5 us per update, batch of 8 14 900 ->
 // 15 950 Mpix/s; with the patch halo staged the same way 40.0 us / 16 600, the kernel 6 000 -> 4 900 instructions (24.5 KB) and 75 -> 24 spilled
 // scalars (profiles/r04_ab_lds_direct_staging.txt; the budgets are checked by tests/test_kernel_budget.py).
-// No barrier; the loads are still in flight when this returns -- the workgroup barrier that precedes every read of the window waits for
-// them (vmcnt(0) is part of its release).
+// No barrier; the loads are still in flight when this returns.  A wave reads window rows that OTHER waves transferred, so every wave drains
+// its own transfers (drain_vmem: s_waitcnt vmcnt(0)) before the workgroup barrier that precedes the first read: a workgroup-scope release
+// only guarantees lgkmcnt(0), and the compiler tracks LDS-direct transfers per wave.  tests/test_kernel_budget.py checks the disassembly.
 template <int SIDE>
 RMDK_D void frame_stage_window(const SeedParams& P, FrameSmem<SIDE>& S, int tid, const FrameWindow& W) {
   typedef const __attribute__((address_space(1))) float* gptr_t;
@@ -221,23 +213,16 @@ RMDK_D void frame_stage_window(const SeedParams& P, FrameSmem<SIDE>& S, int tid,
   }
 }
 
-#ifdef RMD_PROFILE_ROUNDS
-RMDK_D unsigned long long prof_clock() {  // the 100 MHz wall clock, pinned in program order (diagnostics build only)
-  unsigned long long t;
-  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
-  return t;
-}
-#endif
 // Rounds of 256 NCC evaluations over work items [k0, k1) of the tile in LDS with window W; arg-max keys accumulate in S.best.
 // No barrier.
 template <int SIDE>
 RMDK_D void frame_rounds(const SeedParams& P, FrameSmem<SIDE>& S, int tid, int k0, int k1, const FrameWindow& W, unsigned int& n_fallback) {
   using Smem = FrameSmem<SIDE>;
   for (int r0 = k0; r0 < k1; r0 += TILE_PIX) {
-#ifdef RMD_PROFILE_ROUNDS
+    LAB_PROF(
     const unsigned long long prof_t0 = prof_clock();
     const unsigned int prof_fb0 = n_fallback;
-#endif
+    )
     const int kk = r0 + tid;
     int p = -1;
     unsigned long long key = 0ull;
@@ -263,13 +248,13 @@ RMDK_D void frame_rounds(const SeedParams& P, FrameSmem<SIDE>& S, int tid, int k
     // one LDS atomic per evaluation: lanes of one seed hit one address and serialise inside the LDS, which is cheaper than a
     // segmented wave reduction first (12 ds_bpermute round trips)
     if (key != 0ull) atomicMax(&S.best[p], key);
-#ifdef RMD_PROFILE_ROUNDS
+    LAB_PROF(
     {  // diagnostics build only: ticks and count of this wave's rounds with / without an evaluation that left the LDS window
       const bool fb = __any(n_fallback != prof_fb0);
       const unsigned long long dt = prof_clock() - prof_t0;
       if ((tid & 63) == 0) S.prof[tid >> 6] += fb ? (dt << 24) | (1ull << 48) : dt | (1ull << 56);
     }
-#endif
+    )
   }
 }
 
@@ -286,9 +271,7 @@ RMDK_D void frame_search(const SeedParams& P, FrameSmem<SIDE>& S, int tid, int k
   while (k < k_end) {
     FrameWindow W = tile_win;
     int k1 = k_end;
-#ifdef RMD_PROFILE_ROUNDS
-    const unsigned long long prof_p0 = prof_clock();
-#endif
+    LAB_PROF(const unsigned long long prof_p0 = prof_clock();)
     if (!tile_win.valid) {
       // this lane's seed contributes steps [max(k - first, 0), min(kX - first, n) - 1] to the candidate range [k, kX)
       const int j0 = max(k - my_first, 0);
@@ -324,25 +307,18 @@ RMDK_D void frame_search(const SeedParams& P, FrameSmem<SIDE>& S, int tid, int k
         }
       }
       W.ws = (W.x1 - W.x0 + 1) | 1;
-#ifdef RMD_PROFILE_ROUNDS
-      const unsigned long long prof_p1 = prof_clock();
-#endif
+      LAB_PROF(const unsigned long long prof_p1 = prof_clock();)
       frame_stage_window<SIDE>(P, S, tid, W);
       ++n_windows;
+      drain_vmem();  // the LDS-direct transfers of THIS wave have landed before it signals the barrier (see frame_stage_window)
       __syncthreads();
-#ifdef RMD_PROFILE_ROUNDS
-      if (tid == 0) { S.prof[4] += prof_p1 - prof_p0; S.prof[5] += prof_clock() - prof_p1; }
-#endif
+      LAB_PROF(if (tid == 0) { S.prof[4] += prof_p1 - prof_p0; S.prof[5] += prof_clock() - prof_p1; })
     }
-#ifdef RMD_PROFILE_ROUNDS
-    const unsigned long long prof_r0 = prof_clock();
-#endif
+    LAB_PROF(const unsigned long long prof_r0 = prof_clock();)
     frame_rounds<SIDE>(P, S, tid, k, k1, W, n_fallback);
     k = k1;
     __syncthreads();  // the window may be re-staged; S.best is complete for [k_begin, k)
-#ifdef RMD_PROFILE_ROUNDS
-    if (tid == 0) S.prof[6] += prof_clock() - prof_r0;
-#endif
+    LAB_PROF(if (tid == 0) S.prof[6] += prof_clock() - prof_r0;)
   }
 }
 
@@ -364,36 +340,6 @@ RMDK_D int frame_prefix(FrameSmem<SIDE>& S, int tid) {
   }
   S.prefix[tid] = wave_off + incl - n_valid;
   if (tid == 0) S.prefix[TILE_PIX] = total;
-  __syncthreads();
-  return total;
-}
-
-// Exclusive prefix of the step counts (S.packed) -> S.prefix[0..256], and the texel box of all samples of the tile.  If that
-// box fits the LDS window it is staged right away (W.valid).  Returns the tile's number of work items.  Ends with a barrier.
-template <int SIDE>
-RMDK_D int frame_prefix_and_window(const SeedParams& P, FrameSmem<SIDE>& S, int tid, FrameWindow& W) {
-  const int lane = tid & 63, wave = tid >> 6;
-  const unsigned int pk = S.packed[tid];
-  const int n_valid = static_cast<int>(pk & 0xffu);
-  const int incl = wave_scan_i32<WaveAdd>(n_valid);
-  int bx0, by0, bx1, by1;
-  seed_range_box<SIDE>(P, S, tid, n_valid > 0, 0, n_valid - 1, bx0, by0, bx1, by1);
-  block_bbox<SIDE>(S, tid, bx0, by0, bx1, by1, 0);
-  if (lane == 63) S.red[wave][4] = incl;
-  __syncthreads();
-  int wave_off = 0, total = 0;
-#pragma unroll
-  for (int wv = 0; wv < 4; ++wv) {
-    const int v = S.red[wv][4];
-    wave_off += wv < wave ? v : 0;
-    total += v;
-  }
-  S.prefix[tid] = wave_off + incl - n_valid;
-  if (tid == 0) S.prefix[TILE_PIX] = total;
-  block_bbox_read<SIDE>(S, W.x0, W.y0, W.x1, W.y1, 0);
-  W.valid = total > 0 && window_fits(W.x0, W.y0, W.x1, W.y1);
-  W.ws = (W.x1 - W.x0 + 1) | 1;
-  if (W.valid) frame_stage_window<SIDE>(P, S, tid, W);
   __syncthreads();
   return total;
 }
@@ -582,9 +528,6 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
     }
     return;
   }
-#ifdef RMD_PROFILE_ROUNDS
-  unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // fuse: start, triangulated, uncertainty, normpdf, end; segment done; run done
-#endif
   const int tile = blockIdx.y * M.tiles_x + blockIdx.x;                      // within the sequence
   const int tile_g = (NSEQ == 1 ? 0 : seq * M.n_tiles) + tile;               // within the launch
   // A tile in which the previous frame's check left no seed in state UPDATE is DEAD until the next reference frame: BORDER / CONVERGED /
@@ -646,13 +589,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
       int state_prev = ST_UPDATE;
       if (best_ncc < 0.5f) state_prev = ST_NO_MATCH;
       else P.match[y * P.stride2 + x] = make_float2(best_px.x, best_px.y);
-#ifdef RMD_PROFILE_ROUNDS
-      prof_t[0] = prof_clock();
-      const int what = seed_fuse_values(P, Q.T_ref_curr_prev, x, y, state_prev, mu, sigma_sq, a, b, best_px, prof_t + 1);
-      prof_t[4] = prof_clock();
-#else
       const int what = seed_fuse_values(P, Q.T_ref_curr_prev, x, y, state_prev, mu, sigma_sq, a, b, best_px);
-#endif
       if (what == 1) { P.sigma_sq[gi] = sigma_sq; P.mu[gi] = mu; P.a[gi] = a; P.b[gi] = b; }
       else if (what == 2) P.b[gi] = b;
     }
@@ -674,13 +611,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
   const bool live = in_image && state == ST_UPDATE;
   if (live) {
     const Segment seg = epipolar_segment(P, x, y, mu, sigma_sq);
-#ifdef RMD_PROFILE_ROUNDS
-    prof_t[5] = prof_clock();
-#endif
     const ValidRun run = find_valid_run(P, seg, SIDE);
-#ifdef RMD_PROFILE_ROUNDS
-    prof_t[6] = prof_clock();
-#endif
     n_valid = run.n_valid; i_first = run.i_first;
     M.best[gm] = 0ull;
     if (n_valid > 0) {
@@ -734,19 +665,9 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
   if (keeper && tid == 0) M.queue[5] = static_cast<unsigned int>(unit_items);
   if (tid == 0) M.tile_conv[tile_g] = static_cast<unsigned int>(red_c[0] + red_c[1] + red_c[2] + red_c[3]);
   if (tid == 0) M.tile_live[tile_g] = static_cast<unsigned int>(red_l[0] + red_l[1] + red_l[2] + red_l[3]);  // seeds in state UPDATE after this frame's check
-#ifdef RMD_PROFILE_ROUNDS
-  if (P.trace && prof_t[0] != 0ull && prof_t[6] != 0ull) {  // any live lane that ran both the fusion and the set-up: phases of the setup chain, 10 ns ticks
-    auto d = [](unsigned long long a, unsigned long long b) { return static_cast<unsigned long long>(b > a ? (b - a > 511 ? 511 : b - a) : 0); };
-    const unsigned long long w = d(t_start, prof_t[0]) | (d(prof_t[0], prof_t[1]) << 9) | (d(prof_t[1], prof_t[2]) << 18) | (d(prof_t[2], prof_t[3]) << 27) |
-                                 (d(prof_t[3], prof_t[4]) << 36) | (d(prof_t[4], prof_t[5]) << 45) | (d(prof_t[5], prof_t[6]) << 54);
-    P.trace[static_cast<size_t>(tile) * FR_TRACE_WORDS + 2] = w;  // racing lanes: any one of them will do
-  }
-#endif
-#ifndef RMD_PROFILE_ROUNDS
   if (P.trace && tid == 0)  // word 2 of the tile's slot: start (low 32 bits of the 10 ns clock), state ready and end relative to it
     P.trace[static_cast<size_t>(tile) * FR_TRACE_WORDS + 2] = (t_start & 0xffffffffull) | (((t_loaded - t_start) & 0xffffull) << 32) |
                                                              (((wall_clock64() - t_start) & 0xffffull) << 48);
-#endif
   if (total == 0) return;
   const int n_u = units_of(total, unit_rounds);
   if (tid == 0) {
@@ -795,6 +716,8 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
   // loop -- with the loop's own state more than the 104 there are, and every spilled one is a v_writelane / v_readlane pair somewhere hot.
   (void)B_by_value; (void)M_by_value;
   const SeqArgs* const Bq = seq_table();
+  static_assert(sizeof(BatchArgs<NSEQ>) % alignof(MatcherArgs) == 0 && alignof(SeqArgs) <= 8 && alignof(MatcherArgs) <= 8,
+                "the second argument block starts right behind the first in the kernel-argument segment (no padding)");
   const MatcherArgs& M = *reinterpret_cast<const MatcherArgs*>(reinterpret_cast<const char*>(seq_table()) + sizeof(BatchArgs<NSEQ>));
   using Smem = FrameSmem<SIDE>;
   constexpr int HALF = SIDE / 2;
@@ -843,9 +766,7 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
   unsigned long long* const trace0 = NSEQ == 1 ? Bq[0].P.trace : nullptr;  // diagnostics (single sequences only)
   unsigned long long* const tr = trace0 && static_cast<int>(wg_id) < M.n_tiles ? trace0 + static_cast<size_t>(wg_id) * FR_TRACE_WORDS : nullptr;
   if (tr && tid == 0) tr[0] = wall_clock64();
-#ifdef RMD_PROFILE_ROUNDS
-  if (tid < 8) S.prof[tid] = 0ull;
-#endif
+  LAB_PROF(if (tid < 8) S.prof[tid] = 0ull;)
   const int tx = tid & (TILE_W - 1), ty = tid >> 4;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int unit_items = static_cast<int>(*(const __attribute__((address_space(4))) unsigned int*)(M.queue + 5));  // written by the setup kernel
@@ -926,6 +847,7 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
       // (a unit without the box flag belongs to a tile whose sample box the setup kernel found too large for the LDS window: the box is not
       // computed a second time here -- frame_search cuts windows to the unit's own rounds)
       if (!boxed) { W.valid = false; W.x0 = W.y0 = 0; W.x1 = W.y1 = -1; W.ws = 1; }
+      drain_vmem();  // halo and window rows are read by OTHER waves after the barriers below: this wave's LDS-direct transfers must have landed
       total = frame_prefix<SIDE>(S, tid);  // barriers inside
       lds_tile = tile;
       if (tr && tid == 0 && n_done == 0) tr[1] = wall_clock64();
@@ -953,13 +875,56 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
     if (tid == 0) {
       tr[3] = wall_clock64();
       tr[4] = n_items; tr[5] = n_done; tr[6] = static_cast<unsigned long long>(lds_tile >= 0 ? lds_tile : 0);
-#ifdef RMD_PROFILE_ROUNDS
+      LAB_PROF(
       tr[6] = S.prof[0];
       tr[2] = (S.prof[4] & 0xfffffull) | ((S.prof[5] & 0xfffffull) << 20) | ((S.prof[6] & 0xffffffull) << 40);  // window policy, staging, rounds incl. barrier
-#endif
+      )
       tr[7] = fb | (static_cast<unsigned long long>(n_windows) << 32);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-seed finalisation (epipolar_match.cu:131-139 + seed_update.cu:39-121), used by seed_finalize_kernel and by the
+// fused prologue of the setup kernel
+// Decodes the arg-max of one seed whose state is UPDATE, writes the match, runs the Bayesian fusion.  Returns the
+// seed's final state of that frame.
+RMDK_D int finalize_seed(const SeedParams& P, const MatcherArgs& M, int x, int y, int gi) {
+  const unsigned long long key = M.best[gi];
+  F2 best_px = F2{0.0f, 0.0f};
+  float best_ncc = -1.0f;
+  if (key != 0ull) {
+    best_ncc = from_orderable_f32(static_cast<unsigned int>(key >> 32));
+    const int step = static_cast<int>(0xffffffffu - static_cast<unsigned int>(key & 0xffffffffu));
+    const int i_first = static_cast<int>(M.packed[gi] >> 16);
+    const float l = replay_l(M.lfirst[gi], step - i_first);
+    const float2 m = M.mean[gi], d = M.dir[gi];
+    best_px = F2{m.x + l * d.x, m.y + l * d.y};
+  }
+  int state = ST_UPDATE;
+  if (best_ncc < 0.5f) state = ST_NO_MATCH;
+  else P.match[y * P.stride2 + x] = make_float2(best_px.x, best_px.y);
+  seed_fuse(P, x, y, gi, state, P.mu[gi], P.sigma_sq[gi], P.a[gi], P.b[gi], best_px);
+  return state;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 3: the stand-alone finalisation kernel (the per-seed code is finalize_seed above)
+static __global__ __launch_bounds__(256) void seed_finalize_kernel(SeedParams P, MatcherArgs M) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= P.w || y >= P.h) return;
+  const int gi = y * P.stride + x;
+  if (P.conv[gi] != ST_UPDATE) return;  // BORDER / CONVERGED / DIVERGED were settled by seed_setup
+  const int state = finalize_seed(P, M, x, y, gi);
+  if (state != ST_UPDATE) P.conv[gi] = state;
+}
+
+// the stand-alone finalisation of sequence `seq`'s frame whose pipeline was launched last (P must carry that frame's poses)
+inline hipError_t launch_seed_finalize(const SeedParams& P, MatcherWorkspace& ws, hipStream_t stream, int seq = 0) {
+  const MatcherArgs M = matcher_args_of(ws, seq);
+  hipLaunchKernelGGL(seed_finalize_kernel, dim3((P.w + 63) / 64, (P.h + 3) / 4), dim3(64, 4), 0, stream, P, M);
+  return hipGetLastError();
 }
 
 // setup (+ the deferred finalisation of the previous frame of every sequence with fuse_prev; builds the unit list) -> search, for the

@@ -8,6 +8,10 @@
 //   rmd_batch.hip    rmd_hip_batch_*: several SeedMatrix objects stepped by one launch pair, TV-L1 for all of them in one launch sequence
 //   rmd_denoise.hip  rmd::DepthmapDenoiser
 //   rmd_reduce.hip   rmd::ImageReducer, the self tests
+//   rmd_publish.hip  point cloud and coloured convergence map (the steps after the path)
+// Every kernel has ONE home unit (the one that launches it): kernels are defined in their unit's .hip file or in a header only that unit
+// includes (rmd_frame.hpp -> rmd_update.hip, rmd_tv_kernels.hpp -> rmd_denoise.hip); rmd_kernels.hpp / rmd_matcher.hpp hold what the
+// host units share (parameter blocks, device functions, kernel TEMPLATES, which are emitted only where they are instantiated).
 #ifndef RMD_HOST_HPP
 #define RMD_HOST_HPP
 
@@ -32,11 +36,6 @@
 
 #include "rmd_kernels.hpp"
 #include "rmd_matcher.hpp"
-#ifdef RMD_AB_MATCHERS  // retired variants of the update, A/B builds only (tools/ab_make.sh: one translation unit, rmd_all.hip)
-#include "rmd_frame.hpp"
-#include "ab/rmd_matcher_r01.hpp"
-#include "ab/rmd_frame_one_launch.hpp"
-#endif
 
 #define RMD_HIP_VERSION_NUMBER 400
 
@@ -180,18 +179,22 @@ struct rmd_hip_image {
 // link reads issued by a CU delay the loads of the workgroups it shares its memory pipeline with (in place + ahead: search +4.5 us per
 // update); a batch uses in place -- its setup kernels are long enough to hide the link time and the copy engine's 25-30 us of fixed
 // cost per copy is what bounds a step of 4..8 frames (8 sequences: 10 470 -> 12 740 Mpix/s).  Frames that go through the lens-
-// undistortion maps are always staged, without ahead (the remap gathers single bytes).  A/B: RMD_HIP_HOST_FRAMES =
-// staged | staged_ahead | inplace | inplace_ahead.
+// undistortion maps are always staged, without ahead (the remap gathers single bytes).  A/B: RMD_HIP_TUNE_HOST_FRAMES.
 enum { HOST_FRAMES_DEFAULT = -1, HOST_FRAMES_STAGED = 0, HOST_FRAMES_STAGED_AHEAD = 1, HOST_FRAMES_INPLACE = 2, HOST_FRAMES_INPLACE_AHEAD = 3 };
+constexpr int AHEAD_WGS = 128;  // workgroups of the search kernel that bring the next frame in (MatcherArgs::ahead)
+
+// Process-wide settings of the host side (rmd_hip_set_tunable; include/rmd_hip.h lists them).  None changes results.  THE ONE PLACE where
+// the library reads its environment: rmdh::tunables() (rmd_capi.hip) fills the defaults from RMD_HIP_<NAME> at its first call; handles
+// pick the values up when they are created.
+namespace rmdh {
+struct Tunables {
+  int v[RMD_HIP_NUM_TUNABLES];
+};
+Tunables& tunables();
+}  // namespace rmdh
+
 inline int host_frames_mode(bool batch) {
-  static const int forced = [] {
-    const char* e = getenv("RMD_HIP_HOST_FRAMES");
-    if (e && !strcmp(e, "staged")) return static_cast<int>(HOST_FRAMES_STAGED);
-    if (e && !strcmp(e, "staged_ahead")) return static_cast<int>(HOST_FRAMES_STAGED_AHEAD);
-    if (e && !strcmp(e, "inplace")) return static_cast<int>(HOST_FRAMES_INPLACE);
-    if (e && !strcmp(e, "inplace_ahead")) return static_cast<int>(HOST_FRAMES_INPLACE_AHEAD);
-    return static_cast<int>(HOST_FRAMES_DEFAULT);
-  }();
+  const int forced = rmdh::tunables().v[RMD_HIP_TUNE_HOST_FRAMES];
   if (forced != HOST_FRAMES_DEFAULT) return forced;
   return batch ? HOST_FRAMES_INPLACE : HOST_FRAMES_STAGED_AHEAD;
 }
@@ -203,8 +206,6 @@ inline bool frame_ahead(bool remap) {
   const int m = host_frames_mode(false);
   return !remap && (m == HOST_FRAMES_STAGED_AHEAD || m == HOST_FRAMES_INPLACE_AHEAD);
 }
-constexpr int AHEAD_WGS = 128;  // workgroups of the search kernel that bring the next frame in (MatcherArgs::ahead)
-
 constexpr size_t FLAG_WORDS = 16384;
 inline void fill_flag_block(unsigned int* block, unsigned int n, size_t words) {
   for (size_t i = 0; i < words; ++i) block[i] = n;
@@ -229,8 +230,6 @@ inline hipError_t create_stream(hipStream_t* out, int level) {
   int least = 0, greatest = 0;
   if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest)
     return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
-  if (level == 2)
-    if (const char* e = getenv("RMD_HIP_COPY_STREAM_LEVEL")) level = atoi(e);  // (A/B)
   const int prio = level == 0 ? (least + greatest) / 2 : level == 1 ? greatest : least;  // numerically smaller = higher priority
   return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio);
 }
@@ -238,7 +237,6 @@ inline hipError_t create_stream(hipStream_t* out, int level) {
 extern unsigned long g_progress_timeouts;  // diagnostics (RMD_HIP_INGEST_PROFILE): waits for a staging slot that gave up after 2 ms
 extern double g_progress_max_wait_us;   // ... and the longest such wait
 
-namespace rmdk { struct PipeWorkspace; }
 // ---- rmd::SeedMatrix ------------------------------------------------------------------------
 struct rmd_hip_seeds {
   int width = 0, height = 0, patch_side = 5, device = 0, num_cus = 256;
@@ -252,7 +250,7 @@ struct rmd_hip_seeds {
   unsigned long long* h_scalars = nullptr;  // pinned mirror
   // (unit target 2: a single sequence's search is a latency chain with a tail; units of half the size shorten the tail now that a unit's staging is cheap:
   // 45.4 -> 44.3 us per update, profiles/r04_unit_target.txt; a batch keeps 1, its tails are filled by the other stream groups)
-  int opt_matcher = 3, opt_timing = 0, opt_stats = 0, opt_window = 0, opt_local_max = 0, opt_unit_rounds = 0, opt_unit_target = 2;
+  int opt_matcher = 3, opt_timing = 0, opt_stats = 0, opt_unit_target = 2;
   // a SeedMatrix that is a member of a batch (rmd_hip_batch_*) shares the batch's streams and update workspace: its update
   // kernels are launched by the batch, for all members at once; everything else (reference frames, observers) works per member
   struct rmd_hip_batch* batch = nullptr;
@@ -268,12 +266,6 @@ struct rmd_hip_seeds {
   bool finalize_pending = false;
   rmdk::SeedParams P_pending;
   int opt_lazy = 1;
-  // EXPERIMENT, A/B builds only (-DRMD_AB_PIPELINE; RMD_HIP_OPT_PIPELINE, csrc/ab/rmd_pipelined.hpp): one launch per update -- the search of the newest frame stays pending until the
-  // next update() carries it (together with that frame's setup) or an observer forces it (rmdh::seeds_flush)
-  int opt_pipeline = 0;
-  bool search_pending = false;
-  rmdk::SeedParams P_search;                // the frame whose search is pending
-  rmdk::PipeWorkspace* pipe = nullptr;      // allocated at first use (rmd_update.hip)
   // 8-bit ingest: two pinned staging buffers + two device byte planes, used alternately so that the host-side copy of
   // frame k+1 overlaps the device work of frame k; an event per slot says when its H2D copy has been consumed
   static constexpr int SLOTS = 3;           // frames in flight between the host and the update kernels
@@ -304,11 +296,11 @@ struct rmd_hip_seeds {
   int pack_backoff = 0, pack_backoff_len = 15;  // float frames that are not 8-bit levels: the next pack_backoff_len frames are not examined (pack_float_rows_u8)
   unsigned int* h_progress = nullptr;       // pinned: [0] number of the ingested frame whose setup kernel has started, [1] error bits
   unsigned long long zc_number = 0;         // ingested frames so far (the device sees the low 32 bits and compares modulo 2^32)
-  int opt_fused_ingest = 1;                 // RMD_HIP_FUSED_INGEST=0 switches back to the copy-stream pipeline (A/B)
+  int opt_fused_ingest = 1;                 // RMD_HIP_TUNE_FUSED_INGEST = 0 switches back to the copy-stream pipeline (A/B)
   bool ingest_ready = false;                // ingest_init has run
   bool inject_withhold_flag = false;        // test hook (RMD_HIP_OPT_INJECT_FAULT): the arrival flag of the next staged host frame is not sent
   double ingest_us[4] = {0, 0, 0, 0};  // diagnostics (RMD_HIP_INGEST_PROFILE): host time waiting for a slot, copying, submitting; frames
-  bool ingest_profile = false, ingest_host_wait = false;
+  bool ingest_profile = false;
   rmdh::StageTimer timers[RMD_HIP_NUM_SEED_STAGES];
   long long last_stats[16] = {0};
   bool stats_pending = false;
@@ -322,9 +314,6 @@ struct rmd_hip_seeds {
   unsigned int* d_pc_counts = nullptr;  // point cloud (allocated at the first request): per-block counts / offsets, [n_blocks] = total
   float4* d_pc_points = nullptr;        // W x H points
   rmdk::MatcherWorkspace matcher_ws;
-#ifdef RMD_AB_MATCHERS
-  rmdk::FrameWorkspace frame_ws;
-#endif
 };
 
 // rmd_hip_batch_*: up to rmdk::MAX_BATCH SeedMatrix objects of one size whose update() calls are issued together, as ONE launch pair
@@ -436,7 +425,6 @@ int seeds_after_frame(rmd_hip_seeds* s, const float* T_curr_world, const Pending
 int seeds_create_impl(int width, int height, float fx, float fy, float cx, float cy, int patch_side, int max_extent, rmd_hip_batch* batch, int seq, rmd_hip_seeds** out);
 int seeds_destroy_impl(rmd_hip_seeds* s);
 // rmd_update.hip
-void pipe_release(rmd_hip_seeds* s);       // frees the buffers of the one-launch-per-update experiment (rmd_update.hip)
 int seeds_flush(rmd_hip_seeds* s);           // the deferred finalisation of this handle's last update, as a kernel of its own
 int seeds_launch_init(rmd_hip_seeds* s);
 int seeds_launch_update(rmd_hip_seeds* s, const PendingIngest* ingest = nullptr);
@@ -448,6 +436,8 @@ int ingest_reference(rmd_hip_seeds* s, const unsigned char* host_gray, const flo
 int wait_for_progress(volatile unsigned int* progress, unsigned int need, hipStream_t stream);
 // rmd_batch.hip
 int batch_bind_device(const rmd_hip_batch* b);
+// rmd_reduce.hip
+void launch_count_eq(const int* img, int w, int h, int stride, int value, unsigned long long* out_dev, hipStream_t stream);
 // rmd_denoise.hip
 int tv_run(const rmdk::TvParams& P, float* const u[2], float* const uh[2], float2* const p[2], int n_z, int iterations, int opt_iters_per_launch, int opt_geometry,
            hipStream_t stream, hipEvent_t ev0, int* result_index, long* launches);

@@ -5,6 +5,45 @@
 
 using namespace rmdh;
 
+namespace rmdk {  // (kernels of this unit only: each kernel of the library has ONE home translation unit)
+
+// Frame ingest (reference: Depthmap::inputImage, src/depthmap.cpp:95-106 -- cv::Mat::convertTo(CV_32F, 1.0f/255.0f) on the
+// host): 8-bit gray -> f32 plane on the device.  One fp32 multiply per pixel, identical bits to the host conversion.
+// 4 pixels per lane: one 32-bit load, one 128-bit store.
+static __global__ __launch_bounds__(256) void ingest_u8_kernel(const unsigned char* __restrict__ src, int src_pitch, float* __restrict__ dst,
+                                                        int dst_stride, int w, int h) {
+  const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x4 >= w || y >= h) return;
+  const unsigned char* row = src + static_cast<size_t>(y) * src_pitch;
+  float* out = dst + static_cast<size_t>(y) * dst_stride;
+  if (x4 + 3 < w) {
+    const unsigned int v = *reinterpret_cast<const unsigned int*>(row + x4);  // src_pitch and x4 are multiples of 4
+    float4 f;
+    f.x = static_cast<float>(v & 0xffu) * (1.0f / 255.0f);
+    f.y = static_cast<float>((v >> 8) & 0xffu) * (1.0f / 255.0f);
+    f.z = static_cast<float>((v >> 16) & 0xffu) * (1.0f / 255.0f);
+    f.w = static_cast<float>(v >> 24) * (1.0f / 255.0f);
+    *reinterpret_cast<float4*>(out + x4) = f;
+  } else {
+    for (int x = x4; x < w; ++x) out[x] = static_cast<float>(row[x]) * (1.0f / 255.0f);
+  }
+}
+
+// The same with lens undistortion in front (Depthmap::inputImage with is_distorted_, depthmap.cpp:95-106): cv::remap of the
+static __global__ __launch_bounds__(256) void ingest_u8_remap_kernel(const unsigned char* __restrict__ src, int src_pitch,
+                                                              const short2* __restrict__ map1, const unsigned short* __restrict__ map2,
+                                                              float* __restrict__ dst, int dst_stride, int w, int h) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= w || y >= h) return;
+  const short2 m = map1[static_cast<size_t>(y) * w + x];
+  const int f = map2[static_cast<size_t>(y) * w + x] & 1023;
+  dst[static_cast<size_t>(y) * dst_stride + x] = remap_u8_pixel(src, src_pitch, m, f, w, h, [](const unsigned char* p) { return static_cast<int>(*p); });
+}
+
+}  // namespace rmdk
+
 unsigned long g_progress_timeouts = 0;  // diagnostics (RMD_HIP_INGEST_PROFILE): waits for a staging slot that gave up after 2 ms
 double g_progress_max_wait_us = 0.0;    // ... and the longest such wait
 
@@ -28,10 +67,10 @@ namespace rmdh {
 int ingest_init(rmd_hip_seeds* s) {
   if (s->ingest_ready) return RMD_HIP_OK;
   if (!s->copy_stream) HIP_TRY(create_stream(&s->copy_stream, 2));  // (a batch member uses the batch's)
-  s->ingest_profile = getenv("RMD_HIP_INGEST_PROFILE") != nullptr;
-  if (const char* e = getenv("RMD_HIP_INGEST_HOST_WAIT")) s->ingest_host_wait = e[0] == '1';
-  if (const char* e = getenv("RMD_HIP_FUSED_INGEST")) s->opt_fused_ingest = e[0] != '0';
-  if (const char* e = getenv("RMD_HIP_PACK_BACKOFF")) s->pack_backoff_len = atoi(e);  // (tests: 0 examines every float frame)
+  const Tunables& T = tunables();
+  s->ingest_profile = T.v[RMD_HIP_TUNE_INGEST_PROFILE] != 0;
+  s->opt_fused_ingest = T.v[RMD_HIP_TUNE_FUSED_INGEST] != 0;
+  s->pack_backoff_len = T.v[RMD_HIP_TUNE_PACK_BACKOFF];  // (tests: 0 examines every float frame)
   s->ingest_ready = true;
   if (s->batch) {  // a member only ever stages REFERENCE frames (ingest_frame: pinned slot -> plane on the copy stream): events, nothing else
     s->cur_planes[0] = s->planes[RMD_HIP_PLANE_CURR_IMG].data;
@@ -119,8 +158,7 @@ static int ingest_frame(rmd_hip_seeds* s, const unsigned char* host_gray, const 
   // The compute stream has to run behind the staging.  A stream-side wait (barrier packet) costs the compute queue ~6 us per
   // frame even when the event has long fired; the staging of a frame finishes while the PREVIOUS frame's kernels still run,
   // so the host can simply wait for it before it queues this frame's kernels behind them (no bubble, no packet).
-  if (s->ingest_host_wait) HIP_TRY(hipEventSynchronize(s->staged[k]));
-  else HIP_TRY(hipStreamWaitEvent(s->stream, s->staged[k], 0));
+  HIP_TRY(hipStreamWaitEvent(s->stream, s->staged[k], 0));
   if (s->ingest_profile) {
     const double t_d = host_now_us();
     s->ingest_us[0] += t_b - t_a; s->ingest_us[1] += t_c - t_b; s->ingest_us[2] += t_d - t_c; s->ingest_us[3] += 1.0;
@@ -255,8 +293,7 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
       in.next_src = as_u8 ? static_cast<const void*>(s->d_zc_u8[k_next]) : static_cast<const void*>(s->d_zc_f32[k_next]);
     }
     in.common.ahead = s->d_ahead;
-    static const int ahead_wgs = [] { const char* e = getenv("RMD_HIP_AHEAD_WGS"); return e ? atoi(e) : AHEAD_WGS; }();  // (A/B)
-    in.common.ahead_wgs = ahead_wgs;
+    in.common.ahead_wgs = tunables().v[RMD_HIP_TUNE_AHEAD_WGS];
     plane = static_cast<int>(n64 & 1ull);
     in.next_dst = static_cast<float*>(s->cur_planes[plane ^ 1]);
   }

@@ -1,0 +1,23 @@
+// Measurement hooks of the seed kernels.  EMPTY in the product build: LAB_PROF(...) expands to nothing, so rmd_frame.hpp reads as the
+// kernel it is.  A lab build (tools/ab_make.sh prof "-DRMD_LAB_PROFILE_ROUNDS", selected on the GPU box with RMD_HIP_LIB) keeps per-phase
+// ticks of every search workgroup -- window policy, staging, rounds with / without an evaluation served from L2 -- in eight LDS words and
+// writes them into the timeline slot of the workgroup (tools/profile_rounds.py reads them).  Experiments that were measured and dropped
+// (retired matchers, one launch per update, FMA contraction, other tile geometries, ...) are NOT kept behind switches any more: LAB.md
+// lists them with the commit that last carried their code.
+#ifndef RMD_LAB_HPP
+#define RMD_LAB_HPP
+
+#ifdef RMD_LAB_PROFILE_ROUNDS
+#define LAB_PROF(...) __VA_ARGS__
+namespace rmdk {
+__device__ __forceinline__ unsigned long long prof_clock() {  // the 100 MHz wall clock, pinned in program order
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+  return t;
+}
+}  // namespace rmdk
+#else
+#define LAB_PROF(...)
+#endif
+
+#endif  // RMD_LAB_HPP

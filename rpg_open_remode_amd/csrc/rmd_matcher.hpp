@@ -19,7 +19,7 @@
 // gathers its own texels through the vector memory path.  Why not one fused kernel per tile (the first version of this file):
 // kernel time was the time of the heaviest tile (max workgroup 0.6-2.5 M cycles vs 0.1 M average on the benchmark sequence).
 // The round-1 form of the pipeline (setup / plan / search with a tile-wide 66 KB window) and the one-launch frame kernel are
-// retired to csrc/ab/ (A/B builds only).  Results are bit-identical to the reference semantics (tests/test_hip_parity.py).
+// history (LAB.md).  Results are bit-identical to the reference semantics (tests/test_hip_parity.py).
 #ifndef RMD_MATCHER_HPP
 #define RMD_MATCHER_HPP
 
@@ -28,22 +28,15 @@
 namespace rmdk {
 
 constexpr int TILE_W = 16, TILE_H = 16, TILE_PIX = TILE_W * TILE_H;
-constexpr int MAX_UNIT_ROUNDS = 4;  // a work unit is 1..4 rounds of the 256 lanes (chosen per frame by seed_plan)
+constexpr int MAX_UNIT_ROUNDS = 4;  // a work unit is 1..4 rounds of the 256 lanes (chosen per frame from the previous frame's work)
 constexpr int MIN_UNIT_ITEMS = TILE_PIX;
 constexpr int MAX_ITEMS_PER_TILE = TILE_PIX * 144;
 constexpr int UNIT_SHARDS = 16;  // unit lists / counters, tile t -> shard t % UNIT_SHARDS; hand-out counters of the search, workgroup b -> b % UNIT_SHARDS
 constexpr int HANDOUT_STRIDE = 32;  // words between two hand-out counters (128 B: one L2 line each)
 constexpr unsigned int UNIT_TILE_BOX = 0x80000000u;  // flag in a unit's first-item word: words 2, 3 hold the texel box of ALL samples of the unit's tile, and it fits the LDS window
-constexpr int TRACE_FRAMES = 256, TRACE_MAX_SEARCH_WGS = 1024;  // diagnostics (trace_record)
 constexpr int FR_TRACE_FRAMES = 256, FR_TRACE_WORDS = 8;  // timeline of the tile pipeline, per workgroup: start, setup done, own tile done, exit (10 ns ticks), work items, units searched
 
 constexpr int MAX_BATCH = 8;  // sequences one launch pair can carry (the per-sequence parameter blocks travel as kernel arguments: 4 KB)
-
-// per-tile record written by seed_setup, read by seed_search (round-1 pipeline only, csrc/ab/)
-struct TileInfo {
-  int total;               // NCC evaluations of the tile
-  int wx0, wy0, wx1, wy1;  // inclusive texel box of the current image staged for the tile
-};
 
 // Workspace of the update pipeline for `n_seq` independent sequences of one size that are updated by ONE launch pair (a plain
 // SeedMatrix is the case n_seq = 1).  Per-seed planes hold the sequences back to back (`seq_plane` elements each), tiles are
@@ -56,7 +49,6 @@ struct MatcherWorkspace {
   float* d_lfirst = nullptr;  // per seed: accumulated l at the first in-image step
   unsigned int* d_packed = nullptr;      // per seed: first in-image step << 16 | number of in-image steps
   unsigned long long* d_best = nullptr;  // per seed: arg-max key
-  TileInfo* d_tiles = nullptr;           // round-1 pipeline only (A/B builds)
   unsigned int* d_tile_live = nullptr;   // per tile: seeds in state UPDATE after the last frame's check (0: the tile is dead until the next reference frame)
   unsigned int* d_tile_conv = nullptr;   // per tile: seeds that seed_check found CONVERGED in this frame
   uint4* d_units = nullptr;         // work units: (tile, first item | UNIT_TILE_BOX, the tile's sample box x0 | y0 << 16, x1 | y1 << 16)
@@ -71,8 +63,6 @@ struct MatcherWorkspace {
   unsigned int update_number = 0;          // launch pairs so far (modulo 2^32), stamped into h_conv
   int shard_cap = 0;                       // unit-list entries per shard
   int lds_bytes = 160 * 1024;              // LDS per CU of the handle's device (gfx950: 160 KB)
-  int search_flags = 6;                    // SEARCH_FLAGS_DEFAULT (experiments: RMD_HIP_OPT_SEARCH_FLAGS)
-  unsigned long long* d_trace = nullptr;   // diagnostics, allocated on demand: TRACE_FRAMES slices of trace_slice_u64() words (round-1 pipeline)
   unsigned long long* d_wg_trace = nullptr;  // diagnostics, allocated on demand: FR_TRACE_FRAMES slices of wg_trace_slice_u64() words (probes of the search workgroups)
   int max_units = 0;
   bool attr_set_small = false, attr_set_large = false;
@@ -92,9 +82,6 @@ struct MatcherWorkspace {
     if (hipMalloc(reinterpret_cast<void**>(&d_lfirst), n * sizeof(float)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_packed), n * sizeof(unsigned int)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_best), n * sizeof(unsigned long long)) != hipSuccess) return -1;
-#ifdef RMD_AB_MATCHERS
-    if (hipMalloc(reinterpret_cast<void**>(&d_tiles), n_tiles_all * sizeof(TileInfo)) != hipSuccess) return -1;
-#endif
     if (hipMalloc(reinterpret_cast<void**>(&d_tile_live), n_tiles_all * sizeof(unsigned int)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_tile_conv), n_tiles_all * sizeof(unsigned int)) != hipSuccess) return -1;
     shard_cap = static_cast<int>((n_tiles_all + UNIT_SHARDS - 1) / UNIT_SHARDS) * units_per_tile;  // tiles of a shard x units of a tile
@@ -119,15 +106,14 @@ struct MatcherWorkspace {
     return 0;
   }
   int n_tiles() const { return tiles_x * tiles_y; }
-  size_t trace_slice_u64() const { return 2 * (static_cast<size_t>(tiles_x) * tiles_y + 1 + TRACE_MAX_SEARCH_WGS); }
   size_t wg_trace_slice_u64() const { return static_cast<size_t>(tiles_x) * tiles_y * 8; }  // FR_TRACE_WORDS per workgroup / tile
   void release() {
-    void* all[] = {d_mean, d_dir, d_lfirst, d_packed, d_best, d_tiles, d_tile_live, d_tile_conv, d_units, d_handout, d_queue, d_shards, d_trace, d_wg_trace};
+    void* all[] = {d_mean, d_dir, d_lfirst, d_packed, d_best, d_tile_live, d_tile_conv, d_units, d_handout, d_queue, d_shards, d_wg_trace};
     for (void* p : all)
       if (p) (void)hipFree(p);
     if (h_conv) (void)hipHostFree(h_conv);
     d_mean = d_dir = nullptr; d_lfirst = nullptr; d_packed = nullptr; d_best = nullptr;
-    d_tiles = nullptr; d_tile_live = nullptr; d_tile_conv = nullptr; d_units = nullptr; d_handout = nullptr; d_queue = nullptr; d_shards = nullptr; d_trace = nullptr;
+    d_tile_live = nullptr; d_tile_conv = nullptr; d_units = nullptr; d_handout = nullptr; d_queue = nullptr; d_shards = nullptr;
     d_wg_trace = nullptr; h_conv = nullptr; d_conv = nullptr;
   }
 };
@@ -140,9 +126,7 @@ struct MatcherArgs {
   unsigned int* packed;
   unsigned long long* best;
   size_t seq_plane;          // elements per sequence in the five planes above
-  TileInfo* tiles;
   unsigned int* tile_live;   // per tile: seeds in state UPDATE after the last frame's check (see seed_setup_compact_kernel)
-  unsigned int* tile_plan;   // A/B builds, round-1 pipeline: work items per tile (the same buffer: the two pipelines never run interleaved without a reset)
   unsigned int* tile_conv;
   uint4* units;
   unsigned int* handout;     // UNIT_SHARDS counters, HANDOUT_STRIDE words apart (zero at the search kernel's launch)
@@ -158,8 +142,6 @@ struct MatcherArgs {
   int n_tiles;               // tiles of one sequence
   int n_seq;
   int housekeeper;           // the first sequence of the launch that has a frame: tile 0 of it resets the counters of the next launch
-  int search_flags;          // SEARCH_* (rmd_frame.hpp)
-  unsigned long long* trace;  // this frame's slice of the timeline buffer, may be null (round-1 pipeline, see trace_record)
   // Frame ingest for frames handed over in host memory, two forms (rmd_capi.hip chooses).  STAGED: a copy engine brings the frames of all
   // sequences of the launch as they are into staging buffers in HBM and then writes the step's number into `ingest_flag`, both on the
   // copy stream, with NO ordering against the compute stream; a few extra workgroups of the setup kernel wait for the flag themselves
@@ -223,13 +205,6 @@ struct IngestArgs {
   const unsigned int* submitted = nullptr;
   unsigned int* ahead = nullptr;
 };
-
-// Timeline probe of one workgroup (diagnostics): record `slot` of the frame's trace slice gets the workgroup's start and
-// end in 10 ns ticks of the device-wide wall clock.  Slots: one per setup tile, then seed_plan, then the search workgroups.
-RMDK_D void trace_record(unsigned long long* trace, int slot, unsigned long long t0, unsigned long long t1) {
-  trace[2 * slot] = t0;
-  trace[2 * slot + 1] = t1;
-}
 
 RMDK_D unsigned int orderable_f32(float f) {
   const unsigned int u = __float_as_uint(f);
@@ -447,14 +422,8 @@ RMDK_D void ncc_sums_lds_pipelined(const float* __restrict__ base, int stride, c
         const float img = rmd_lerp(by, hprev[k], hcur[k]);
         const float templ = tm[cur][k];
         sum_img += img;
-#ifdef RMD_EXPERIMENT_FMA  // diagnostics build (tools/ab_make.sh fma -DRMD_EXPERIMENT_FMA): what a contracted arithmetic contract would gain -- the
-                           // reference's own nvcc build contracts these two (CMakeLists.txt:25); NOT the product's arithmetic, results differ
-        sum_img_sq = __builtin_fmaf(img, img, sum_img_sq);
-        sum_img_templ = __builtin_fmaf(img, templ, sum_img_templ);
-#else
-        sum_img_sq += img * img;
-        sum_img_templ += img * templ;
-#endif
+        sum_img_sq += img * img;  // (one rounding per operation: the contract is "no contraction"; what contracting these two would gain
+        sum_img_templ += img * templ;  //  was measured -- +2.5 % / +5.3 % -- and declined, LAB.md)
       }
     }
 #pragma unroll
@@ -465,77 +434,32 @@ RMDK_D void ncc_sums_lds_pipelined(const float* __restrict__ base, int stride, c
 
 
 // ------------------------------------------------------------------------------------------------
-// per-seed finalisation (epipolar_match.cu:131-139 + seed_update.cu:39-121), used by seed_finalize_kernel and by the
-// fused prologue of the setup kernel
-// Decodes the arg-max of one seed whose state is UPDATE, writes the match, runs the Bayesian fusion.  Returns the
-// seed's final state of that frame.
-RMDK_D int finalize_seed(const SeedParams& P, const MatcherArgs& M, int x, int y, int gi) {
-  const unsigned long long key = M.best[gi];
-  F2 best_px = F2{0.0f, 0.0f};
-  float best_ncc = -1.0f;
-  if (key != 0ull) {
-    best_ncc = from_orderable_f32(static_cast<unsigned int>(key >> 32));
-    const int step = static_cast<int>(0xffffffffu - static_cast<unsigned int>(key & 0xffffffffu));
-    const int i_first = static_cast<int>(M.packed[gi] >> 16);
-    const float l = replay_l(M.lfirst[gi], step - i_first);
-    const float2 m = M.mean[gi], d = M.dir[gi];
-    best_px = F2{m.x + l * d.x, m.y + l * d.y};
-  }
-  int state = ST_UPDATE;
-  if (best_ncc < 0.5f) state = ST_NO_MATCH;
-  else P.match[y * P.stride2 + x] = make_float2(best_px.x, best_px.y);
-  seed_fuse(P, x, y, gi, state, P.mu[gi], P.sigma_sq[gi], P.a[gi], P.b[gi], best_px);
-  return state;
-}
-
-// ------------------------------------------------------------------------------------------------
-// stage 3: the stand-alone finalisation kernel (the per-seed code is finalize_seed above)
-static __global__ __launch_bounds__(256) void seed_finalize_kernel(SeedParams P, MatcherArgs M) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= P.w || y >= P.h) return;
-  const int gi = y * P.stride + x;
-  if (P.conv[gi] != ST_UPDATE) return;  // BORDER / CONVERGED / DIVERGED were settled by seed_setup
-  const int state = finalize_seed(P, M, x, y, gi);
-  if (state != ST_UPDATE) P.conv[gi] = state;
-}
-
-// ------------------------------------------------------------------------------------------------
 inline MatcherArgs matcher_args(const MatcherWorkspace& ws) {
   MatcherArgs M;
   M.mean = ws.d_mean; M.dir = ws.d_dir; M.lfirst = ws.d_lfirst; M.packed = ws.d_packed; M.best = ws.d_best;
   M.seq_plane = ws.seq_plane;
-  M.tiles = ws.d_tiles; M.tile_live = ws.d_tile_live; M.tile_plan = ws.d_tile_live; M.tile_conv = ws.d_tile_conv; M.units = ws.d_units; M.handout = ws.d_handout;
+  M.tile_live = ws.d_tile_live; M.tile_conv = ws.d_tile_conv; M.units = ws.d_units; M.handout = ws.d_handout;
   M.tiles_x = ws.tiles_x; M.tiles_y = ws.tiles_y; M.n_tiles = ws.tiles_x * ws.tiles_y; M.n_seq = ws.n_seq;
   M.queue = ws.d_queue;
   M.shards_cur = ws.d_shards + (ws.frame % 3) * UNIT_SHARDS;
   M.shards_prev = ws.frame > 0 ? ws.d_shards + ((ws.frame + 2) % 3) * UNIT_SHARDS : nullptr;
   M.shards_next = ws.d_shards + ((ws.frame + 1) % 3) * UNIT_SHARDS;
-  M.search_flags = ws.search_flags;
   M.housekeeper = 0;
   M.conv_out = ws.d_conv;
   M.update_number = ws.update_number;
   M.shard_cap = ws.shard_cap;
-  M.trace = nullptr;
   M.ingest_kind = 0; M.ingest_pitch = 0; M.ingest_wgs = 0; M.ingest_flag = nullptr; M.progress = nullptr; M.ingest_number = 0u;
   M.ahead_wgs = 0; M.submitted = nullptr; M.ahead = nullptr;
   return M;
 }
 
-// the planes of ONE sequence of the workspace, for the per-sequence kernels (stand-alone finalisation, round-1 pipeline)
+// the planes of ONE sequence of the workspace, for the per-sequence kernels (the stand-alone finalisation)
 inline MatcherArgs matcher_args_of(const MatcherWorkspace& ws, int seq) {
   MatcherArgs M = matcher_args(ws);
   const size_t off = ws.seq_plane * static_cast<size_t>(seq);
   M.mean += off; M.dir += off; M.lfirst += off; M.packed += off; M.best += off;
-  M.tile_live += static_cast<size_t>(seq) * M.n_tiles; M.tile_plan = M.tile_live; M.tile_conv += static_cast<size_t>(seq) * M.n_tiles;
+  M.tile_live += static_cast<size_t>(seq) * M.n_tiles; M.tile_conv += static_cast<size_t>(seq) * M.n_tiles;
   return M;
-}
-
-// the stand-alone finalisation of sequence `seq`'s frame whose pipeline was launched last (P must carry that frame's poses)
-inline hipError_t launch_seed_finalize(const SeedParams& P, MatcherWorkspace& ws, hipStream_t stream, int seq = 0) {
-  const MatcherArgs M = matcher_args_of(ws, seq);
-  hipLaunchKernelGGL(seed_finalize_kernel, dim3((P.w + 63) / 64, (P.h + 3) / 4), dim3(64, 4), 0, stream, P, M);
-  return hipGetLastError();
 }
 
 }  // namespace rmdk

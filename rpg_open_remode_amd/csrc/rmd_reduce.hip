@@ -4,6 +4,116 @@
 
 using namespace rmdh;
 
+namespace rmdk {  // (kernels of this unit only: each kernel of the library has ONE home translation unit)
+
+// Reductions (reduction_kernels.cu:57-159): wave-level shuffles, one atomic / one partial per block.
+static __global__ __launch_bounds__(256) void count_eq_kernel(const int* __restrict__ img, int w, int h, int stride, int value,
+                                                       unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long wave_part[4];
+  unsigned long long c = 0;
+  for (int y = blockIdx.y; y < h; y += gridDim.y) {
+    const int* row = img + static_cast<size_t>(y) * stride;
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < w; x += gridDim.x * blockDim.x) c += (row[x] == value);
+  }
+  c = wave_sum_u64(c);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_part[wave] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long t = wave_part[0] + wave_part[1] + wave_part[2] + wave_part[3];
+    if (t) atomicAdd(out, t);
+  }
+}
+
+// pass 1: one fp64 partial per block, in a fixed order; pass 2: one block folds the partials.
+static __global__ __launch_bounds__(256) void sum_partial_kernel(const float* __restrict__ img, int w, int h, int stride,
+                                                          double* __restrict__ partials) {
+  __shared__ double wave_part[4];
+  double acc = 0.0;
+  for (int y = blockIdx.y; y < h; y += gridDim.y) {
+    const float* row = img + static_cast<size_t>(y) * stride;
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < w; x += gridDim.x * blockDim.x) acc += static_cast<double>(row[x]);
+  }
+  acc = wave_sum_f64(acc);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    partials[blockIdx.y * gridDim.x + blockIdx.x] = ((wave_part[0] + wave_part[1]) + wave_part[2]) + wave_part[3];
+}
+// integer image sum (ImageReducer<int>::sum, reduction.cu:186): exact in 64 bits, the caller truncates to int like the
+// reference's int accumulation wraps
+static __global__ __launch_bounds__(256) void sum_i32_kernel(const int* __restrict__ img, int w, int h, int stride, unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long wave_part[4];
+  unsigned long long acc = 0;
+  for (int y = blockIdx.y; y < h; y += gridDim.y) {
+    const int* row = img + static_cast<size_t>(y) * stride;
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < w; x += gridDim.x * blockDim.x) acc += static_cast<unsigned long long>(static_cast<long long>(row[x]));
+  }
+  acc = wave_sum_u64(acc);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, wave_part[0] + wave_part[1] + wave_part[2] + wave_part[3]);
+}
+
+static __global__ __launch_bounds__(64) void sum_final_kernel(const double* __restrict__ partials, int n, float* __restrict__ out) {
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) acc += partials[i];
+  acc = wave_sum_f64(acc);
+  if (threadIdx.x == 0) *out = static_cast<float>(acc);
+}
+
+// ------------------------------------------------------------------------------------------
+// device side of the arithmetic contract, for the self test
+// self test of the DPP wave primitives of rmd_device.hpp against the shuffle forms: mismatching lanes -> *bad
+static __global__ __launch_bounds__(64) void wave_primitives_selftest_kernel(unsigned int seed, unsigned int* bad) {
+  const int lane = threadIdx.x;
+  unsigned int h = seed * 2654435761u + static_cast<unsigned int>(lane) * 40503u + blockIdx.x * 97u;
+  h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+  const int v = static_cast<int>(h % 2001u) - 1000;
+  int add = v, mn = v, mx = v;
+  for (int off = 32; off > 0; off >>= 1) {
+    add += __shfl_xor(add, off, 64);
+    mn = min(mn, __shfl_xor(mn, off, 64));
+    mx = max(mx, __shfl_xor(mx, off, 64));
+  }
+  int incl = v;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  const bool ok = wave_reduce_i32<WaveAdd>(v) == add && wave_reduce_i32<WaveMin>(v) == mn && wave_reduce_i32<WaveMax>(v) == mx &&
+                  wave_scan_i32<WaveAdd>(v) == incl;
+  if (!ok) atomicAdd(bad, 1u);
+}
+
+static __global__ void math_eval_kernel(int op, const float* x, const float* y, const float* z, float* out, size_t n) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float r;
+  switch (op) {
+    case 0: r = rmd_expf(x[i]); break;
+    case 1: r = rmd_sinf(x[i]); break;
+    case 2: r = rmd_acosf(x[i]); break;
+    case 3: r = rmd_rsqrtf(x[i]); break;
+    case 4: r = sqrtf(x[i]); break;
+    case 5: r = x[i] / y[i]; break;
+    default: r = rmd_lerp(x[i], y[i], z[i]); break;
+  }
+  out[i] = r;
+}
+
+}  // namespace rmdk
+
+namespace rmdh {
+// countEqual on `stream` into *out_dev (zeroed by the caller); for rmd_hip_seeds_converged_count (rmd_capi.hip)
+void launch_count_eq(const int* img, int w, int h, int stride, int value, unsigned long long* out_dev, hipStream_t stream) {
+  const dim3 block(256), grid((w + 255) / 256, h < 64 ? h : 64);
+  hipLaunchKernelGGL(rmdk::count_eq_kernel, grid, block, 0, stream, img, w, h, stride, value, out_dev);
+}
+}  // namespace rmdh
+
 // ---- ImageReducer ---------------------------------------------------------------------------
 namespace {
 

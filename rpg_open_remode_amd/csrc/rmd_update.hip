@@ -2,9 +2,6 @@
 // reference as seed_init_kernel + the two-launch pipeline of rmd_frame.hpp): launches for one SeedMatrix and for the stream groups of a batch.
 #include "rmd_host.hpp"
 #include "rmd_frame.hpp"
-#ifdef RMD_AB_PIPELINE
-#include "ab/rmd_pipelined.hpp"  // experiment, A/B builds only: one launch per update (measured and dropped)
-#endif
 
 namespace rmdh {
 
@@ -32,35 +29,9 @@ rmdk::SeqArgs seq_args_of(const rmd_hip_seeds* s, const rmdk::SeedParams& P) {
 }
 }  // namespace
 
-#ifdef RMD_AB_PIPELINE
-void pipe_release(rmd_hip_seeds* s) {
-  if (s->pipe) { s->pipe->release(); delete s->pipe; s->pipe = nullptr; }
-}
-
-// one-launch-per-update experiment: the pending search of the newest frame as a launch of its own; its finalisation is then pending like
-// that of any other update
-static int pipe_flush_search(rmd_hip_seeds* s) {
-  if (!s->search_pending) return RMD_HIP_OK;
-  s->search_pending = false;
-  rmdk::SeqArgs Qs;
-  memset(&Qs, 0, sizeof(Qs));
-  Qs.P = s->P_search; Qs.active = 1;
-  TRY(dispatch_side(s->patch_side, [&](auto side) {
-    HIP_TRY((rmdk::launch_pipe_search_only<decltype(side)::value>(Qs, s->matcher_ws, *s->pipe, s->stream, s->num_cus)));
-    return RMD_HIP_OK;
-  }));
-  s->P_pending = s->P_search;
-  s->finalize_pending = true;
-  return RMD_HIP_OK;
-}
-#else
-void pipe_release(rmd_hip_seeds*) {}
-static int pipe_flush_search(rmd_hip_seeds*) { return RMD_HIP_OK; }
-#endif
 
 // the deferred finalisation of this handle's last update, as a kernel of its own (an observer is about to look at the state)
 int seeds_flush(rmd_hip_seeds* s) {
-  TRY(pipe_flush_search(s));
   if (s->finalize_pending) {
     s->finalize_pending = false;
     HIP_TRY(rmdk::launch_seed_finalize(s->P_pending, *s->mws, s->stream, s->seq));
@@ -86,9 +57,6 @@ int seeds_launch_update(rmd_hip_seeds* s, const PendingIngest* ingest) {
   if (s->opt_stats == 1) {
     HIP_TRY(hipMemsetAsync(s->d_scalars + 1, 0, 16 * sizeof(unsigned long long), s->stream));
     P.stats = s->d_scalars + 1;
-  } else if (s->opt_stats == 2 && s->opt_matcher == 1 && s->matcher_ws.d_trace) {  // timeline probes only: the pipeline runs as in production
-    P.trace = s->matcher_ws.d_trace + static_cast<size_t>(s->trace_frame % rmdk::TRACE_FRAMES) * s->matcher_ws.trace_slice_u64();
-    ++s->trace_frame;
   }
   int rc;
   if (s->opt_timing == 2) ++s->region_updates;
@@ -101,50 +69,7 @@ int seeds_launch_update(rmd_hip_seeds* s, const PendingIngest* ingest) {
         TRY(seeds_flush(s));
         const dim3 block(64, 4), grid((s->width + 63) / 64, (s->height + 3) / 4);
         hipLaunchKernelGGL((rmdk::seed_update_pixel_kernel<SIDE>), grid, block, 0, s->stream, P);
-#ifdef RMD_AB_MATCHERS
-      } else if (s->opt_matcher == 2) {
-        TRY(seeds_flush(s));
-        unsigned long long* slice = nullptr;
-        if (s->opt_stats == 2 && s->frame_ws.d_trace) {  // timeline probes
-          slice = s->frame_ws.d_trace + static_cast<size_t>(s->trace_frame % rmdk::FR_TRACE_FRAMES) * s->frame_ws.trace_slice_u64();
-          ++s->trace_frame;
-        }
-        HIP_TRY(rmdk::launch_seed_frame<SIDE>(P, s->frame_ws, s->stream, s->num_cus, s->opt_local_max, s->opt_unit_rounds, slice));
-      } else if (s->opt_matcher == 1) {
-        const bool fuse = s->finalize_pending;
-        const rmdk::Pose T_prev = fuse ? s->P_pending.T_ref_curr : P.T_ref_curr;
-        HIP_TRY(rmdk::launch_seed_update_tile<SIDE>(P, s->matcher_ws, s->stream, s->num_cus, s->opt_window, fuse, T_prev));
-        s->P_pending = P;
-        s->P_pending.stats = nullptr;
-        s->P_pending.trace = nullptr;
-        s->finalize_pending = true;
-        if (!s->opt_lazy || s->opt_stats == 1) TRY(seeds_flush(s));
-#endif
-#ifdef RMD_AB_PIPELINE
-      } else if (s->opt_pipeline && !ingest && s->opt_stats == 0 && s->opt_lazy && !s->batch) {
-        // EXPERIMENT (csrc/rmd_pipelined.hpp): one launch per update -- this frame's setup (with the finalisation of the frame before) rides on
-        // the search of the frame before; its own search stays pending
-        if (!s->pipe) {
-          s->pipe = new (std::nothrow) rmdk::PipeWorkspace();
-          if (!s->pipe || s->pipe->allocate(s->matcher_ws) != 0) return fail(RMD_HIP_ERR_RUNTIME, "update: buffers of the one-launch pipeline");
-        }
-        if (!s->search_pending) {
-          const rmdk::SeqArgs Qn = seq_args_of(s, P);  // fuses the finalisation that is pending, if one is
-          HIP_TRY((rmdk::launch_pipe_setup<SIDE>(Qn, s->matcher_ws, *s->pipe, s->stream, s->num_cus, s->opt_unit_target)));
-        } else {
-          rmdk::SeqArgs Qs, Qn;
-          memset(&Qs, 0, sizeof(Qs)); memset(&Qn, 0, sizeof(Qn));
-          Qs.P = s->P_search; Qs.active = 1;
-          Qn.P = P; Qn.active = 1; Qn.fuse_prev = 1; Qn.T_ref_curr_prev = s->P_search.T_ref_curr;
-          HIP_TRY((rmdk::launch_pipe_search_setup<SIDE>(Qs, Qn, s->matcher_ws, *s->pipe, s->stream, s->num_cus, s->opt_unit_target)));
-        }
-        s->finalize_pending = false;
-        s->search_pending = true;
-        s->P_search = P;
-        s->async_count_valid = false;
-#endif
       } else {
-        TRY(pipe_flush_search(s));  // (A/B builds with the one-launch experiment: a frame of another kind, or the option has just been cleared)
         rmdk::SeedParams Pt = P;
         if (s->opt_stats == 2 && s->matcher_ws.d_wg_trace) {  // timeline probes of the setup tiles and the search workgroups
           Pt.trace = s->matcher_ws.d_wg_trace + static_cast<size_t>(s->trace_frame % rmdk::FR_TRACE_FRAMES) * s->matcher_ws.wg_trace_slice_u64();

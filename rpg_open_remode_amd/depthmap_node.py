@@ -128,6 +128,5 @@ class DepthmapNode:
         self.publisher_.publishDepthmapAndPointCloud()
 
     def publishConvergenceMap(self):  # :175-182
-        if not hasattr(self.depthmap_, "convergenceBGR8"):  # (the device colouring reads the convergence plane where it lives)
-            self.depthmap_.downloadConvergenceMap()
+        self.depthmap_.downloadConvergenceMap()  # (:177: the host mirror is refreshed here whether or not the colouring needs it)
         self.publisher_.publishConvergenceMap()

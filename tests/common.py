@@ -67,26 +67,11 @@ def ulp_distance(a, b):
 # Matcher variants every parity test runs: 0 = per-pixel kernel (the reference's shape), 3 = the two-launch tile pipeline (the
 # default).
 MATCHERS = [0, 3]
-# Retired device implementations of the same update, compiled only into A/B builds of the library (-DRMD_AB_MATCHERS, tools/ab_make.sh):
-# 1 = the round-1 pipeline (66 KB search window), 2 = the one-launch frame kernel, 21 = the frame kernel with every tile of more than
-# one round of work handed out between workgroups.  Their test skips itself on the product build.
-OTHER_MATCHERS = [1, 2, 21]
 
 
 def apply_matcher(seeds, matcher):
     from rpg_open_remode_amd import api
-    if matcher in OTHER_MATCHERS:
-        import pytest
-        try:
-            seeds.setOption(api.OPT_MATCHER, api.MATCHER_FRAME if matcher == 21 else matcher)
-        except api.RmdHipError:
-            pytest.skip("retired matcher: A/B builds of librmd_hip.so only")
-    if matcher == 21:
-        seeds.setOption(api.OPT_MATCHER, api.MATCHER_FRAME)
-        seeds.setOption(api.OPT_LOCAL_MAX, 256)
-        seeds.setOption(api.OPT_UNIT_ROUNDS, 1)
-    else:
-        seeds.setOption(api.OPT_MATCHER, matcher)
+    seeds.setOption(api.OPT_MATCHER, matcher)
     return seeds
 
 

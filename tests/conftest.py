@@ -35,8 +35,8 @@ def has_gpu():
 
 
 # A skipped parity test is a broken parity test: on a GPU run (-m gpu) every skip that is not one of the intended ones fails the session.
-# Intended: the retired matchers (tests/common.py: they exist in A/B builds of the library only).
-INTENDED_GPU_SKIPS = ("test_other_matchers_bit_exact",)
+# Intended skips are listed by REASON only (none by test name any more: the retired matchers left the library in round 5).
+INTENDED_GPU_SKIPS = ()
 INTENDED_SKIP_REASONS = ("needs glibc",)  # tests/glibc_parity.py::require_pinned_glibc (never taken on this image)
 _unintended_skips = []
 

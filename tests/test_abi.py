@@ -113,3 +113,27 @@ def test_float_frames_of_8bit_levels_are_recognised_on_the_host(wh):
         img[pos] = np.float32(0.1234)
         assert pack(img)[0] == 0
     assert pack((levels * np.float32(0.999)).astype(np.float32))[0] == 0
+
+
+def test_tunables_are_set_and_read_in_one_place():
+    """process-wide settings: set / get round trip, range checks, and the environment preset (read once, by rmdh::tunables(), in a fresh process)"""
+    import subprocess
+    import sys
+    from rpg_open_remode_amd import api
+    old = api.getTunable(api.TUNE_PACK_BACKOFF)
+    api.setTunable(api.TUNE_PACK_BACKOFF, 3)
+    assert api.getTunable(api.TUNE_PACK_BACKOFF) == 3
+    api.setTunable(api.TUNE_PACK_BACKOFF, old)
+    for bad in ((api.TUNE_HOST_FRAMES, 4), (api.TUNE_BATCH_GROUPS, 5), (api.TUNE_COPY_THREADS, 0), (99, 0)):
+        with pytest.raises(api.RmdHipError):
+            api.setTunable(*bad)
+    code = ("from rpg_open_remode_amd import api; "
+            "print(api.getTunable(api.TUNE_HOST_FRAMES), api.getTunable(api.TUNE_BATCH_GROUPS), api.getTunable(api.TUNE_COPY_THREADS), api.getTunable(api.TUNE_FUSED_INGEST))")
+    env = dict(os.environ, RMD_HIP_HOST_FRAMES="inplace_ahead", RMD_HIP_BATCH_GROUPS="2", RMD_HIP_FUSED_INGEST="0")
+    env.pop("RMD_HIP_COPY_THREADS", None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), check=True).stdout
+    assert out.split() == ["3", "2", "4", "0"], out
+    # the library reads its environment in ONE place
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rpg_open_remode_amd", "csrc")
+    hits = [f for f in sorted(os.listdir(csrc)) if os.path.isfile(os.path.join(csrc, f)) and "getenv(" in open(os.path.join(csrc, f)).read()]
+    assert hits == ["rmd_capi.hip"], hits

@@ -86,3 +86,50 @@ def test_search_kernel_stages_its_window_lds_direct(code_object):
                          capture_output=True, text=True, check=True).stdout
     assert dis.count("global_load_lds_dword") >= 3, "window (two call sites) and patch halo are expected to be staged with global_load_lds_dword"
     assert "scratch_" not in dis
+
+
+def test_lds_direct_transfers_are_drained_before_the_barrier_that_publishes_them(code_object):
+    """global_load_lds_dword writes LDS behind the compiler's back: a wave reads window / halo rows that OTHER waves transferred, and nothing but
+    an explicit s_waitcnt vmcnt(0) in EVERY wave before the workgroup barrier orders that (a workgroup-scope release guarantees lgkmcnt(0)
+    only).  Layout-order scan of the search kernels: between an LDS-direct load and the next s_barrier there must be a vmcnt(0) wait."""
+    for kernel in (SEARCH, SEARCH_BATCH):
+        dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", f"--disassemble-symbols={kernel}vNS_9BatchArgsIXT0_EEENS_11MatcherArgsE", code_object],
+                             capture_output=True, text=True, check=True).stdout
+        pending, n_loads, n_barriers = False, 0, 0
+        for line in dis.splitlines():
+            ins = line.strip()
+            if ins.startswith("global_load_lds_dword"):
+                pending, n_loads = True, n_loads + 1
+            elif ins.startswith("s_waitcnt") and re.search(r"vmcnt\(0\)", ins):
+                pending = False
+            elif ins.startswith("s_barrier"):
+                n_barriers += 1
+                assert not pending, f"{kernel}: an s_barrier follows a global_load_lds_dword without s_waitcnt vmcnt(0) in between"
+        assert n_loads >= 3 and n_barriers >= 4, (n_loads, n_barriers)
+
+
+def test_every_kernel_has_one_home_code_object():
+    """each translation unit of librmd_hip.so is a code object of its own; a `static __global__` kernel in a header every unit includes would be
+    compiled into all of them (round 4: count_eq_kernel, convergence_bgr8_kernel and a dozen others sat in five code objects each)"""
+    objdump, readelf = os.path.join(LLVM, "llvm-objdump"), os.path.join(LLVM, "llvm-readelf")
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("the LLVM binary tools of the ROCm image are not installed")
+    d = tempfile.mkdtemp(prefix="rmd_co_")
+    try:
+        lib = os.path.join(d, "lib.so")
+        shutil.copy(_lib.LIB_PATH, lib)
+        subprocess.run([objdump, "--offloading", lib], cwd=d, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        homes = {}
+        for f in sorted(os.listdir(d)):
+            if "gfx950" not in f:
+                continue
+            syms = subprocess.run([readelf, "--dyn-syms", "--wide", os.path.join(d, f)], capture_output=True, text=True, check=True).stdout
+            for line in syms.splitlines():
+                c = line.split()
+                if len(c) >= 8 and c[3] == "FUNC" and "kernel" in c[7]:
+                    homes.setdefault(c[7], []).append(f)
+        assert len(homes) >= 40, sorted(homes)
+        twice = {k: v for k, v in homes.items() if len(v) != 1}
+        assert not twice, twice
+    finally:
+        shutil.rmtree(d, ignore_errors=True)

@@ -11,7 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--b", default="1,2,4,8"); ap.add_argument("--size", default="640x480"); ap.add_argument("--frames", type=int, default=200)
 ap.add_argument("--passes", type=int, default=3); ap.add_argument("--side", type=int, default=9); ap.add_argument("--u8", action="store_true")
 ap.add_argument("--unit-target", type=int, default=1); ap.add_argument("--same-scene", action="store_true")
-ap.add_argument("--flags", default="6", help="comma-separated RMD_HIP_OPT_SEARCH_FLAGS values to run one after the other")
+ap.add_argument("--flags", default="6", help="(retired; kept so that old command lines still parse)")
 ap.add_argument("--per-step", action="store_true", help="also: one more pass with a synchronisation after every step, wall time of selected steps")
 a = ap.parse_args()
 W, H = (int(v) for v in a.size.split("x"))
@@ -48,7 +48,6 @@ def run_pass(b, n):
 for n, flags in [(n, f) for f in (int(v) for v in a.flags.split(",")) for n in sizes]:
     b = api.SeedMatrixBatch(n, W, H, api.PinholeCamera(*seqs[0].K), patch_side=a.side)
     b.setOption(api.OPT_UNIT_TARGET, a.unit_target)
-    b.setOption(api.OPT_SEARCH_FLAGS, flags)
     run_pass(b, n)
     b.sync()
     b.setOption(api.OPT_TIMING, 2)
