@@ -27,6 +27,7 @@ per step, rmd_hip_batch_*), "cpu_baseline" (the reference's own kernels on the h
 far the result is from the untouched reference, measured on the same run).
 """
 import argparse
+import resource
 import glob
 import hashlib
 import json
@@ -218,6 +219,37 @@ def cpu_reference_run(frame_fn, width, height, K, n_frames, side, min_depth, max
         d = O.Denoiser(olib, width, height)
         d.set_large_sigma_sq(max_depth - min_depth)
         den = d.denoise(s, TV_LAMBDA, tv_iters)
+
+    # SURVEY 8(d) "CPU baseline timing": (i) one thread and (ii) all cores, for the reference's own kernels (Oracle A, kind "reference") AND for
+    # the restatement (Oracle B, kind "port").  The one-thread figures are taken on updates 1..SHORT (a thread needs seconds per update there;
+    # every seed is live on them, so they are the sequence's most expensive updates) with the all-cores figure on the SAME updates beside them.
+    SHORT = max(1, min(10, max(3, 800000 // (width * height)), n_frames - 1))
+
+    def rate(okind, threads, n_updates):
+        ol = O.OracleLib(okind, side)
+        (ol.lib.ref_set_num_threads if okind == "ref" else ol.lib.orc_set_num_threads)(threads)
+        sd = O.Seeds(ol, width, height, K)
+        sd.set_reference(img0, T0, min_depth, max_depth)
+        frames = [frame_fn(k) for k in range(1, n_updates + 1)]
+        t = time.perf_counter()
+        for img, T in frames:
+            sd.update(img, T)
+        dt_ = time.perf_counter() - t
+        sd.close()
+        return {"value": round(width * height * n_updates / dt_ / 1e6, 4), "unit": "Mpix/s", "cores": int(threads), "sample": f"updates 1..{n_updates}, {dt_:.1f} s"}
+
+    if budget_s >= 10.0:
+        kinds = (["ref"] if kind == "reference" else []) + (["port"] if O.available("port", side) else [])
+        for okind in kinds:
+            entry = {"one_thread": rate(okind, 1, SHORT), "all_cores_same_updates": rate(okind, cores, SHORT)}
+            if okind == "ref" or kind == "port":  # the object's own kind: its whole-sequence figure is the headline above
+                out.update(entry)
+            if okind == "port":
+                full = rate("port", cores, n) if kind == "reference" else {k: out[k] for k in ("value", "unit", "cores")}
+                port = {"kind": "port", "what": "CPU restatement of the reference (oracle/remode_oracle.cpp), bit-identical to the reference's kernels", **full, **entry}
+                if kind == "reference":
+                    out["port"] = port
+        (olib.lib.ref_set_num_threads if kind == "reference" else olib.lib.orc_set_num_threads)(cores)
     return out, n, state, den, kind
 
 
@@ -375,19 +407,24 @@ def main():
     batch.barrier(device)
     torch.cuda.synchronize()
     seeds.timingReset()
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)  # CPU time of ALL threads of this process (the library's copy helpers included)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run_pass(seeds)
+    t_submitted = time.perf_counter()  # every update() has returned (frames copied, launches queued); the device is still busy
     seeds.sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    host_cpu_s = (ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime)
+    host_submit_s = t_submitted - t0
     batch.barrier(device)
     kernel_ms, kernel_updates = seeds.timing(api.STAGE_UPDATE)  # device time of the region / update() calls in it
     seeds.setOption(api.OPT_TIMING, 0)
     converged = seeds.getConvergedCount()
     n_updates = (F - 1) * args.steps          # update() calls of ONE sequence; a batch steps B sequences per call
     units = float(W * H * n_updates * B)
-    max_elapsed, total_units, per_rank = batch.gather_throughput(elapsed, units, device, extra=(float(n_updates * B), float(converged), float(B)))
+    max_elapsed, total_units, per_rank = batch.gather_throughput(elapsed, units, device, extra=(float(n_updates * B), float(converged), float(B), host_cpu_s, host_submit_s))
 
     # ---- the rest is reporting on rank 0; other ranks idle at the final barrier
     result = None
@@ -633,7 +670,13 @@ def main():
             "roofline_denoiser": roofline_tv, "cpu_baseline": cpu,
             "resident": resident, "h2d_inclusive": other_path, "float_frames": floats, "heavy_prefix": heavy, "batched_per_gpu": batched,
             "parity": PARITY_NOTE, "parity_vs_glibc_reference": glibc,
-            "per_rank": [{"elapsed_s": round(r[0], 6), "mpix": r[1] / 1e6, "updates": int(r[2]), "converged": int(r[3]), "sequences": int(r[4])} for r in per_rank],
+            "per_rank": [{"elapsed_s": round(r[0], 6), "mpix": r[1] / 1e6, "updates": int(r[2]), "converged": int(r[3]), "sequences": int(r[4]),
+                          "host_cpu_s": round(r[5], 4), "host_cores_busy": round(r[5] / r[0], 3), "host_submit_us_per_update": round(r[6] / max(r[2] / max(r[4], 1.0), 1.0) * 1e6, 2)}
+                         for r in per_rank],
+            # host side of the timed region on rank 0: CPU seconds of all of the process's threads (getrusage), the same as cores kept busy, and
+            # the wall time per update() call until the call returned (frame copied into the pinned ring, two launches queued) -- the device
+            # time per update is roofline.avg_launch_us; a host that needs longer than that paces the run
+            "host_cpu_s": round(host_cpu_s, 4), "host_cores_busy": round(host_cpu_s / elapsed, 3), "host_submit_us_per_update": round(host_submit_s / n_updates * 1e6, 2),
         }
     batch.barrier(device)
     if rank == 0:

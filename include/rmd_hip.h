@@ -89,7 +89,10 @@ typedef struct rmd_hip_batch rmd_hip_batch_t;
 #define RMD_HIP_TUNE_COPY_THREADS 5   /* host threads that copy a large frame into the pinned ring, 1..16 (4); read when the first large frame arrives */
 #define RMD_HIP_TUNE_FUSED_INGEST 6   /* 1 (default): host frames are converted by the update's own kernels; 0: upload + conversion kernel on the copy stream */
 #define RMD_HIP_TUNE_INGEST_PROFILE 7 /* 1: a handle prints the host time per frame it spent waiting / copying / submitting when it is destroyed */
-#define RMD_HIP_NUM_TUNABLES 8
+#define RMD_HIP_TUNE_HOST_WAIT 8      /* how update() waits for a free slot of its pinned frame ring (the device is up to three frames behind the caller): 1
+                                         (default) = spin for 5 us, then sleep in steps of ~15 us (the waiting thread's timer slack is set to 2 us);
+                                         0 = spin only (one core per handle that is fed host frames at full speed) */
+#define RMD_HIP_NUM_TUNABLES 9
 int rmd_hip_set_tunable(int tunable, int value);
 int rmd_hip_get_tunable(int tunable, int* value);
 
@@ -116,8 +119,10 @@ int rmd_hip_image_info(const rmd_hip_image_t* img, int* kind, int* width, int* h
                        size_t* stride_elems, void** device_data);
 
 /* ---- rmd::SeedMatrix (seed_matrix.cu) -------------------------------------------------- */
-/* ctor :28-80.  patch_side = RMD_CORR_PATCH_SIDE (3, 5, 7 or 9; CMakeLists.txt:50-51),
- * max_extent = RMD_MAX_EXTENT_EPIPOLAR_SEARCH (CMakeLists.txt:52-53); both compile-time in the reference. */
+/* ctor :28-80.  patch_side = RMD_CORR_PATCH_SIDE (3, 5, 7 or 9; CMakeLists.txt:50-51: "must be odd", default 5),
+ * max_extent = RMD_MAX_EXTENT_EPIPOLAR_SEARCH in pixels (CMakeLists.txt:52-53, default 100), 1..178: both are compile-time constants of the
+ * reference and run-time arguments here.  Bounds: the NCC block is instantiated for the four sides above; a seed's search steps are numbered in
+ * 8 bits (255 steps of 0.7 pixels = 178 pixels).  Anything else is RMD_HIP_ERR_INVALID_ARG at creation. */
 int rmd_hip_seeds_create(int width, int height, float fx, float fy, float cx, float cy, int patch_side, int max_extent,
                          rmd_hip_seeds_t** out);
 int rmd_hip_seeds_destroy(rmd_hip_seeds_t* s);
@@ -222,7 +227,7 @@ int rmd_hip_seeds_trace_download(rmd_hip_seeds_t* s, int frame, unsigned long lo
 /* ---- batched mode: several independent SeedMatrix objects stepped by ONE launch pair ------------------------------------------
  * BASELINE configs[3] / north_star "a batched mode shards independent image sequences": sequences do not interact (seed_matrix.cu
  * keeps no state outside the object once the global texture references are gone), and a single 640x480 frame cannot occupy 256 CUs.
- * A batch owns `n` (1..8) SeedMatrix objects of one size on the current device; each is a full rmd_hip_seeds_t -- set_reference*,
+ * A batch owns `n` (1..24: up to three stream groups of up to eight sequences, one launch pair per group and step) SeedMatrix objects of one size on the current device; each is a full rmd_hip_seeds_t -- set_reference*,
  * download, plane views, converged_count, point_cloud, denoise all work per member, exactly as for a stand-alone object -- except
  * that update* is issued for all members at once with the calls below (seed_matrix.cu:120-158 per member: same arithmetic, same
  * results bit for bit as that member stepped alone) and that rmd_hip_batch_destroy releases the members. */

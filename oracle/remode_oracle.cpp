@@ -31,6 +31,66 @@
 #define RMD_MAX_EXTENT 100
 #endif
 
+#if defined(RMD_ORACLE_CUDALIKE)
+// Build "cudalike" (oracle/Makefile: libremode_oracle_cudalike_s<side>.so): every operation that the reference's REAL build -- nvcc
+// -use_fast_math (CMakeLists.txt:25) reading images through the texture unit (texture_memory.cuh:45-66) -- evaluates differently from the
+// IEEE / fp32-filter contract goes through a hook with a run-time switch (orc_set_cudalike), so that the distance between the contract and
+// a physical CUDA run can be BOUNDED on the CPU, switch by switch (tests/cudalike_tolerance.py).  With every switch off the
+// hooks are the plain operations: this build then equals the "libm" build -- and Oracle A -- bit for bit (tests/test_oracle_pin.py).
+// Models, not the hardware (which is not available):
+//   TEX8        bilinear weights quantised to 8 fractional bits (CUDA programming guide, "Linear Filtering": 9-bit fixed point with 8 bits of
+//               fractional value), round to nearest, and the guide's 4-tap form (1-a)(1-b)T00 + a(1-b)T10 + (1-a)b T01 + ab T11 in fp32
+//   TEX8_TRUNC  the same with truncated instead of rounded weights (the guide does not say which)
+//   DIV         x / y -> x * (1.0f / y)  (__fdividef / div.approx: <= 2 ulp)
+//   SQRT        sqrtf(x) -> x * rsqrt(x), rsqrtf(x) -> correctly rounded 1/sqrt(x)  (sqrt.approx / rsqrt.approx: <= 2 ulp; the contract's
+//               rsqrtf is 1.0f / sqrtf(x), two roundings)
+//   EXP         expf(x) -> exp2(x * log2(e)) with the product rounded to fp32 (__expf = ex2.approx(x * 1.4427f): 2 + |1.16 x| ulp)
+//   SIN         sinf(x) -> the correctly rounded value moved by a hash of the argument's bits, uniformly in [-2, 2] ulp (any other <= 2.5-ulp sine)
+//   SIN_ABS     sinf(x) -> rounded to a grid of 2^-21: the ABSOLUTE error bound the guide documents for __sinf (2^-21.41 on [-pi, pi]) taken
+//               literally -- an upper bracket: near zero (gamma_plus in triangulation.cu:65-66) real hardware is far better than its bound
+//   ACOS        acosf / atan2f -> correctly rounded, moved by a hash in [-2, 2] ulp (CUDA's acosf: 2 ulp, its atan2f: 3 ulp)
+//   FTZ         flush-to-zero and denormals-are-zero for every fp32 operation (MXCSR), as -ftz=true
+// FMA contraction (-fmad=true) is a compile-time matter: the "cudalike_fma" build is this one compiled with -ffp-contract=fast.
+#include <xmmintrin.h>
+#include <pmmintrin.h>
+namespace cudalike {
+enum { TEX8 = 1, TEX8_TRUNC = 2, DIV = 4, SQRT = 8, EXP = 16, SIN = 32, SIN_ABS = 64, ACOS = 128, FTZ = 256 };
+static int flags = 0;
+inline void thread_mode() {
+  _MM_SET_FLUSH_ZERO_MODE((flags & FTZ) ? _MM_FLUSH_ZERO_ON : _MM_FLUSH_ZERO_OFF);
+  _MM_SET_DENORMALS_ZERO_MODE((flags & FTZ) ? _MM_DENORMALS_ZERO_ON : _MM_DENORMALS_ZERO_OFF);
+}
+inline float moved(float v, float arg, int max_ulp) {  // v moved by h(arg) in [-max_ulp, max_ulp] units in the last place
+  if (!isfinite(v) || v == 0.0f) return v;
+  uint32_t h;
+  memcpy(&h, &arg, 4);
+  h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+  int n = static_cast<int>(h % static_cast<uint32_t>(2 * max_ulp + 1)) - max_ulp;
+  for (; n > 0; --n) v = nextafterf(v, INFINITY);
+  for (; n < 0; ++n) v = nextafterf(v, -INFINITY);
+  return v;
+}
+inline float div(float x, float y) { return (flags & DIV) ? x * (1.0f / y) : x / y; }
+inline float sqrt_(float x) { return (flags & SQRT) ? (x == 0.0f || isinf(x) ? x : x * static_cast<float>(1.0 / sqrt(static_cast<double>(x)))) : sqrtf(x); }
+inline float rsqrt_(float x) { return (flags & SQRT) ? static_cast<float>(1.0 / sqrt(static_cast<double>(x))) : 1.0f / sqrtf(x); }
+inline float exp_(float x) { return (flags & EXP) ? static_cast<float>(exp2(static_cast<double>(x * 1.4426950408889634f))) : expf(x); }
+inline float sin_(float x) {
+  if (flags & SIN_ABS) return static_cast<float>(rint(sin(static_cast<double>(x)) * 2097152.0) / 2097152.0);
+  if (flags & SIN) return moved(static_cast<float>(sin(static_cast<double>(x))), x, 2);
+  return sinf(x);
+}
+inline float acos_(float x) { return (flags & ACOS) ? moved(static_cast<float>(acos(static_cast<double>(x))), x, 2) : acosf(x); }
+inline float atan2_(float y, float x) { return (flags & ACOS) ? moved(static_cast<float>(atan2(static_cast<double>(y), static_cast<double>(x))), x, 2) : atan2f(y, x); }
+}  // namespace cudalike
+#define ORC_EXPF cudalike::exp_
+#define ORC_SINF cudalike::sin_
+#define ORC_ACOSF cudalike::acos_
+#define ORC_ATAN2F cudalike::atan2_
+#define ODIV(x, y) cudalike::div((x), (y))
+#define OSQRT(x) cudalike::sqrt_(x)
+#define ORSQRT(x) cudalike::rsqrt_(x)
+#define ORC_THREAD_MODE() cudalike::thread_mode()
+#else
 #ifdef RMD_ORACLE_LIBM
 #define ORC_EXPF expf
 #define ORC_SINF sinf
@@ -39,6 +99,12 @@
 #define ORC_EXPF rmd_expf
 #define ORC_SINF rmd_sinf
 #define ORC_ACOSF rmd_acosf
+#endif
+#define ORC_ATAN2F atan2f
+#define ODIV(x, y) ((x) / (y))
+#define OSQRT(x) sqrtf(x)
+#define ORSQRT(x) rmd_rsqrtf(x)
+#define ORC_THREAD_MODE() ((void)0)
 #endif
 
 namespace {
@@ -54,14 +120,14 @@ struct V2 { float x, y; };
 
 inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // helper_math.h:1248-1251
 inline float dot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }              // helper_math.h:1244-1247
-inline float norm(V3 v) { return sqrtf(dot(v, v)); }                        // helper_vector_types.cuh:23-28
-inline float norm(V2 v) { return sqrtf(dot(v, v)); }
+inline float norm(V3 v) { return OSQRT(dot(v, v)); }                        // helper_vector_types.cuh:23-28
+inline float norm(V2 v) { return OSQRT(dot(v, v)); }
 inline V3 normalize(V3 v) {  // helper_math.h:1309-1313
-  const float inv = rmd_rsqrtf(dot(v, v));
+  const float inv = ORSQRT(dot(v, v));
   return V3{v.x * inv, v.y * inv, v.z * inv};
 }
 inline V2 normalize(V2 v) {  // helper_math.h:1304-1308
-  const float inv = rmd_rsqrtf(dot(v, v));
+  const float inv = ORSQRT(dot(v, v));
   return V2{v.x * inv, v.y * inv};
 }
 inline V3 scale(V3 v, float s) { return V3{v.x * s, v.y * s, v.z * s}; }
@@ -100,9 +166,9 @@ inline V3 pose_apply(const Pose& p, V3 v) {  // se3.cuh:164-168: translate(rotat
 
 struct Camera {  // pinhole_camera.cuh:27-63
   float fx, fy, cx, cy;
-  V3 cam2world(float u, float v) const { return V3{(u - cx) / fx, (v - cy) / fy, 1.0f}; }
-  V2 world2cam(V3 p) const { return V2{fx * p.x / p.z + cx, fy * p.y / p.z + cy}; }
-  float one_pix_angle() const { return atan2f(1.0f, 2.0f * fx) * 2.0f; }
+  V3 cam2world(float u, float v) const { return V3{ODIV(u - cx, fx), ODIV(v - cy, fy), 1.0f}; }
+  V2 world2cam(V3 p) const { return V2{ODIV(fx * p.x, p.z) + cx, ODIV(fy * p.y, p.z) + cy}; }
+  float one_pix_angle() const { return ORC_ATAN2F(1.0f, 2.0f * fx) * 2.0f; }
 };
 
 inline long clampi(long v, long lo, long hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -120,6 +186,13 @@ float tex_linear(const float* plane, int w, int h, float x, float y) {
   const long i1 = (fi + 1.0f) < 0.0f ? 0 : ((fi + 1.0f) > wmax ? w - 1 : static_cast<long>(fi + 1.0f));
   const long j1 = (fj + 1.0f) < 0.0f ? 0 : ((fj + 1.0f) > hmax ? h - 1 : static_cast<long>(fj + 1.0f));
   const float t00 = plane[j0 * w + i0], t10 = plane[j0 * w + i1], t01 = plane[j1 * w + i0], t11 = plane[j1 * w + i1];
+#ifdef RMD_ORACLE_CUDALIKE
+  if (cudalike::flags & (cudalike::TEX8 | cudalike::TEX8_TRUNC)) {  // 8-bit weights, the programming guide's 4-tap form
+    const float aq = ((cudalike::flags & cudalike::TEX8_TRUNC) ? floorf(a * 256.0f) : rintf(a * 256.0f)) * (1.0f / 256.0f);
+    const float bq = ((cudalike::flags & cudalike::TEX8_TRUNC) ? floorf(b * 256.0f) : rintf(b * 256.0f)) * (1.0f / 256.0f);
+    return (1.0f - aq) * (1.0f - bq) * t00 + aq * (1.0f - bq) * t10 + (1.0f - aq) * bq * t01 + aq * bq * t11;
+  }
+#endif
   const float h0 = a == 0.0f ? t00 : rmd_lerp(a, t00, t10);
   const float h1 = a == 0.0f ? t01 : rmd_lerp(a, t01, t11);
   return b == 0.0f ? h0 : rmd_lerp(b, h0, h1);
@@ -144,6 +217,7 @@ void seed_init(Seeds& s) {
 #pragma omp parallel for schedule(static)
   for (int y = 0; y < h; ++y)
     for (int x = 0; x < w; ++x) {
+      ORC_THREAD_MODE();
       float sum_t = 0.0f, sum_t_sq = 0.0f;
       for (int py = 0; py < SIDE; ++py)
         for (int px = 0; px < SIDE; ++px) {
@@ -168,14 +242,15 @@ void seed_check(Seeds& s) {
 #pragma omp parallel for schedule(static)
   for (int y = 0; y < h; ++y)
     for (int x = 0; x < w; ++x) {
+      ORC_THREAD_MODE();
       const size_t i = static_cast<size_t>(y) * w + x;
       if (static_cast<size_t>(x) > x_hi || static_cast<size_t>(y) > y_hi || x < SIDE || y < SIDE) {
         s.conv[i] = BORDER;
         continue;
       }
       const float sig = s.sigma_sq[i], a = s.a[i], b = s.b[i];
-      if ((a / (a + b)) > s.eta_inlier && sig < s.epsilon) s.conv[i] = CONVERGED;
-      else if ((a - 1) / (a + b - 2) < s.eta_outlier) s.conv[i] = DIVERGED;
+      if (ODIV(a, a + b) > s.eta_inlier && sig < s.epsilon) s.conv[i] = CONVERGED;
+      else if (ODIV(a - 1, a + b - 2) < s.eta_outlier) s.conv[i] = DIVERGED;
       else s.conv[i] = UPDATE;
     }
 }
@@ -187,12 +262,13 @@ void epipolar_match(Seeds& s, const Pose& T_curr_ref) {
 #pragma omp parallel for schedule(dynamic, 2) reduction(+ : live, evals, steps)
   for (int y = 0; y < h; ++y)
     for (int x = 0; x < w; ++x) {
+      ORC_THREAD_MODE();
       const size_t i = static_cast<size_t>(y) * w + x;
       const int state = s.conv[i];
       if (state == BORDER || state == CONVERGED || state == DIVERGED) continue;
       ++live;
       const float mu = s.mu[i];
-      const float sigma = sqrtf(s.sigma_sq[i]);
+      const float sigma = OSQRT(s.sigma_sq[i]);
       const V3 f_ref = normalize(s.cam.cam2world(static_cast<float>(x), static_cast<float>(y)));
       const V2 px_mean = s.cam.world2cam(pose_apply(T_curr_ref, scale(f_ref, mu)));
       const float d_lo = mu - 3.0f * sigma;
@@ -226,7 +302,7 @@ void epipolar_match(Seeds& s, const Pose& T_curr_ref) {
           }
         const float num = static_cast<float>(AREA) * sum_img_templ - sum_img * sum_templ;
         const float den = (static_cast<float>(AREA) * sum_img_sq - sum_img * sum_img) * denom;
-        const float ncc = num * rmd_rsqrtf(den + FLT_MIN);
+        const float ncc = num * ORSQRT(den + FLT_MIN);
         if (ncc > best_ncc) {
           best_px = px;
           best_ncc = ncc;
@@ -257,8 +333,8 @@ V3 triangulate(V3 f_ref, V3 f_cur, const Pose& T_ref_curr) {
   const float A1 = -A2;
   const float A3 = dot(V3{-f2.x, -f2.y, -f2.z}, f2);
   const float det = A0 * A3 - A1 * A2;
-  const float l0 = (A3 * bx - A1 * by) / det;
-  const float l1 = (-A2 * bx + A0 * by) / det;
+  const float l0 = ODIV(A3 * bx - A1 * by, det);
+  const float l1 = ODIV(-A2 * bx + A0 * by, det);
   const V3 xm = V3{l0 * f_ref.x, l0 * f_ref.y, l0 * f_ref.z};
   const V3 xn = V3{t.x + l1 * f2.x, t.y + l1 * f2.y, t.z + l1 * f2.z};
   return V3{(xm.x + xn.x) / 2.0f, (xm.y + xn.y) / 2.0f, (xm.z + xn.z) / 2.0f};
@@ -269,19 +345,19 @@ float triangulation_uncertainty(float z, V3 f_ref, V3 t, float one_pix_angle) {
   const V3 a = V3{f_ref.x * z - t.x, f_ref.y * z - t.y, f_ref.z * z - t.z};
   const float t_norm = norm(t);
   const float a_norm = norm(a);
-  const float alpha = ORC_ACOSF(dot(f_ref, t) / t_norm);
-  const float beta = ORC_ACOSF((-dot(a, t)) / (t_norm * a_norm));
+  const float alpha = ORC_ACOSF(ODIV(dot(f_ref, t), t_norm));
+  const float beta = ORC_ACOSF(ODIV(-dot(a, t), t_norm * a_norm));
   const float beta_plus = beta + one_pix_angle;
   const float gamma_plus = static_cast<float>(RMD_PI_D - static_cast<double>(alpha) - static_cast<double>(beta_plus));
-  const float z_plus = t_norm * ORC_SINF(beta_plus) / ORC_SINF(gamma_plus);
+  const float z_plus = ODIV(t_norm * ORC_SINF(beta_plus), ORC_SINF(gamma_plus));
   return z_plus - z;
 }
 
 // seed_update.cu:30-37
 float normpdf(float x, float mu, float sigma_sq) {
-  const float e = ORC_EXPF(-(x - mu) * (x - mu) / (2.0f * sigma_sq));
+  const float e = ORC_EXPF(ODIV(-(x - mu) * (x - mu), 2.0f * sigma_sq));
   const float two_pi_ss = static_cast<float>(static_cast<double>(2.0f) * RMD_PI_D * static_cast<double>(sigma_sq));
-  return e * rmd_rsqrtf(two_pi_ss);
+  return e * ORSQRT(two_pi_ss);
 }
 
 // seed_update.cu:39-121
@@ -292,6 +368,7 @@ void seed_update(Seeds& s, const Pose& T_ref_curr) {
 #pragma omp parallel for schedule(static)
   for (int y = 0; y < h; ++y)
     for (int x = 0; x < w; ++x) {
+      ORC_THREAD_MODE();
       const size_t i = static_cast<size_t>(y) * w + x;
       const int state = s.conv[i];
       if (state == CONVERGED || state == DIVERGED) continue;
@@ -304,23 +381,23 @@ void seed_update(Seeds& s, const Pose& T_ref_curr) {
         const float depth = norm(P);
         const float tau = triangulation_uncertainty(depth, f_ref, t, one_pix);
         const float tau_sq = tau * tau;
-        const float s_sq = (tau_sq * sigma_sq) / (tau_sq + sigma_sq);
-        const float m = s_sq * (mu / sigma_sq + depth / tau_sq);
-        float c1 = (a / (a + b)) * normpdf(depth, mu, sigma_sq + tau_sq);
-        float c2 = (b / (a + b)) * (1.0f / s.depth_range);
+        const float s_sq = ODIV(tau_sq * sigma_sq, tau_sq + sigma_sq);
+        const float m = s_sq * (ODIV(mu, sigma_sq) + ODIV(depth, tau_sq));
+        float c1 = ODIV(a, a + b) * normpdf(depth, mu, sigma_sq + tau_sq);
+        float c2 = ODIV(b, a + b) * ODIV(1.0f, s.depth_range);
         const float norm_const = c1 + c2;
-        c1 = c1 / norm_const;
-        c2 = c2 / norm_const;
-        const float f = c1 * ((a + 1.0f) / (a + b + 1.0f)) + c2 * (a / (a + b + 1.0f));
-        const float e = c1 * (((a + 1.0f) * (a + 2.0f)) / ((a + b + 1.0f) * (a + b + 2.0f))) +
-                        c2 * (a * (a + 1.0f) / ((a + b + 1.0f) * (a + b + 2.0f)));
+        c1 = ODIV(c1, norm_const);
+        c2 = ODIV(c2, norm_const);
+        const float f = c1 * ODIV(a + 1.0f, a + b + 1.0f) + c2 * ODIV(a, a + b + 1.0f);
+        const float e = c1 * ODIV((a + 1.0f) * (a + 2.0f), (a + b + 1.0f) * (a + b + 2.0f)) +
+                        c2 * ODIV(a * (a + 1.0f), (a + b + 1.0f) * (a + b + 2.0f));
         if (isnan(c1 * m)) continue;
         const float mu_prime = c1 * m + c2 * mu;
         s.sigma_sq[i] = c1 * (s_sq + m * m) + c2 * (sigma_sq + mu * mu) - mu_prime * mu_prime;
         s.mu[i] = mu_prime;
-        const float a_prime = (e - f) / (f - e / f);
+        const float a_prime = ODIV(e - f, f - ODIV(e, f));
         s.a[i] = a_prime;
-        s.b[i] = a_prime * (1.0f - f) / f;
+        s.b[i] = ODIV(a_prime * (1.0f - f), f);
       } else if (state == NO_MATCH) {
         s.b[i] = s.b[i] + 1.0f;
       }
@@ -348,6 +425,16 @@ int orc_uses_libm(void) {
 #endif
 }
 void orc_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+// cudalike build only: which operations follow the model of the reference's real CUDA build (bit mask, see the top of this file); 0 elsewhere
+int orc_set_cudalike(int flags) {
+#ifdef RMD_ORACLE_CUDALIKE
+  cudalike::flags = flags;
+  return 1;
+#else
+  (void)flags;
+  return 0;
+#endif
+}
 int orc_max_threads(void) { return omp_get_max_threads(); }
 
 // ---- rmd::SeedMatrix (seed_matrix.cu) -------------------------------------------------
@@ -477,8 +564,9 @@ int orc_denoiser_denoise_planes(void* dp, const float* mu, const float* sigma_sq
   const float large = d.large_sigma_sq, tau = d.tau, sigma = d.sigma, theta = d.theta;
 #pragma omp parallel for schedule(static)
   for (size_t i = 0; i < n; ++i) {
-    const float E_pi = a[i] / (a[i] + b[i]);
-    const float v = (E_pi * sigma_sq[i] + (1.0f - E_pi) * large) / large;
+    ORC_THREAD_MODE();
+    const float E_pi = ODIV(a[i], a[i] + b[i]);
+    const float v = ODIV(E_pi * sigma_sq[i] + (1.0f - E_pi) * large, large);
     d.g[i] = v > 1.0f ? v : 1.0f;
     d.u[i] = mu[i];
     d.u_head[i] = mu[i];
@@ -490,6 +578,7 @@ int orc_denoiser_denoise_planes(void* dp, const float* mu, const float* sigma_sq
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < h; ++y)
       for (int x = 0; x < w; ++x) {
+        ORC_THREAD_MODE();
         const size_t i = static_cast<size_t>(y) * w + x;
         const float g = d.g[i], cu = d.u[i];
         const int xe = x + 1 < w - 1 ? x + 1 : w - 1, ys = y + 1 < h - 1 ? y + 1 : h - 1;
@@ -497,15 +586,16 @@ int orc_denoiser_denoise_planes(void* dp, const float* mu, const float* sigma_sq
         const float gy = d.u_head[static_cast<size_t>(ys) * w + x] - cu;
         const float tx = g * gx * sigma + d.px[i];
         const float ty = g * gy * sigma + d.py[i];
-        const float mag = sqrtf(tx * tx + ty * ty);
+        const float mag = OSQRT(tx * tx + ty * ty);
         const float den = 1.0f > mag ? 1.0f : mag;
-        d.px_new[i] = tx / den;
-        d.py_new[i] = ty / den;
+        d.px_new[i] = ODIV(tx, den);
+        d.py_new[i] = ODIV(ty, den);
       }
     // primal step for every pixel (:87-115)
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < h; ++y)
       for (int x = 0; x < w; ++x) {
+        ORC_THREAD_MODE();
         const size_t i = static_cast<size_t>(y) * w + x;
         const float noisy = mu[i], old_u = d.u[i], g = d.g[i];
         float cpx = d.px_new[i], cpy = d.py_new[i];

@@ -32,7 +32,7 @@ KIND_F32, KIND_I32, KIND_F32X2 = 0, 1, 2
 OPT_MATCHER, OPT_TIMING, OPT_COLLECT_STATS, OPT_LAZY_FINALIZE, OPT_UNIT_TARGET = 0, 1, 2, 4, 7  # include/rmd_hip.h: RMD_HIP_OPT_*
 OPT_INJECT_FAULT = 9  # test hook, see include/rmd_hip.h
 # process-wide settings of the host side (include/rmd_hip.h: RMD_HIP_TUNE_*; the environment presets them: RMD_HIP_<NAME>)
-TUNE_HOST_FRAMES, TUNE_BATCH_GROUPS, TUNE_AHEAD_WGS, TUNE_PACK_BACKOFF, TUNE_FLOAT_AS_BYTES, TUNE_COPY_THREADS, TUNE_FUSED_INGEST, TUNE_INGEST_PROFILE = range(8)
+TUNE_HOST_FRAMES, TUNE_BATCH_GROUPS, TUNE_AHEAD_WGS, TUNE_PACK_BACKOFF, TUNE_FLOAT_AS_BYTES, TUNE_COPY_THREADS, TUNE_FUSED_INGEST, TUNE_INGEST_PROFILE, TUNE_HOST_WAIT = range(9)
 HOST_FRAMES_DEFAULT, HOST_FRAMES_STAGED, HOST_FRAMES_STAGED_AHEAD, HOST_FRAMES_INPLACE, HOST_FRAMES_INPLACE_AHEAD = -1, 0, 1, 2, 3
 
 
@@ -45,7 +45,7 @@ def getTunable(tunable):
     v = ctypes.c_int()
     check(_lib.lib().rmd_hip_get_tunable(int(tunable), ctypes.byref(v)))
     return v.value
-MAX_BATCH = 8  # sequences one SeedMatrixBatch can hold (rmdk::MAX_BATCH)
+MAX_BATCH = 24  # sequences one SeedMatrixBatch can hold (rmdk::MAX_BATCH: three stream groups of up to eight)
 MATCHER_PIXEL, MATCHER_PIPELINE = 0, 3
 STAGE_SEED_INIT, STAGE_UPDATE, STAGE_COUNT = 0, 1, 2
 DENOISE_OPT_TIMING, DENOISE_OPT_ITERS_PER_LAUNCH, DENOISE_OPT_GEOMETRY = 1, 2, 3

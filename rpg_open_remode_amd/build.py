@@ -165,12 +165,23 @@ def build_reference_host_programs(force=False, verbose=False):
             _run(cmd, verbose=verbose)
 
 
+def build_apps(force=False, verbose=False):
+    """apps/bench_main: the C++ timed driver over include/rmd/ (the Python bench's timed region without the interpreter)"""
+    src, out = os.path.join(ROOT, "apps", "bench_main.cpp"), os.path.join(ROOT, "apps", "bench_main")
+    deps = [src, os.path.join(HERE, "librmd_hip.so"), os.path.join(HERE, "librmd_synth.so")] + [os.path.join(ROOT, "include", "rmd", f) for f in os.listdir(os.path.join(ROOT, "include", "rmd"))]
+    if force or _newer(out, deps):
+        _run(["g++", "-std=c++11", "-O2", "-DRMD_CORR_PATCH_SIDE=9", "-I" + os.path.join(ROOT, "include"), src, "-L" + HERE, "-lrmd_hip", "-lrmd_synth",
+              "-Wl,-rpath," + HERE, "-Wl,-rpath,$ORIGIN/../rpg_open_remode_amd", "-o", out], verbose=verbose)
+    return out
+
+
 def build_all(force=False, verbose=False, report=True):
     """everything; prints one line saying what was compiled and what was found up to date (the driver's build check reads it)"""
     build_hip(force, verbose)
     build_synth(force, verbose)
     build_oracles(force, verbose)
     build_reference_host_programs(force, verbose)
+    build_apps(force, verbose)
     if report:
         r = build_hip.last_report
         print(f"[rpg_open_remode_amd.build] librmd_hip.so: compiled {r['compiled'] or 'nothing'} for gfx950, reused {r['reused'] or 'nothing'}, "

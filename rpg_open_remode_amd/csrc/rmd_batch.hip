@@ -187,6 +187,8 @@ int rmd_hip_batch_create(int n, int width, int height, float fx, float fy, float
   if (want_groups < 1) want_groups = 1;
   if (want_groups > rmd_hip_batch::MAX_GROUPS) want_groups = rmd_hip_batch::MAX_GROUPS;
   if (want_groups > n) want_groups = n;
+  // a group is ONE launch pair, and a launch pair carries at most MAX_GROUP_SEQ sequences (their parameter blocks are kernel arguments)
+  while (want_groups * rmdk::MAX_GROUP_SEQ < n) ++want_groups;
   b->n_groups = want_groups;
   b->opt_unit_target = 1;  // (2x / 3x as many, smaller units: +4 % with one group of 4, nothing with two groups)
   const size_t pitch = (static_cast<size_t>(width) * 4 + 255) / 256 * 256;  // as image_alloc lays the members' planes out
@@ -196,7 +198,7 @@ int rmd_hip_batch_create(int n, int width, int height, float fx, float fy, float
     G.n = n / b->n_groups + (g < n % b->n_groups ? 1 : 0);  // the larger groups first
     // (one priority level each, see create_stream; a fourth group shares the first one's pool)
     if (create_stream(&G.stream, g % 3) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: hipStreamCreate failed"));
-    if (G.ws.allocate(width, height, static_cast<int>(pitch / 4), G.n) != 0) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: update workspace"));
+    if (G.ws.allocate(width, height, static_cast<int>(pitch / 4), G.n, max_extent) != 0) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: update workspace"));
     if (hipHostMalloc(reinterpret_cast<void**>(&G.h_progress), 64, hipHostMallocMapped) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: progress words"));
     G.h_progress[0] = G.h_progress[1] = 0u;
     if (hipEventCreate(&G.ev) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: event"));

@@ -36,8 +36,9 @@ Tunables& tunables() {
     t.v[RMD_HIP_TUNE_COPY_THREADS] = 4;
     t.v[RMD_HIP_TUNE_FUSED_INGEST] = 1;
     t.v[RMD_HIP_TUNE_INGEST_PROFILE] = 0;
+    t.v[RMD_HIP_TUNE_HOST_WAIT] = 1;
     static const char* const names[RMD_HIP_NUM_TUNABLES] = {"RMD_HIP_HOST_FRAMES", "RMD_HIP_BATCH_GROUPS", "RMD_HIP_AHEAD_WGS", "RMD_HIP_PACK_BACKOFF",
-                                                            "RMD_HIP_FLOAT_AS_BYTES", "RMD_HIP_COPY_THREADS", "RMD_HIP_FUSED_INGEST", "RMD_HIP_INGEST_PROFILE"};
+                                                            "RMD_HIP_FLOAT_AS_BYTES", "RMD_HIP_COPY_THREADS", "RMD_HIP_FUSED_INGEST", "RMD_HIP_INGEST_PROFILE", "RMD_HIP_HOST_WAIT"};
     for (int k = 0; k < RMD_HIP_NUM_TUNABLES; ++k) {
       const char* e = getenv(names[k]);
       if (!e || !e[0]) continue;
@@ -161,7 +162,7 @@ int rmd_hip_version(void) { return RMD_HIP_VERSION_NUMBER; }
 
 int rmd_hip_set_tunable(int tunable, int value) {
   if (tunable < 0 || tunable >= RMD_HIP_NUM_TUNABLES) return fail(RMD_HIP_ERR_INVALID_ARG, "set_tunable: unknown tunable %d", tunable);
-  static const int lo[RMD_HIP_NUM_TUNABLES] = {-1, 0, 1, 0, 0, 1, 0, 0}, hi[RMD_HIP_NUM_TUNABLES] = {3, 4, 1024, 1 << 20, 1, 16, 1, 1};
+  static const int lo[RMD_HIP_NUM_TUNABLES] = {-1, 0, 1, 0, 0, 1, 0, 0, 0}, hi[RMD_HIP_NUM_TUNABLES] = {3, 4, 1024, 1 << 20, 1, 16, 1, 1, 1};
   if (value < lo[tunable] || value > hi[tunable])
     return fail(RMD_HIP_ERR_INVALID_ARG, "set_tunable: value %d of tunable %d outside [%d, %d]", value, tunable, lo[tunable], hi[tunable]);
   tunables().v[tunable] = value;
@@ -340,8 +341,9 @@ int rmdh::seeds_create_impl(int width, int height, float fx, float fy, float cx,
   if (width <= 0 || height <= 0) return fail(RMD_HIP_ERR_INVALID_ARG, "seeds_create: bad size %dx%d", width, height);
   if (!side_supported(patch_side))
     return fail(RMD_HIP_ERR_INVALID_ARG, "seeds_create: unsupported patch side %d (3, 5, 7, 9)", patch_side);
-  if (max_extent <= 0 || max_extent > 100)
-    return fail(RMD_HIP_ERR_INVALID_ARG, "seeds_create: max_extent %d outside (0, 100]", max_extent);
+  if (max_extent <= 0 || max_extent > rmdk::MAX_EXTENT_LIMIT)
+    return fail(RMD_HIP_ERR_INVALID_ARG, "seeds_create: max_extent %d outside (0, %d] (a seed's search steps are numbered in 8 bits: 255 steps of 0.7 pixels)", max_extent,
+                rmdk::MAX_EXTENT_LIMIT);
   int ndev = 0;
   TRY(rmd_hip_device_count(&ndev));
   rmd_hip_seeds* s = new (std::nothrow) rmd_hip_seeds();
@@ -388,7 +390,7 @@ int rmdh::seeds_create_impl(int width, int height, float fx, float fy, float cx,
   P.cam = rmdk::Cam{fx, fy, cx, cy};
   P.one_pix_angle = atan2f(1.0f, 2.0f * fx) * 2.0f;  // pinhole_camera.cuh:56-59
   P.max_extent = static_cast<float>(max_extent);
-  if (!batch && s->matcher_ws.allocate(width, height, P.stride) != 0) return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: update workspace"));
+  if (!batch && s->matcher_ws.allocate(width, height, P.stride, 1, max_extent) != 0) return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: update workspace"));
   if (batch && (grp->ws.stride != P.stride || grp->ws.tiles_x != (width + rmdk::TILE_W - 1) / rmdk::TILE_W || grp->ws.tiles_y != (height + rmdk::TILE_H - 1) / rmdk::TILE_H))
     return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: the batch's workspace has another geometry"));
   hipDeviceProp_t prop;

@@ -1,6 +1,6 @@
 // The seed update of one frame -- seed_check (src/seed_check.cu:28-67), the epipolar NCC search (src/epipolar_match.cu:37-140),
 // triangulation + Bayesian fusion (src/seed_update.cu:39-121, src/triangulation.cu) -- as TWO launches on one stream, for one
-// sequence or for up to MAX_BATCH independent sequences of one size at once (the path shards perfectly across sequences, and a
+// sequence or for up to MAX_GROUP_SEQ independent sequences of one size at once (the path shards perfectly across sequences, and a
 // single 640x480 frame cannot occupy 256 CUs):
 //
 //   seed_setup_compact   one workgroup per 16x16 tile (and sequence), one lane per seed: the deferred finalisation of the
@@ -33,6 +33,17 @@ namespace rmdk {
 constexpr int FR_MIN_WAVES = 3;   // __launch_bounds__ of the search kernel (five workgroups per CU at 96 VGPRs: measured, slower -- LAB.md)
 constexpr int FR_WIN_CAP = 5632;  // texels of the LDS window (22 KB); any shape with (width | 1) * height <= FR_WIN_CAP
 constexpr int FR_UNIT_ROUNDS = 4, FR_UNIT_ITEMS = FR_UNIT_ROUNDS * TILE_PIX;
+constexpr int FR_MAX_ROWS = 255;   // rows of an LDS window (one entry of the row table each; 8 bits in a unit entry)
+constexpr int FR_MAX_WIDTH = 511;  // texels per window row (9 bits in a unit entry)
+// The LDS window is a SHEARED band, not a box: window row q (image row y0 + q) holds the image columns x0 + shear_of(y0 + q - yref, m) ...
+// + ww - 1, where m / 2048 is the band's slope in columns per row (|m| < 16384) and yref the tile's first row.  The samples of a tile lie
+// along nearly parallel epipolar segments up to max_extent pixels long: a box around a diagonal bundle of 100-pixel segments is 97 x 68
+// texels -- more than the window holds -- although the bundle itself covers a band 16-35 texels wide (tests/sim_window_policy.py: on the
+// benchmark sequence three work units in four of the light updates 24..55 / ~100 / ~160 had no window that held them: 8-15 % of those
+// updates' evaluations read their texels from L2, a round took 7.3 instead of 4.6 us).  m = 0 is the box.
+constexpr int FR_SHEAR_BITS = 11;
+constexpr unsigned int TILE_WANTS_BAND = 0x10000u;  // flag in a tile's word of MatcherArgs::tile_live (its low half: seeds in state UPDATE)
+RMDK_D int shear_of(int q, int m) { return (q * m) >> FR_SHEAR_BITS; }  // (arithmetic shift: floor, q may be negative)
 
 // ---- agent-scope accessors (global address space, sc1) ---------------------------------------------------------------
 RMDK_D unsigned int ld_agent(const unsigned int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -55,9 +66,21 @@ struct FrameSmem {
   int prefix[TILE_PIX + 1];
   unsigned int packed[TILE_PIX];   // state << 16 | first in-image step << 8 | number of in-image steps
   int red[4][12];
+  int row_start[FR_MAX_ROWS + 1];  // the window's row table: image texel (X, y0 + q) is win[row_start[q] + X] (frame_stage_window)
   alignas(16) unsigned int bcast[8];  // [0] the workgroup's next unit
   LAB_PROF(unsigned long long prof[8];)  // lab builds (rmd_lab.hpp): per-phase ticks of the workgroup
 };
+
+// do all texels an IRREGULAR footprint at px may touch -- the regular one widened by a texel on every side -- lie inside the window?
+template <int SIDE>
+RMDK_D bool irregular_in_window(F2 px, const int* __restrict__ row_start, int ws, int wy0, int rows, int ww) {
+  constexpr int OFFSET = -SIDE / 2;
+  if (!(isfinite(px.x) && isfinite(px.y))) return false;
+  const int x_lo = static_cast<int>(floorf(px.x)) + OFFSET - 1, q_lo = static_cast<int>(floorf(px.y)) + OFFSET - 1 - wy0, q_hi = q_lo + SIDE + 2;
+  if (q_lo < 0 || q_hi >= rows) return false;
+  const int c_a = x_lo + row_start[q_lo] - q_lo * ws, c_b = x_lo + row_start[q_hi] - q_hi * ws;
+  return min(c_a, c_b) >= 0 && max(c_a, c_b) + SIDE + 2 < ww;
+}
 
 // One NCC evaluation at px; the LDS window has a run-time row stride.  Two sources for the current-image samples, same
 // arithmetic in both: the LDS window when the (regular) footprint lies inside it -- practically always, the window is cut to
@@ -65,7 +88,7 @@ struct FrameSmem {
 // steps, and samples outside a clamped window).  The second path is deliberately compact (rolled loops): the kernel's code
 // has to stay resident in the instruction cache while workgroups are in all of its phases at once.
 template <int SIDE>
-RMDK_D float ncc_at_dyn(const SeedParams& P, F2 px, const float* __restrict__ win, int ws, int wx0, int wy0, int wx1, int wy1,
+RMDK_D float ncc_at_dyn(const SeedParams& P, F2 px, const float* __restrict__ win, const int* __restrict__ row_start, int ws, int wy0, int rows, int ww,
                         const float* __restrict__ ref_patch, int ref_stride, float sum_templ, float denom, unsigned int& n_fallback) {
   constexpr int OFFSET = -SIDE / 2;
   constexpr float AREA = static_cast<float>(SIDE * SIDE);
@@ -73,16 +96,8 @@ RMDK_D float ncc_at_dyn(const SeedParams& P, F2 px, const float* __restrict__ wi
   int ix[SIDE], iy[SIDE];
   float ax[SIDE], ay[SIDE];
   bool reg_x = true, reg_y = true;
-  // wave-uniform branches, one per axis (a wave whose x positions straddle a power of two replays the roundings of x only)
-  if (__all(axis_is_uniform<SIDE>(px.x))) {
-    const float fx = floorf(px.x);
-    const float wx = px.x - fx;
-    ix[0] = static_cast<int>(fx) + OFFSET;
-#pragma unroll
-    for (int k = 0; k < SIDE; ++k) ax[k] = wx;
-  } else {
-    reg_x = axis_params<SIDE>(px.x, ix, ax);
-  }
+  // wave-uniform branches, one per axis (a wave whose x positions straddle a power of two replays the roundings of x only).  The rows first:
+  // they say where in the window's row table the footprint starts
   if (__all(axis_is_uniform<SIDE>(px.y))) {
     const float fy = floorf(px.y);
     const float wy = px.y - fy;
@@ -92,11 +107,32 @@ RMDK_D float ncc_at_dyn(const SeedParams& P, F2 px, const float* __restrict__ wi
   } else {
     reg_y = axis_params<SIDE>(px.y, iy, ay);
   }
+  // Inside the window: texel rows q0 .. q0 + SIDE exist and the footprint's columns lie inside the first and the last of them (the shear is
+  // monotone, so inside every row between).  The window's row table says where a texel row starts in the LDS (a sheared band has no constant
+  // row stride): three entries are read here -- first row, second row, last row -- at a clamped index whatever q0 is (no branch around the
+  // reads), requested BEFORE the columns' parameters are worked out; the evaluation block reads the others two rows ahead of their use.
+  // (All SIDE + 1 entries held in registers across the block cost 15 VGPRs: 116 instead of 101, and at 120 allocated registers four search
+  // waves leave no room on a SIMD for a setup wave of another stream group of a batch -- a batch of 8 lost 5 %.)
+  const int q0 = iy[0] - wy0;
+  const int qc = max(0, min(q0, rows - 1 - SIDE));
+  const int qws = __mul24(qc, ws);  // (qc < 256, ws < 512: the full-rate 24-bit multiply)
+  int off_first = row_start[qc], off_second = row_start[qc + 1], off_last = row_start[qc + SIDE];
+  __builtin_amdgcn_sched_barrier(0);
+  if (__all(axis_is_uniform<SIDE>(px.x))) {
+    const float fx = floorf(px.x);
+    const float wx = px.x - fx;
+    ix[0] = static_cast<int>(fx) + OFFSET;
+#pragma unroll
+    for (int k = 0; k < SIDE; ++k) ax[k] = wx;
+  } else {
+    reg_x = axis_params<SIDE>(px.x, ix, ax);
+  }
+  asm volatile("" : "+v"(off_first), "+v"(off_second), "+v"(off_last));
   const bool regular = reg_x && reg_y;
-  const bool in_window = regular && ix[0] >= wx0 && iy[0] >= wy0 && ix[0] + SIDE <= wx1 && iy[0] + SIDE <= wy1;
+  const int c_first = ix[0] + off_first - qws, c_last = ix[0] + off_last - (qws + SIDE * ws);  // columns within their window rows
+  const bool in_window = regular && q0 == qc && min(c_first, c_last) >= 0 && max(c_first, c_last) + SIDE < ww;
   if (in_window) {
-    ncc_sums_lds_pipelined<SIDE>(win + (iy[0] - wy0) * ws + (ix[0] - wx0), ws, ax, ay, ref_patch, ref_stride, sum_img, sum_img_sq,
-                                 sum_img_templ);
+    ncc_sums_lds_pipelined<SIDE>(win + ix[0], row_start + q0, off_first, off_second, ax, ay, ref_patch, ref_stride, sum_img, sum_img_sq, sum_img_templ);
   } else if (regular) {
     // outside the window (a clamped window, a seed that wandered off): the same separable filter on texel rows from L2, fully
     // unrolled so that the loads overlap -- a rolled loop costs a memory round trip per row and made the few such evaluations
@@ -104,6 +140,33 @@ RMDK_D float ncc_at_dyn(const SeedParams& P, F2 px, const float* __restrict__ wi
     ++n_fallback;
     ncc_sums_regular<SIDE, 0>(P.cur + iy[0] * P.cur_stride + ix[0], P.cur_stride, ax, ay, ref_patch, ref_stride, sum_img, sum_img_sq,
                               sum_img_templ);
+  } else if (irregular_in_window<SIDE>(px, row_start, ws, wy0, rows, ww)) {
+    // An irregular footprint (the replayed roundings moved a column or a row by a texel: ~1e-6 of the steps) whose neighbourhood lies inside the
+    // window: sample by sample like the path below, but from the LDS.  From L2 such an evaluation is 81 x 4 dependent round trips -- 15-20 us
+    // in ONE lane, and with a quarter of a million evaluations per light update every third or fourth update had one: its workgroup ended
+    // at 30 us where the others ended at 17 (profiles/r04_timeline_light_frames.txt: the "slowest workgroups" of updates 31, 34).
+#pragma unroll 1
+    for (int m = 0; m < SIDE; ++m) {
+      const float cy = px.y + static_cast<float>(OFFSET + m) + 0.5f;
+      const float yb = cy - 0.5f, fj = floorf(yb), b = yb - fj;  // (tex_linear_global's arithmetic, the row part once per row)
+      const int q = static_cast<int>(fj) - wy0;
+      const float* const r0 = win + row_start[q];
+      const float* const r1 = win + row_start[q + 1];
+#pragma unroll 3
+      for (int k = 0; k < SIDE; ++k) {
+        const float cx = px.x + static_cast<float>(OFFSET + k) + 0.5f;
+        const float xb = cx - 0.5f, fi = floorf(xb), a = xb - fi;
+        const int i0 = static_cast<int>(fi);
+        const float t00 = r0[i0], t10 = r0[i0 + 1], t01 = r1[i0], t11 = r1[i0 + 1];
+        const float h0 = a == 0.0f ? t00 : rmd_lerp(a, t00, t10);
+        const float h1 = a == 0.0f ? t01 : rmd_lerp(a, t01, t11);
+        const float img = b == 0.0f ? h0 : rmd_lerp(b, h0, h1);
+        const float templ = ref_patch[m * ref_stride + k];
+        sum_img += img;
+        sum_img_sq += img * img;
+        sum_img_templ += img * templ;
+      }
+    }
   } else {
     ++n_fallback;
 #pragma unroll 1
@@ -125,22 +188,31 @@ RMDK_D float ncc_at_dyn(const SeedParams& P, F2 px, const float* __restrict__ wi
   return num * rmd_rsqrtf(den + FLT_MIN);
 }
 
-// Texel box of the samples of steps [j0, j1] (relative to the first in-image step) of this lane's seed.  The positions come
-// from l = l_first + 0.7 j, which is within 1e-3 px of the replayed value; a sample at p touches texels
-// floor(p) - HALF .. floor(p) + HALF + 1 (one more for the replayed roundings), the box keeps another texel to spare.
-// A box that misses a sample costs speed, not correctness (ncc_at_dyn reads L2 then).
+// The band (see shear_of) around one sample position: a sample at p touches texels floor(p) - HALF .. floor(p) + HALF + 1 in both axes (one
+// more for the replayed roundings, another to spare); in band coordinates u = X - shear_of(Y - yref, m) its columns span
+// [xlo - max shear, xhi - min shear] over its rows.  Accumulates into (u0, y0, u1, y1).
+RMDK_D void band_add_point(float px, float py, int half, int m, int yref, int& u0, int& y0, int& u1, int& y1) {
+  const int fx = static_cast<int>(floorf(px)), fy = static_cast<int>(floorf(py));
+  const int ylo = fy - half - 1, yhi = fy + half + 2;
+  const int sa = shear_of(ylo - yref, m), sb = shear_of(yhi - yref, m);
+  u0 = min(u0, fx - half - 1 - max(sa, sb)); u1 = max(u1, fx + half + 2 - min(sa, sb));
+  y0 = min(y0, ylo); y1 = max(y1, yhi);
+}
+constexpr int BAND_NONE_LO = 0x3fffffff, BAND_NONE_HI = -0x3fffffff;  // identities of the reductions below (band columns may be negative)
+
+// Band of the samples of steps [j0, j1] (relative to the first in-image step) of this lane's seed.  The positions come from
+// l = l_first + 0.7 j, which is within 1e-3 px of the replayed value; u is linear along a segment, so its two ends bound it.  A band
+// that misses a sample costs speed, not correctness (ncc_at_dyn reads L2 then).  Rows are clamped to the image.
 template <int SIDE>
-RMDK_D void seed_range_box(const SeedParams& P, const FrameSmem<SIDE>& S, int tid, bool has, int j0, int j1, int& x0, int& y0, int& x1, int& y1) {
+RMDK_D void seed_range_band(const SeedParams& P, const FrameSmem<SIDE>& S, int tid, bool has, int j0, int j1, int m, int yref, int& u0, int& y0, int& u1, int& y1) {
   constexpr int HALF = SIDE / 2;
-  x0 = 0x7fffffff; y0 = 0x7fffffff; x1 = -1; y1 = -1;
+  u0 = BAND_NONE_LO; y0 = BAND_NONE_LO; u1 = BAND_NONE_HI; y1 = BAND_NONE_HI;
   if (!has) return;
   const float lf = S.l_first[tid], mx = S.mean_x[tid], my = S.mean_y[tid], dx = S.dir_x[tid], dy = S.dir_y[tid];
   const float la = lf + 0.7f * static_cast<float>(j0), lb = lf + 0.7f * static_cast<float>(j1);
-  const float ax = mx + la * dx, bx = mx + lb * dx, ay = my + la * dy, by = my + lb * dy;
-  x0 = max(static_cast<int>(floorf(fminf(ax, bx))) - HALF - 1, 0);
-  y0 = max(static_cast<int>(floorf(fminf(ay, by))) - HALF - 1, 0);
-  x1 = min(static_cast<int>(floorf(fmaxf(ax, bx))) + HALF + 2, P.w - 1);
-  y1 = min(static_cast<int>(floorf(fmaxf(ay, by))) + HALF + 2, P.h - 1);
+  band_add_point(mx + la * dx, my + la * dy, HALF, m, yref, u0, y0, u1, y1);
+  band_add_point(mx + lb * dx, my + lb * dy, HALF, m, yref, u0, y0, u1, y1);
+  y0 = max(y0, 0); y1 = min(y1, P.h - 1);
 }
 
 // min / max of four ints over the workgroup (all 256 threads call; result uniform)
@@ -158,38 +230,42 @@ RMDK_D void block_bbox_read(const FrameSmem<SIDE>& S, int& x0, int& y0, int& x1,
   x1 = max(max(S.red[0][slot + 2], S.red[1][slot + 2]), max(S.red[2][slot + 2], S.red[3][slot + 2]));
   y1 = max(max(S.red[0][slot + 3], S.red[1][slot + 3]), max(S.red[2][slot + 3], S.red[3][slot + 3]));
 }
-RMDK_D bool window_fits(int x0, int y0, int x1, int y1) {
-  return x1 >= x0 && y1 >= y0 && ((x1 - x0 + 1) | 1) * (y1 - y0 + 1) <= FR_WIN_CAP;
+RMDK_D bool window_fits(int u0, int y0, int u1, int y1) {  // inclusive band columns and rows
+  const int ww = u1 - u0 + 1, rows = y1 - y0 + 1;
+  return u1 >= u0 && y1 >= y0 && rows <= FR_MAX_ROWS && ww <= FR_MAX_WIDTH && (ww | 1) * rows <= FR_WIN_CAP;
 }
 
 // The LDS window of the current image, workgroup-uniform.
 struct FrameWindow {
-  int x0, y0, x1, y1;  // inclusive texel box
-  int ws;              // row stride in LDS
-  bool valid;          // staged and covering every sample of the tile in LDS
+  int x0, y0;    // window row q = image row y0 + q; its LDS column 0 = image column x0 + shear_of(y0 + q - yref, m)
+  int ww, rows;  // texels per row, rows
+  int ws;        // row stride in LDS (ww | 1)
+  int m, yref;   // the band's shear (m / 2048 columns per row; 0: a box) and the image row it is counted from (the tile's first row)
+  bool valid;    // staged and covering every sample of the tile in LDS
+  RMDK_D void set(int u0, int y0_, int u1, int y1) { x0 = u0; y0 = y0_; ww = u1 - u0 + 1; rows = y1 - y0_ + 1; ws = ww | 1; }
+  RMDK_D void clear() { x0 = y0 = 0; ww = rows = 0; ws = 1; valid = false; }
 };
 
-// A sample box that does not fit the LDS window, cut down around its centre (the evaluations whose footprint falls outside read L2).  The cut
+// A band that does not fit the LDS window, cut down around its centre (the evaluations whose footprint falls outside read L2).  The cut
 // favours a shape the row-wise staging below fetches with few instructions: at most 64 columns -- one column chunk, every lane of a row's
-// load in use -- by up to 86 rows when the box is tall, the full width (a few chunks of a few rows) when it is flat.
+// load in use -- by up to 86 rows when the band is tall, the full width (a few chunks of a few rows) when it is flat.
 RMDK_D void clamp_window(FrameWindow& W) {
-  const int ww = W.x1 - W.x0 + 1, wh = W.y1 - W.y0 + 1;
   constexpr int FLAT = 43;  // rows: (128 | 1) * 43 <= FR_WIN_CAP
-  const int nw = wh > FLAT ? min(ww, 64) : min(ww, (FR_WIN_CAP / wh - 1) | 1);
-  const int nh = min(wh, FR_WIN_CAP / (nw | 1));
-  W.x0 += (ww - nw) / 2; W.x1 = W.x0 + nw - 1;
-  W.y0 += (wh - nh) / 2; W.y1 = W.y0 + nh - 1;
+  const int ww = W.ww, wh = W.rows;
+  const int nw = wh > FLAT ? min(ww, 64) : min(ww, min((FR_WIN_CAP / wh - 1) | 1, FR_MAX_WIDTH));
+  const int nh = min(min(wh, FR_WIN_CAP / (nw | 1)), FR_MAX_ROWS);
+  W.x0 += (ww - nw) / 2; W.y0 += (wh - nh) / 2;  // (x0 is the band's column origin at ANY row: the shear is anchored at yref, not at y0)
+  W.ww = nw; W.rows = nh; W.ws = nw | 1;
 }
 
-// Stage texels [x0, x1] x [y0, y1] of the current image into the LDS window, ROW-WISE and LDS-DIRECT: wave v takes rows v, v + 4, ...; one
+// Stage the band W of the current image into the LDS window, ROW-WISE and LDS-DIRECT: wave v takes rows v, v + 4, ...; one
 // global_load_lds_dword per row and 64-column chunk brings 64 consecutive texels straight into the window (the instruction writes to a
-// wave-uniform LDS base + lane x 4 bytes: exactly a row of the window; lanes past the row's end are masked out), no vector register and
-// no ds_write in between -- so ALL rows of a wave are in flight together and the window arrives in ONE memory round trip whatever its
-// shape, six instructions per row (one of them on the vector ALU).  History: element-wise staging (a division of the element index by the
-// run-time width per texel: 25 vector instructions per texel row) -> row-wise through registers, 12 rows per lane in flight (a full
-// 64 x 86 window: two round trips, 4-7 us of an unboxed unit's 23) -> this: one sequence 43.4 -> 40.5 us per update, batch of 8 14 900 ->
-// 15 950 Mpix/s; with the patch halo staged the same way 40.0 us / 16 600, the kernel 6 000 -> 4 900 instructions (24.5 KB) and 75 -> 24 spilled
-// scalars (profiles/r04_ab_lds_direct_staging.txt; the budgets are checked by tests/test_kernel_budget.py).
+// wave-uniform LDS base + lane x 4 bytes: exactly a row of the window; lanes past the row's end -- or outside the image, where a band may
+// reach but no footprint does -- are masked out), no vector register and no ds_write in between -- so ALL rows of a wave are in flight
+// together and the window arrives in ONE memory round trip whatever its shape; the row's first column is scalar arithmetic.  Also writes
+// the window's row table.  History: element-wise staging (a division of the element index by the run-time width per texel: 25 vector
+// instructions per texel row) -> row-wise through registers, 12 rows per lane in flight (a full 64 x 86 window: two round trips, 4-7 us of
+// an unboxed unit's 23) -> LDS-direct boxes (round 4: one sequence 43.4 -> 40.0 us per update) -> sheared bands (round 5).
 // No barrier; the loads are still in flight when this returns.  A wave reads window rows that OTHER waves transferred, so every wave drains
 // its own transfers (drain_vmem: s_waitcnt vmcnt(0)) before the workgroup barrier that precedes the first read: a workgroup-scope release
 // only guarantees lgkmcnt(0), and the compiler tracks LDS-direct transfers per wave.  tests/test_kernel_budget.py checks the disassembly.
@@ -199,18 +275,31 @@ RMDK_D void frame_stage_window(const SeedParams& P, FrameSmem<SIDE>& S, int tid,
   typedef __attribute__((address_space(3))) float* lptr_t;
   constexpr int WAVES = TILE_PIX / 64;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ww = W.x1 - W.x0 + 1, wh = W.y1 - W.y0 + 1;
   const size_t stride = static_cast<size_t>(P.cur_stride);
-  const float* const first = P.cur + static_cast<size_t>(W.y0 + wave) * stride + W.x0;  // this wave's first row
-  for (int c0 = 0; c0 < ww; c0 += 64) {  // (uniform: at most three column chunks, (ww | 1) * wh <= FR_WIN_CAP)
+  // Does the band stay inside the image's columns on every row?  (The shear is monotone: its first and last row decide.)  Nearly always --
+  // and then a row is scalar arithmetic plus ONE vector instruction, the load itself: the lane's column offset is the same on every row.
+  const int xs_a = W.x0 + shear_of(W.y0 - W.yref, W.m), xs_b = W.x0 + shear_of(W.y0 + W.rows - 1 - W.yref, W.m);
+  const bool inside = min(xs_a, xs_b) >= 0 && max(xs_a, xs_b) + W.ww <= P.w;
+  for (int c0 = 0; c0 < W.ww; c0 += 64) {  // (uniform: at most eight column chunks, nearly always one)
     const int c = c0 + lane;
-    if (c < ww) {
-      const float* src = first + c;
-      float* dst = S.win + wave * W.ws + c0;  // uniform over the wave
-      for (int r = wave; r < wh; r += WAVES, src += WAVES * stride, dst += WAVES * W.ws)
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 4, 0, 0);
+    if (c < W.ww) {
+      if (inside) {
+        const float* row = P.cur + static_cast<size_t>(W.y0 + wave) * stride;  // scalar
+        float* dst = S.win + wave * W.ws + c0;                                 // uniform over the wave
+        for (int r = wave; r < W.rows; r += WAVES, row += WAVES * stride, dst += WAVES * W.ws) {
+          const int xs = W.x0 + shear_of(W.y0 + r - W.yref, W.m);  // scalar
+          __builtin_amdgcn_global_load_lds((gptr_t)(row + xs + c), (lptr_t)dst, 4, 0, 0);
+        }
+      } else {  // a band that reaches past the image's left or right edge (no footprint does): those lanes are masked out, row by row
+        for (int r = wave; r < W.rows; r += WAVES) {
+          const int y = W.y0 + r, xs = W.x0 + shear_of(y - W.yref, W.m), col = xs + c;
+          if (col >= 0 && col < P.w)
+            __builtin_amdgcn_global_load_lds((gptr_t)(P.cur + static_cast<size_t>(y) * stride + col), (lptr_t)(S.win + r * W.ws + c0), 4, 0, 0);
+        }
+      }
     }
   }
+  if (tid <= W.rows) S.row_start[tid] = __mul24(tid, W.ws) - (W.x0 + shear_of(W.y0 + tid - W.yref, W.m));
 }
 
 // Rounds of 256 NCC evaluations over work items [k0, k1) of the tile in LDS with window W; arg-max keys accumulate in S.best.
@@ -238,7 +327,7 @@ RMDK_D void frame_rounds(const SeedParams& P, FrameSmem<SIDE>& S, int tid, int k
       const float l = replay_l(S.l_first[p], j);  // the reference accumulates l; replay it
       const F2 px = F2{S.mean_x[p] + l * S.dir_x[p], S.mean_y[p] + l * S.dir_y[p]};
       const int ptx = p & (TILE_W - 1), pty = p >> 4;
-      const float ncc = ncc_at_dyn<SIDE>(P, px, S.win, W.ws, W.x0, W.y0, W.x1, W.y1, S.ref + pty * Smem::REF_W + ptx, Smem::REF_W,
+      const float ncc = ncc_at_dyn<SIDE>(P, px, S.win, S.row_start, W.ws, W.y0, W.rows, W.ww, S.ref + pty * Smem::REF_W + ptx, Smem::REF_W,
                                         S.sum_templ[p], S.denom[p], n_fallback);
       if (ncc > -1.0f) {  // NaN and anything the reference's "ncc > best_ncc" would never accept are dropped
         const unsigned int step = ((S.packed[p] >> 8) & 0xffu) + static_cast<unsigned int>(j);
@@ -275,38 +364,39 @@ RMDK_D void frame_search(const SeedParams& P, FrameSmem<SIDE>& S, int tid, int k
     if (!tile_win.valid) {
       // this lane's seed contributes steps [max(k - first, 0), min(kX - first, n) - 1] to the candidate range [k, kX)
       const int j0 = max(k - my_first, 0);
+      int u0, y0, u1, y1;
       {
-        int bx0, by0, bx1, by1;
-        seed_range_box<SIDE>(P, S, tid, my_n > 0 && my_first < k1 && my_first + my_n > k, j0, min(k1 - my_first, my_n) - 1, bx0, by0, bx1, by1);
-        block_bbox<SIDE>(S, tid, bx0, by0, bx1, by1, 0);
+        int bu0, by0, bu1, by1;
+        seed_range_band<SIDE>(P, S, tid, my_n > 0 && my_first < k1 && my_first + my_n > k, j0, min(k1 - my_first, my_n) - 1, W.m, W.yref, bu0, by0, bu1, by1);
+        block_bbox<SIDE>(S, tid, bu0, by0, bu1, by1, 0);
         __syncthreads();
-        block_bbox_read<SIDE>(S, W.x0, W.y0, W.x1, W.y1, 0);
+        block_bbox_read<SIDE>(S, u0, y0, u1, y1, 0);
       }
-      if (!window_fits(W.x0, W.y0, W.x1, W.y1)) {
+      if (!window_fits(u0, y0, u1, y1)) {
         const int kb = min(k_end, k + FR_UNIT_ITEMS), kc = min(k_end, k + TILE_PIX);
-        int bx0, by0, bx1, by1, cx0, cy0, cx1, cy1;
-        // a box over the same items as the one that has just failed is not reduced again: the 4-round box when at most four rounds are left
-        // (units of the product pipeline: always), the one-round box when at most one is (most units of a light frame: one reduction pass and
+        int bu0, by0, bu1, by1, cu0, cy0, cu1, cy1;
+        // a band over the same items as the one that has just failed is not reduced again: the 4-round band when at most four rounds are left
+        // (units of the product pipeline: always), the one-round band when at most one is (most units of a light frame: one reduction pass and
         // one barrier instead of two, 1 us of a unit's 2.3 us of window policy)
         const bool four = kb < k_end, one = kc < kb;
         if (four) {
-          seed_range_box<SIDE>(P, S, tid, my_n > 0 && my_first < kb && my_first + my_n > k, j0, min(kb - my_first, my_n) - 1, bx0, by0, bx1, by1);
-          block_bbox<SIDE>(S, tid, bx0, by0, bx1, by1, 4);
+          seed_range_band<SIDE>(P, S, tid, my_n > 0 && my_first < kb && my_first + my_n > k, j0, min(kb - my_first, my_n) - 1, W.m, W.yref, bu0, by0, bu1, by1);
+          block_bbox<SIDE>(S, tid, bu0, by0, bu1, by1, 4);
         }
         if (one) {
-          seed_range_box<SIDE>(P, S, tid, my_n > 0 && my_first < kc && my_first + my_n > k, j0, min(kc - my_first, my_n) - 1, cx0, cy0, cx1, cy1);
-          block_bbox<SIDE>(S, tid, cx0, cy0, cx1, cy1, 8);
+          seed_range_band<SIDE>(P, S, tid, my_n > 0 && my_first < kc && my_first + my_n > k, j0, min(kc - my_first, my_n) - 1, W.m, W.yref, cu0, cy0, cu1, cy1);
+          block_bbox<SIDE>(S, tid, cu0, cy0, cu1, cy1, 8);
         }
         if (four || one) __syncthreads();
-        if (four) block_bbox_read<SIDE>(S, W.x0, W.y0, W.x1, W.y1, 4);
+        if (four) block_bbox_read<SIDE>(S, u0, y0, u1, y1, 4);
         k1 = kb;
-        if (!window_fits(W.x0, W.y0, W.x1, W.y1)) {
-          if (one) block_bbox_read<SIDE>(S, W.x0, W.y0, W.x1, W.y1, 8);
+        if (!window_fits(u0, y0, u1, y1)) {
+          if (one) block_bbox_read<SIDE>(S, u0, y0, u1, y1, 8);
           k1 = kc;
-          if (!window_fits(W.x0, W.y0, W.x1, W.y1)) clamp_window(W);  // cut down around the box's centre; the rest reads L2
         }
       }
-      W.ws = (W.x1 - W.x0 + 1) | 1;
+      W.set(u0, y0, u1, y1);
+      if (!window_fits(u0, y0, u1, y1)) clamp_window(W);  // cut down around the band's centre; the rest reads L2
       LAB_PROF(const unsigned long long prof_p1 = prof_clock();)
       frame_stage_window<SIDE>(P, S, tid, W);
       ++n_windows;
@@ -424,13 +514,21 @@ RMDK_D void ingest_staged(int kind, int pitch, const void* src_v, float* __restr
   }
 }
 
+// Words 2, 3 of a unit entry: the tile's window -- column origin (16 bits, signed: a band may start left of the image) | first row << 16;
+// rows (8 bits) | texels per row (9 bits) << 8 | shear (15 bits, signed) << 17.  A unit without UNIT_TILE_BOX carries the shear only.
+RMDK_D unsigned int unit_pack_origin(int x0, int y0) { return (static_cast<unsigned int>(x0) & 0xffffu) | (static_cast<unsigned int>(y0) << 16); }
+RMDK_D unsigned int unit_pack_shape(int rows, int ww, int m) {
+  return static_cast<unsigned int>(rows) | (static_cast<unsigned int>(ww) << 8) | (static_cast<unsigned int>(m) << 17);
+}
+static_assert(FR_MAX_ROWS < (1 << 8) && FR_MAX_WIDTH < (1 << 9), "window shape fields of a unit entry");
+
 constexpr int INGEST_WGS = 128;  // workgroups (per sequence) that bring a host frame into the current-image plane (the only ones that may wait)
 constexpr int INGEST_WGS_REMAP = 512;  // with lens undistortion (two dependent round trips per pixel): a quarter of the chip's wave slots at most
 constexpr int INGEST_WGS_IN_PLACE = 256;  // frames read in place from pinned host memory: enough requests in flight to cover the host link's latency
 
 template <int SIDE, int NSEQ>
 __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<NSEQ> B, MatcherArgs M, int target_units) {
-  __shared__ int red_i[4], red_c[4], red_l[4], red_b[4][4];
+  __shared__ int red_i[4], red_c[4], red_l[4], red_b[4][6];
   __shared__ unsigned int s_base;
   constexpr int HALF = SIDE / 2;
   const int seq = NSEQ == 1 ? 0 : static_cast<int>(blockIdx.z);
@@ -536,7 +634,13 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
   // light frames of the benchmark sequence that is four tiles in five, which used to fetch 44 bytes per pixel and run the check for nothing.
   // (tile_live: written at the end of this kernel by the tile's own workgroup, read here one launch later; fuse_prev = nobody touched the
   // planes in between.  The launch's housekeeping below must not depend on tile 0 being alive.)
-  const bool dead_tile = Q.fuse_prev && *(const __attribute__((address_space(4))) unsigned int*)(M.tile_live + tile_g) == 0u;
+  // (the tile's word: seeds in state UPDATE after the previous frame's check | TILE_WANTS_BAND, see below)
+  const unsigned int tile_word = *(const __attribute__((address_space(4))) unsigned int*)(M.tile_live + tile_g);
+  const bool dead_tile = Q.fuse_prev && (tile_word & 0xffffu) == 0u;
+  // A tile whose samples did not fit a BOX-shaped window one frame ago (a bundle of long diagonal segments) gets a sheared band this frame;
+  // everybody else -- nearly every tile of nearly every frame -- pays nothing for the machinery: no slope, no second pair of reductions.  (The
+  // first frame on which a tile's box does not fit goes to the search kernel's own window policy, as before round 5.)
+  const bool want_band = LAB_SHEAR_HINT((tile_word & TILE_WANTS_BAND) != 0u);
   // the seed's state: requested before anything else, so that the scalar-load chains below (kernel arguments, the previous frame's
   // counters) run while these are in flight
   if (dead_tile && !(tile == 0 && seq == M.housekeeper)) return;  // (the keeper goes on: its loads are as harmless as they were)
@@ -594,6 +698,22 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
       else if (what == 2) P.b[gi] = b;
     }
   }
+  // The band along which this tile's samples lie (shear_of): the slope of the epipolar line of the tile's CENTRE pixel.  The ray of pixel p
+  // projects to the line through the epipole e = proj(t) (depth 0) and the vanishing point v = proj(R K^-1 p) (depth infinity) whatever the
+  // seed's depth estimate is, so the direction needs no state, no reduction and no hint from the previous frame: every lane computes the same
+  // number from the kernel arguments (here, where the pose is in scalar registers anyway: the segments below use it).  v - e scaled by t_z: (fx (t_z X / Z - t_x), fy (t_z Y / Z - t_y)) -- finite
+  // for a sideways motion (t_z = 0, epipole at infinity).  Approximate reciprocals: the slope steers window shapes, never results.
+  int m_tile = 0;
+  if (want_band) {  // (uniform over the workgroup)
+    const Pose& T = P.T_curr_ref;
+    const float fcx = (static_cast<float>(blockIdx.x * TILE_W + TILE_W / 2) - P.cam.cx) * __builtin_amdgcn_rcpf(P.cam.fx);
+    const float fcy = (static_cast<float>(blockIdx.y * TILE_H + TILE_H / 2) - P.cam.cy) * __builtin_amdgcn_rcpf(P.cam.fy);
+    const float X = T.d[0] * fcx + T.d[1] * fcy + T.d[2], Y = T.d[4] * fcx + T.d[5] * fcy + T.d[6], Z = T.d[8] * fcx + T.d[9] * fcy + T.d[10];
+    const float iz = __builtin_amdgcn_rcpf(Z);
+    const float dx = P.cam.fx * (T.d[11] * X * iz - T.d[3]), dy = P.cam.fy * (T.d[11] * Y * iz - T.d[7]);
+    // flatter than 8 columns per row: a box holds such a bundle (0); a point behind the camera or a degenerate pose: a box as well
+    if (Z > 0.0f && fabsf(dx) < 7.9f * fabsf(dy)) m_tile = static_cast<int>(rintf(dx * __builtin_amdgcn_rcpf(dy) * static_cast<float>(1 << FR_SHEAR_BITS)));
+  }
   int state = ST_BORDER;
   if (in_image) {
     // A seed that the PREVIOUS frame's check (the same lane, one launch ago: fuse_prev says nobody touched the planes in between) found
@@ -607,7 +727,8 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
   if (P.trace) t_loaded = wall_clock64();
   int n_valid = 0, i_first = 0;
   unsigned int n_steps = 0, n_evals = 0;
-  int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = -1, by1 = -1;  // texel box of this seed's samples (see seed_range_box)
+  int bx0 = BAND_NONE_LO, by0 = BAND_NONE_LO, bx1 = BAND_NONE_HI, by1 = BAND_NONE_HI;  // texel box of this seed's samples ...
+  int bu0 = BAND_NONE_LO, bu1 = BAND_NONE_HI;                                          // ... and their band under the tile's shear (band_add_point)
   const bool live = in_image && state == ST_UPDATE;
   if (live) {
     const Segment seg = epipolar_segment(P, x, y, mu, sigma_sq);
@@ -624,6 +745,12 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
       by0 = max(static_cast<int>(floorf(fminf(run.px_first.y, run.px_last.y))) - HALF - 1, 0);
       bx1 = min(static_cast<int>(floorf(fmaxf(run.px_first.x, run.px_last.x))) + HALF + 2, P.w - 1);
       by1 = min(static_cast<int>(floorf(fmaxf(run.px_first.y, run.px_last.y))) + HALF + 2, P.h - 1);
+      if (want_band) {  // the same under the tile's shear (rows as above: the band's rows are the box's)
+        int ty0 = BAND_NONE_LO, ty1 = BAND_NONE_HI;
+        const int yref = static_cast<int>(blockIdx.y) * TILE_H;
+        band_add_point(run.px_first.x, run.px_first.y, HALF, m_tile, yref, bu0, ty0, bu1, ty1);
+        band_add_point(run.px_last.x, run.px_last.y, HALF, m_tile, yref, bu0, ty0, bu1, ty1);
+      }
     }
     if (P.stats) {  // diagnostics only: the full walk, counting what the reference would visit / evaluate
       for (float l = -seg.half_length; l <= seg.half_length; l += 0.7f, ++n_steps) {
@@ -651,9 +778,14 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
     tot = wave_reduce_i32<WaveAdd>(n_valid);
     bx0 = wave_reduce_i32<WaveMin>(bx0); by0 = wave_reduce_i32<WaveMin>(by0);
     bx1 = wave_reduce_i32<WaveMax>(bx1); by1 = wave_reduce_i32<WaveMax>(by1);
+    if (want_band) { bu0 = wave_reduce_i32<WaveMin>(bu0); bu1 = wave_reduce_i32<WaveMax>(bu1); }
   }
   const int n_live = __popcll(__ballot(live));
-  if (lane == 0) { red_i[wave] = tot; red_c[wave] = n_conv; red_l[wave] = n_live; red_b[wave][0] = bx0; red_b[wave][1] = by0; red_b[wave][2] = bx1; red_b[wave][3] = by1; }
+  if (lane == 0) {
+    red_i[wave] = tot; red_c[wave] = n_conv; red_l[wave] = n_live;
+    red_b[wave][0] = bx0; red_b[wave][1] = by0; red_b[wave][2] = bx1; red_b[wave][3] = by1;
+    red_b[wave][4] = bu0; red_b[wave][5] = bu1;
+  }
   __syncthreads();
   const int total = red_i[0] + red_i[1] + red_i[2] + red_i[3];
   const int unit_items = unit_rounds * TILE_PIX;
@@ -664,7 +796,12 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
   if (keeper && tid < UNIT_SHARDS) M.handout[tid * HANDOUT_STRIDE] = 0u;  // the search kernel's hand-out counters
   if (keeper && tid == 0) M.queue[5] = static_cast<unsigned int>(unit_items);
   if (tid == 0) M.tile_conv[tile_g] = static_cast<unsigned int>(red_c[0] + red_c[1] + red_c[2] + red_c[3]);
-  if (tid == 0) M.tile_live[tile_g] = static_cast<unsigned int>(red_l[0] + red_l[1] + red_l[2] + red_l[3]);  // seeds in state UPDATE after this frame's check
+  // the tile's box of this frame (uniform: every thread reads the four waves' partial results)
+  const int tx0 = min(min(red_b[0][0], red_b[1][0]), min(red_b[2][0], red_b[3][0])), ty0 = min(min(red_b[0][1], red_b[1][1]), min(red_b[2][1], red_b[3][1]));
+  const int tx1 = max(max(red_b[0][2], red_b[1][2]), max(red_b[2][2], red_b[3][2])), ty1 = max(max(red_b[0][3], red_b[1][3]), max(red_b[2][3], red_b[3][3]));
+  const bool box = window_fits(tx0, ty0, tx1, ty1);
+  if (tid == 0)  // seeds in state UPDATE after this frame's check | does the NEXT frame's setup reduce a band for this tile?
+    M.tile_live[tile_g] = static_cast<unsigned int>(red_l[0] + red_l[1] + red_l[2] + red_l[3]) | (total > 0 && !box ? TILE_WANTS_BAND : 0u);
   if (P.trace && tid == 0)  // word 2 of the tile's slot: start (low 32 bits of the 10 ns clock), state ready and end relative to it
     P.trace[static_cast<size_t>(tile) * FR_TRACE_WORDS + 2] = (t_start & 0xffffffffull) | (((t_loaded - t_start) & 0xffffull) << 32) |
                                                              (((wall_clock64() - t_start) & 0xffffull) << 48);
@@ -676,13 +813,15 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
   }
   __syncthreads();
   if (tid < n_u) {
-    const int x0 = min(min(red_b[0][0], red_b[1][0]), min(red_b[2][0], red_b[3][0])), y0 = min(min(red_b[0][1], red_b[1][1]), min(red_b[2][1], red_b[3][1]));
-    const int x1 = max(max(red_b[0][2], red_b[1][2]), max(red_b[2][2], red_b[3][2])), y1 = max(max(red_b[0][3], red_b[1][3]), max(red_b[2][3], red_b[3][3]));
-    const bool boxed = window_fits(x0, y0, x1, y1);  // (coordinates are < 2^15: they pack into 16 bits each)
+    const int x0 = tx0, y0 = ty0, x1 = tx1, y1 = ty1;
+    const int u0 = min(min(red_b[0][4], red_b[1][4]), min(red_b[2][4], red_b[3][4])), u1 = max(max(red_b[0][5], red_b[1][5]), max(red_b[2][5], red_b[3][5]));
+    // the window that holds ALL samples of the tile, if there is one: the box when that fits, else the band along the tile's shear; else the
+    // search kernel cuts windows to each unit's own samples (along the same shear, which travels with the unit either way)
+    const bool band = !box && want_band && m_tile != 0 && window_fits(u0, y0, u1, y1);
+    const int wx0 = box ? x0 : u0, ww = (box ? x1 : u1) - wx0 + 1, rows = y1 - y0 + 1, m = box ? 0 : m_tile;
     M.units[static_cast<size_t>(tile_g % UNIT_SHARDS) * M.shard_cap + s_base + tid] =
-        make_uint4(static_cast<unsigned int>(tile_g), static_cast<unsigned int>(tid * unit_items) | (boxed ? UNIT_TILE_BOX : 0u),
-                   boxed ? static_cast<unsigned int>(x0) | (static_cast<unsigned int>(y0) << 16) : 0u,
-                   boxed ? static_cast<unsigned int>(x1) | (static_cast<unsigned int>(y1) << 16) : 0u);
+        make_uint4(static_cast<unsigned int>(tile_g), static_cast<unsigned int>(tid * unit_items) | (box || band ? UNIT_TILE_BOX : 0u),
+                   box || band ? unit_pack_origin(wx0, y0) : 0u, unit_pack_shape(box || band ? rows : 0, box || band ? ww : 0, m));
   }
 }
 
@@ -775,7 +914,7 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
   const SeqArgs* Qp = seq_table();  // the sequence of the tile in LDS (one sequence: the named argument, see the setup kernel)
   size_t so = 0;                    // ... and where its seeds start in the workspace planes
   FrameWindow W;
-  W.valid = false; W.x0 = W.y0 = 0; W.x1 = W.y1 = -1; W.ws = 1;
+  W.clear(); W.m = 0; W.yref = 0;
   // Unit wg_id is ours for free.  When there are more units than workgroups the rest is handed out by sixteen counters (workgroup
   // b draws from counter b % 16, which deals the units n_wg + b % 16 + 16 k: one counter word for a thousand workgroups serialises
   // their returning atomics for 12 us).  Claiming the next unit while the current one is searched was measured twice and lost twice: throughout
@@ -830,10 +969,11 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
           __builtin_amdgcn_global_load_lds((gptr_t)(row + ref_col), (lptr_t)(S.ref + ry * Smem::REF_W), 4, 0, 0);
         }
       }
+      W.m = static_cast<int>(box1) >> 17; W.yref = y0;  // the tile's shear travels with every unit (frame_search cuts its windows along it)
       if (boxed) {
-        W.x0 = static_cast<int>(box0 & 0xffffu); W.y0 = static_cast<int>(box0 >> 16);
-        W.x1 = static_cast<int>(box1 & 0xffffu); W.y1 = static_cast<int>(box1 >> 16);
-        W.ws = (W.x1 - W.x0 + 1) | 1;
+        W.x0 = static_cast<int>(static_cast<short>(box0 & 0xffffu)); W.y0 = static_cast<int>(box0 >> 16);
+        W.rows = static_cast<int>(box1 & 0xffu); W.ww = static_cast<int>((box1 >> 8) & 0x1ffu);
+        W.ws = W.ww | 1;
         W.valid = true;
         frame_stage_window<SIDE>(P, S, tid, W);
       }
@@ -846,7 +986,7 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
       S.best[tid] = 0ull;
       // (a unit without the box flag belongs to a tile whose sample box the setup kernel found too large for the LDS window: the box is not
       // computed a second time here -- frame_search cuts windows to the unit's own rounds)
-      if (!boxed) { W.valid = false; W.x0 = W.y0 = 0; W.x1 = W.y1 = -1; W.ws = 1; }
+      if (!boxed) W.clear();  // (keeps m and yref)
       drain_vmem();  // halo and window rows are read by OTHER waves after the barriers below: this wave's LDS-direct transfers must have landed
       total = frame_prefix<SIDE>(S, tid);  // barriers inside
       lds_tile = tile;
@@ -928,7 +1068,7 @@ inline hipError_t launch_seed_finalize(const SeedParams& P, MatcherWorkspace& ws
 }
 
 // setup (+ the deferred finalisation of the previous frame of every sequence with fuse_prev; builds the unit list) -> search, for the
-// `n_seq` sequences of B (NSEQ = 1: one sequence; NSEQ = MAX_BATCH: 2..MAX_BATCH of them).  The caller zeroes ws.d_shards and sets
+// `n_seq` sequences of B (NSEQ = 1: one sequence; NSEQ = MAX_GROUP_SEQ: 2..MAX_GROUP_SEQ of them).  The caller zeroes ws.d_shards and sets
 // ws.frame = 0 whenever a sequence restarts.
 template <int SIDE, int NSEQ>
 inline hipError_t launch_seed_pipeline_compact(const BatchArgs<NSEQ>& B, int n_seq, MatcherWorkspace& ws, hipStream_t stream, int num_cus,

@@ -7,6 +7,13 @@
 #ifndef RMD_LAB_HPP
 #define RMD_LAB_HPP
 
+// A/B of the round-5 sheared window (tools/ab_make.sh noshear "-DRMD_LAB_NO_SHEAR"): no tile ever asks for a band, i.e. all windows are boxes
+#ifdef RMD_LAB_NO_SHEAR
+#define LAB_SHEAR_HINT(m) false
+#else
+#define LAB_SHEAR_HINT(m) (m)
+#endif
+
 #ifdef RMD_LAB_PROFILE_ROUNDS
 #define LAB_PROF(...) __VA_ARGS__
 namespace rmdk {

@@ -30,13 +30,20 @@ namespace rmdk {
 constexpr int TILE_W = 16, TILE_H = 16, TILE_PIX = TILE_W * TILE_H;
 constexpr int MAX_UNIT_ROUNDS = 4;  // a work unit is 1..4 rounds of the 256 lanes (chosen per frame from the previous frame's work)
 constexpr int MIN_UNIT_ITEMS = TILE_PIX;
-constexpr int MAX_ITEMS_PER_TILE = TILE_PIX * 144;
+// Search steps of one seed: l = -half; l <= half; l += 0.7f with half <= max_extent / 2 (epipolar_match.cu:75,88), i.e. at most
+// floor(max_extent / 0.7) + 1.  Step numbers and counts live in 8-bit fields (the search kernel's descriptors, FrameSmem::packed): 255 steps,
+// i.e. max_extent <= 178 -- the reference's RMD_MAX_EXTENT_EPIPOLAR_SEARCH is an unbounded compile-time constant with default 100
+// (CMakeLists.txt:52-53); beyond 178 the fields would have to be widened.
+constexpr int MAX_EXTENT_LIMIT = 178;
+inline int max_search_steps(int max_extent) { return static_cast<int>(static_cast<float>(max_extent) / 0.7f) + 2; }
+static_assert(static_cast<int>(MAX_EXTENT_LIMIT / 0.7f) + 1 <= 255, "step numbers of a seed fit 8 bits");
 constexpr int UNIT_SHARDS = 16;  // unit lists / counters, tile t -> shard t % UNIT_SHARDS; hand-out counters of the search, workgroup b -> b % UNIT_SHARDS
 constexpr int HANDOUT_STRIDE = 32;  // words between two hand-out counters (128 B: one L2 line each)
 constexpr unsigned int UNIT_TILE_BOX = 0x80000000u;  // flag in a unit's first-item word: words 2, 3 hold the texel box of ALL samples of the unit's tile, and it fits the LDS window
 constexpr int FR_TRACE_FRAMES = 256, FR_TRACE_WORDS = 8;  // timeline of the tile pipeline, per workgroup: start, setup done, own tile done, exit (10 ns ticks), work items, units searched
 
-constexpr int MAX_BATCH = 8;  // sequences one launch pair can carry (the per-sequence parameter blocks travel as kernel arguments: 4 KB)
+constexpr int MAX_GROUP_SEQ = 8;  // sequences ONE launch pair can carry (the per-sequence parameter blocks travel as kernel arguments: 4 KB)
+constexpr int MAX_BATCH = 3 * MAX_GROUP_SEQ;  // sequences of a batch: it steps its members in up to three stream groups, one launch pair each (rmd_hip_batch)
 
 // Workspace of the update pipeline for `n_seq` independent sequences of one size that are updated by ONE launch pair (a plain
 // SeedMatrix is the case n_seq = 1).  Per-seed planes hold the sequences back to back (`seq_plane` elements each), tiles are
@@ -68,7 +75,7 @@ struct MatcherWorkspace {
   bool attr_set_small = false, attr_set_large = false;
   bool attr_set_compact[4][2] = {{false, false}, {false, false}, {false, false}, {false, false}};  // per patch side, {one sequence, batch}
   int compact_wg_per_cu[4][2] = {{1, 1}, {1, 1}, {1, 1}, {1, 1}};
-  int allocate(int w, int h, int stride_elems, int sequences = 1) {
+  int allocate(int w, int h, int stride_elems, int sequences = 1, int max_extent = 100) {
     tiles_x = (w + TILE_W - 1) / TILE_W;
     tiles_y = (h + TILE_H - 1) / TILE_H;
     stride = stride_elems;
@@ -76,7 +83,7 @@ struct MatcherWorkspace {
     seq_plane = static_cast<size_t>(stride) * h;
     const size_t n = seq_plane * n_seq;
     const size_t n_tiles_all = static_cast<size_t>(tiles_x) * tiles_y * n_seq;
-    const int units_per_tile = (MAX_ITEMS_PER_TILE + MIN_UNIT_ITEMS - 1) / MIN_UNIT_ITEMS;
+    const int units_per_tile = max_search_steps(max_extent);  // a tile of 256 seeds with every step in the image, in units of one round
     if (hipMalloc(reinterpret_cast<void**>(&d_mean), n * sizeof(float2)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_dir), n * sizeof(float2)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_lfirst), n * sizeof(float)) != hipSuccess) return -1;
@@ -92,8 +99,8 @@ struct MatcherWorkspace {
     if (hipMemset(d_handout, 0, UNIT_SHARDS * HANDOUT_STRIDE * sizeof(unsigned int)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_queue), 8 * sizeof(unsigned int)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_shards), 3 * UNIT_SHARDS * sizeof(unsigned long long)) != hipSuccess) return -1;
-    if (hipHostMalloc(reinterpret_cast<void**>(&h_conv), MAX_BATCH * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) return -1;
-    for (int q = 0; q < MAX_BATCH; ++q) h_conv[q] = 0ull;
+    if (hipHostMalloc(reinterpret_cast<void**>(&h_conv), MAX_GROUP_SEQ * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) return -1;
+    for (int q = 0; q < MAX_GROUP_SEQ; ++q) h_conv[q] = 0ull;
     void* dev = nullptr;
     if (hipHostGetDevicePointer(&dev, h_conv, 0) != hipSuccess) return -1;
     d_conv = static_cast<unsigned long long*>(dev);
@@ -190,7 +197,7 @@ template <int NSEQ>
 struct BatchArgs {
   SeqArgs seq[NSEQ];
 };
-static_assert(sizeof(BatchArgs<MAX_BATCH>) + sizeof(MatcherArgs) + 64 <= 4096, "kernel arguments are limited to 4 KB");
+static_assert(sizeof(BatchArgs<MAX_GROUP_SEQ>) + sizeof(MatcherArgs) + 64 <= 4096, "kernel arguments are limited to 4 KB");
 RMDK_D const SeqArgs* seq_table() { return (const SeqArgs*)__builtin_amdgcn_kernarg_segment_ptr(); }  // (C cast: from the constant address space)
 
 // what the caller of the pipeline hands over when the frames came from host memory
@@ -396,21 +403,27 @@ RMDK_D void ncc_sums_regular(const float* __restrict__ base, int rt_stride, cons
 // last row with all 81 products alive (168 VGPRs + scratch); pinned by volatile inline assembly it costs 125 VGPRs, is bit-identical and
 // gains nothing on the heaviest updates (490 -> 494 us for a batch of 8); pairs of columns through the vertical filter cost 114 extra moves.
 template <int SIDE>
-RMDK_D void ncc_sums_lds_pipelined(const float* __restrict__ base, int stride, const float (&ax)[SIDE], const float (&ay)[SIDE],
-                                   const float* __restrict__ ref_patch, int ref_stride, float& sum_img, float& sum_img_sq,
+RMDK_D void ncc_sums_lds_pipelined(const float* __restrict__ win_x, const int* __restrict__ row_start, int off_first, int off_second, const float (&ax)[SIDE],
+                                   const float (&ay)[SIDE], const float* __restrict__ ref_patch, int ref_stride, float& sum_img, float& sum_img_sq,
                                    float& sum_img_templ) {
+  // win_x = the window + the footprint's first image column; row_start = the window's row table at the footprint's first row: texel row r of
+  // the footprint starts at win_x[row_start[r]] (a sheared window has no constant row stride).  Entries 0 and 1 come from the caller; entry
+  // r + 2 is requested while row r is worked on -- two rows ahead of the texel reads that need it, so that it costs no wait and two registers.
   float t[2][SIDE + 1], tm[2][SIDE], hprev[SIDE], hcur[SIDE];
+  int off_next = off_second, off_after = 0;
 #pragma unroll
-  for (int c = 0; c <= SIDE; ++c) t[0][c] = base[c];
+  for (int c = 0; c <= SIDE; ++c) t[0][c] = (win_x + off_first)[c];
 #pragma unroll
   for (int r = 0; r <= SIDE; ++r) {
     const int cur = r & 1, nxt = cur ^ 1;
     if (r < SIDE) {
-      const float* row = base + (r + 1) * stride;
+      const float* row = win_x + off_next;  // texel row r + 1
+      if (r + 2 <= SIDE) off_after = row_start[r + 2];
 #pragma unroll
       for (int c = 0; c <= SIDE; ++c) t[nxt][c] = row[c];
 #pragma unroll
       for (int k = 0; k < SIDE; ++k) tm[nxt][k] = ref_patch[r * ref_stride + k];  // template row r, used with texel rows r, r + 1
+      off_next = off_after;
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

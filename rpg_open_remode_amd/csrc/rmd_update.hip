@@ -114,7 +114,7 @@ int batch_launch(rmd_hip_batch* b, unsigned int active, const rmdk::IngestArgs* 
     rmd_hip_batch::Group& G = b->groups[g];
     const unsigned int g_active = (active >> G.first) & ((1u << G.n) - 1u);
     if (!g_active) continue;
-    rmdk::BatchArgs<rmdk::MAX_BATCH> B;
+    rmdk::BatchArgs<rmdk::MAX_GROUP_SEQ> B;
     memset(&B, 0, sizeof(B));
     for (int j = 0; j < G.n; ++j) {
       rmd_hip_seeds* m = b->members[G.first + j];
@@ -149,7 +149,7 @@ int batch_launch(rmd_hip_batch* b, unsigned int active, const rmdk::IngestArgs* 
         B1.seq[0] = B.seq[0];
         HIP_TRY((rmdk::launch_seed_pipeline_compact<SIDE, 1>(B1, 1, G.ws, G.stream, b->num_cus, b->opt_unit_target, ingest ? &in : nullptr)));
       } else {
-        HIP_TRY((rmdk::launch_seed_pipeline_compact<SIDE, rmdk::MAX_BATCH>(B, G.n, G.ws, G.stream, b->num_cus, b->opt_unit_target, ingest ? &in : nullptr)));
+        HIP_TRY((rmdk::launch_seed_pipeline_compact<SIDE, rmdk::MAX_GROUP_SEQ>(B, G.n, G.ws, G.stream, b->num_cus, b->opt_unit_target, ingest ? &in : nullptr)));
       }
       return RMD_HIP_OK;
     });

@@ -37,7 +37,8 @@ def has_gpu():
 # A skipped parity test is a broken parity test: on a GPU run (-m gpu) every skip that is not one of the intended ones fails the session.
 # Intended skips are listed by REASON only (none by test name any more: the retired matchers left the library in round 5).
 INTENDED_GPU_SKIPS = ()
-INTENDED_SKIP_REASONS = ("needs glibc",)  # tests/glibc_parity.py::require_pinned_glibc (never taken on this image)
+INTENDED_SKIP_REASONS = ("needs glibc",  # tests/glibc_parity.py::require_pinned_glibc (never taken on this image)
+                         "needs two HIP devices")  # tests/test_concurrency.py: the second-device variant (the measurement lease has one GPU)
 _unintended_skips = []
 
 

@@ -4,6 +4,8 @@
   OracleLib("ref_rmd", side)   -> oracle/_ref/libremode_ref_rmd_s<side>.so Oracle A with expf/sinf/acosf from csrc/rmd_math.h
   OracleLib("port", side)      -> oracle/libremode_oracle_s<side>.so       Oracle B: our restatement, rmd_math.h transcendentals
   OracleLib("port_libm", side) -> oracle/libremode_oracle_libm_s<side>.so  Oracle B with glibc transcendentals (== A bit for bit)
+  OracleLib("cudalike", 9)     -> oracle/libremode_oracle_cudalike_s9.so   the libm build with run-time switches (set_cudalike) that model the
+                                  reference's real CUDA build: 8-bit texture weights, -use_fast_math; "cudalike_fma": contracted as well
 
 All three expose the same Seeds / Denoiser objects so tests can swap them freely.
 """
@@ -30,6 +32,12 @@ def lib_path(kind, side):
         return os.path.join(ORACLE_DIR, f"libremode_oracle_s{side}.so")
     if kind == "port_libm":
         return os.path.join(ORACLE_DIR, f"libremode_oracle_libm_s{side}.so")
+    if kind == "port_e150":  # Oracle B / Oracle A (shared math) built with RMD_MAX_EXTENT_EPIPOLAR_SEARCH = 150 (side 9 only)
+        return os.path.join(ORACLE_DIR, f"libremode_oracle_e150_s{side}.so")
+    if kind == "ref_rmd_e150":
+        return os.path.join(ORACLE_DIR, "_ref", f"libremode_ref_rmd_e150_s{side}.so")
+    if kind in ("cudalike", "cudalike_fma"):  # Oracle B with run-time switches towards the reference's real CUDA build (side 9 only; remode_oracle.cpp)
+        return os.path.join(ORACLE_DIR, f"libremode_oracle_{kind}_s{side}.so")
     raise ValueError(kind)
 
 
@@ -83,6 +91,8 @@ class OracleLib:
         if not kind.startswith("ref"):
             L.orc_seeds_last_stats.argtypes = [_c_p, _c_p]
             L.orc_set_num_threads.argtypes = [_c_i]
+            L.orc_set_cudalike.argtypes = [_c_i]
+            L.orc_set_cudalike.restype = _c_i
             L.orc_max_threads.restype = _c_i
             for name in ("expf", "sinf", "acosf", "rsqrtf"):
                 fn = getattr(L, "orc_math_" + name)
@@ -95,6 +105,12 @@ class OracleLib:
 
     def fn(self, name):
         return getattr(self.lib, self.prefix + name)
+
+    # switches of the "cudalike" builds (remode_oracle.cpp); a no-op returning False on the other builds
+    TEX8, TEX8_TRUNC, DIV, SQRT, EXP, SIN, SIN_ABS, ACOS, FTZ = 1, 2, 4, 8, 16, 32, 64, 128, 256
+
+    def set_cudalike(self, flags):
+        return bool(self.lib.orc_set_cudalike(int(flags)))
 
     def reduce_sum(self, img):
         img = np.ascontiguousarray(img, np.float32)

@@ -173,3 +173,36 @@ def test_batch_denoise_equals_every_member_denoised_alone(n):
                 assert O.count_mismatch(b[i].pointCloud(den.result()), b[i].pointCloud(b.denoiseResult(i))) == 0
     assert b.denoise(ranges, 0.5, 5, download=False) is None
     assert O.planes_equal(b.denoiseResult(n - 1).getDevData(), b.denoise(ranges, 0.5, 5)[n - 1])
+
+
+@pytest.mark.parametrize("n", [11, 16, 24])
+def test_batches_beyond_eight_members_run_as_three_groups(n):
+    """A launch pair carries at most eight sequences (their parameter blocks are kernel arguments), a batch up to three stream groups of them:
+    11, 16 and 24 members (groups of 4+4+3, 6+5+5, 8+8+8), 8-bit host frames and resident frames alternating, a member sitting a step out --
+    every member against Oracle B on every plane, and TV-L1 for all of them in one launch sequence against the stand-alone denoiser."""
+    side = 5
+    seqs = [sequence(171, 113, 9, scene) for scene in range(n)]
+    b = _batch(seqs, side)
+    orcs = [_oracle(seq, side) for seq in seqs]
+    dev = [_device_frames(seq) for seq in seqs]
+    for k in range(1, 9):
+        skip = k % n if k in (3, 6) else -1  # this member has no frame in this step
+        if k % 2:
+            b.updateU8([None if i == skip else seq.gray[k] for i, seq in enumerate(seqs)], [seq.T_curr_world[k] for seq in seqs])
+        else:
+            b.updateDevice([None if i == skip else d[k].data for i, d in enumerate(dev)], [d[k].stride for d in dev], [seq.T_curr_world[k] for seq in seqs])
+        for i, (o, seq) in enumerate(zip(orcs, seqs)):
+            if i != skip:
+                o.update(seq.images[k], seq.T_curr_world[k])
+        if k in (1, 4, 8):
+            for i in range(n):
+                assert_states_equal(orcs[i].state(), b[i].state(), f"batch of {n}, member {i}, step {k}")
+                assert b[i].getConvergedCount() == orcs[i].converged_count()
+    ranges = [seq.max_depth - seq.min_depth for seq in seqs]
+    got = b.denoise(ranges, 0.5, 21)
+    for i in (0, n // 2, n - 1):
+        den = api.DepthmapDenoiser(seqs[i].width, seqs[i].height)
+        den.setLargeSigmaSq(ranges[i])
+        assert O.planes_equal(den.denoise(b[i].getMu(), b[i].getSigmaSq(), b[i].getA(), b[i].getB(), 0.5, 21), got[i])
+    with pytest.raises(api.RmdHipError):
+        api.SeedMatrixBatch(25, 64, 48, api.PinholeCamera(*seqs[0].K), patch_side=side)

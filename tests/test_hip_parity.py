@@ -632,3 +632,45 @@ def test_float_frames_of_8bit_levels_travel_as_bytes_and_mix_with_other_floats(s
             got = host.download(api.PLANE_CURR_IMG)
             assert np.array_equal(got.view(np.uint32), frames[k].view(np.uint32)), f"current image after frame {k}"
     assert_states_equal(res.state(), host.state(), "float host frames of mixed kinds")
+
+
+@pytest.mark.parametrize("matcher", MATCHERS)
+def test_max_extent_150_equals_the_reference_built_with_that_extent(matcher):
+    """RMD_MAX_EXTENT_EPIPOLAR_SEARCH is a compile-time constant of the reference that its CMakeLists leaves to the user (CMakeLists.txt:52-53);
+    here it is a constructor argument (1..178).  With the prior variance inflated (3 sigma beyond the depth range on both sides) every search is
+    capped: 150 pixels = 215 steps per seed, step numbers and counts far beyond the 143 of the default extent -- against Oracle B and the
+    reference's own sources, both built with -DRMD_MAX_EXTENT_EPIPOLAR_SEARCH=150.  A batch of two members takes the same argument."""
+    full = sequence(320, 240, 41)
+    rng = full.max_depth - full.min_depth
+    wide = np.full((full.height, full.width), 4.0 * rng * rng, np.float32)
+    kinds = ["port_e150"] + (["ref_rmd_e150"] if O.available("ref_rmd_e150", 9) else [])
+    for kind in kinds:
+        hip = api.SeedMatrix(full.width, full.height, api.PinholeCamera(*full.K), patch_side=9, max_extent=150)
+        apply_matcher(hip, matcher)
+        orc = _oracle_seeds(kind, full, 9)
+        hip.setReferenceImage(full.images[0], full.T_curr_world[0], full.min_depth, full.max_depth)
+        orc.set_reference(full.images[0], full.T_curr_world[0], full.min_depth, full.max_depth)
+        hip.upload(O.PLANE_SIGMA_SQ, wide)
+        orc.upload(O.PLANE_SIGMA_SQ, wide)
+        for n, k in enumerate((4, 8, 12, 16), 1):
+            hip.update(full.images[k], full.T_curr_world[k])
+            orc.update(full.images[k], full.T_curr_world[k])
+            assert_states_equal(orc.state(), hip.state(), f"max_extent 150, {kind}, matcher {matcher}, update {n}")
+            if kind.startswith("port"):
+                st = orc.last_stats()
+                assert st["steps"] == 215 * st["live_seeds"] and st["ncc_evals"] > 150 * st["live_seeds"], st  # every search capped at 150 px, most of it in the image
+    b = api.SeedMatrixBatch(2, full.width, full.height, api.PinholeCamera(*full.K), patch_side=9, max_extent=150)
+    orcs = [_oracle_seeds("port_e150", full, 9) for _ in range(2)]
+    for i in range(2):
+        b[i].setReferenceImage(full.images[4 * i], full.T_curr_world[4 * i], full.min_depth, full.max_depth)
+        orcs[i].set_reference(full.images[4 * i], full.T_curr_world[4 * i], full.min_depth, full.max_depth)
+        b[i].upload(O.PLANE_SIGMA_SQ, wide)
+        orcs[i].upload(O.PLANE_SIGMA_SQ, wide)
+    for k in (8, 12, 16):
+        b.update([full.images[k], full.images[k + 4]], [full.T_curr_world[k], full.T_curr_world[k + 4]])
+        orcs[0].update(full.images[k], full.T_curr_world[k])
+        orcs[1].update(full.images[k + 4], full.T_curr_world[k + 4])
+    for i in range(2):
+        assert_states_equal(orcs[i].state(), b[i].state(), f"batch member {i}, max_extent 150")
+    with pytest.raises(api.RmdHipError):
+        api.SeedMatrix(64, 48, api.PinholeCamera(*full.K), patch_side=9, max_extent=179)

@@ -216,3 +216,39 @@ def test_reference_with_system_libm_equals_reference_with_shared_math(side):
         assert_states_equal(r, p, f"side {side} update {k + 1}: glibc build vs shared-math build of the reference")
     n = seq.width * seq.height
     assert (ref[-1][O.PLANE_CONV] == O.CONVERGED).sum() > 0.05 * n
+
+
+@needs_ref
+def test_cudalike_model_with_every_switch_off_is_the_reference():
+    """The model of the reference's real CUDA build (remode_oracle.cpp, tests/cudalike_tolerance.py) routes every division, square root,
+    transcendental and texture fetch through a hook: with all switches off those hooks are the plain operations, i.e. that build equals Oracle A
+    bit for bit (states through convergence, adversarial states, TV-L1) -- which is what makes its switched-on runs a statement about the
+    reference.  Each switch alone moves the result (none is dead), flush-to-zero excepted: the path produces no subnormals on this input."""
+    seq = sequence(160, 120, 30)
+    _, ref = _run("ref", 9, seq, 29)
+    lib = O.OracleLib("cudalike", 9)
+    assert lib.set_cudalike(0)
+    s, got = _run("cudalike", 9, seq, 29)
+    for k in (0, 7, 28):
+        assert_states_equal(ref[k], got[k], f"cudalike(0) vs reference, update {k + 1}")
+    rng = np.random.default_rng(99)
+    seq4 = sequence(192, 144, 4)
+    st0 = random_state(seq4.width, seq4.height, seq4, rng, 9)
+    _, ref4 = _run("ref", 9, seq4, 3, state0=st0)
+    _, got4 = _run("cudalike", 9, seq4, 3, state0=st0)
+    assert_states_equal(ref4[-1], got4[-1], "cudalike(0) vs reference, adversarial states")
+    sr, _ = _run("ref", 9, seq, 29)
+    dr, dg = O.Denoiser(O.OracleLib("ref", 9), seq.width, seq.height), O.Denoiser(lib, seq.width, seq.height)
+    for d in (dr, dg):
+        d.set_large_sigma_sq(seq.max_depth - seq.min_depth)
+    assert O.planes_equal(dr.denoise(sr, 0.5, 40), dg.denoise(s, 0.5, 40))
+    moved = {}
+    for name in ("TEX8", "TEX8_TRUNC", "DIV", "SQRT", "EXP", "SIN", "SIN_ABS", "ACOS"):
+        lib.set_cudalike(getattr(O.OracleLib, name))
+        try:
+            _, sw = _run("cudalike", 9, seq, 12)
+        finally:
+            lib.set_cudalike(0)
+        moved[name] = O.count_mismatch(got[11][O.PLANE_MU], sw[11][O.PLANE_MU])
+    assert all(v > 0 for v in moved.values()), moved
+    assert not O.OracleLib("port_libm", 9).set_cudalike(1)  # the other builds have no such switch

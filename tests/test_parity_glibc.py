@@ -53,3 +53,39 @@ def test_config1_equals_the_untouched_reference():
     assert hip.getConvergedCount() == ref.converged_count() and r["converged_in_both"] > 0.5 * r["pixels"]
     assert r["converged_mask_mismatches"] == 0 and r["convergence_state_mismatches"] == 0
     assert r["depth_rmse_all_seeds_m"] == 0.0 and r["denoised_rmse_m"] == 0.0 and r["depth_frac_bit_identical"] == 1.0
+
+
+def test_config3_scenes_1_to_7_equal_the_untouched_reference_end_to_end():
+    """BASELINE configs[3]: eight independent 640x480 sequences (scenes 0..7).  Scene 0 is the test above; here scenes 1..7 are followed by
+    Oracle A (the reference's own kernels, system libm) over ALL 199 updates, stepped as ONE batch of seven on the device: every state plane
+    of every member after the last update, the converged counts along the way, and TV-L1 (0.5, 200) of all seven maps in one launch sequence."""
+    glibc_parity.require_pinned_glibc()
+    if not O.available("ref", 9):
+        pytest.skip("oracle/_ref not present")
+    from rpg_open_remode_amd import synth
+    W, H, F, scenes = 640, 480, 200, list(range(1, 8))
+    olib = O.OracleLib("ref", 9)
+    K = synth.intrinsics(W, H)
+    b = api.SeedMatrixBatch(len(scenes), W, H, api.PinholeCamera(*K), patch_side=9)
+    refs, seqs = [], []
+    for i, sc in enumerate(scenes):  # (one scene at a time in host memory: a rendered sequence is 250 MB)
+        seqs.append(synth.Sequence(W, H, F, sc))
+    for i, seq in enumerate(seqs):
+        r = O.Seeds(olib, W, H, K)
+        r.set_reference(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+        b[i].setReferenceImage(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+        refs.append(r)
+    for k in range(1, F):
+        b.update([s.images[k] for s in seqs], [s.T_curr_world[k] for s in seqs])
+        for i, s in enumerate(seqs):
+            refs[i].update(s.images[k], s.T_curr_world[k])
+        if k in (5, 60, 140):
+            for i in range(len(scenes)):
+                assert b[i].getConvergedCount() == refs[i].converged_count(), (scenes[i], k)
+    dens = b.denoise([s.max_depth - s.min_depth for s in seqs], 0.5, 200)
+    for i, s in enumerate(seqs):
+        assert_states_equal(refs[i].state(), b[i].state(), f"scene {scenes[i]}: HIP (batch member) vs the reference (system libm) after 199 updates")
+        rd = O.Denoiser(olib, W, H)
+        rd.set_large_sigma_sq(s.max_depth - s.min_depth)
+        assert O.planes_equal(rd.denoise(refs[i], 0.5, 200), dens[i]), f"scene {scenes[i]}: TV-L1"
+        assert refs[i].converged_count() > 0.5 * W * H
