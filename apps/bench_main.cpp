@@ -9,9 +9,8 @@
 // in three frame modes: "u8" (the headline: every frame an 8-bit image in pageable host memory, rmd_hip_seeds_update_u8), "resident" (frames in
 // HBM, read in place, rmd_hip_seeds_update_device) and "float" (rmd::SeedMatrix::update(float*), the reference's own signature).  Prints one
 // JSON line per mode: Mpix/s, us per update (wall and device), host CPU seconds of the process over the region (getrusage: all threads) and
-// the wall time per update() until the call returned.  --host-only: the same host work against a handle whose update kernels are never
-// launched is not possible through the ABI; instead --ranks-probe N forks N processes that run the u8 mode concurrently (one GPU or several) and
-// reports each one's rate and CPU time -- what eight ranks cost the host.
+// the wall time per update() until the call returned.  --ranks-probe N forks N processes that run the u8 mode concurrently (scenes 0..N-1, device
+// rank % device_count) and reports each one's rate and CPU time: what N ranks cost the host (profiles/r05_nranks/).
 //
 // Build: rpg_open_remode_amd/build.py::build_apps (g++, links librmd_hip.so and librmd_synth.so).  Nothing here touches oracle/.
 #include <rmd/seed_matrix.cuh>
@@ -88,11 +87,13 @@ Sequence render(int w, int h, int n, unsigned scene, bool want_float) {
 }
 
 struct Result { double wall_s, device_ms, cpu_s, submit_s; long updates; size_t converged; };
+int g_unit_target = 0;  // --unit-target: RMD_HIP_OPT_UNIT_TARGET (0: the library's default)
 
 Result run_mode(const Sequence& q, const std::string& mode, int steps, int warmup) {
   rmd::PinholeCamera cam(static_cast<float>(q.K[0]), static_cast<float>(q.K[1]), static_cast<float>(q.K[2]), static_cast<float>(q.K[3]));
   rmd::SeedMatrix seeds(q.w, q.h, cam);
   rmd_hip_seeds_t* h = seeds.handle();
+  if (g_unit_target > 0) check(rmd_hip_seeds_set_option(h, RMD_HIP_OPT_UNIT_TARGET, g_unit_target), "set_option");
   std::vector<rmd_hip_image_t*> dev;
   std::vector<const float*> dev_ptr;
   size_t dev_stride = 0;
@@ -157,6 +158,7 @@ void print_line(const Sequence& q, const std::string& mode, int steps, int warmu
 
 int main(int argc, char** argv) {
   int w = 640, h = 480, frames = 200, steps = 5, warmup = 1, scene = 0, ranks = 0, threads = 4;
+  g_unit_target = 0;
   std::string modes = "u8,resident";
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
@@ -169,6 +171,7 @@ int main(int argc, char** argv) {
     else if (a == "--modes") modes = next();
     else if (a == "--ranks-probe") ranks = atoi(next());
     else if (a == "--render-threads") threads = atoi(next());
+    else if (a == "--unit-target") g_unit_target = atoi(next());
     else { fprintf(stderr, "usage: bench_main [--size WxH] [--frames F] [--steps K] [--warmup W] [--scene S] [--modes u8,resident,float] [--ranks-probe N]\n"); return 1; }
   }
   rmd_synth_set_threads(threads);

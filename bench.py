@@ -76,7 +76,7 @@ def parse():
     ap.add_argument("--tv-iters", type=int, default=0, help="TV-L1 iterations of the separately reported denoise (default 200; 500 at 1920x1080)")
     ap.add_argument("--resident", action="store_true", help="timed region with the frames already resident in HBM (rmd_hip_seeds_update_device) instead "
                     "of 8-bit frames from host memory; the line says so")
-    ap.add_argument("--batch", default="2,4,8", help="batch sizes of the batched_per_gpu section (empty: skip it)")
+    ap.add_argument("--batch", default="2,4,8,16", help="batch sizes of the batched_per_gpu section (empty: skip it)")
     ap.add_argument("--batch-per-gpu", type=int, default=1, help="B independent sequences per rank, stepped as ONE batch (rmd_hip_batch_*): rank r runs scenes "
                     "r*B .. r*B+B-1; the headline stays whole-job pixels / max elapsed.  Default 1: one sequence per GPU (the driver's BENCH / SCALE lines)")
     ap.add_argument("--dist", action="store_true", help="create the torch.distributed (RCCL) group even for a single rank")

@@ -90,7 +90,7 @@ typedef struct rmd_hip_batch rmd_hip_batch_t;
 #define RMD_HIP_TUNE_FUSED_INGEST 6   /* 1 (default): host frames are converted by the update's own kernels; 0: upload + conversion kernel on the copy stream */
 #define RMD_HIP_TUNE_INGEST_PROFILE 7 /* 1: a handle prints the host time per frame it spent waiting / copying / submitting when it is destroyed */
 #define RMD_HIP_TUNE_HOST_WAIT 8      /* how update() waits for a free slot of its pinned frame ring (the device is up to three frames behind the caller): 1
-                                         (default) = spin for 5 us, then sleep in steps of ~15 us (the waiting thread's timer slack is set to 2 us);
+                                         (default) = spin for 2 us, then sleep in steps of ~15 us (the waiting thread's timer slack is set to 2 us);
                                          0 = spin only (one core per handle that is fed host frames at full speed) */
 #define RMD_HIP_NUM_TUNABLES 9
 int rmd_hip_set_tunable(int tunable, int value);

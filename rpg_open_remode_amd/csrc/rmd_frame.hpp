@@ -796,17 +796,22 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
   if (keeper && tid < UNIT_SHARDS) M.handout[tid * HANDOUT_STRIDE] = 0u;  // the search kernel's hand-out counters
   if (keeper && tid == 0) M.queue[5] = static_cast<unsigned int>(unit_items);
   if (tid == 0) M.tile_conv[tile_g] = static_cast<unsigned int>(red_c[0] + red_c[1] + red_c[2] + red_c[3]);
-  // the tile's box of this frame (uniform: every thread reads the four waves' partial results)
-  const int tx0 = min(min(red_b[0][0], red_b[1][0]), min(red_b[2][0], red_b[3][0])), ty0 = min(min(red_b[0][1], red_b[1][1]), min(red_b[2][1], red_b[3][1]));
-  const int tx1 = max(max(red_b[0][2], red_b[1][2]), max(red_b[2][2], red_b[3][2])), ty1 = max(max(red_b[0][3], red_b[1][3]), max(red_b[2][3], red_b[3][3]));
-  const bool box = window_fits(tx0, ty0, tx1, ty1);
+  // the tile's box of this frame: needed by the lanes that write a unit entry and by lane 0 (the tile's word)
+  const int n_units_tile = total > 0 ? units_of(total, unit_rounds) : 0;
+  int tx0 = 0, ty0 = 0, tx1 = -1, ty1 = -1;
+  bool box = false;
+  if (tid == 0 || tid < n_units_tile) {
+    tx0 = min(min(red_b[0][0], red_b[1][0]), min(red_b[2][0], red_b[3][0])); ty0 = min(min(red_b[0][1], red_b[1][1]), min(red_b[2][1], red_b[3][1]));
+    tx1 = max(max(red_b[0][2], red_b[1][2]), max(red_b[2][2], red_b[3][2])); ty1 = max(max(red_b[0][3], red_b[1][3]), max(red_b[2][3], red_b[3][3]));
+    box = window_fits(tx0, ty0, tx1, ty1);
+  }
   if (tid == 0)  // seeds in state UPDATE after this frame's check | does the NEXT frame's setup reduce a band for this tile?
     M.tile_live[tile_g] = static_cast<unsigned int>(red_l[0] + red_l[1] + red_l[2] + red_l[3]) | (total > 0 && !box ? TILE_WANTS_BAND : 0u);
   if (P.trace && tid == 0)  // word 2 of the tile's slot: start (low 32 bits of the 10 ns clock), state ready and end relative to it
     P.trace[static_cast<size_t>(tile) * FR_TRACE_WORDS + 2] = (t_start & 0xffffffffull) | (((t_loaded - t_start) & 0xffffull) << 32) |
                                                              (((wall_clock64() - t_start) & 0xffffull) << 48);
   if (total == 0) return;
-  const int n_u = units_of(total, unit_rounds);
+  const int n_u = n_units_tile;
   if (tid == 0) {
     const unsigned long long old = atomicAdd(&M.shards_cur[tile_g % UNIT_SHARDS], (static_cast<unsigned long long>(total) << 32) | static_cast<unsigned long long>(n_u));
     s_base = static_cast<unsigned int>(old);  // units reserved so far in this shard
@@ -819,9 +824,10 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
     // search kernel cuts windows to each unit's own samples (along the same shear, which travels with the unit either way)
     const bool band = !box && want_band && m_tile != 0 && window_fits(u0, y0, u1, y1);
     const int wx0 = box ? x0 : u0, ww = (box ? x1 : u1) - wx0 + 1, rows = y1 - y0 + 1, m = box ? 0 : m_tile;
+    const bool whole = box || band;  // (leaving a LARGE tile window that many one-round units share to the units -- each cuts its own -- gains nothing: LAB.md)
     M.units[static_cast<size_t>(tile_g % UNIT_SHARDS) * M.shard_cap + s_base + tid] =
-        make_uint4(static_cast<unsigned int>(tile_g), static_cast<unsigned int>(tid * unit_items) | (box || band ? UNIT_TILE_BOX : 0u),
-                   box || band ? unit_pack_origin(wx0, y0) : 0u, unit_pack_shape(box || band ? rows : 0, box || band ? ww : 0, m));
+        make_uint4(static_cast<unsigned int>(tile_g), static_cast<unsigned int>(tid * unit_items) | (whole ? UNIT_TILE_BOX : 0u),
+                   whole ? unit_pack_origin(wx0, y0) : 0u, unit_pack_shape(whole ? rows : 0, whole ? ww : 0, m));
   }
 }
 

@@ -175,7 +175,7 @@ static int ingest_frame(rmd_hip_seeds* s, const unsigned char* host_gray, const 
 // Wait (on the host, without touching the device) until the setup kernel of step `need` has started, as reported through the pinned word
 // `progress`: the staging buffers of SLOTS steps ago are free then.  Numbers are compared modulo 2^32 like the kernel's test.
 // The word is written by the DEVICE (a store of the setup kernel into pinned memory): there is nothing a futex or a condition variable could
-// be woken by.  So: a polite spin for the first 5 us (the usual wait when the host is barely ahead), then short sleeps -- the caller is up
+// be woken by.  So: a polite spin for the first 2 us (the usual wait when the host is barely ahead), then short sleeps -- the caller is up
 // to three frames (>= 100 us of device work) ahead of the kernel it waits for, an overslept wake-up of a few microseconds stalls nothing, and a
 // rank's host thread no longer burns a whole core while the device works (eight ranks share the 16 CPUs of the measurement box's quota:
 // profiles/r05_nranks/).  Linux rounds a sleep up by the thread's timer slack (50 us by default): the waiting thread's slack is set to
@@ -192,7 +192,7 @@ int wait_for_progress(volatile unsigned int* progress, unsigned int need, hipStr
         HIP_TRY(hipStreamSynchronize(stream));
         break;
       }
-      if (may_sleep && waited > 5.0) {
+      if (may_sleep && waited > 2.0) {
         static thread_local bool slack_set = false;
         if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 2000UL, 0UL, 0UL, 0UL); slack_set = true; }
         timespec ts = {0, 8000};  // 8 us + the slack + the scheduler's wake-up: 15-20 us in practice

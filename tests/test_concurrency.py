@@ -27,10 +27,9 @@ def _device_count():
     return n.value
 
 
-def _run_all(device, concurrent):
+def _run_all(device, concurrent, seqs):
     import ctypes
     from rpg_open_remode_amd import _lib
-    seqs = {s: synth.Sequence(W, H, F, s) for s in range(6)}
     cam = api.PinholeCamera(*seqs[0].K)
     results, errors = {}, []
 
@@ -91,8 +90,9 @@ def _run_all(device, concurrent):
 
 
 def _check(device):
-    alone = _run_all(device, concurrent=False)
-    together = _run_all(device, concurrent=True)
+    seqs = {s: synth.Sequence(W, H, F, s) for s in range(6)}  # (rendered once: 6 x 61 frames)
+    alone = _run_all(device, False, seqs)
+    together = _run_all(device, True, seqs)
     for scene in (0, 1):
         assert_states_equal(alone[("single", scene)][0], together[("single", scene)][0], f"single sequence, scene {scene}: alone vs among three other handles")
         assert alone[("single", scene)][1] == together[("single", scene)][1]
@@ -102,7 +102,7 @@ def _check(device):
         assert O.planes_equal(a, b)
     assert all(O.planes_equal(alone[("denoise",)][0], x) for x in alone[("denoise",)][1:])
     # and the stand-alone results are the oracle's (scene 0, every plane)
-    seq = synth.Sequence(W, H, F, 0)
+    seq = seqs[0]
     orc = O.Seeds(O.OracleLib("port", 9), W, H, seq.K)
     orc.set_reference(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
     for k in range(1, F):

@@ -1,7 +1,7 @@
 """The compiled update kernels stay inside the budgets their performance depends on (CPU test: reads the gfx950 code objects inside
 librmd_hip.so with the LLVM tools of the ROCm image; nothing runs).
 
-DESIGN.md 4.1 measured each of these as a first-order quantity: the search kernel must fit four workgroups per CU (<= 128 VGPRs, no scratch),
+DESIGN.md 4.1 measured each of these as a first-order quantity: the search kernel must fit four workgroups per CU and leave room for a setup wave beside them (<= 112 VGPRs, no scratch),
 its code must stay resident in the instruction cache two CUs share (a build of 10 500 instructions ran 17 % slower), scalar spills are vector
 instructions at every workgroup's entry, and the LDS window is staged LDS-direct (global_load_lds_dword: one memory round trip per window)."""
 import os
@@ -63,7 +63,8 @@ def _symbol_size(co, prefix):
 @pytest.mark.parametrize("kernel", [SEARCH, SEARCH_BATCH])
 def test_search_kernel_fits_four_workgroups_per_cu(code_object, kernel):
     md = _metadata(code_object, kernel)
-    assert md["vgpr_count"] <= 128, md          # 512 VGPRs per SIMD / 4 waves
+    assert md["vgpr_count"] <= 112, md          # 512 VGPRs per SIMD / 4 waves = 128; at <= 112 ALLOCATED registers (granule 8) four search waves leave 64 for a
+                                                # setup wave (56) of another stream group of a batch: at 116 (120 allocated) a batch of 8 lost 5 % (LAB.md, round 5)
     assert md["vgpr_spill_count"] == 0 and md["private_segment_fixed_size"] == 0, md  # no scratch
     assert md["sgpr_spill_count"] <= 64, md     # every spilled scalar is a v_writelane / v_readlane pair somewhere hot (138 at the start of round 4)
     assert md["group_segment_fixed_size"] == 0  # the 36.3 KB window + descriptors are dynamic LDS (4 x 36.3 KB <= 160 KB per CU)

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): supporting evidence of round 4 next to tools/profile_r04.sh -- the other BASELINE sizes, batched mode
+# Runs on the GPU box (via gpurun): supporting evidence of a round next to tools/profile_round.sh -- the other BASELINE sizes, batched mode
 # (stream groups, TV-L1 for all members), N ranks x B sequences on the one-GPU lease, live use, the reference's own programs on the
-# library, the retired matchers.  Output: gpurun_out/summary_<tag>/.   usage: tools/evidence_r04.sh <tag> [parts]
+# library, the retired matchers.  Output: gpurun_out/summary_<tag>/.   usage: tools/evidence_round.sh <tag> [parts]
 set -u
-TAG=${1:-r04}; PARTS=${2:-sizes,batch,live,ref,nranks,abmatch,first}
+TAG=${1:-r05}; PARTS=${2:-sizes,batch,live,ref,nranks,first}
 export TMPDIR=/tmp
 ROOT=$(pwd)
 SUM=$ROOT/gpurun_out/summary_$TAG
@@ -16,10 +16,10 @@ if [[ $PARTS == *sizes* ]]; then
 fi
 if [[ $PARTS == *batch* ]]; then
   echo "== batched mode: stream groups (same scene for every member), host frames"
-  { echo "# python tools/batch_bench.py --same-scene (default: up to three stream groups)"; python tools/batch_bench.py --b 1,2,3,4,6,8 --same-scene --passes 2 2>&1 | grep flags
+  { echo "# python tools/batch_bench.py --same-scene (default: up to three stream groups)"; python tools/batch_bench.py --b 1,2,3,4,6,8,12,16,24 --same-scene --passes 2 2>&1 | grep flags
     echo "# RMD_HIP_BATCH_GROUPS=1 (one launch pair for all members)"; RMD_HIP_BATCH_GROUPS=1 python tools/batch_bench.py --b 2,4,8 --same-scene --passes 2 2>&1 | grep flags
     echo "# RMD_HIP_BATCH_GROUPS=2"; RMD_HIP_BATCH_GROUPS=2 python tools/batch_bench.py --b 4,8 --same-scene --passes 2 2>&1 | grep flags
-    echo "# scenes 0..B-1, frames resident / 8-bit host frames"; python tools/batch_bench.py --b 1,2,4,8 --passes 3 2>&1 | grep flags; python tools/batch_bench.py --b 4,8 --passes 3 --u8 2>&1 | grep flags
+    echo "# scenes 0..B-1, frames resident / 8-bit host frames"; python tools/batch_bench.py --b 1,2,4,8,16 --passes 3 2>&1 | grep flags; python tools/batch_bench.py --b 4,8,16 --passes 3 --u8 2>&1 | grep flags
   } > "$SUM/${TAG}_batch_ab.txt" 2>&1; cat "$SUM/${TAG}_batch_ab.txt"
 fi
 if [[ $PARTS == *first* ]]; then
@@ -48,11 +48,5 @@ if [[ $PARTS == *nranks* ]]; then
   timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29613 bench.py --gpus 2 --batch-per-gpu 4 --steps 3 --warmup 1 --no-extras > "$SUM/${TAG}_nranks/two_ranks_x_four_sequences_one_gpu.json" 2> "$SUM/${TAG}_nranks/two_ranks_x4.err"; cut -c1-160 "$SUM/${TAG}_nranks/two_ranks_x_four_sequences_one_gpu.json"
   echo "-- one rank x eight sequences (--batch-per-gpu 8)"
   timeout 600 python bench.py --batch-per-gpu 8 --steps 3 --warmup 1 --no-extras > "$SUM/${TAG}_nranks/one_rank_x_eight_sequences.json" 2> "$SUM/${TAG}_nranks/one_rank_x8.err"; cut -c1-160 "$SUM/${TAG}_nranks/one_rank_x_eight_sequences.json"
-fi
-if [[ $PARTS == *abmatch* ]]; then
-  echo "== retired matchers (A/B build of the library, build_ab/librmd_hip_ab.so, selected with RMD_HIP_LIB): parity test of variants 1, 2, 21"
-  if [ -f build_ab/librmd_hip_ab.so ]; then
-    RMD_HIP_LIB=$ROOT/build_ab/librmd_hip_ab.so python -m pytest tests/test_hip_parity.py -m gpu -q -k "other_matchers" 2>&1 | tail -2 | tee "$SUM/${TAG}_ab_matchers_parity.txt"
-  fi
 fi
 ls -la "$SUM"

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): the round-4 measurement set.  Raw rocprofv3 output under gpurun_out/prof_<tag>/,
+# Runs on the GPU box (via gpurun): a round's measurement set (rounds 4 and 5).  Raw rocprofv3 output under gpurun_out/prof_<tag>/,
 # compact summaries (what gets committed under profiles/) under gpurun_out/summary_<tag>/.
-# usage: tools/profile_r04.sh <tag> [parts: bench,trace,restrace,pmc,tv1080]
+# usage: tools/profile_round.sh <tag> [parts: bench,trace,restrace,pmc,tv1080]
 set -u
-TAG=${1:-r04}; PARTS=${2:-bench,trace,restrace,pmc,tv1080}
+TAG=${1:-r05}; PARTS=${2:-bench,trace,restrace,pmc,tv1080}
 export TMPDIR=/tmp
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
