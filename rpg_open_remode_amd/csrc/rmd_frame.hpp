@@ -11,12 +11,13 @@
 //                        comes from the previous frame's total work.  It also counts the seeds it found CONVERGED (per tile).
 //                        A few extra workgroups bring frames that were handed over in host memory into the current-image plane.
 //   seed_search_compact  persistent workgroups (4 per CU) take unit blockIdx.x of the sixteen lists read as one list and pull
-//                        further units with one returning atomic each.  Per unit the LDS window of the current image is cut to
-//                        the unit's own samples (38 KB of LDS per workgroup); one NCC evaluation per (seed, step) pair and lane
-//                        with the separable, software-pipelined filter block of rmd_matcher.hpp; arg-max per seed with a 64-bit
-//                        LDS atomic max on {orderable(ncc), ~step}, handed to the global key plane when the workgroup changes
-//                        tile.  Its last workgroup adds up the per-tile CONVERGED counts and mirrors them to pinned host memory
-//                        (getConvergedCount without a device synchronisation).
+//                        further units with one returning atomic each.  The LDS window of the current image (5 632 texels) is a BAND
+//                        sheared along the tile's epipolar direction (a box when the samples fit one): the window of all samples
+//                        of the tile when the setup kernel found one, else cut to the unit's own samples; one NCC evaluation per
+//                        (seed, step) pair and lane with the separable, software-pipelined filter block of rmd_matcher.hpp; arg-max
+//                        per seed with a 64-bit LDS atomic max on {orderable(ncc), ~step}, handed to the global key plane when the
+//                        workgroup changes tile.  Its last workgroup adds up the per-tile CONVERGED counts and mirrors them to
+//                        pinned host memory (getConvergedCount without a device synchronisation).
 //
 // Tiles are numbered sequence-major (tile_global = seq * n_tiles + tile): unit lists, shard counters and the persistent search
 // workgroups are shared by all sequences of a launch; everything per sequence (planes, poses, the pending finalisation, the
@@ -640,7 +641,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
   // A tile whose samples did not fit a BOX-shaped window one frame ago (a bundle of long diagonal segments) gets a sheared band this frame;
   // everybody else -- nearly every tile of nearly every frame -- pays nothing for the machinery: no slope, no second pair of reductions.  (The
   // first frame on which a tile's box does not fit goes to the search kernel's own window policy, as before round 5.)
-  const bool want_band = LAB_SHEAR_HINT((tile_word & TILE_WANTS_BAND) != 0u);
+  const bool want_band = LAB_WANT_BAND((tile_word & TILE_WANTS_BAND) != 0u);
   // the seed's state: requested before anything else, so that the scalar-load chains below (kernel arguments, the previous frame's
   // counters) run while these are in flight
   if (dead_tile && !(tile == 0 && seq == M.housekeeper)) return;  // (the keeper goes on: its loads are as harmless as they were)

@@ -9,9 +9,9 @@
 
 // A/B of the round-5 sheared window (tools/ab_make.sh noshear "-DRMD_LAB_NO_SHEAR"): no tile ever asks for a band, i.e. all windows are boxes
 #ifdef RMD_LAB_NO_SHEAR
-#define LAB_SHEAR_HINT(m) false
+#define LAB_WANT_BAND(flag) false
 #else
-#define LAB_SHEAR_HINT(m) (m)
+#define LAB_WANT_BAND(flag) (flag)
 #endif
 
 #ifdef RMD_LAB_PROFILE_ROUNDS

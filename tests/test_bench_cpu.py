@@ -76,7 +76,7 @@ def test_committed_counters_belong_to_the_committed_kernels():
     b, _ = _bench([])
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     if t.get("kernel_source_sha256") != b.kernel_source_sha256():
-        pytest.skip("kernel sources changed since the last PMC pass (tools/profile_r03.sh): bench.py reports roofline_valu as stale")
+        pytest.skip("kernel sources changed since the last PMC pass (tools/profile_round.sh): bench.py reports roofline_valu as stale")
     assert b.valu_roofline(46e-6, t)["frac"] > 0.1
 
 

@@ -74,7 +74,7 @@ def test_config3_scenes_1_to_7_equal_the_untouched_reference_end_to_end():
         pytest.skip("oracle/_ref not present")
     from rpg_open_remode_amd import synth
     W, H, F, scenes, checks = 640, 480, 200, list(range(1, 8)), (5, 60, 140, 199)
-    olib = O.OracleLib("ref", 9)
+    olib, portlib = O.OracleLib("ref", 9), O.OracleLib("port_libm", 9)
     K = synth.intrinsics(W, H)
     seqs = [synth.Sequence(W, H, F, sc) for sc in scenes]
     want = []
@@ -86,9 +86,16 @@ def test_config3_scenes_1_to_7_equal_the_untouched_reference_end_to_end():
             r.update(seq.images[k], seq.T_curr_world[k])
             if k in checks:
                 counts[k] = r.converged_count()
-        rd = O.Denoiser(olib, W, H)
+        # TV-L1 of the reference's final state: through Oracle B's denoiser, which equals the reference's own TV kernel bit for bit
+        # (test_oracle_pin.py::test_denoiser_port_equals_reference_kernel_bit_for_bit; scene 0 above runs the reference's kernel itself) -- Oracle A
+        # emulates that kernel's barrier with one fibre per CUDA thread and its blocks serially: 70 s per 640x480 map
+        st = r.state()
+        rd = O.Denoiser(portlib, W, H)
         rd.set_large_sigma_sq(seq.max_depth - seq.min_depth)
-        want.append({"counts": counts, "state": r.state(), "denoised": rd.denoise(r, 0.5, 200)})
+        den = np.empty((H, W), np.float32)
+        planes = [np.ascontiguousarray(st[p], np.float32) for p in (O.PLANE_MU, O.PLANE_SIGMA_SQ, O.PLANE_A, O.PLANE_B)]
+        assert portlib.lib.orc_denoiser_denoise_planes(rd.ptr, *[p.ctypes.data for p in planes], den.ctypes.data, 0.5, 200) == 0
+        want.append({"counts": counts, "state": st, "denoised": den})
         rd.close()
         r.close()
     b = api.SeedMatrixBatch(len(scenes), W, H, api.PinholeCamera(*K), patch_side=9)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json from the PMC passes of tools/profile_r02.sh: HBM-side bytes and VALU wave-instructions per update()
+"""profiles/traffic.json from the PMC passes of tools/profile_round.sh: HBM-side bytes and VALU wave-instructions per update()
 (means over the update() calls of ONE complete pass of the 200-frame sequence), TV-L1 bytes per launch.
 usage: make_traffic.py <raw_dir> <out.json>"""
 import csv, glob, json, os, sys
@@ -43,7 +43,7 @@ def kernel_source_sha256():
 
 
 W, H, UPDATES = 640, 480, 199
-res = {"source": "rocprofv3 --pmc passes of `python bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-extras` (tools/profile_r04.sh): one complete pass "
+res = {"source": "rocprofv3 --pmc passes of `python bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-extras` (tools/profile_round.sh): one complete pass "
                  "of configs[1] (setReferenceImage + 199 update() calls, 8-bit frames from host memory) followed by the TV-L1 denoise; sums over the pass "
                  "divided by 199",
        "kernel_source_sha256": kernel_source_sha256(),
