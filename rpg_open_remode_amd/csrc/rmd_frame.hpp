@@ -522,6 +522,8 @@ RMDK_D unsigned int unit_pack_shape(int rows, int ww, int m) {
   return static_cast<unsigned int>(rows) | (static_cast<unsigned int>(ww) << 8) | (static_cast<unsigned int>(m) << 17);
 }
 static_assert(FR_MAX_ROWS < (1 << 8) && FR_MAX_WIDTH < (1 << 9), "window shape fields of a unit entry");
+constexpr int UNIT_ROUNDS_SHIFT = 30;  // word 0 of a unit entry: tile | (rounds per unit - 1) << 30
+static_assert(MAX_UNIT_ROUNDS <= 4, "two bits of a unit entry");
 
 constexpr int INGEST_WGS = 128;  // workgroups (per sequence) that bring a host frame into the current-image plane (the only ones that may wait)
 constexpr int INGEST_WGS_REMAP = 512;  // with lens undistortion (two dependent round trips per pixel): a quarter of the chip's wave slots at most
@@ -795,7 +797,6 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
   const bool keeper = tile == 0 && seq == M.housekeeper;
   if (keeper && tid < UNIT_SHARDS) M.shards_next[tid] = 0ull;  // the set the NEXT frame counts in (nobody reads it now)
   if (keeper && tid < UNIT_SHARDS) M.handout[tid * HANDOUT_STRIDE] = 0u;  // the search kernel's hand-out counters
-  if (keeper && tid == 0) M.queue[5] = static_cast<unsigned int>(unit_items);
   if (tid == 0) M.tile_conv[tile_g] = static_cast<unsigned int>(red_c[0] + red_c[1] + red_c[2] + red_c[3]);
   // the tile's box of this frame: needed by the lanes that write a unit entry and by lane 0 (the tile's word)
   const int n_units_tile = total > 0 ? units_of(total, unit_rounds) : 0;
@@ -814,6 +815,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
   if (total == 0) return;
   const int n_u = n_units_tile;
   if (tid == 0) {
+    // (issued right behind the first barrier instead, the compiler still waits for the answer where it is issued -- the branch's end)
     const unsigned long long old = atomicAdd(&M.shards_cur[tile_g % UNIT_SHARDS], (static_cast<unsigned long long>(total) << 32) | static_cast<unsigned long long>(n_u));
     s_base = static_cast<unsigned int>(old);  // units reserved so far in this shard
   }
@@ -827,22 +829,31 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
     const int wx0 = box ? x0 : u0, ww = (box ? x1 : u1) - wx0 + 1, rows = y1 - y0 + 1, m = box ? 0 : m_tile;
     const bool whole = box || band;  // (leaving a LARGE tile window that many one-round units share to the units -- each cuts its own -- gains nothing: LAB.md)
     M.units[static_cast<size_t>(tile_g % UNIT_SHARDS) * M.shard_cap + s_base + tid] =
-        make_uint4(static_cast<unsigned int>(tile_g), static_cast<unsigned int>(tid * unit_items) | (whole ? UNIT_TILE_BOX : 0u),
+        make_uint4(static_cast<unsigned int>(tile_g) | (static_cast<unsigned int>(unit_rounds - 1) << UNIT_ROUNDS_SHIFT), static_cast<unsigned int>(tid * unit_items) | (whole ? UNIT_TILE_BOX : 0u),
                    whole ? unit_pack_origin(wx0, y0) : 0u, unit_pack_shape(whole ? rows : 0, whole ? ww : 0, m));
   }
 }
 
-// The shards' unit lists read as ONE list: entry `g` lives in shard s with first[s] <= g < first[s + 1].  The sixteen counts were
-// written by the setup kernel -- the launch before this one -- and nobody writes them while this kernel runs: they are read through the
-// scalar path (constant address space) every time they are needed, sixteen words from the scalar cache, instead of being kept in
-// seventeen scalar registers across the whole kernel (which, with the kernel arguments, overflowed the scalar register file: 104
-// spills to vector-register lanes, two hundred v_writelane / v_readlane per workgroup -- executed by all 1 024 workgroups of every
-// launch, most of which have no unit on a light frame).
+// Who searches which unit.  The setup kernel appends a tile's units to the list of shard (tile % UNIT_SHARDS); the sixteen counts were written
+// by that kernel -- the launch before this one -- and nobody writes them while this kernel runs: they are read through the scalar path
+// (constant address space) every time they are needed, sixteen words from the scalar cache, instead of being kept in seventeen scalar
+// registers across the whole kernel (which, with the kernel arguments, overflowed the scalar register file: 104 spills to vector-register
+// lanes, two hundred v_writelane / v_readlane per workgroup -- executed by all 1 024 workgroups of every launch, most of which have no unit
+// on a light frame).  Two numberings (seed_search_compact_kernel chooses per frame):
+//  * the shards' lists read as ONE list: entry g lives in the shard s with first[s] <= g < first[s + 1] (unit_entry); workgroup b starts
+//    with unit b, the rest is handed out by counters;
+//  * light frames -- no shard holds more units than a sixteenth of the grid --: entry i of shard s belongs to workgroup 16 i + s.
 typedef const __attribute__((address_space(4))) unsigned long long* const_u64_ptr;
 RMDK_D unsigned int unit_count(const_u64_ptr counts) {
   unsigned int n = 0u;
 #pragma unroll
   for (int q = 0; q < UNIT_SHARDS; ++q) n += static_cast<unsigned int>(counts[q]);
+  return n;
+}
+RMDK_D unsigned int unit_max(const_u64_ptr counts) {
+  unsigned int n = 0u;
+#pragma unroll
+  for (int q = 0; q < UNIT_SHARDS; ++q) n = max(n, static_cast<unsigned int>(counts[q]));
   return n;
 }
 RMDK_D const uint4* unit_entry(const MatcherArgs& M, const_u64_ptr counts, unsigned int g) {  // g uniform: scalar arithmetic
@@ -872,6 +883,18 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
   const int tid = threadIdx.x;
   // One step ahead (MatcherArgs::ahead): the first ahead_wgs workgroups -- dispatched first, so they never queue behind the persistent
   // ones -- bring the next host frame into the other current-image plane if the setup kernel found it in the ring, and leave.
+  {  // the kernel arguments every workgroup needs first, requested TOGETHER (left alone the compiler fetches ahead_wgs, waits, branches, and
+     // only then asks for the pointers behind which the counts and the first unit lie: one more scalar round trip in front of every unit)
+    const int a = M.ahead_wgs, cap = M.shard_cap;
+    const unsigned int g = gridDim.x;
+    const void* p0 = M.units; const void* p1 = M.shards_cur; const void* p2 = M.conv_out;
+    // ... and one word from each of the other 64-byte lines of the argument segment that a workgroup with a unit reads on its way to the
+    // tile's descriptor loads (image geometry, diagnostics pointer, workspace planes): the segment lies in device memory, and every line
+    // touched for the first time in front of those loads was a miss of the scalar cache on that chain
+    const int w0 = Bq[0].P.w;
+    const void* p3 = Bq[0].P.trace; const void* p4 = M.mean;
+    asm volatile("" :: "s"(a), "s"(cap), "s"(g), "s"(p0), "s"(p1), "s"(p2), "s"(w0), "s"(p3), "s"(p4));
+  }
   if (NSEQ == 1 && blockIdx.x < static_cast<unsigned int>(M.ahead_wgs)) {
     const unsigned int next = M.ingest_number + 1u;
     if (ld_agent(M.ahead) != next) return;
@@ -889,7 +912,17 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
   }
   const unsigned int wg_id = blockIdx.x - static_cast<unsigned int>(M.ahead_wgs), n_wg = gridDim.x - static_cast<unsigned int>(M.ahead_wgs);
   const const_u64_ptr counts = (const_u64_ptr)(M.shards_cur);
+  // On a LIGHT frame -- no shard holds more units than a sixteenth of the grid, which is nearly every frame after a sequence's first twenty --
+  // the units are not numbered through the shards (unit_entry: the counts first, then the entry: two scalar round trips in front of every
+  // workgroup's first descriptor loads) but taken where they lie: entry i of shard s belongs to workgroup 16 i + s, whose address needs no
+  // count.  The workgroup requests that entry together with the counts and learns from them whether what came back is a unit.  (Consecutive
+  // units of a tile go to workgroups 16 apart: the same XCD -- they share the tile's window in its L2 --, CUs two apart.)
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(4))) u32x4* const_entry_ptr;
+  const unsigned int my_shard = wg_id & (UNIT_SHARDS - 1), my_index = wg_id / UNIT_SHARDS;
+  const u32x4 e_here = *(const_entry_ptr)(M.units + static_cast<size_t>(my_shard) * M.shard_cap + min(my_index, static_cast<unsigned int>(M.shard_cap) - 1u));
   const unsigned int n_units = unit_count(counts);
+  const bool light = unit_max(counts) <= n_wg / UNIT_SHARDS;
   // The LAST workgroup (it has no unit of its own on all but the heaviest frames) adds up the per-tile counts of seeds the setup kernel
   // found CONVERGED and mirrors them, stamped with this update's number, to pinned host memory: getConvergedCount() after an update
   // needs no device synchronisation and no kernel of its own (seed_matrix.cu:195-198, depthmap_node.cpp:142-153).
@@ -908,14 +941,13 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
       __syncthreads();
     }
   }
-  if (wg_id >= n_units) return;  // no unit for this workgroup: on a light frame most of the grid leaves here, a few dozen scalar instructions in
+  if (light ? my_index >= static_cast<unsigned int>(counts[my_shard]) : wg_id >= n_units) return;  // no unit for this workgroup: on a light frame most of the grid leaves here, a few dozen scalar instructions in
   unsigned long long* const trace0 = NSEQ == 1 ? Bq[0].P.trace : nullptr;  // diagnostics (single sequences only)
   unsigned long long* const tr = trace0 && static_cast<int>(wg_id) < M.n_tiles ? trace0 + static_cast<size_t>(wg_id) * FR_TRACE_WORDS : nullptr;
   if (tr && tid == 0) tr[0] = wall_clock64();
   LAB_PROF(if (tid < 8) S.prof[tid] = 0ull;)
   const int tx = tid & (TILE_W - 1), ty = tid >> 4;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int unit_items = static_cast<int>(*(const __attribute__((address_space(4))) unsigned int*)(M.queue + 5));  // written by the setup kernel
   unsigned int n_fallback = 0, n_windows = 0, n_done = 0, n_items = 0;
   int lds_tile = -1, x0 = 0, y0 = 0, total = 0;
   const SeqArgs* Qp = seq_table();  // the sequence of the tile in LDS (one sequence: the named argument, see the setup kernel)
@@ -932,13 +964,13 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
   const unsigned int cls = wg_id & (UNIT_SHARDS - 1);
   // the unit entries were written by the setup kernel, the launch before this one: scalar loads (the address is uniform, the words land in
   // scalar registers, nothing waits on the vector memory counter)
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  typedef const __attribute__((address_space(4))) u32x4* const_entry_ptr;
-  unsigned int u = wg_id;
-  u32x4 e = *(const_entry_ptr)unit_entry(M, counts, u);
+  unsigned int u = light ? 0u : wg_id;  // (light: any number below n_units -- the loop below ends after this workgroup's one unit)
+  u32x4 e = e_here;
+  if (!light) e = *(const_entry_ptr)unit_entry(M, counts, u);
   while (u < n_units) {
     // the unit: (tile, first item | UNIT_TILE_BOX, the texel box of all samples of the tile) -- uniform over the workgroup: scalar registers
-    const int tile = static_cast<int>(e.x);
+    const int tile = static_cast<int>(e.x & ((1u << UNIT_ROUNDS_SHIFT) - 1u));
+    const int unit_items = (static_cast<int>(e.x >> UNIT_ROUNDS_SHIFT) + 1) * TILE_PIX;  // the unit size travels with the unit: no word of the setup kernel's to fetch first
     const unsigned int fy = e.y;
     const int first = static_cast<int>(fy & ~UNIT_TILE_BOX);
     const bool boxed = (fy & UNIT_TILE_BOX) != 0u;
@@ -951,6 +983,14 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
       const int seq = NSEQ == 1 ? 0 : tile / M.n_tiles;
       const int tile_s = NSEQ == 1 ? tile : tile - seq * M.n_tiles;  // within its sequence
       if (NSEQ > 1) Qp = seq_table() + seq;
+      {  // what stands between the unit's entry and the tile's descriptor loads, requested together (at its point of use each of these
+         // scalar loads is waited for on its own: seven scalar-cache round trips in a row on every workgroup's way to its first unit)
+        const SeedParams& Pq = Qp->P;
+        const int a0 = Pq.w, a1 = Pq.h, a2 = Pq.stride, a3 = M.tiles_x;
+        const void* q0 = M.mean; const void* q1 = M.dir; const void* q2 = M.lfirst; const void* q3 = M.packed;
+        const void* q4 = Pq.sum_templ; const void* q5 = Pq.denom; const void* q6 = Pq.ref;
+        asm volatile("" :: "s"(a0), "s"(a1), "s"(a2), "s"(a3), "s"(q0), "s"(q1), "s"(q2), "s"(q3), "s"(q4), "s"(q5), "s"(q6));
+      }
       so = NSEQ == 1 ? 0 : static_cast<size_t>(seq) * M.seq_plane;
       const SeedParams& P = Qp->P;
       const int tile_y = tile_s / M.tiles_x, tile_x = tile_s - tile_y * M.tiles_x;

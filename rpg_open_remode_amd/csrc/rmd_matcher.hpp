@@ -62,7 +62,6 @@ struct MatcherWorkspace {
   unsigned int* d_handout = nullptr;  // UNIT_SHARDS hand-out counters of the search kernel, HANDOUT_STRIDE words apart
   // counters of the current frame: [0] work units (round-1 plan kernel), [1] units handed out beyond the static first round,
   // [5] items per unit
-  unsigned int* d_queue = nullptr;
   unsigned long long* d_shards = nullptr;  // 3 sets (frame % 3) of UNIT_SHARDS counters {work items << 32 | units}
   unsigned long long* h_conv = nullptr;    // pinned, one word per sequence: {update number << 32 | CONVERGED seeds at the start of that update}
   unsigned long long* d_conv = nullptr;    // its device address
@@ -97,7 +96,6 @@ struct MatcherWorkspace {
     if (hipMalloc(reinterpret_cast<void**>(&d_units), static_cast<size_t>(max_units) * sizeof(uint4)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_handout), UNIT_SHARDS * HANDOUT_STRIDE * sizeof(unsigned int)) != hipSuccess) return -1;
     if (hipMemset(d_handout, 0, UNIT_SHARDS * HANDOUT_STRIDE * sizeof(unsigned int)) != hipSuccess) return -1;
-    if (hipMalloc(reinterpret_cast<void**>(&d_queue), 8 * sizeof(unsigned int)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_shards), 3 * UNIT_SHARDS * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (hipHostMalloc(reinterpret_cast<void**>(&h_conv), MAX_GROUP_SEQ * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) return -1;
     for (int q = 0; q < MAX_GROUP_SEQ; ++q) h_conv[q] = 0ull;
@@ -109,18 +107,17 @@ struct MatcherWorkspace {
     if (hipMemset(d_best, 0, n * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (hipMemset(d_tile_conv, 0, n_tiles_all * sizeof(unsigned int)) != hipSuccess) return -1;
     if (hipMemset(d_tile_live, 0, n_tiles_all * sizeof(unsigned int)) != hipSuccess) return -1;
-    if (hipMemset(d_queue, 0, 8 * sizeof(unsigned int)) != hipSuccess) return -1;
     return 0;
   }
   int n_tiles() const { return tiles_x * tiles_y; }
   size_t wg_trace_slice_u64() const { return static_cast<size_t>(tiles_x) * tiles_y * 8; }  // FR_TRACE_WORDS per workgroup / tile
   void release() {
-    void* all[] = {d_mean, d_dir, d_lfirst, d_packed, d_best, d_tile_live, d_tile_conv, d_units, d_handout, d_queue, d_shards, d_wg_trace};
+    void* all[] = {d_mean, d_dir, d_lfirst, d_packed, d_best, d_tile_live, d_tile_conv, d_units, d_handout, d_shards, d_wg_trace};
     for (void* p : all)
       if (p) (void)hipFree(p);
     if (h_conv) (void)hipHostFree(h_conv);
     d_mean = d_dir = nullptr; d_lfirst = nullptr; d_packed = nullptr; d_best = nullptr;
-    d_tile_live = nullptr; d_tile_conv = nullptr; d_units = nullptr; d_handout = nullptr; d_queue = nullptr; d_shards = nullptr;
+    d_tile_live = nullptr; d_tile_conv = nullptr; d_units = nullptr; d_handout = nullptr; d_shards = nullptr;
     d_wg_trace = nullptr; h_conv = nullptr; d_conv = nullptr;
   }
 };
@@ -137,7 +134,6 @@ struct MatcherArgs {
   unsigned int* tile_conv;
   uint4* units;
   unsigned int* handout;     // UNIT_SHARDS counters, HANDOUT_STRIDE words apart (zero at the search kernel's launch)
-  unsigned int* queue;       // this frame's counters (see MatcherWorkspace)
   unsigned long long* shards_cur;         // this frame's shard counters (zero at launch)
   const unsigned long long* shards_prev;  // the previous frame's (null: no previous frame)
   unsigned long long* shards_next;        // cleared by this frame's setup for the next one
@@ -453,7 +449,6 @@ inline MatcherArgs matcher_args(const MatcherWorkspace& ws) {
   M.seq_plane = ws.seq_plane;
   M.tile_live = ws.d_tile_live; M.tile_conv = ws.d_tile_conv; M.units = ws.d_units; M.handout = ws.d_handout;
   M.tiles_x = ws.tiles_x; M.tiles_y = ws.tiles_y; M.n_tiles = ws.tiles_x * ws.tiles_y; M.n_seq = ws.n_seq;
-  M.queue = ws.d_queue;
   M.shards_cur = ws.d_shards + (ws.frame % 3) * UNIT_SHARDS;
   M.shards_prev = ws.frame > 0 ? ws.d_shards + ((ws.frame + 2) % 3) * UNIT_SHARDS : nullptr;
   M.shards_next = ws.d_shards + ((ws.frame + 1) % 3) * UNIT_SHARDS;
