@@ -42,11 +42,11 @@ fi
 if [[ $PARTS == *nranks* ]]; then
   echo "== ranks on the one-GPU lease (all ranks compute on device 0; the launch path the driver uses for --gpus N)"
   mkdir -p "$SUM/${TAG}_nranks"
-  timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --dist --steps 3 --warmup 1 --no-extras > "$SUM/${TAG}_nranks/one_rank_rccl.json" 2> "$SUM/${TAG}_nranks/one_rank.err"; cut -c1-160 "$SUM/${TAG}_nranks/one_rank_rccl.json"
-  timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus 2 --steps 3 --warmup 1 --no-extras > "$SUM/${TAG}_nranks/two_ranks_one_gpu.json" 2> "$SUM/${TAG}_nranks/two_ranks.err"; cut -c1-160 "$SUM/${TAG}_nranks/two_ranks_one_gpu.json"
+  timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --dist --steps 3 --warmup 1 --no-extras | grep '^{"metric"' > "$SUM/${TAG}_nranks/one_rank_rccl.json" 2> "$SUM/${TAG}_nranks/one_rank.err"; cut -c1-160 "$SUM/${TAG}_nranks/one_rank_rccl.json"
+  timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus 2 --steps 3 --warmup 1 --no-extras | grep '^{"metric"' > "$SUM/${TAG}_nranks/two_ranks_one_gpu.json" 2> "$SUM/${TAG}_nranks/two_ranks.err"; cut -c1-160 "$SUM/${TAG}_nranks/two_ranks_one_gpu.json"
   echo "-- two ranks x four sequences each (N GPUs x B sequences, configs[3] composed with the batched mode)"
-  timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29613 bench.py --gpus 2 --batch-per-gpu 4 --steps 3 --warmup 1 --no-extras > "$SUM/${TAG}_nranks/two_ranks_x_four_sequences_one_gpu.json" 2> "$SUM/${TAG}_nranks/two_ranks_x4.err"; cut -c1-160 "$SUM/${TAG}_nranks/two_ranks_x_four_sequences_one_gpu.json"
+  timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29613 bench.py --gpus 2 --batch-per-gpu 4 --steps 3 --warmup 1 --no-extras | grep '^{"metric"' > "$SUM/${TAG}_nranks/two_ranks_x_four_sequences_one_gpu.json" 2> "$SUM/${TAG}_nranks/two_ranks_x4.err"; cut -c1-160 "$SUM/${TAG}_nranks/two_ranks_x_four_sequences_one_gpu.json"
   echo "-- one rank x eight sequences (--batch-per-gpu 8)"
-  timeout 600 python bench.py --batch-per-gpu 8 --steps 3 --warmup 1 --no-extras > "$SUM/${TAG}_nranks/one_rank_x_eight_sequences.json" 2> "$SUM/${TAG}_nranks/one_rank_x8.err"; cut -c1-160 "$SUM/${TAG}_nranks/one_rank_x_eight_sequences.json"
+  timeout 600 python bench.py --batch-per-gpu 8 --steps 3 --warmup 1 --no-extras | grep '^{"metric"' > "$SUM/${TAG}_nranks/one_rank_x_eight_sequences.json" 2> "$SUM/${TAG}_nranks/one_rank_x8.err"; cut -c1-160 "$SUM/${TAG}_nranks/one_rank_x_eight_sequences.json"
 fi
 ls -la "$SUM"
