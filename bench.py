@@ -433,9 +433,11 @@ def main():
     seeds.timingReset()
     ru0 = resource.getrusage(resource.RUSAGE_SELF)  # CPU time of ALL threads of this process (the library's copy helpers included)
     t0 = time.perf_counter()
+    pass_marks = [t0]
     for _ in range(args.steps):
         run_pass(seeds)
-    t_submitted = time.perf_counter()  # every update() has returned (frames copied, launches queued); the device is still busy
+        pass_marks.append(time.perf_counter())  # (the caller is at most three frames ahead of the device: a pass's submit time is its device time +- 0.1 ms)
+    t_submitted = pass_marks[-1]  # every update() has returned (frames copied, launches queued); the device is still busy
     seeds.sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -700,6 +702,10 @@ def main():
             # the wall time per update() call until the call returned (frame copied into the pinned ring, two launches queued) -- the device
             # time per update is roofline.avg_launch_us; a host that needs longer than that paces the run
             "host_cpu_s": round(host_cpu_s, 4), "host_cores_busy": round(host_cpu_s / elapsed, 3), "host_submit_us_per_update": round(host_submit_s / n_updates * 1e6, 2),
+            # spread inside the timed region (rank 0): the K passes one by one, as the caller sees them -- the time between the returns of the last
+            # update() of consecutive passes; the caller runs at most three frames ahead of the device, so a pass is its device time +- 0.1 ms
+            "pass_ms": {"min": round(min(b - a for a, b in zip(pass_marks, pass_marks[1:])) * 1e3, 4),
+                        "max": round(max(b - a for a, b in zip(pass_marks, pass_marks[1:])) * 1e3, 4), "passes": len(pass_marks) - 1},
         }
     batch.barrier(device)
     if rank == 0:
