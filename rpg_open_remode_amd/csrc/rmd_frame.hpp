@@ -881,8 +881,6 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem& S = *reinterpret_cast<Smem*>(smem_raw);
   const int tid = threadIdx.x;
-  // One step ahead (MatcherArgs::ahead): the first ahead_wgs workgroups -- dispatched first, so they never queue behind the persistent
-  // ones -- bring the next host frame into the other current-image plane if the setup kernel found it in the ring, and leave.
   {  // the kernel arguments every workgroup needs first, requested TOGETHER (left alone the compiler fetches ahead_wgs, waits, branches, and
      // only then asks for the pointers behind which the counts and the first unit lie: one more scalar round trip in front of every unit)
     const int a = M.ahead_wgs, cap = M.shard_cap;
@@ -895,6 +893,8 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
     const void* p3 = Bq[0].P.trace; const void* p4 = M.mean;
     asm volatile("" :: "s"(a), "s"(cap), "s"(g), "s"(p0), "s"(p1), "s"(p2), "s"(w0), "s"(p3), "s"(p4));
   }
+  // One step ahead (MatcherArgs::ahead): the first ahead_wgs workgroups -- dispatched first, so they never queue behind the persistent
+  // ones -- bring the next host frame into the other current-image plane if the setup kernel found it in the ring, and leave.
   if (NSEQ == 1 && blockIdx.x < static_cast<unsigned int>(M.ahead_wgs)) {
     const unsigned int next = M.ingest_number + 1u;
     if (ld_agent(M.ahead) != next) return;
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
   }
   const unsigned int wg_id = blockIdx.x - static_cast<unsigned int>(M.ahead_wgs), n_wg = gridDim.x - static_cast<unsigned int>(M.ahead_wgs);
   const const_u64_ptr counts = (const_u64_ptr)(M.shards_cur);
-  // On a LIGHT frame -- no shard holds more units than a sixteenth of the grid, which is nearly every frame after a sequence's first twenty --
+  // On a LIGHT frame -- no shard holds more units than a sixteenth of the grid, which is every frame of the benchmark sequence after its first ~75 --
   // the units are not numbered through the shards (unit_entry: the counts first, then the entry: two scalar round trips in front of every
   // workgroup's first descriptor loads) but taken where they lie: entry i of shard s belongs to workgroup 16 i + s, whose address needs no
   // count.  The workgroup requests that entry together with the counts and learns from them whether what came back is a unit.  (Consecutive
