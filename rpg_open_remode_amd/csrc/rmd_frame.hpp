@@ -522,6 +522,7 @@ RMDK_D unsigned int unit_pack_shape(int rows, int ww, int m) {
   return static_cast<unsigned int>(rows) | (static_cast<unsigned int>(ww) << 8) | (static_cast<unsigned int>(m) << 17);
 }
 static_assert(FR_MAX_ROWS < (1 << 8) && FR_MAX_WIDTH < (1 << 9), "window shape fields of a unit entry");
+constexpr int unit_tail_shift(int shard) { return shard >= 14 ? 2 : shard >= 12 ? 1 : 0; }  // see seed_setup_compact_kernel
 constexpr int UNIT_ROUNDS_SHIFT = 30;  // word 0 of a unit entry: tile | (rounds per unit - 1) << 30
 static_assert(MAX_UNIT_ROUNDS <= 4, "two bits of a unit entry");
 
@@ -674,6 +675,13 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
     static_assert(MAX_UNIT_ROUNDS == 4, "the ladder below is ceil(items / per_round) clamped to 1..4");
     unit_rounds = items > 3 * per_round ? 4 : items > 2 * per_round ? 3 : items > per_round ? 2 : 1;  // no 64-bit division
   }
+  // Graduated unit sizes (one sequence per launch only).  The search kernel's hand-out deals the shards' lists one after the other, so the units
+  // of the last shards are the last to be searched, and while the last unit runs every other workgroup waits: up to one unit's time, a fifth of
+  // the kernel on the frames that have two to five units per workgroup.  The tiles of shards 12, 13 cut their work into units of half the frame's
+  // size, those of shards 14, 15 into quarters (at least one round): 12 % more units, the wait at the end a quarter as long -- update 1 96 -> 92.5 us,
+  // a sequence 38.2 -> 37.6 us per update (profiles/r05_ab_unit_tail.txt).  In a batch the other stream groups' kernels fill that wait already
+  // and the smaller units only cost their staging: -3 ... -4 % with every graduation tried; there all units of a frame have one size.
+  if (NSEQ == 1) unit_rounds = max(1, unit_rounds >> unit_tail_shift(tile_g % UNIT_SHARDS));
   // what the planes hold now (known only when the previous frame's values were loaded for its finalisation): a seed that has
   // converged or diverged keeps writing the same state and an empty descriptor, a third of this kernel's stores -- skipped
   int conv_old = -1;
