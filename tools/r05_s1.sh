@@ -17,7 +17,7 @@ unset RMD_HIP_LIB
 python tools/first_update_bench.py --b 1,8 --label product >> $OUT/rates.txt 2>&1
 python tools/search_timeline.py --brief > $OUT/timeline_product.txt 2>&1
 cat $OUT/rates.txt
-{ for W in 1 0 2; do
+{ for W in 1 0; do  # (the run recorded in profiles/r05_host_wait_modes.txt also had an adaptive variant, since dropped)
     echo "== RMD_HIP_HOST_WAIT=$W, 1920x1080 x 300 frames, 8-bit host frames (apps/bench_main)"; RMD_HIP_HOST_WAIT=$W RMD_HIP_INGEST_PROFILE=1 apps/bench_main --size 1920x1080 --frames 300 --steps 2 --warmup 1 --modes u8 2>&1 | cut -c1-700
     echo "== RMD_HIP_HOST_WAIT=$W, 640x480 x 200 frames"; RMD_HIP_HOST_WAIT=$W apps/bench_main --steps 5 --warmup 1 --modes u8 2>&1 | cut -c1-700
   done

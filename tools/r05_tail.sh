@@ -1,5 +1,6 @@
 #!/bin/bash
-# GPU box: graduated unit sizes (csrc/rmd_lab.hpp, RMD_LAB_TAIL = 0..3; libraries built with tools/ab_make.sh tailN "-DRMD_LAB_TAIL=N"), alternating on one box.
+# GPU box: graduated unit sizes -- libraries build_ab/librmd_hip_tailN.so, each built (tools/ab_make.sh) from a variant of unit_tail_shift()
+# in csrc/rmd_frame.hpp (N = 0: no graduation; the variants are listed in profiles/r05_ab_unit_tail.txt), alternating on one box.
 # usage: tools/r05_tail.sh <tag>
 set -u
 export TMPDIR=/tmp

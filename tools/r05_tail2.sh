@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: graduated unit sizes, second sweep (one sequence only: a batch loses with every variant).   usage: tools/r05_tail2.sh <tag>
+# GPU box: graduated unit sizes, second sweep (one sequence only: a batch loses with every variant); libraries as in tools/r05_tail.sh.
 set -u
 export TMPDIR=/tmp
 TAG=${1:-tail2}; ROOT=$(pwd); OUT=$ROOT/gpurun_out/r05_$TAG; mkdir -p $OUT; : > $OUT/rates.txt
