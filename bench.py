@@ -705,7 +705,7 @@ def main():
             # spread inside the timed region (rank 0): the K passes one by one, as the caller sees them -- the time between the returns of the last
             # update() of consecutive passes; the caller runs at most three frames ahead of the device, so a pass is its device time +- 0.1 ms
             "pass_ms": ({"min": round(min(b - a for a, b in zip(pass_marks, pass_marks[1:])) * 1e3, 4),
-                         "max": round(max(b - a for a, b in zip(pass_marks, pass_marks[1:])) * 1e3, 4), "passes": len(pass_marks) - 1} if len(pass_marks) > 1 else None),
+                         "max": round(max(b - a for a, b in zip(pass_marks, pass_marks[1:])) * 1e3, 4), "passes": len(pass_marks) - 1} if (len(pass_marks) > 1 and not args.resident) else None),  # (resident frames: nothing holds the caller back, its marks say nothing)
         }
     batch.barrier(device)
     if rank == 0:
