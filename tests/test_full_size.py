@@ -107,12 +107,12 @@ class LazySequence:
 
 
 def _long_run(w, h, n_frames, oracle_updates, compare_every, what, deep=()):
-    """Pipeline (default matcher, 8-bit frames through the ingest path) against the per-pixel kernel over the whole configured
-    length, against the oracle on the first updates (where every seed is live and the searches are longest) and again DEEP into the
-    sequence: at every update k0 of `deep` a fresh Oracle B is started from the pipeline's state planes at k0 (mu, sigma_sq, a, b: all
-    the state there is -- the convergence plane is recomputed by every update's seed_check) and follows the next three updates, where
-    most seeds have converged and the work lists are sparse.  (The epipolar-match plane keeps values of EARLIER frames for seeds that
-    found no match since: it is compared by the per-pixel kernel, which has seen those frames; the restarted oracle has not.)"""
+    """Pipeline (default matcher, 8-bit frames through the ingest path) against ORACLE B OVER THE WHOLE CONFIGURED LENGTH -- the oracle follows
+    every update; all planes and the update's work statistics are compared on the first `oracle_updates` updates (where every seed is live
+    and the searches are longest), all planes again at every `compare_every`-th update and at the last one -- and against the per-pixel kernel
+    at the same points.  In addition, at every update k0 of `deep` a fresh Oracle B is started from the pipeline's state planes at k0 (mu,
+    sigma_sq, a, b: all the state there is -- the convergence plane is recomputed by every update's seed_check) and follows the next three
+    updates with a comparison after each, where most seeds have converged and the work lists are sparse."""
     seq = LazySequence(w, h, n_frames)
     cam = api.PinholeCamera(*seq.K)
     hip, base = api.SeedMatrix(w, h, cam, patch_side=9), api.SeedMatrix(w, h, cam, patch_side=9)
@@ -131,8 +131,8 @@ def _long_run(w, h, n_frames, oracle_updates, compare_every, what, deep=()):
         img = synth_float(g)
         hip.updateU8(g, T)
         base.update(img, T)
+        orc.update(img, T)
         if k <= oracle_updates:
-            orc.update(img, T)
             assert_states_equal(orc.state(), hip.state(), f"{what} update {k} vs the oracle")
             st, ost = hip.lastStats(), orc.last_stats()
             assert (st["live_seeds"], st["steps"], st["ncc_evals"]) == (ost["live_seeds"], ost["steps"], ost["ncc_evals"])
@@ -140,7 +140,9 @@ def _long_run(w, h, n_frames, oracle_updates, compare_every, what, deep=()):
             if k == oracle_updates:
                 hip.setOption(api.OPT_COLLECT_STATS, 0)
         elif k % compare_every == 0 or k == n_frames - 1:
-            assert_states_equal(base.state(), hip.state(), f"{what}: pipeline vs per-pixel kernel after {k} updates")
+            st_hip = hip.state()
+            assert_states_equal(orc.state(), st_hip, f"{what}: pipeline vs the oracle that has followed all {k} updates")
+            assert_states_equal(base.state(), st_hip, f"{what}: pipeline vs per-pixel kernel after {k} updates")
         if k in deep:
             st = hip.state()
             deep_orc = O.Seeds(O.OracleLib("port", 9), w, h, seq.K)
@@ -154,7 +156,7 @@ def _long_run(w, h, n_frames, oracle_updates, compare_every, what, deep=()):
             assert hip.getConvergedCount() == deep_orc.converged_count()
             if k == deep_until:
                 deep_orc = None
-    assert hip.getConvergedCount() == base.getConvergedCount()
+    assert hip.getConvergedCount() == base.getConvergedCount() == orc.converged_count()
     return seq, hip, max_steps_per_seed
 
 
