@@ -89,6 +89,26 @@ class SeedMatrix {
     return downloadPointCloud(depth.handle(), host_xyzi, capacity);
   }
 
+  // Extension (not in the reference class): publication off the update stream -- what DepthmapNode::denoiseAndPublishResults /
+  // publishConvergenceMap (depthmap_node.cpp:165-182) compute between two messages, requested without waiting for it.  publishAsync snapshots
+  // the state (one device-to-device kernel) and queues TV-L1 denoising (lambda, iterations; setLargeSigmaSq(depth_range)), the point cloud of
+  // the converged seeds, the coloured convergence map and / or the convergence plane (RMD_HIP_PUBLISH_* bits) on the handle's second stream;
+  // setReferenceImage / update may follow at once.  collectPublication hands over the oldest publication not collected yet: true and the
+  // products in the caller's buffers (NULL: not wanted), false when it is still in flight and `wait` is false.  At most
+  // RMD_HIP_PUBLISH_SLOTS publications may be uncollected.
+  int publishAsync(unsigned int what, float depth_range, float lambda, int iterations) {
+    int ticket = 0;
+    detail::throw_on_error(rmd_hip_seeds_publish_async(handle_, what, depth_range, lambda, iterations, &ticket), "SeedMatrix: publishAsync failed");
+    return ticket;
+  }
+  bool collectPublication(bool wait, unsigned int* what, int* ticket, float* host_depth, float* host_xyzi, size_t capacity, size_t* n_points,
+                          unsigned char* host_bgr, int* host_convergence) {
+    const int rc = rmd_hip_seeds_publish_collect(handle_, wait ? 1 : 0, what, ticket, host_depth, host_xyzi, capacity, n_points, host_bgr, host_convergence);
+    if (rc == RMD_HIP_BUSY) return false;
+    detail::throw_on_error(rc, "SeedMatrix: collectPublication failed");
+    return true;
+  }
+
 #if RMD_BUILD_TESTS
   void downloadSigmaSq(float* host_align_row_maj) const { download(RMD_HIP_PLANE_SIGMA_SQ, host_align_row_maj); }
   void downloadA(float* host_align_row_maj) const { download(RMD_HIP_PLANE_A, host_align_row_maj); }

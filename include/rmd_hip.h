@@ -92,7 +92,9 @@ typedef struct rmd_hip_batch rmd_hip_batch_t;
 #define RMD_HIP_TUNE_HOST_WAIT 8      /* how update() waits for a free slot of its pinned frame ring (the device is up to three frames behind the caller): 1
                                          (default) = spin for 2 us, then sleep in steps of ~15 us (the waiting thread's timer slack is set to 2 us);
                                          0 = spin only (one core per handle that is fed host frames at full speed) */
-#define RMD_HIP_NUM_TUNABLES 9
+#define RMD_HIP_TUNE_RING_DEPTH 9     /* frames (a batch: steps) that may be in flight between update() and the setup kernel that consumes them = slots of the pinned
+                                         frame ring, 3..8; 0 (default) = the library's choice: 6 for a SeedMatrix, 5 for a batch */
+#define RMD_HIP_NUM_TUNABLES 10
 int rmd_hip_set_tunable(int tunable, int value);
 int rmd_hip_get_tunable(int tunable, int* value);
 
@@ -185,6 +187,25 @@ int rmd_hip_seeds_point_cloud(rmd_hip_seeds_t* s, const rmd_hip_image_t* depth, 
  * B = G = R (cv::cvtColor GRAY2BGR), blue = 255 where the seed is CONVERGED, red = 255 where it is DIVERGED.  host_bgr: W x H x 3 bytes,
  * packed (what cv::Mat CV_8UC3 / sensor_msgs BGR8 hold).  Replaces downloadConvergence (4 B/pixel) + a host loop by a 3 B/pixel download. */
 int rmd_hip_seeds_convergence_bgr8(rmd_hip_seeds_t* s, unsigned char* host_bgr);
+/* Publication OFF the update stream (live use: DepthmapNode::denoiseAndPublishResults / publishConvergenceMap, depthmap_node.cpp:165-182, whose
+ * std::async only blocks by accident of a discarded future).  rmd_hip_seeds_publish_async snapshots what the requested products need -- mu,
+ * sigma_sq, a, b, convergence, reference image, T_world_ref: one device-to-device kernel on the handle's stream -- and queues, on a second stream
+ * of the handle, the work the reference does between two messages: DepthmapDenoiser::denoise(lambda, iterations) of the snapshot
+ * (depthmap_denoiser.cu:179-224, setLargeSigmaSq(depth_range)), the CONVERGED-masked point cloud of the denoised map (publisher.cpp:54-104), the
+ * coloured convergence map (:112-147), the int32 convergence plane, and their transfers into pinned host memory.  It returns at once: the caller
+ * goes on with setReferenceImage / update, whose kernels run beside the publication's.  rmd_hip_seeds_publish_collect hands over the OLDEST
+ * publication that has not been collected: RMD_HIP_OK and the products in the caller's buffers (any of them may be NULL), RMD_HIP_BUSY when it is
+ * still in flight and `wait` is 0, RMD_HIP_ERR_NOT_READY when there is none.  Up to RMD_HIP_PUBLISH_SLOTS publications may be uncollected at a
+ * time; results are those of the synchronous calls on the state at the time of the request, bit for bit (tests/test_publish_async.py). */
+#define RMD_HIP_BUSY 1
+#define RMD_HIP_PUBLISH_DEPTH 1u            /* TV-L1 denoised depth map, W x H floats */
+#define RMD_HIP_PUBLISH_CLOUD 2u            /* XYZI points of the converged seeds from that map (implies DEPTH) */
+#define RMD_HIP_PUBLISH_CONVERGENCE_BGR 4u  /* coloured convergence map, W x H x 3 bytes */
+#define RMD_HIP_PUBLISH_CONVERGENCE 8u      /* convergence states, W x H int32 */
+#define RMD_HIP_PUBLISH_SLOTS 3
+int rmd_hip_seeds_publish_async(rmd_hip_seeds_t* s, unsigned int what, float depth_range, float lambda, int iterations, int* ticket);
+int rmd_hip_seeds_publish_collect(rmd_hip_seeds_t* s, int wait, unsigned int* what, int* ticket, float* host_depth, float* host_xyzi, size_t capacity,
+                                  size_t* n_points, unsigned char* host_bgr, int* host_convergence);
 int rmd_hip_seeds_dist_from_ref(const rmd_hip_seeds_t* s, float* dist);
 /* blocks until all work queued by this handle has finished */
 int rmd_hip_seeds_sync(const rmd_hip_seeds_t* s);

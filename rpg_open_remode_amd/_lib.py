@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(HERE, "librmd_hip.so")
 HEADER_PATH = os.path.join(ROOT, "include", "rmd_hip.h")
 
 OK, ERR_INVALID_ARG, ERR_RUNTIME, ERR_NOT_READY, ERR_NO_DEVICE = 0, -1, -2, -3, -4
+BUSY = 1  # rmd_hip_seeds_publish_collect: the oldest publication is still in flight (not an error)
 
 
 class RmdHipError(RuntimeError):
@@ -64,6 +65,8 @@ SIGNATURES = {
     "rmd_hip_seeds_last_diagnostics": (_i, [_p, _p]),
     "rmd_hip_seeds_trace_download": (_i, [_p, _i, _p, _sz, _c.POINTER(_sz)]),
     "rmd_hip_seeds_point_cloud": (_i, [_p, _p, _p, _sz, _c.POINTER(_sz)]),
+    "rmd_hip_seeds_publish_async": (_i, [_p, _c.c_uint, _f, _f, _i, _c.POINTER(_i)]),
+    "rmd_hip_seeds_publish_collect": (_i, [_p, _i, _c.POINTER(_c.c_uint), _c.POINTER(_i), _p, _p, _sz, _c.POINTER(_sz), _p, _p]),
     "rmd_hip_seeds_init_undistortion_map": (_i, [_p, _f, _f, _f, _f]),
     "rmd_hip_seeds_undistortion_map": (_i, [_p, _p, _p]),
     "rmd_hip_compute_undistortion_map": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _p, _p]),

@@ -31,8 +31,10 @@ PLANE_SUM_TEMPL, PLANE_CONST_TEMPL_DENOM, PLANE_EPIPOLAR_MATCHES, PLANE_REF_IMG,
 KIND_F32, KIND_I32, KIND_F32X2 = 0, 1, 2
 OPT_MATCHER, OPT_TIMING, OPT_COLLECT_STATS, OPT_LAZY_FINALIZE, OPT_UNIT_TARGET = 0, 1, 2, 4, 7  # include/rmd_hip.h: RMD_HIP_OPT_*
 OPT_INJECT_FAULT = 9  # test hook, see include/rmd_hip.h
+PUBLISH_DEPTH, PUBLISH_CLOUD, PUBLISH_CONVERGENCE_BGR, PUBLISH_CONVERGENCE = 1, 2, 4, 8  # include/rmd_hip.h: RMD_HIP_PUBLISH_*
+
 # process-wide settings of the host side (include/rmd_hip.h: RMD_HIP_TUNE_*; the environment presets them: RMD_HIP_<NAME>)
-TUNE_HOST_FRAMES, TUNE_BATCH_GROUPS, TUNE_AHEAD_WGS, TUNE_PACK_BACKOFF, TUNE_FLOAT_AS_BYTES, TUNE_COPY_THREADS, TUNE_FUSED_INGEST, TUNE_INGEST_PROFILE, TUNE_HOST_WAIT = range(9)
+TUNE_HOST_FRAMES, TUNE_BATCH_GROUPS, TUNE_AHEAD_WGS, TUNE_PACK_BACKOFF, TUNE_FLOAT_AS_BYTES, TUNE_COPY_THREADS, TUNE_FUSED_INGEST, TUNE_INGEST_PROFILE, TUNE_HOST_WAIT, TUNE_RING_DEPTH = range(10)
 HOST_FRAMES_DEFAULT, HOST_FRAMES_STAGED, HOST_FRAMES_STAGED_AHEAD, HOST_FRAMES_INPLACE, HOST_FRAMES_INPLACE_AHEAD = -1, 0, 1, 2, 3
 
 
@@ -402,6 +404,33 @@ class SeedMatrix:
         check(_lib.lib().rmd_hip_seeds_dist_from_ref(self.ptr, ctypes.byref(out)))
         return float(out.value)
 
+    def publishAsync(self, what, depth_range=0.0, lam=0.5, iterations=200):
+        """rmd_hip_seeds_publish_async: snapshot the state and queue its publication products (PUBLISH_* bits: TV-L1 denoised depth map, point
+        cloud of the converged seeds, coloured convergence map, int32 convergence plane) on the handle's second stream; returns the ticket
+        at once -- setReferenceImage / update may follow immediately (DepthmapNode::denoiseAndPublishResults, depthmap_node.cpp:165-182)."""
+        t = ctypes.c_int()
+        check(_lib.lib().rmd_hip_seeds_publish_async(self.ptr, int(what), float(depth_range), float(lam), int(iterations), ctypes.byref(t)))
+        return int(t.value)
+
+    def collectPublication(self, wait=True):
+        """rmd_hip_seeds_publish_collect: the OLDEST uncollected publication as a dict {"ticket", "what", "depth", "points", "bgr", "convergence"}
+        (the products that were requested), or None when it is still in flight and wait is False.  Raises when there is none."""
+        if not hasattr(self, "_pub_bufs"):
+            n = self.width * self.height
+            self._pub_bufs = (np.empty((self.height, self.width), np.float32), np.empty((n, 4), np.float32),
+                              np.empty((self.height, self.width, 3), np.uint8), np.empty((self.height, self.width), np.int32))
+        depth, pts, bgr, conv = self._pub_bufs
+        what, ticket, n_pts = ctypes.c_uint(), ctypes.c_int(), ctypes.c_size_t()
+        rc = _lib.lib().rmd_hip_seeds_publish_collect(self.ptr, 1 if wait else 0, ctypes.byref(what), ctypes.byref(ticket), depth.ctypes.data, pts.ctypes.data,
+                                                      pts.shape[0], ctypes.byref(n_pts), bgr.ctypes.data, conv.ctypes.data)
+        if rc == _lib.BUSY:
+            return None
+        check(rc)
+        w = int(what.value)
+        return {"ticket": int(ticket.value), "what": w,
+                "depth": depth.copy() if w & PUBLISH_DEPTH else None, "points": pts[:int(n_pts.value)].copy() if w & PUBLISH_CLOUD else None,
+                "bgr": bgr.copy() if w & PUBLISH_CONVERGENCE_BGR else None, "convergence": conv.copy() if w & PUBLISH_CONVERGENCE else None}
+
     # --- extras ---
     def sync(self):
         check(_lib.lib().rmd_hip_seeds_sync(self.ptr))
@@ -641,6 +670,7 @@ class Depthmap:
 
     def setReferenceImage(self, img_curr, T_curr_world, min_depth, max_depth):  # depthmap.cpp:63-83
         self.denoiser_.setLargeSigmaSq(max_depth - min_depth)
+        self.depth_range_ = float(np.float32(max_depth) - np.float32(min_depth))  # what setLargeSigmaSq was given: the publications' TV-L1 uses it too
         ret = self.seeds_.setReferenceImageU8(self._check_u8(img_curr), T_curr_world, min_depth, max_depth)
         if getattr(self, "is_distorted_", False):  # ref_img_undistorted_8uc1_ (depthmap.cpp:74-79): the undistorted frame, back in 8 bits
             self.ref_img_8uc1_ = np.rint(self.seeds_.download(PLANE_REF_IMG) * np.float32(255.0)).astype(np.uint8)
@@ -677,6 +707,22 @@ class Depthmap:
         """what Publisher::publishConvergenceMap builds from getConvergenceMap() and getReferenceImage() (publisher.cpp:112-147), on the
         device (no int32 download, no host loop)"""
         return self.seeds_.convergenceBGR8()
+
+    def publishAsync(self, what, lam=0.5, iterations=200):
+        """downloadDenoisedDepthmap / downloadConvergenceMap / the publisher's point cloud and coloured map as ONE request that does not block
+        (SeedMatrix.publishAsync): the products belong to the state at this moment; the next setReferenceImage / update may follow at once."""
+        return self.seeds_.publishAsync(what, getattr(self, "depth_range_", 0.0), lam, iterations)
+
+    def collectPublication(self, wait=True):
+        """the oldest publication requested with publishAsync (None: still in flight and wait is False); refreshes the host mirrors the
+        reference's getters return (getDepthmap, getConvergenceMap)"""
+        pub = self.seeds_.collectPublication(wait)
+        if pub is not None:
+            if pub["depth"] is not None:
+                self.output_depth_32fc1_ = pub["depth"]
+            if pub["convergence"] is not None:
+                self.output_convergence_int_ = pub["convergence"]
+        return pub
 
     def getConvergedPercentage(self):  # depthmap.cpp:152-156
         return float(np.float32(self.getConvergedCount()) / np.float32(self.width_ * self.height_) * np.float32(100.0))

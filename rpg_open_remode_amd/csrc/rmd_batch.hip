@@ -35,12 +35,13 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
     active |= 1u << i;
   }
   if (!active) return RMD_HIP_OK;
+  const double t_a = b->ingest_profile ? host_now_us() : 0.0;
   const unsigned long long n64 = ++b->step_number;
   const unsigned int n = static_cast<unsigned int>(n64);
-  const int k = static_cast<int>(n64 % rmd_hip_batch::SLOTS);
+  const int k = static_cast<int>(n64 % static_cast<unsigned long long>(b->slots));
   // Slot k was last read by the setup kernels of the step recorded in slot_step[k]; such a kernel is done once a LATER setup kernel of
   // the same group has started (the progress word), or, if the group has not been launched since, once its stream is idle.
-  static_assert(rmd_hip_batch::SLOTS == 3, "Group::slot_step");
+  static_assert(rmd_hip_batch::SLOTS_MAX <= 8, "Group::slot_step");
   for (int g = 0; g < b->n_groups; ++g) {
     rmd_hip_batch::Group& G = b->groups[g];
     const unsigned long long used = G.slot_step[k];
@@ -48,11 +49,16 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
     if (G.last_step > used) TRY(wait_for_progress(G.h_progress, static_cast<unsigned int>(used) + 1u, G.stream));
     else HIP_TRY(hipStreamSynchronize(G.stream));
   }
+  const double t_b = b->ingest_profile ? host_now_us() : 0.0;
+  if (b->ingest_profile) {
+    const int lead = static_cast<int>(n - *static_cast<volatile unsigned int*>(b->groups[0].h_progress));
+    ++b->ingest_lead[lead < 0 ? 0 : lead > 4 ? 4 : lead];
+  }
   const size_t need = static_cast<size_t>(b->n) * static_cast<size_t>(m0->width) * m0->height * sizeof(float);  // float frames: the larger kind
   if (b->stage_bytes < need) {
     for (int g = 0; g < b->n_groups; ++g) HIP_TRY(hipStreamSynchronize(b->groups[g].stream));
     HIP_TRY(hipStreamSynchronize(b->copy_stream));
-    for (int q = 0; q < rmd_hip_batch::SLOTS; ++q) {
+    for (int q = 0; q < b->slots; ++q) {
       if (b->h_stage[q]) (void)hipHostFree(b->h_stage[q]);
       if (b->d_stage[q]) (void)hipFree(b->d_stage[q]);
       b->h_stage[q] = nullptr; b->d_stage[q] = nullptr;
@@ -91,6 +97,7 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
     }
   }
   if (n_segs) CopyPool::instance().copy_many(segs, n_segs, frame_bytes);  // the frames of the step, spread over the copy threads
+  const double t_c = b->ingest_profile ? host_now_us() : 0.0;
   const bool in_place = frame_in_place(true, any_maps);  // (the remap gathers single bytes: staged)
   const unsigned char* frames_dev = b->d_stage[k];
   rmdk::IngestArgs in;
@@ -113,6 +120,7 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
   in.pitch = u8_pitch;
   in.number = n;
   in.no_remap = packed;
+  in.profile = b->ingest_profile;
   for (int i = 0; i < b->n; ++i) {
     if (!((active >> i) & 1u)) continue;
     rmd_hip_seeds* m = b->members[i];
@@ -124,7 +132,12 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
     rmd_hip_batch::Group& G = b->groups[g];
     if ((active >> G.first) & ((1u << G.n) - 1u)) { G.slot_step[k] = n64; G.last_step = n64; }
   }
-  return batch_launch(b, active, &in, frames_dev, frame_bytes);
+  const int rc = batch_launch(b, active, &in, frames_dev, frame_bytes);
+  if (b->ingest_profile) {
+    const double t_d = host_now_us();
+    b->ingest_us[0] += t_b - t_a; b->ingest_us[1] += t_c - t_b; b->ingest_us[2] += t_d - t_c; b->ingest_us[3] += 1.0;
+  }
+  return rc;
 }
 
 }  // namespace
@@ -137,9 +150,19 @@ int rmd_hip_batch_destroy(rmd_hip_batch_t* b) {
   for (auto& G : b->groups)
     if (G.stream) (void)hipStreamSynchronize(G.stream);
   if (b->copy_stream) (void)hipStreamSynchronize(b->copy_stream);
+  if (b->ingest_profile && b->ingest_us[3] > 0) {
+    fprintf(stderr, "[rmd_hip ingest] batch of %d, %.0f steps: wait for slot %.2f us, host copy %.2f us, submit %.2f us per step; longest wait %.0f us, %lu waits gave up after 2 ms; "
+                    "steps handed over <=0 / 1 / 2 / 3 / >=4 ahead of group 0's newest started setup kernel: %lu / %lu / %lu / %lu / %lu\n",
+            b->n, b->ingest_us[3], b->ingest_us[0] / b->ingest_us[3], b->ingest_us[1] / b->ingest_us[3], b->ingest_us[2] / b->ingest_us[3], g_progress_max_wait_us,
+            g_progress_timeouts, b->ingest_lead[0], b->ingest_lead[1], b->ingest_lead[2], b->ingest_lead[3], b->ingest_lead[4]);
+    for (int g = 0; g < b->n_groups; ++g)
+      if (b->groups[g].h_progress)
+        fprintf(stderr, "[rmd_hip ingest]   group %d: steps whose setup kernel converted its frames %u, of which it waited for %u (%u polls)\n", g,
+                b->groups[g].h_progress[2], b->groups[g].h_progress[3], b->groups[g].h_progress[4]);
+  }
   for (int i = 0; i < rmdk::MAX_BATCH; ++i)
     if (b->members[i]) (void)seeds_destroy_impl(b->members[i]);
-  for (int q = 0; q < rmd_hip_batch::SLOTS; ++q) {
+  for (int q = 0; q < rmd_hip_batch::SLOTS_MAX; ++q) {
     if (b->h_stage[q]) (void)hipHostFree(b->h_stage[q]);
     if (b->d_stage[q]) (void)hipFree(b->d_stage[q]);
   }
@@ -190,6 +213,8 @@ int rmd_hip_batch_create(int n, int width, int height, float fx, float fy, float
   // a group is ONE launch pair, and a launch pair carries at most MAX_GROUP_SEQ sequences (their parameter blocks are kernel arguments)
   while (want_groups * rmdk::MAX_GROUP_SEQ < n) ++want_groups;
   b->n_groups = want_groups;
+  b->ingest_profile = tunables().v[RMD_HIP_TUNE_INGEST_PROFILE] != 0;
+  if (tunables().v[RMD_HIP_TUNE_RING_DEPTH] > 0) b->slots = tunables().v[RMD_HIP_TUNE_RING_DEPTH] < 3 ? 3 : tunables().v[RMD_HIP_TUNE_RING_DEPTH];
   b->opt_unit_target = 1;  // (2x / 3x as many, smaller units: +4 % with one group of 4, nothing with two groups)
   const size_t pitch = (static_cast<size_t>(width) * 4 + 255) / 256 * 256;  // as image_alloc lays the members' planes out
   for (int g = 0; g < b->n_groups; ++g) {
@@ -200,13 +225,13 @@ int rmd_hip_batch_create(int n, int width, int height, float fx, float fy, float
     if (create_stream(&G.stream, g % 3) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: hipStreamCreate failed"));
     if (G.ws.allocate(width, height, static_cast<int>(pitch / 4), G.n, max_extent) != 0) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: update workspace"));
     if (hipHostMalloc(reinterpret_cast<void**>(&G.h_progress), 64, hipHostMallocMapped) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: progress words"));
-    G.h_progress[0] = G.h_progress[1] = 0u;
+    for (int q = 0; q < 16; ++q) G.h_progress[q] = 0u;
     if (hipEventCreate(&G.ev) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: event"));
   }
   if (create_stream(&b->copy_stream, 2) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: hipStreamCreate failed"));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, b->device) == hipSuccess && prop.multiProcessorCount > 0) b->num_cus = prop.multiProcessorCount;
-  if (hipHostMalloc(reinterpret_cast<void**>(&b->h_seq), rmd_hip_batch::SLOTS * FLAG_SLOT_WORDS * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess ||
+  if (hipHostMalloc(reinterpret_cast<void**>(&b->h_seq), rmd_hip_batch::SLOTS_MAX * FLAG_SLOT_WORDS * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&b->d_flag), FLAG_ALLOC_BYTES) != hipSuccess || hipMemset(b->d_flag, 0, FLAG_ALLOC_BYTES) != hipSuccess)
     return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: ingest words"));
   b->n = n;  // (group_of needs it while the members are created)

@@ -23,6 +23,9 @@ int fail(int code, const char* fmt, ...) {
 }
 const char* last_error() { return g_last_error; }
 
+// accepted values per tunable (rmd_hip_set_tunable AND the environment presets)
+static const int tunable_lo[RMD_HIP_NUM_TUNABLES] = {-1, 0, 1, 0, 0, 1, 0, 0, 0, 0}, tunable_hi[RMD_HIP_NUM_TUNABLES] = {3, 4, 1024, 1 << 20, 1, 16, 1, 1, 1, 8};
+
 // The library's process-wide settings and THE ONE PLACE where it reads its environment (include/rmd_hip.h: RMD_HIP_TUNE_*): the
 // defaults come from RMD_HIP_<NAME>, once, at the first call; rmd_hip_set_tunable overrides them for handles created afterwards.
 Tunables& tunables() {
@@ -37,19 +40,32 @@ Tunables& tunables() {
     t.v[RMD_HIP_TUNE_FUSED_INGEST] = 1;
     t.v[RMD_HIP_TUNE_INGEST_PROFILE] = 0;
     t.v[RMD_HIP_TUNE_HOST_WAIT] = 1;
+    t.v[RMD_HIP_TUNE_RING_DEPTH] = 0;
     static const char* const names[RMD_HIP_NUM_TUNABLES] = {"RMD_HIP_HOST_FRAMES", "RMD_HIP_BATCH_GROUPS", "RMD_HIP_AHEAD_WGS", "RMD_HIP_PACK_BACKOFF",
-                                                            "RMD_HIP_FLOAT_AS_BYTES", "RMD_HIP_COPY_THREADS", "RMD_HIP_FUSED_INGEST", "RMD_HIP_INGEST_PROFILE", "RMD_HIP_HOST_WAIT"};
+                                                            "RMD_HIP_FLOAT_AS_BYTES", "RMD_HIP_COPY_THREADS", "RMD_HIP_FUSED_INGEST", "RMD_HIP_INGEST_PROFILE", "RMD_HIP_HOST_WAIT",
+                                                            "RMD_HIP_RING_DEPTH"};
+    // A preset from the environment passes the same range check as rmd_hip_set_tunable; one that fails it -- or does not parse -- is IGNORED
+    // with a line on stderr (a negative RMD_HIP_AHEAD_WGS used to go straight into the search kernel's grid arithmetic).
     for (int k = 0; k < RMD_HIP_NUM_TUNABLES; ++k) {
       const char* e = getenv(names[k]);
       if (!e || !e[0]) continue;
+      long v = 0;
+      bool parsed = false;
       if (k == RMD_HIP_TUNE_HOST_FRAMES) {  // by name, or by number
         static const char* const modes[4] = {"staged", "staged_ahead", "inplace", "inplace_ahead"};
         for (int m = 0; m < 4; ++m)
-          if (!strcmp(e, modes[m])) t.v[k] = m;
-        if (e[0] >= '0' && e[0] <= '3' && !e[1]) t.v[k] = e[0] - '0';
-      } else {
-        t.v[k] = atoi(e);
+          if (!strcmp(e, modes[m])) { v = m; parsed = true; }
       }
+      if (!parsed) {
+        char* end = nullptr;
+        v = strtol(e, &end, 10);
+        parsed = end != e && *end == '\0';
+      }
+      if (!parsed || v < tunable_lo[k] || v > tunable_hi[k]) {
+        fprintf(stderr, "[rmd_hip] %s=%s ignored: %s [%d, %d]\n", names[k], e, parsed ? "outside" : "not a number in", tunable_lo[k], tunable_hi[k]);
+        continue;
+      }
+      t.v[k] = static_cast<int>(v);
     }
     return t;
   }();
@@ -162,9 +178,8 @@ int rmd_hip_version(void) { return RMD_HIP_VERSION_NUMBER; }
 
 int rmd_hip_set_tunable(int tunable, int value) {
   if (tunable < 0 || tunable >= RMD_HIP_NUM_TUNABLES) return fail(RMD_HIP_ERR_INVALID_ARG, "set_tunable: unknown tunable %d", tunable);
-  static const int lo[RMD_HIP_NUM_TUNABLES] = {-1, 0, 1, 0, 0, 1, 0, 0, 0}, hi[RMD_HIP_NUM_TUNABLES] = {3, 4, 1024, 1 << 20, 1, 16, 1, 1, 1};
-  if (value < lo[tunable] || value > hi[tunable])
-    return fail(RMD_HIP_ERR_INVALID_ARG, "set_tunable: value %d of tunable %d outside [%d, %d]", value, tunable, lo[tunable], hi[tunable]);
+  if (value < tunable_lo[tunable] || value > tunable_hi[tunable])
+    return fail(RMD_HIP_ERR_INVALID_ARG, "set_tunable: value %d of tunable %d outside [%d, %d]", value, tunable, tunable_lo[tunable], tunable_hi[tunable]);
   tunables().v[tunable] = value;
   return RMD_HIP_OK;
 }
@@ -282,11 +297,17 @@ int rmdh::seeds_destroy_impl(rmd_hip_seeds* s) {
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   for (auto& t : s->timers) t.destroy();
   if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);
-  if (s->ingest_profile && s->ingest_us[3] > 0)
+  publish_release(s);
+  if (s->ingest_profile && s->ingest_us[3] > 0) {
     fprintf(stderr, "[rmd_hip ingest] %.0f frames: wait for slot %.2f us, host copy %.2f us, submit %.2f us per frame; longest wait %.0f us, %lu waits gave up after 2 ms\n",
             s->ingest_us[3], s->ingest_us[0] / s->ingest_us[3], s->ingest_us[1] / s->ingest_us[3], s->ingest_us[2] / s->ingest_us[3], g_progress_max_wait_us,
             g_progress_timeouts);
-  for (int k = 0; k < rmd_hip_seeds::RING; ++k) {
+    if (s->h_progress)
+      fprintf(stderr, "[rmd_hip ingest] frames handed over <=0 / 1 / 2 / 3 / >=4 ahead of the newest setup kernel that had started: %lu / %lu / %lu / %lu / %lu; "
+                      "converted by their own setup kernel (not one step ahead) %u, of which the kernel waited for %u (%u polls)\n",
+              s->ingest_lead[0], s->ingest_lead[1], s->ingest_lead[2], s->ingest_lead[3], s->ingest_lead[4], s->h_progress[2], s->h_progress[3], s->h_progress[4]);
+  }
+  for (int k = 0; k < rmd_hip_seeds::RING_MAX; ++k) {
     if (s->h_zc_u8[k]) (void)hipHostFree(s->h_zc_u8[k]);
     if (s->h_zc_f32[k]) (void)hipHostFree(s->h_zc_f32[k]);
     if (s->d_zc_u8[k]) (void)hipFree(s->d_zc_u8[k]);

@@ -308,6 +308,11 @@ RMDK_D void frame_stage_window(const SeedParams& P, FrameSmem<SIDE>& S, int tid,
 template <int SIDE>
 RMDK_D void frame_rounds(const SeedParams& P, FrameSmem<SIDE>& S, int tid, int k0, int k1, const FrameWindow& W, unsigned int& n_fallback) {
   using Smem = FrameSmem<SIDE>;
+  // ncc_at_dyn's in-window test reads the row table at q0, q0 + 1, q0 + SIDE with q0 clamped to [0, rows - 1 - SIDE]: it needs a window of
+  // at least SIDE + 1 rows.  Every window cut to in-image samples has SIDE + 3 or more (a sample's rows floor(y) - HALF - 1 .. floor(y) +
+  // HALF + 2 lie inside the image: the guard of epipolar_match.cu:91-97 keeps y in [SIDE, h - SIDE)), and clamp_window keeps min(rows, 43);
+  // a window that broke that rule is treated as empty -- zero usable columns, every evaluation reads L2 -- instead of trusted (scalar, once per call).
+  const int ww_usable = W.rows > SIDE ? W.ww : 0;
   for (int r0 = k0; r0 < k1; r0 += TILE_PIX) {
     LAB_PROF(
     const unsigned long long prof_t0 = prof_clock();
@@ -328,7 +333,7 @@ RMDK_D void frame_rounds(const SeedParams& P, FrameSmem<SIDE>& S, int tid, int k
       const float l = replay_l(S.l_first[p], j);  // the reference accumulates l; replay it
       const F2 px = F2{S.mean_x[p] + l * S.dir_x[p], S.mean_y[p] + l * S.dir_y[p]};
       const int ptx = p & (TILE_W - 1), pty = p >> 4;
-      const float ncc = ncc_at_dyn<SIDE>(P, px, S.win, S.row_start, W.ws, W.y0, W.rows, W.ww, S.ref + pty * Smem::REF_W + ptx, Smem::REF_W,
+      const float ncc = ncc_at_dyn<SIDE>(P, px, S.win, S.row_start, W.ws, W.y0, W.rows, ww_usable, S.ref + pty * Smem::REF_W + ptx, Smem::REF_W,
                                         S.sum_templ[p], S.denom[p], n_fallback);
       if (ncc > -1.0f) {  // NaN and anything the reference's "ncc > best_ncc" would never accept are dropped
         const unsigned int step = ((S.packed[p] >> 8) & 0xffu) + static_cast<unsigned int>(j);
@@ -486,33 +491,52 @@ RMDK_D void ingest_in_place(int kind, int pitch, const void* src_v, float* __res
   }
 }
 
-// A staged frame (MatcherArgs::ingest_kind) converted into a current-image plane by workgroup `part` of `parts`, for the search kernel's
-// bringers: the copy had completed before an EARLIER kernel saw its flag, so plain loads will do.
-RMDK_D void ingest_staged(int kind, int pitch, const void* src_v, float* __restrict__ dst, int w, int h, int stride, int part, int parts, int tid) {
-  if (kind == 1) {
-    const unsigned int* src = static_cast<const unsigned int*>(src_v);
-    const int per_row = pitch >> 2, total = per_row * h;
-    for (int d = part * TILE_PIX + tid; d < total; d += parts * TILE_PIX) {
-      const unsigned int u = src[d];
-      const int row = d / per_row, x4 = (d - row * per_row) * 4;
-      float* out = dst + static_cast<size_t>(row) * stride + x4;
-      const float f0 = static_cast<float>(u & 0xffu) * (1.0f / 255.0f), f1 = static_cast<float>((u >> 8) & 0xffu) * (1.0f / 255.0f);
-      const float f2 = static_cast<float>((u >> 16) & 0xffu) * (1.0f / 255.0f), f3 = static_cast<float>(u >> 24) * (1.0f / 255.0f);
-      if (x4 + 3 < w) *reinterpret_cast<float4*>(out) = make_float4(f0, f1, f2, f3);
-      else {
-        if (x4 < w) out[0] = f0;
-        if (x4 + 1 < w) out[1] = f1;
-        if (x4 + 2 < w) out[2] = f2;
-      }
-    }
-  } else {
-    const float* src = static_cast<const float*>(src_v);
-    const int total = w * h;
-    for (int d = part * TILE_PIX + tid; d < total; d += parts * TILE_PIX) {
-      const int row = d / w;
-      dst[static_cast<size_t>(row) * stride + (d - row * w)] = src[d];
-    }
+// Dword `d` of an 8-bit frame (rows of `per_row` dwords, four pixels each) -> its four floats in the current-image plane: x (1/255) like
+// Depthmap::inputImage's convertTo(CV_32F, 1.0f / 255.0f) (depthmap.cpp:105), one fp32 multiply per pixel.
+RMDK_D void store_u8x4(float* __restrict__ dst, int stride, int w, int per_row, int d, unsigned int u) {
+  const int row = d / per_row, x4 = (d - row * per_row) * 4;
+  float* out = dst + static_cast<size_t>(row) * stride + x4;
+  const float f0 = static_cast<float>(u & 0xffu) * (1.0f / 255.0f), f1 = static_cast<float>((u >> 8) & 0xffu) * (1.0f / 255.0f);
+  const float f2 = static_cast<float>((u >> 16) & 0xffu) * (1.0f / 255.0f), f3 = static_cast<float>(u >> 24) * (1.0f / 255.0f);
+  if (x4 + 3 < w) *reinterpret_cast<float4*>(out) = make_float4(f0, f1, f2, f3);  // plane rows and x4 are multiples of 16 bytes
+  else {
+    if (x4 < w) out[0] = f0;
+    if (x4 + 1 < w) out[1] = f1;
+    if (x4 + 2 < w) out[2] = f2;
   }
+}
+
+// A frame in a staging buffer in HBM (MatcherArgs::ingest_kind: 1 = 8-bit rows of `pitch` bytes, 2 = w x h floats) converted into a
+// current-image plane by workgroup `part` of `parts`.  INGEST_BATCH dwords per lane are requested before the first is used: a lane's requests
+// are `parts` x 256 dwords apart (every instruction fully coalesced), and the whole frame is a round trip or two instead of one per dword --
+// at 1920x1080 a lane of 128 workgroups has sixteen dwords to fetch, and fetched one by one (the loads could not be moved across the stores
+// of the iteration before) the conversion took longer than the setup kernel it rides in.  LOAD: plain loads for the search kernel's
+// bringers (the copy had completed before an EARLIER kernel saw its flag), agent-scope loads for a frame's own setup kernel (the copy
+// may complete while the kernel runs).
+constexpr int INGEST_BATCH = 4;
+template <typename LOAD>
+RMDK_D void ingest_staged(int kind, int pitch, const void* src_v, float* __restrict__ dst, int w, int h, int stride, int part, int parts, int tid, LOAD load) {
+  const unsigned int* src = static_cast<const unsigned int*>(src_v);
+  const int per_row = kind == 1 ? pitch >> 2 : w, total = per_row * h, step = parts * TILE_PIX;
+  auto put = [&](int d, unsigned int u) {
+    if (d >= total) return;
+    if (kind == 1) store_u8x4(dst, stride, w, per_row, d, u);
+    else {
+      const int row = d / w;
+      dst[static_cast<size_t>(row) * stride + (d - row * w)] = __uint_as_float(u);
+    }
+  };
+  static_assert(INGEST_BATCH == 4, "the four requests below");
+  for (int d0 = part * TILE_PIX + tid; d0 < total; d0 += INGEST_BATCH * step) {
+    const int d1 = d0 + step, d2 = d1 + step, d3 = d2 + step;
+    const unsigned int v0 = load(src + d0), v1 = load(src + min(d1, total - 1)), v2 = load(src + min(d2, total - 1)), v3 = load(src + min(d3, total - 1));
+    put(d0, v0); put(d1, v1); put(d2, v2); put(d3, v3);
+  }
+}
+// workgroups that convert a staged frame of `dwords` dwords: INGEST_BATCH requests per lane, at most `cap`
+inline int ingest_workgroups(long long dwords, int cap) {
+  const long long want = (dwords + static_cast<long long>(TILE_PIX) * INGEST_BATCH - 1) / (static_cast<long long>(TILE_PIX) * INGEST_BATCH);
+  return static_cast<int>(want < cap ? (want < 1 ? 1 : want) : cap);
 }
 
 // Words 2, 3 of a unit entry: the tile's window -- column origin (16 bits, signed: a band may start left of the image) | first row << 16;
@@ -526,7 +550,7 @@ constexpr int unit_tail_shift(int shard) { return shard >= 14 ? 2 : shard >= 12 
 constexpr int UNIT_ROUNDS_SHIFT = 30;  // word 0 of a unit entry: tile | (rounds per unit - 1) << 30
 static_assert(MAX_UNIT_ROUNDS <= 4, "two bits of a unit entry");
 
-constexpr int INGEST_WGS = 128;  // workgroups (per sequence) that bring a host frame into the current-image plane (the only ones that may wait)
+constexpr int INGEST_WGS = 512;  // at most this many workgroups (per sequence) bring a staged host frame into the current-image plane (the only ones that may wait): ingest_workgroups()
 constexpr int INGEST_WGS_REMAP = 512;  // with lens undistortion (two dependent round trips per pixel): a quarter of the chip's wave slots at most
 constexpr int INGEST_WGS_IN_PLACE = 256;  // frames read in place from pinned host memory: enough requests in flight to cover the host link's latency
 
@@ -545,42 +569,65 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int tx = tid & (TILE_W - 1), ty = tid >> 4;
-  const int x = blockIdx.x * TILE_W + tx, y = blockIdx.y * TILE_H + ty;
-  const bool in_image = x < P.w && y < P.h;
+  // rows [0, M.ingest_rows) of the grid belong to the frame-ingest workgroups (below), the tile grid follows
+  const int tile_by = static_cast<int>(blockIdx.y) - M.ingest_rows;
+  const int x = blockIdx.x * TILE_W + tx, y = tile_by * TILE_H + ty;
+  const bool in_image = x < P.w && y < P.h && tile_by >= 0;
   const int gi = in_image ? y * P.stride + x : 0;
   const size_t gm = (NSEQ == 1 ? 0 : static_cast<size_t>(seq) * M.seq_plane) + gi;  // the same seed in the workspace planes
   const unsigned long long t_start = P.trace ? wall_clock64() : 0ull;  // timeline probes (diagnostics)
   unsigned long long t_loaded = 0ull;
-  // frame ingest (see MatcherArgs): the workgroups BELOW the tile grid (blockIdx.y >= tiles_y, at most INGEST_WGS of them per sequence,
-  // launched only when host frames are pending) wait for the staging copy's flag and convert the staged frame into the current-image
-  // plane.  Only these few workgroups ever wait: if every tile workgroup did, a device filled with waiting waves could keep a copy
-  // that is carried out by a blit kernel from ever running.  The wait is bounded; a copy that never arrives is reported through
-  // progress[1].  The flag is read with agent-scope acquire loads and the staged frame with agent-scope loads: the copy may finish
-  // after this kernel has started.
-  const int wg = blockIdx.y * gridDim.x + blockIdx.x;
-  if (static_cast<int>(blockIdx.y) >= M.tiles_y) {
-    const int iw = (static_cast<int>(blockIdx.y) - M.tiles_y) * gridDim.x + blockIdx.x;
+  // frame ingest (see MatcherArgs): the workgroups IN FRONT of the tile grid (blockIdx.y < ingest_rows, at most INGEST_WGS of them per
+  // sequence, launched only when host frames are pending) wait for the staging copy's flag and convert the staged frame into the
+  // current-image plane.  They are dispatched first: the conversion runs beside the tiles' latency chains instead of behind the last of
+  // them (below the tile grid, as until round 5, a 1920x1080 frame's conversion started when the last of 8 160 tile workgroups had been
+  // placed and made the kernel 15 us longer).  Only these few workgroups ever wait: if every tile workgroup did, a device filled with
+  // waiting waves could keep a copy that is carried out by a blit kernel from ever running.  The wait is bounded; a copy that never
+  // arrives is reported through progress[1].  The flag is read with agent-scope acquire loads and the staged frame with agent-scope
+  // loads: the copy may finish after this kernel has started.
+  const int wg = tile_by * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x);
+  if (tile_by < 0 || tile_by >= M.tiles_y) {
+    // One step ahead: the verdict for the NEXT frame -- has it been handed over (a pinned host word, frames read in place) / arrived in HBM (the
+    // arrival flag of its ring slot)? -- falls to ONE extra row of workgroups behind the tile grid: dispatched last, so that it is taken as late
+    // as this kernel can take it (the search kernel's bringers act on it).  (Taken by the last tile workgroup instead, the branch cost the
+    // tile path its last free scalar registers: the compiler reserved a scratch segment for every wave of the kernel.)
+    if (tile_by >= M.tiles_y) {
+      if (NSEQ == 1 && M.ahead && blockIdx.x == 0 && tid == 0) {
+        const unsigned int next = M.ingest_number + 1u;
+        __hip_atomic_store(M.ahead, static_cast<int>(ld_system(M.submitted) - next) >= 0 ? next : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
+    const int iw = static_cast<int>(blockIdx.y * gridDim.x + blockIdx.x);
     if (iw >= M.ingest_wgs) return;
-    // step numbers are compared modulo 2^32 (a live system never stops counting): "behind" = the signed difference is negative
-    auto behind = [&]() { return static_cast<int>(__hip_atomic_load(M.ingest_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - M.ingest_number) < 0; };
+    // step numbers are compared modulo 2^32 (a live system never stops counting): "behind" = the signed difference is negative.
+    // The flag and the staged frame are read with RELAXED agent-scope loads and NO acquire fence: on this part an agent-scope acquire is a
+    // cache invalidation (buffer_inv sc1: the vector L1 AND the lines of this XCD's L2 that other agents may have written), issued by every
+    // wave that executes it -- two per ingest wave until round 5, a few hundred of them at the head of every setup kernel with host frames,
+    // thrown at the L2 the tile workgroups are loading their seeds' state through (1920x1080, conversion left to the setup kernel: 147 us
+    // per update with them, profiles/r06_*).  What the acquire was there for holds without it: the frame's loads are agent-scope loads
+    // themselves (they never hit a stale line), and they are issued after the branch that consumed the flag -- the hardware issues a
+    // wave's instructions in order and does not speculate; the compiler is kept from moving them by the barrier below.
+    auto behind = [&]() { return static_cast<int>(ld_agent(M.ingest_flag) - M.ingest_number) < 0; };
     // No flag: the frame is read IN PLACE from the pinned host buffer the caller's frame was copied into before this kernel was
     // launched (ingest_in_place: 16 bytes per lane and request over the host link; a 640x480 8-bit frame is one round trip of 75
     // workgroups plus 6 us of link time) -- no copy engine, no staging in HBM, nothing to wait for.
     const bool in_place = M.ingest_flag == nullptr;
-    if (NSEQ == 1 && M.ahead) {  // one step ahead (see MatcherArgs): the verdict for the next frame, and whether this one has been brought in already
-      if (iw == 0 && tid == 0) {
-        const unsigned int next = M.ingest_number + 1u;
-        // (the word says: handed over -- a pinned host word, frames read in place -- or arrived in HBM -- the arrival flag of its ring slot)
-        __hip_atomic_store(M.ahead, static_cast<int>(ld_system(M.submitted) - next) >= 0 ? next : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if (ld_agent(M.ahead + 2) == M.ingest_number) return;
-    }
+    // one step ahead (see MatcherArgs): has this frame been brought in already, by the bringers of the previous update's search kernel?
+    if (NSEQ == 1 && M.ahead && ld_agent(M.ahead + 2) == M.ingest_number) return;
+    unsigned int spins = 0u;
     if (!in_place && behind()) {
-      unsigned int spins = 0u;
       while (behind() && ++spins < (1u << 18)) __builtin_amdgcn_s_sleep(16);
       if (behind() && tid == 0) __hip_atomic_store(M.progress + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (!in_place) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // nothing below is read before the flag has been seen (once per workgroup)
+    if (M.ingest_profile && iw == 0 && tid == 0 && seq == M.housekeeper) {  // diagnostics: this frame was not converted one step ahead; did it keep the kernel waiting?
+      __hip_atomic_fetch_add(M.progress + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (spins) {
+        __hip_atomic_fetch_add(M.progress + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_fetch_add(M.progress + 4, spins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    asm volatile("" ::: "memory");  // nothing below is read before the flag has been seen
     if (M.ingest_kind == 1 && Q.ingest_map1) {  // cv::remap through the undistortion maps first (depthmap.cpp:99), destination pixels four at a time per lane
       const unsigned char* src = reinterpret_cast<const unsigned char*>(Q.ingest_u8);
       const int total = P.w * P.h, step = M.ingest_wgs * TILE_PIX;
@@ -606,31 +653,13 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
     } else if (in_place) {
       ingest_in_place(M.ingest_kind, M.ingest_pitch, M.ingest_kind == 1 ? static_cast<const void*>(Q.ingest_u8) : static_cast<const void*>(Q.ingest_f32),
                       Q.ingest_dst, P.w, P.h, P.stride, iw, M.ingest_wgs, tid);
-    } else if (M.ingest_kind == 1) {  // x (1/255): Depthmap::inputImage's convertTo(CV_32F, 1.0f / 255.0f), depthmap.cpp:105 -- one fp32 multiply per pixel
-      const int per_row = M.ingest_pitch >> 2, total = per_row * P.h;
-      for (int d = iw * TILE_PIX + tid; d < total; d += M.ingest_wgs * TILE_PIX) {
-        const unsigned int v = ld_agent(Q.ingest_u8 + d);
-        const int row = d / per_row, x4 = (d - row * per_row) * 4;
-        float* out = Q.ingest_dst + static_cast<size_t>(row) * P.stride + x4;
-        const float f0 = static_cast<float>(v & 0xffu) * (1.0f / 255.0f), f1 = static_cast<float>((v >> 8) & 0xffu) * (1.0f / 255.0f);
-        const float f2 = static_cast<float>((v >> 16) & 0xffu) * (1.0f / 255.0f), f3 = static_cast<float>(v >> 24) * (1.0f / 255.0f);
-        if (x4 + 3 < P.w) *reinterpret_cast<float4*>(out) = make_float4(f0, f1, f2, f3);  // plane rows and x4 are multiples of 16 bytes
-        else {
-          if (x4 < P.w) out[0] = f0;
-          if (x4 + 1 < P.w) out[1] = f1;
-          if (x4 + 2 < P.w) out[2] = f2;
-        }
-      }
-    } else {
-      const int total = P.w * P.h;
-      for (int d = iw * TILE_PIX + tid; d < total; d += M.ingest_wgs * TILE_PIX) {
-        const int row = d / P.w;
-        Q.ingest_dst[static_cast<size_t>(row) * P.stride + (d - row * P.w)] = __uint_as_float(ld_agent(reinterpret_cast<const unsigned int*>(Q.ingest_f32) + d));
-      }
+    } else {  // the staged frame: x (1/255) for 8-bit frames (store_u8x4), floats as they are
+      ingest_staged(M.ingest_kind, M.ingest_pitch, M.ingest_kind == 1 ? static_cast<const void*>(Q.ingest_u8) : static_cast<const void*>(Q.ingest_f32), Q.ingest_dst,
+                    P.w, P.h, P.stride, iw, M.ingest_wgs, tid, [](const unsigned int* p) { return ld_agent(p); });
     }
     return;
   }
-  const int tile = blockIdx.y * M.tiles_x + blockIdx.x;                      // within the sequence
+  const int tile = tile_by * M.tiles_x + static_cast<int>(blockIdx.x);      // within the sequence
   const int tile_g = (NSEQ == 1 ? 0 : seq * M.n_tiles) + tile;               // within the launch
   // A tile in which the previous frame's check left no seed in state UPDATE is DEAD until the next reference frame: BORDER / CONVERGED /
   // DIVERGED are absorbing (nothing but the finalisation of an UPDATE seed ever changes sigma_sq, a, b), so every plane, the tile's CONVERGED
@@ -718,7 +747,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
   if (want_band) {  // (uniform over the workgroup)
     const Pose& T = P.T_curr_ref;
     const float fcx = (static_cast<float>(blockIdx.x * TILE_W + TILE_W / 2) - P.cam.cx) * __builtin_amdgcn_rcpf(P.cam.fx);
-    const float fcy = (static_cast<float>(blockIdx.y * TILE_H + TILE_H / 2) - P.cam.cy) * __builtin_amdgcn_rcpf(P.cam.fy);
+    const float fcy = (static_cast<float>(tile_by * TILE_H + TILE_H / 2) - P.cam.cy) * __builtin_amdgcn_rcpf(P.cam.fy);
     const float X = T.d[0] * fcx + T.d[1] * fcy + T.d[2], Y = T.d[4] * fcx + T.d[5] * fcy + T.d[6], Z = T.d[8] * fcx + T.d[9] * fcy + T.d[10];
     const float iz = __builtin_amdgcn_rcpf(Z);
     const float dx = P.cam.fx * (T.d[11] * X * iz - T.d[3]), dy = P.cam.fy * (T.d[11] * Y * iz - T.d[7]);
@@ -758,7 +787,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
       by1 = min(static_cast<int>(floorf(fmaxf(run.px_first.y, run.px_last.y))) + HALF + 2, P.h - 1);
       if (want_band) {  // the same under the tile's shear (rows as above: the band's rows are the box's)
         int ty0 = BAND_NONE_LO, ty1 = BAND_NONE_HI;
-        const int yref = static_cast<int>(blockIdx.y) * TILE_H;
+        const int yref = tile_by * TILE_H;
         band_add_point(run.px_first.x, run.px_first.y, HALF, m_tile, yref, bu0, ty0, bu1, ty1);
         band_add_point(run.px_last.x, run.px_last.y, HALF, m_tile, yref, bu0, ty0, bu1, ty1);
       }
@@ -908,7 +937,8 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
     if (ld_agent(M.ahead) != next) return;
     const SeedParams& P = Bq[0].P;
     if (M.ingest_flag == nullptr) ingest_in_place(M.ingest_kind, M.ingest_pitch, Bq[0].next_src, Bq[0].next_dst, P.w, P.h, P.stride, static_cast<int>(blockIdx.x), M.ahead_wgs, tid);
-    else ingest_staged(M.ingest_kind, M.ingest_pitch, Bq[0].next_src, Bq[0].next_dst, P.w, P.h, P.stride, static_cast<int>(blockIdx.x), M.ahead_wgs, tid);
+    else ingest_staged(M.ingest_kind, M.ingest_pitch, Bq[0].next_src, Bq[0].next_dst, P.w, P.h, P.stride, static_cast<int>(blockIdx.x), M.ahead_wgs, tid,
+                       [](const unsigned int* p) { return *p; });
     // The last one to finish publishes the frame.  Plane and number are read by the NEXT kernels only, and a kernel's stores are all
     // visible to the kernels behind it on the stream: no fence here (an agent-scope fence writes back and invalidates the L2 the
     // searching workgroups live on -- a hundred of them made every update 20 us longer).
@@ -1155,15 +1185,22 @@ inline hipError_t launch_seed_pipeline_compact(const BatchArgs<NSEQ>& B, int n_s
   const int resident = num_cus * ws.compact_wg_per_cu[SIDE / 2 - 1][KIND];
   dim3 tiles(ws.tiles_x, ws.tiles_y, n_seq);
   const SeedParams& P0 = B.seq[0].P;
-  if (M.ingest_kind) {  // the ingest workgroups: rows below the tile grid
+  if (M.ingest_kind) {  // the ingest workgroups: rows in front of the tile grid
     bool remap = false;
     for (int q = 0; q < n_seq; ++q) remap = remap || (M.ingest_kind == 1 && B.seq[q].ingest_map1);
     const long long dwords = M.ingest_kind == 1 && !remap ? static_cast<long long>(M.ingest_pitch >> 2) * P0.h : static_cast<long long>(P0.w) * P0.h;
     const bool in_place = M.ingest_flag == nullptr;  // 16 bytes per lane and request
-    const long long requests = in_place ? (dwords + 3) / 4 : dwords;
-    const long long want = (requests + TILE_PIX - 1) / TILE_PIX, cap = remap ? INGEST_WGS_REMAP : in_place ? INGEST_WGS_IN_PLACE : INGEST_WGS;
-    M.ingest_wgs = static_cast<int>(want < cap ? want : cap);
-    tiles.y += static_cast<unsigned int>((M.ingest_wgs + ws.tiles_x - 1) / ws.tiles_x);
+    if (remap || in_place) {
+      const long long requests = in_place ? (dwords + 3) / 4 : dwords;
+      const long long want = (requests + TILE_PIX - 1) / TILE_PIX, cap = remap ? INGEST_WGS_REMAP : INGEST_WGS_IN_PLACE;
+      M.ingest_wgs = static_cast<int>(want < cap ? want : cap);
+    } else {
+      M.ingest_wgs = ingest_workgroups(dwords, INGEST_WGS);
+    }
+    M.ingest_rows = (M.ingest_wgs + ws.tiles_x - 1) / ws.tiles_x;
+    M.ingest_profile = ingest->profile ? 1 : 0;
+    tiles.y += static_cast<unsigned int>(M.ingest_rows);
+    if (NSEQ == 1 && M.ahead) tiles.y += 1u;  // the row behind the tile grid that takes the verdict for the next frame
   }
   const int target_units = resident * target_mult;
   hipLaunchKernelGGL((seed_setup_compact_kernel<SIDE, NSEQ>), tiles, dim3(TILE_PIX), 0, stream, B, M, target_units);

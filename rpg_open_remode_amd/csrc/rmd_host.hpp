@@ -284,11 +284,15 @@ struct rmd_hip_seeds {
   // RING slots: the caller may be RING - 1 frames ahead of the setup kernel that has started last.  With three, frame n was handed over
   // when setup n - 2 started and reached HBM 55-60 us later (host copy, submission, 35-45 us of copy engine) -- after setup n - 1 had
   // looked for it, so it was rarely converted one step ahead (rmdk::MatcherArgs::ahead); with four it always is.
-  static constexpr int RING = 4;
-  unsigned char* h_zc_u8[RING] = {};
-  float* h_zc_f32[RING] = {};
-  unsigned char* d_zc_u8[RING] = {};
-  float* d_zc_f32[RING] = {};
+  // Round 6: the depth is a run-time value (RMD_HIP_TUNE_RING_DEPTH; default 6).  At 1920x1080 a light update takes 60 us and a frame needs
+  // 130 us from the moment its slot is free to its arrival in HBM (the caller's wake-up, 2 MB into the pinned slot, two submissions, 50 us of
+  // copy engine): with four slots every fourth frame missed its step-ahead conversion.
+  static constexpr int RING_MAX = 8;
+  int ring = 6;
+  unsigned char* h_zc_u8[RING_MAX] = {};
+  float* h_zc_f32[RING_MAX] = {};
+  unsigned char* d_zc_u8[RING_MAX] = {};
+  float* d_zc_f32[RING_MAX] = {};
   unsigned int* h_seq = nullptr;            // pinned, one block per slot: the frame number the copy stream writes into d_zc_flag
   unsigned int* d_zc_flag = nullptr;        // device, one block per ring slot: number of the last frame whose copy into that slot's staging buffer has completed
   unsigned int* h_submitted = nullptr;      // pinned, [kind * RING + slot]: number of the newest 8-bit (kind 0) / float (kind 1) frame that is complete in that ring slot (frames read in place, one step ahead)
@@ -300,6 +304,7 @@ struct rmd_hip_seeds {
   bool ingest_ready = false;                // ingest_init has run
   bool inject_withhold_flag = false;        // test hook (RMD_HIP_OPT_INJECT_FAULT): the arrival flag of the next staged host frame is not sent
   double ingest_us[4] = {0, 0, 0, 0};  // diagnostics (RMD_HIP_INGEST_PROFILE): host time waiting for a slot, copying, submitting; frames
+  unsigned long ingest_lead[5] = {0, 0, 0, 0, 0};  // ... and how many frames the caller was ahead of the newest setup kernel that had started when it handed a frame over (<= 0, 1, 2, 3, >= 4)
   bool ingest_profile = false;
   rmdh::StageTimer timers[RMD_HIP_NUM_SEED_STAGES];
   long long last_stats[16] = {0};
@@ -313,6 +318,28 @@ struct rmd_hip_seeds {
   unsigned char* h_bgr = nullptr;       // ... and their pinned landing buffer
   unsigned int* d_pc_counts = nullptr;  // point cloud (allocated at the first request): per-block counts / offsets, [n_blocks] = total
   float4* d_pc_points = nullptr;        // W x H points
+  // Publication off the update stream (rmd_hip_seeds_publish_async, rmd_publish.hip), everything allocated at the first request.  One slot per
+  // publication in flight: the snapshot of the state it publishes and its products in pinned host memory; the TV-L1 workspace and the point
+  // cloud's counters are shared -- the publications run one after the other on pub_stream.
+  struct Publication {
+    rmd_hip_image mu, sigma_sq, a, b, conv, ref;  // snapshot (written by the update stream, read by pub_stream)
+    rmdk::Pose T_world_ref;
+    float* h_depth = nullptr;            // pinned, W x H
+    float4* h_points = nullptr;          // pinned + mapped, W x H: the point-cloud kernel writes here over the host link
+    unsigned int* h_total = nullptr;     // pinned + mapped: number of points
+    unsigned char* h_bgr = nullptr;      // pinned, W x H x 3
+    int* h_conv = nullptr;               // pinned, W x H
+    hipEvent_t snapped = nullptr, done = nullptr;
+    unsigned int what = 0;
+    int ticket = 0;
+    bool pending = false;
+  };
+  Publication* pub[RMD_HIP_PUBLISH_SLOTS] = {};
+  hipStream_t pub_stream = nullptr;
+  rmd_hip_image pub_u[2], pub_u_head[2], pub_p[2], pub_g;  // TV-L1 workspace of the publications
+  unsigned int* pub_pc_counts = nullptr;
+  unsigned char* pub_d_bgr = nullptr;
+  int pub_oldest = 0, pub_pending = 0, pub_tickets = 0;
   rmdk::MatcherWorkspace matcher_ws;
 };
 
@@ -329,7 +356,7 @@ struct rmd_hip_batch {
     rmdk::MatcherWorkspace ws;
     int first = 0, n = 0;                   // members [first, first + n)
     unsigned int* h_progress = nullptr;     // pinned: [0] step whose setup kernel has started, [1] error bits (see ingest_current_fused)
-    unsigned long long slot_step[3] = {0, 0, 0};  // host frames: the step of this group's last launch that read staging slot k (0: none)
+    unsigned long long slot_step[8] = {};   // host frames: the step of this group's last launch that read staging slot k (0: none)
     unsigned long long last_step = 0;       // ... and of its last launch altogether
     hipEvent_t ev = nullptr;                // fork / join of the region timer
   };
@@ -339,15 +366,19 @@ struct rmd_hip_batch {
   hipStream_t copy_stream = nullptr;
   // frames handed over in host memory: the frames of one step, back to back, through SLOTS pinned buffers and SLOTS staging buffers
   // (see ingest_current_fused: the same protocol, one sequence number per step)
-  static constexpr int SLOTS = 3;
-  unsigned char* h_stage[SLOTS] = {};
-  unsigned char* d_stage[SLOTS] = {};
+  static constexpr int SLOTS_MAX = 8;
+  int slots = 5;                            // steps in flight between the caller and the setup kernels (RMD_HIP_TUNE_RING_DEPTH; 3 until round 5)
+  unsigned char* h_stage[SLOTS_MAX] = {};
+  unsigned char* d_stage[SLOTS_MAX] = {};
   size_t stage_bytes = 0;                   // capacity of each of the buffers above
   unsigned int* h_seq = nullptr;
   unsigned int* d_flag = nullptr;
   unsigned long long step_number = 0;
   int opt_timing = 0, opt_unit_target = 1;
   int pack_backoff = 0;
+  bool ingest_profile = false;              // diagnostics (RMD_HIP_INGEST_PROFILE), as for a single SeedMatrix: host time per step waiting for a slot, copying, submitting; steps
+  double ingest_us[4] = {0, 0, 0, 0};
+  unsigned long ingest_lead[5] = {0, 0, 0, 0, 0};  // steps handed over <= 0, 1, 2, 3, >= 4 ahead of the newest setup kernel of the first group that had started
   hipEvent_t region_start = nullptr, region_stop = nullptr;
   long region_updates = 0;
   // TV-L1 for all members in one launch sequence (rmd_hip_batch_denoise), allocated at the first request: the denoiser's planes hold the
@@ -436,6 +467,8 @@ int ingest_reference(rmd_hip_seeds* s, const unsigned char* host_gray, const flo
 int wait_for_progress(volatile unsigned int* progress, unsigned int need, hipStream_t stream);
 // rmd_batch.hip
 int batch_bind_device(const rmd_hip_batch* b);
+// rmd_publish.hip
+void publish_release(rmd_hip_seeds* s);      // waits for the publications in flight and releases everything rmd_hip_seeds_publish_async allocated
 // rmd_reduce.hip
 void launch_count_eq(const int* img, int w, int h, int stride, int value, unsigned long long* out_dev, hipStream_t stream);
 // rmd_denoise.hip

@@ -74,6 +74,10 @@ int ingest_init(rmd_hip_seeds* s) {
   s->opt_fused_ingest = T.v[RMD_HIP_TUNE_FUSED_INGEST] != 0;
   s->pack_backoff_len = T.v[RMD_HIP_TUNE_PACK_BACKOFF];  // (tests: 0 examines every float frame)
   s->ingest_ready = true;
+  {
+    const int depth = T.v[RMD_HIP_TUNE_RING_DEPTH];
+    if (depth > 0) s->ring = depth < 3 ? 3 : depth;  // (three: the caller's slot, the copy engine's, the one the kernels read)
+  }
   if (s->batch) {  // a member only ever stages REFERENCE frames (ingest_frame: pinned slot -> plane on the copy stream): events, nothing else
     s->cur_planes[0] = s->planes[RMD_HIP_PLANE_CURR_IMG].data;
     s->u8_pitch = (s->width + 3) / 4 * 4;
@@ -86,13 +90,13 @@ int ingest_init(rmd_hip_seeds* s) {
     return RMD_HIP_OK;
   }
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_progress), 64, hipHostMallocMapped));
-  s->h_progress[0] = s->h_progress[1] = 0u;
-  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_seq), rmd_hip_seeds::RING * FLAG_SLOT_WORDS * sizeof(unsigned int), hipHostMallocDefault));
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_flag), 2 * rmd_hip_seeds::RING * FLAG_ALLOC_BYTES));  // one flag block per ring slot and kind of frame
-  HIP_TRY(hipMemset(s->d_zc_flag, 0, 2 * rmd_hip_seeds::RING * FLAG_ALLOC_BYTES));
+  for (int q = 0; q < 16; ++q) s->h_progress[q] = 0u;
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_seq), rmd_hip_seeds::RING_MAX * FLAG_SLOT_WORDS * sizeof(unsigned int), hipHostMallocDefault));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_flag), 2 * rmd_hip_seeds::RING_MAX * FLAG_ALLOC_BYTES));  // one flag block per ring slot and kind of frame
+  HIP_TRY(hipMemset(s->d_zc_flag, 0, 2 * rmd_hip_seeds::RING_MAX * FLAG_ALLOC_BYTES));
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_submitted), 64, hipHostMallocMapped));
-  static_assert(2 * rmd_hip_seeds::RING * sizeof(unsigned int) <= 64, "h_submitted");
-  for (int q = 0; q < 2 * rmd_hip_seeds::RING; ++q) s->h_submitted[q] = 0u;
+  static_assert(2 * rmd_hip_seeds::RING_MAX * sizeof(unsigned int) <= 64, "h_submitted");
+  for (int q = 0; q < 2 * rmd_hip_seeds::RING_MAX; ++q) s->h_submitted[q] = 0u;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_ahead), 64));
   HIP_TRY(hipMemset(s->d_ahead, 0, 64));
   HIP_TRY(hipStreamSynchronize(nullptr));
@@ -178,31 +182,40 @@ static int ingest_frame(rmd_hip_seeds* s, const unsigned char* host_gray, const 
 // be woken by.  So: a polite spin for the first 2 us (the usual wait when the host is barely ahead), then short sleeps -- the caller is up
 // to three frames (>= 100 us of device work) ahead of the kernel it waits for, an overslept wake-up of a few microseconds stalls nothing, and a
 // rank's host thread no longer burns a whole core while the device works (eight ranks share the 16 CPUs of the measurement box's quota:
-// profiles/r05_nranks/).  Linux rounds a sleep up by the thread's timer slack (50 us by default): the waiting thread's slack is set to
-// 2 us, once.  RMD_HIP_TUNE_HOST_WAIT = 0 restores the pure spin (A/B).
+// profiles/r05_nranks/).  Linux rounds a sleep up by the thread's timer slack (50 us by default): the slack is 2 us WHILE THIS FUNCTION
+// SLEEPS and the caller's own value again when it returns (a library does not leave a scheduling attribute of the application's thread
+// changed -- threads created later would inherit it); if the slack cannot be read or set the wait goes on with the caller's slack, in
+// coarser steps.  RMD_HIP_TUNE_HOST_WAIT = 0 restores the pure spin (A/B).
 int wait_for_progress(volatile unsigned int* progress, unsigned int need, hipStream_t stream) {
   auto behind = [&]() { return static_cast<int>(*progress - need) < 0; };
   if (behind()) {
     const double t0 = host_now_us();
     const bool may_sleep = tunables().v[RMD_HIP_TUNE_HOST_WAIT] != 0;
+    long saved_slack = -1;  // >= 0: the caller's timer slack, to be restored
+    int rc = RMD_HIP_OK;
     while (behind()) {
       const double waited = host_now_us() - t0;
       if (waited > 2000.0) {  // far behind (or another matcher ran the frames in between): an idle stream has read everything
         ++g_progress_timeouts;
-        HIP_TRY(hipStreamSynchronize(stream));
+        if (hipStreamSynchronize(stream) != hipSuccess) rc = fail(RMD_HIP_ERR_RUNTIME, "waiting for a free slot of the frame ring: hipStreamSynchronize failed");
         break;
       }
       if (may_sleep && waited > 2.0) {
-        static thread_local bool slack_set = false;
-        if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 2000UL, 0UL, 0UL, 0UL); slack_set = true; }
+        if (saved_slack < 0) {
+          const long cur = prctl(PR_GET_TIMERSLACK, 0UL, 0UL, 0UL, 0UL);
+          if (cur > 2000 && prctl(PR_SET_TIMERSLACK, 2000UL, 0UL, 0UL, 0UL) == 0) saved_slack = cur;
+          else saved_slack = 0;  // (already fine, or not ours to change: nothing to restore)
+        }
         timespec ts = {0, 8000};  // 8 us + the slack + the scheduler's wake-up: 15-20 us in practice
         (void)nanosleep(&ts, nullptr);
       } else {
         cpu_relax();
       }
     }
+    if (saved_slack > 0) (void)prctl(PR_SET_TIMERSLACK, static_cast<unsigned long>(saved_slack), 0UL, 0UL, 0UL);
     const double w = host_now_us() - t0;
     if (w > g_progress_max_wait_us) g_progress_max_wait_us = w;
+    return rc;
   }
   return RMD_HIP_OK;
 }
@@ -211,18 +224,23 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
   const double t_a = s->ingest_profile ? host_now_us() : 0.0;
   const unsigned long long n64 = ++s->zc_number;
   const unsigned int n = static_cast<unsigned int>(n64);
-  const int k = static_cast<int>(n64 % rmd_hip_seeds::RING);
-  if (n64 > static_cast<unsigned long long>(rmd_hip_seeds::RING)) TRY(wait_for_progress(s->h_progress, n - rmd_hip_seeds::RING + 1u, s->stream));
+  const unsigned int ring = static_cast<unsigned int>(s->ring);
+  const int k = static_cast<int>(n64 % ring);
+  if (n64 > static_cast<unsigned long long>(ring)) TRY(wait_for_progress(s->h_progress, n - ring + 1u, s->stream));
   const double t_b = s->ingest_profile ? host_now_us() : 0.0;
+  if (s->ingest_profile) {  // how far ahead of the device is the caller?  frame n is handed over while setup `started` is the newest that has begun
+    const int lead = static_cast<int>(n - *static_cast<volatile unsigned int*>(s->h_progress));
+    ++s->ingest_lead[lead < 0 ? 0 : lead > 4 ? 4 : lead];
+  }
   PendingIngest in;
   bool in_place = false;
   // every ring slot has its own arrival flag, one per kind of frame (8-bit / float: they use different staging buffers): the setup kernel
   // of frame n asks for frame n's; its verdict for frame n + 1 reads the flag of that slot for ITS kind, which a frame of the other kind never sets
-  auto flag_of = [&](int kind, int slot) { return s->d_zc_flag + (static_cast<size_t>(kind) * rmd_hip_seeds::RING + slot) * (FLAG_ALLOC_BYTES / sizeof(unsigned int)); };
+  auto flag_of = [&](int kind, int slot) { return s->d_zc_flag + (static_cast<size_t>(kind) * rmd_hip_seeds::RING_MAX + slot) * (FLAG_ALLOC_BYTES / sizeof(unsigned int)); };
   void* stage_src = nullptr; void* stage_dst = nullptr; size_t stage_bytes = 0;
   auto ensure_u8_ring = [&]() -> int {
     const size_t bytes = static_cast<size_t>(s->u8_pitch) * s->height;
-    for (int q = 0; q < rmd_hip_seeds::RING; ++q) {  // (all slots at once: the search kernel is told where the NEXT frame will be)
+    for (int q = 0; q < s->ring; ++q) {  // (all slots at once: the search kernel is told where the NEXT frame will be)
       if (s->h_zc_u8[q]) continue;
       HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_zc_u8[q]), bytes + 16, hipHostMallocDefault));
       HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_u8[q]), bytes));
@@ -263,7 +281,7 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
     in.common.pitch = s->u8_pitch;
   } else {
     const size_t bytes = static_cast<size_t>(s->width) * s->height * sizeof(float);
-    for (int q = 0; q < rmd_hip_seeds::RING; ++q) {
+    for (int q = 0; q < s->ring; ++q) {
       if (s->h_zc_f32[q]) continue;
       HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_zc_f32[q]), bytes + 16, hipHostMallocDefault));
       HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_f32[q]), bytes));
@@ -294,15 +312,15 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
   }
   int plane = 0;  // one plane is enough: setup k writes it after search k - 1 has run (same stream)
   if (ahead) {  // ... unless the previous update's search kernel brings the frame in: frame n lives in plane n % 2
-    const int kind = as_u8 ? 0 : 1, k_next = static_cast<int>((n64 + 1) % rmd_hip_seeds::RING);
+    const int kind = as_u8 ? 0 : 1, k_next = static_cast<int>((n64 + 1) % ring);
     void* dev = nullptr;
     if (in_place) {
       // frame n is complete in ITS slot, for ITS kind: the verdict of setup n - 1 read this very word, and setup n's verdict for frame n + 1
       // reads the word of slot k_next for this kind -- which a frame of the other kind, or a frame two steps ahead, never sets (one word
       // per kind for the whole ring let setup n take "frame n + 2 of this kind is there" for "frame n + 1 is", and convert stale bytes)
-      __atomic_store_n(&s->h_submitted[kind * rmd_hip_seeds::RING + k], n, __ATOMIC_RELEASE);
+      __atomic_store_n(&s->h_submitted[kind * rmd_hip_seeds::RING_MAX + k], n, __ATOMIC_RELEASE);
       HIP_TRY(hipHostGetDevicePointer(&dev, s->h_submitted, 0));
-      in.common.submitted = static_cast<const unsigned int*>(dev) + kind * rmd_hip_seeds::RING + k_next;
+      in.common.submitted = static_cast<const unsigned int*>(dev) + kind * rmd_hip_seeds::RING_MAX + k_next;
       HIP_TRY(hipHostGetDevicePointer(&dev, as_u8 ? static_cast<void*>(s->h_zc_u8[k_next]) : static_cast<void*>(s->h_zc_f32[k_next]), 0));
       in.next_src = dev;
     } else {
@@ -310,7 +328,12 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
       in.next_src = as_u8 ? static_cast<const void*>(s->d_zc_u8[k_next]) : static_cast<const void*>(s->d_zc_f32[k_next]);
     }
     in.common.ahead = s->d_ahead;
-    in.common.ahead_wgs = tunables().v[RMD_HIP_TUNE_AHEAD_WGS];
+    {  // no more bringers than the frame has work for (rmdk::INGEST_BATCH requests per lane)
+      const long long dwords = as_u8 ? static_cast<long long>(s->u8_pitch >> 2) * s->height : static_cast<long long>(s->width) * s->height;
+      const long long want = (dwords + 1023) / 1024;  // (staged: INGEST_BATCH dwords per lane; in place: one 16-byte request)
+      const int cap = tunables().v[RMD_HIP_TUNE_AHEAD_WGS];
+      in.common.ahead_wgs = static_cast<int>(want < cap ? (want < 1 ? 1 : want) : cap);
+    }
     plane = static_cast<int>(n64 & 1ull);
     in.next_dst = static_cast<float*>(s->cur_planes[plane ^ 1]);
   }
@@ -321,6 +344,7 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
   HIP_TRY(hipHostGetDevicePointer(&dev_progress, s->h_progress, 0));
   in.common.progress = static_cast<unsigned int*>(dev_progress);
   in.common.number = n;
+  in.common.profile = s->ingest_profile;
   s->P.cur = static_cast<const float*>(im.data);
   s->P.cur_stride = s->P.stride;
   const int rc = seeds_after_frame(s, T_curr_world, &in);

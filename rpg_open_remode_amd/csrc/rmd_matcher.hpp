@@ -154,10 +154,14 @@ struct MatcherArgs {
   // The frames and their destinations are per sequence (SeqArgs).  ingest_kind 0: the frames are resident already.
   int ingest_kind;                 // 1: 8-bit rows of ingest_pitch bytes (a multiple of 4), four pixels per dword; 2: float rows of P.w elements, unpadded
   int ingest_pitch;
-  int ingest_wgs;                  // workgroups below the tile grid (per sequence) that do the conversion
+  int ingest_wgs;                  // workgroups (per sequence) that do the conversion: the first ones of the setup grid ...
+  int ingest_rows;                 // ... which occupy this many grid rows IN FRONT of the tile grid (tile row = blockIdx.y - ingest_rows)
+  int ingest_profile;              // diagnostics (RMD_HIP_INGEST_PROFILE): count into progress[2..4]
   const unsigned int* ingest_flag; // device word: number of the last step whose staging copy (into this step's buffers) has completed; null: in place
   unsigned int* progress;          // pinned host words: [0] <- ingest_number when this setup starts (everything before it has
-                                   // completed: the host may reuse that step's buffers), [1] |= 1 if the flag never came
+                                   // completed: the host may reuse that step's buffers), [1] |= 1 if the flag never came;
+                                   // diagnostics: [2] frames converted by their own setup kernel (not one step ahead), [3] of those, frames
+                                   // the kernel had to wait for, [4] polls of those waits
   unsigned int ingest_number;
   // Host frames ONE STEP AHEAD (single sequences): the caller hands frame n + 1 over while the device is still busy with frame n or
   // n - 1.  One lane of the setup kernel of frame n looks at `submitted` -- has frame n + 1 arrived in its staging buffer (staged) /
@@ -204,6 +208,7 @@ struct IngestArgs {
   unsigned int* progress = nullptr;
   unsigned int number = 0;
   bool no_remap = false;  // 8-bit frames that must not go through the lens-undistortion maps (float frames that travel as bytes)
+  bool profile = false;   // count conversions / waits into progress[2..4] (MatcherArgs::ingest_profile)
   int ahead_wgs = 0;  // see MatcherArgs::ahead
   const unsigned int* submitted = nullptr;
   unsigned int* ahead = nullptr;
@@ -456,7 +461,7 @@ inline MatcherArgs matcher_args(const MatcherWorkspace& ws) {
   M.conv_out = ws.d_conv;
   M.update_number = ws.update_number;
   M.shard_cap = ws.shard_cap;
-  M.ingest_kind = 0; M.ingest_pitch = 0; M.ingest_wgs = 0; M.ingest_flag = nullptr; M.progress = nullptr; M.ingest_number = 0u;
+  M.ingest_kind = 0; M.ingest_pitch = 0; M.ingest_wgs = 0; M.ingest_rows = 0; M.ingest_profile = 0; M.ingest_flag = nullptr; M.progress = nullptr; M.ingest_number = 0u;
   M.ahead_wgs = 0; M.submitted = nullptr; M.ahead = nullptr;
   return M;
 }

@@ -130,6 +130,25 @@ static __global__ __launch_bounds__(256) void convergence_bgr8_kernel(const floa
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The snapshot a publication works on (rmd_hip_seeds_publish_async): up to six planes of one pitch copied as flat arrays of 16-byte vectors --
+// the planes' rows are padded to 256 bytes, padding travels along.  One launch on the update stream: 24 + 24 bytes per pixel at most.
+typedef unsigned int snap_vec_t __attribute__((ext_vector_type(4)));
+struct SnapshotArgs {
+  const snap_vec_t* src[6];
+  snap_vec_t* dst[6];
+  int n_planes;
+  unsigned int n_vec;  // 16-byte vectors per plane
+};
+static __global__ __launch_bounds__(256) void snapshot_kernel(SnapshotArgs A) {
+  const SnapshotArgs* const a = (const SnapshotArgs*)__builtin_amdgcn_kernarg_segment_ptr();  // (indexed in place: no copy of the pointer arrays into scratch)
+  (void)A;
+  const unsigned int step = gridDim.x * blockDim.x;
+  for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < a->n_vec; i += step) {
+    for (int q = 0; q < a->n_planes; ++q) a->dst[q][i] = __builtin_nontemporal_load(a->src[q] + i);
+  }
+}
+
 }  // namespace rmdk
 
 extern "C" {
@@ -194,4 +213,183 @@ int rmd_hip_seeds_convergence_bgr8(rmd_hip_seeds_t* s, unsigned char* host_bgr) 
   return RMD_HIP_OK;
 }
 
+// ---- publication off the update stream (include/rmd_hip.h: rmd_hip_seeds_publish_async / _collect) -------------------------------------
+int rmd_hip_seeds_publish_async(rmd_hip_seeds_t* s, unsigned int what, float depth_range, float lambda, int iterations, int* ticket) {
+  if (!s) return fail(RMD_HIP_ERR_INVALID_ARG, "publish_async: null handle");
+  const unsigned int known = RMD_HIP_PUBLISH_DEPTH | RMD_HIP_PUBLISH_CLOUD | RMD_HIP_PUBLISH_CONVERGENCE_BGR | RMD_HIP_PUBLISH_CONVERGENCE;
+  if (what == 0u || (what & ~known)) return fail(RMD_HIP_ERR_INVALID_ARG, "publish_async: unknown products 0x%x", what);
+  if (what & RMD_HIP_PUBLISH_CLOUD) what |= RMD_HIP_PUBLISH_DEPTH;
+  if ((what & RMD_HIP_PUBLISH_DEPTH) && iterations < 0) return fail(RMD_HIP_ERR_INVALID_ARG, "publish_async: negative iteration count");
+  if (!s->has_reference) return fail(RMD_HIP_ERR_NOT_READY, "publish_async: no reference image set");
+  if (s->pub_pending >= RMD_HIP_PUBLISH_SLOTS)
+    return fail(RMD_HIP_ERR_NOT_READY, "publish_async: %d publications are waiting to be collected (rmd_hip_seeds_publish_collect)", s->pub_pending);
+  TRY(seeds_bind_device(s));
+  const int w = s->width, h = s->height;
+  const size_t n_pix = static_cast<size_t>(w) * h;
+  if (!s->pub_stream) {
+    HIP_TRY(create_stream(&s->pub_stream, 1));  // its own priority level: never on the hardware queue of the update or the copy stream (create_stream)
+    rmd_hip_image* f32[] = {&s->pub_u[0], &s->pub_u[1], &s->pub_u_head[0], &s->pub_u_head[1], &s->pub_g};
+    for (auto* im : f32) TRY(image_alloc(im, RMD_HIP_KIND_F32, w, h));
+    for (int k = 0; k < 2; ++k) TRY(image_alloc(&s->pub_p[k], RMD_HIP_KIND_F32X2, w, h));
+    const int n_blocks = static_cast<int>((n_pix + rmdk::PC_BLOCK - 1) / rmdk::PC_BLOCK);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->pub_pc_counts), (static_cast<size_t>(n_blocks) + 1) * sizeof(unsigned int)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->pub_d_bgr), (n_pix * 3 + 15) & ~static_cast<size_t>(15)));
+  }
+  const int slot = (s->pub_oldest + s->pub_pending) % RMD_HIP_PUBLISH_SLOTS;
+  if (!s->pub[slot]) {
+    rmd_hip_seeds::Publication* np = new (std::nothrow) rmd_hip_seeds::Publication();
+    if (!np) return fail(RMD_HIP_ERR_RUNTIME, "publish_async: out of host memory");
+    s->pub[slot] = np;  // (whatever a failure below leaves half-built is released with the handle)
+    rmd_hip_image* f32[] = {&np->mu, &np->sigma_sq, &np->a, &np->b, &np->ref};
+    for (auto* im : f32) TRY(image_alloc(im, RMD_HIP_KIND_F32, w, h));
+    TRY(image_alloc(&np->conv, RMD_HIP_KIND_I32, w, h));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&np->h_depth), n_pix * sizeof(float)));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&np->h_points), n_pix * sizeof(float4), hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&np->h_total), 64, hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&np->h_bgr), n_pix * 3));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&np->h_conv), n_pix * sizeof(int)));
+    HIP_TRY(hipEventCreateWithFlags(&np->snapped, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&np->done, hipEventDisableTiming));
+  }
+  rmd_hip_seeds::Publication& pb = *s->pub[slot];
+  const bool want_depth = (what & RMD_HIP_PUBLISH_DEPTH) != 0u, want_cloud = (what & RMD_HIP_PUBLISH_CLOUD) != 0u;
+  const bool want_bgr = (what & RMD_HIP_PUBLISH_CONVERGENCE_BGR) != 0u, want_conv = (what & RMD_HIP_PUBLISH_CONVERGENCE) != 0u;
+  // the state must be final where the products read it: mu, sigma_sq, a, b and the NO_MATCH states come from the deferred finalisation; the
+  // colours do not (CONVERGED / DIVERGED were settled by the update's seed_check: rmd_hip_seeds_convergence_bgr8)
+  if (want_depth || want_conv) TRY(seeds_flush(s));
+  rmdk::SnapshotArgs A;
+  memset(&A, 0, sizeof(A));
+  auto add = [&](const void* src, rmd_hip_image& dst) { A.src[A.n_planes] = static_cast<const rmdk::snap_vec_t*>(src); A.dst[A.n_planes] = static_cast<rmdk::snap_vec_t*>(dst.data); ++A.n_planes; };
+  if (want_depth) { add(s->P.mu, pb.mu); add(s->P.sigma_sq, pb.sigma_sq); add(s->P.a, pb.a); add(s->P.b, pb.b); }
+  if (want_cloud || want_bgr || want_conv) add(s->P.conv, pb.conv);
+  if (want_cloud || want_bgr) add(s->P.ref, pb.ref);
+  A.n_vec = static_cast<unsigned int>(pb.mu.pitch * static_cast<size_t>(h) / 16);  // (every f32 / i32 plane of the handle has this pitch)
+  hipLaunchKernelGGL(rmdk::snapshot_kernel, dim3((A.n_vec + 255) / 256 < 2048u ? (A.n_vec + 255) / 256 : 2048u), dim3(256), 0, s->stream, A);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(pb.snapped, s->stream));
+  pb.T_world_ref = s->T_world_ref;
+  HIP_TRY(hipStreamWaitEvent(s->pub_stream, pb.snapped, 0));
+  const size_t row = static_cast<size_t>(w) * 4;
+  const rmd_hip_image* depth_img = nullptr;
+  if (want_depth) {
+    rmdk::TvParams P;
+    P.w = w; P.h = h;
+    P.stride = static_cast<int>(s->pub_g.stride);
+    P.stride2 = static_cast<int>(s->pub_p[0].stride);
+    P.mu = static_cast<const float*>(pb.mu.data); P.sigma_sq = static_cast<const float*>(pb.sigma_sq.data);
+    P.a = static_cast<const float*>(pb.a.data); P.b = static_cast<const float*>(pb.b.data);
+    P.in_stride = static_cast<int>(pb.mu.stride);
+    P.g = static_cast<float*>(s->pub_g.data);
+    P.large_sigma_sq = depth_range * depth_range / 72.0f;  // DepthmapDenoiser::setLargeSigmaSq, depthmap_denoiser.cu:226-229
+    const float L = sqrtf(8.0f);                          // denoise::DeviceData constructor, depthmap_denoiser.cu:124-141
+    P.tau = 0.02f; P.sigma = (1 / (L * L)) / P.tau; P.theta = 0.5f; P.lambda = lambda;
+    P.members = nullptr; P.member_stride = 0; P.member_stride2 = 0;
+    float* us[2] = {static_cast<float*>(s->pub_u[0].data), static_cast<float*>(s->pub_u[1].data)};
+    float* uhs[2] = {static_cast<float*>(s->pub_u_head[0].data), static_cast<float*>(s->pub_u_head[1].data)};
+    float2* ps[2] = {static_cast<float2*>(s->pub_p[0].data), static_cast<float2*>(s->pub_p[1].data)};
+    int cur_buf = 0;
+    long n_launches = 0;
+    TRY(tv_run(P, us, uhs, ps, 1, iterations, 0, 0, s->pub_stream, nullptr, &cur_buf, &n_launches));
+    depth_img = &s->pub_u[cur_buf];
+    HIP_TRY(hipMemcpy2DAsync(pb.h_depth, row, depth_img->data, depth_img->pitch, row, h, hipMemcpyDeviceToHost, s->pub_stream));
+  }
+  if (want_cloud) {
+    rmdk::PointCloudParams P;
+    P.w = w; P.h = h;
+    P.stride = static_cast<int>(pb.conv.stride);
+    P.depth = static_cast<const float*>(depth_img->data);
+    P.depth_stride = static_cast<int>(depth_img->stride);
+    P.conv = static_cast<const int*>(pb.conv.data);
+    P.ref = static_cast<const float*>(pb.ref.data);
+    P.cam = s->P.cam;
+    P.T_world_ref = pb.T_world_ref;
+    const int n_blocks = static_cast<int>((n_pix + rmdk::PC_BLOCK - 1) / rmdk::PC_BLOCK);
+    void *d_points = nullptr, *d_total = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&d_points, pb.h_points, 0));
+    HIP_TRY(hipHostGetDevicePointer(&d_total, pb.h_total, 0));
+    hipLaunchKernelGGL(rmdk::pc_count_kernel, dim3(n_blocks), dim3(rmdk::PC_BLOCK), 0, s->pub_stream, P, s->pub_pc_counts);
+    hipLaunchKernelGGL(rmdk::pc_scan_kernel, dim3(1), dim3(1024), 0, s->pub_stream, s->pub_pc_counts, n_blocks, static_cast<unsigned int*>(d_total));
+    // the points go straight into pinned host memory (posted writes over the host link, 16 bytes per lane): their number is not known when the
+    // transfers are queued, and a copy of all W x H slots would move the unconverged ones too
+    hipLaunchKernelGGL(rmdk::pc_write_kernel, dim3(n_blocks), dim3(rmdk::PC_BLOCK), 0, s->pub_stream, P, s->pub_pc_counts, static_cast<float4*>(d_points),
+                       static_cast<unsigned int>(n_pix));
+    HIP_TRY(hipGetLastError());
+  }
+  if (want_bgr) {
+    const long long groups = (static_cast<long long>(n_pix) + 3) / 4;
+    hipLaunchKernelGGL(rmdk::convergence_bgr8_kernel, dim3(static_cast<unsigned int>((groups + 255) / 256)), dim3(256), 0, s->pub_stream,
+                       static_cast<const float*>(pb.ref.data), static_cast<const int*>(pb.conv.data), w, h, static_cast<int>(pb.conv.stride), s->pub_d_bgr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(pb.h_bgr, s->pub_d_bgr, n_pix * 3, hipMemcpyDeviceToHost, s->pub_stream));
+  }
+  if (want_conv) HIP_TRY(hipMemcpy2DAsync(pb.h_conv, row, pb.conv.data, pb.conv.pitch, row, h, hipMemcpyDeviceToHost, s->pub_stream));
+  HIP_TRY(hipEventRecord(pb.done, s->pub_stream));
+  pb.what = what;
+  pb.ticket = ++s->pub_tickets;
+  pb.pending = true;
+  ++s->pub_pending;
+  if (ticket) *ticket = pb.ticket;
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_seeds_publish_collect(rmd_hip_seeds_t* s, int wait, unsigned int* what, int* ticket, float* host_depth, float* host_xyzi, size_t capacity,
+                                  size_t* n_points, unsigned char* host_bgr, int* host_convergence) {
+  if (!s) return fail(RMD_HIP_ERR_INVALID_ARG, "publish_collect: null handle");
+  if (s->pub_pending == 0) return fail(RMD_HIP_ERR_NOT_READY, "publish_collect: no publication in flight");
+  TRY(seeds_bind_device(s));
+  rmd_hip_seeds::Publication& pb = *s->pub[s->pub_oldest];
+  if (wait) HIP_TRY(hipEventSynchronize(pb.done));
+  else {
+    const hipError_t e = hipEventQuery(pb.done);
+    if (e == hipErrorNotReady) return RMD_HIP_BUSY;
+    HIP_TRY(e);
+  }
+  const size_t n_pix = static_cast<size_t>(s->width) * s->height;
+  if (what) *what = pb.what;
+  if (ticket) *ticket = pb.ticket;
+  if ((pb.what & RMD_HIP_PUBLISH_DEPTH) && host_depth) memcpy(host_depth, pb.h_depth, n_pix * sizeof(float));
+  size_t total = 0;
+  if (pb.what & RMD_HIP_PUBLISH_CLOUD) {
+    total = *static_cast<volatile unsigned int*>(pb.h_total);
+    const size_t n_copy = total < capacity ? total : capacity;
+    if (host_xyzi && n_copy) memcpy(host_xyzi, pb.h_points, n_copy * sizeof(float4));
+  }
+  if (n_points) *n_points = total;
+  if ((pb.what & RMD_HIP_PUBLISH_CONVERGENCE_BGR) && host_bgr) memcpy(host_bgr, pb.h_bgr, n_pix * 3);
+  if ((pb.what & RMD_HIP_PUBLISH_CONVERGENCE) && host_convergence) memcpy(host_convergence, pb.h_conv, n_pix * sizeof(int));
+  pb.pending = false;
+  s->pub_oldest = (s->pub_oldest + 1) % RMD_HIP_PUBLISH_SLOTS;
+  --s->pub_pending;
+  return RMD_HIP_OK;
+}
+
 }  // extern "C"
+
+namespace rmdh {
+
+void publish_release(rmd_hip_seeds* s) {
+  if (s->pub_stream) (void)hipStreamSynchronize(s->pub_stream);
+  for (auto*& pb : s->pub) {
+    if (!pb) continue;
+    rmd_hip_image* planes[] = {&pb->mu, &pb->sigma_sq, &pb->a, &pb->b, &pb->conv, &pb->ref};
+    for (auto* im : planes)
+      if (im->owns && im->data) (void)hipFree(im->data);
+    void* pinned[] = {pb->h_depth, pb->h_points, pb->h_total, pb->h_bgr, pb->h_conv};
+    for (void* q : pinned)
+      if (q) (void)hipHostFree(q);
+    if (pb->snapped) (void)hipEventDestroy(pb->snapped);
+    if (pb->done) (void)hipEventDestroy(pb->done);
+    delete pb;
+    pb = nullptr;
+  }
+  rmd_hip_image* ws[] = {&s->pub_u[0], &s->pub_u[1], &s->pub_u_head[0], &s->pub_u_head[1], &s->pub_p[0], &s->pub_p[1], &s->pub_g};
+  for (auto* im : ws)
+    if (im->owns && im->data) { (void)hipFree(im->data); im->data = nullptr; }
+  if (s->pub_pc_counts) (void)hipFree(s->pub_pc_counts);
+  if (s->pub_d_bgr) (void)hipFree(s->pub_d_bgr);
+  if (s->pub_stream) (void)hipStreamDestroy(s->pub_stream);
+  s->pub_pc_counts = nullptr; s->pub_d_bgr = nullptr; s->pub_stream = nullptr;
+  s->pub_pending = 0;
+}
+
+}  // namespace rmdh

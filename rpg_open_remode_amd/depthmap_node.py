@@ -27,14 +27,17 @@ class Publisher:
         self.pc_ = np.zeros((0, 4), np.float32)  # the reference never clears its cloud: every publication appends (publisher.cpp:83)
         self._pc_store = np.zeros((0, 4), np.float32)  # what pc_ is a view of: grown by doubling, so that appending does not copy the whole cloud every time
 
-    def publishDepthmap(self):
+    def publishDepthmap(self, depth=None):
+        """depth: the map of a collected asynchronous publication (default: the Depthmap's host mirror, as in the reference)"""
         if self.on_depthmap:
-            self.on_depthmap(self.depthmap_.getDepthmap())
+            self.on_depthmap(self.depthmap_.getDepthmap() if depth is None else depth)
         if self.verbose:
             print("INFO: publishing depth map")
 
-    def publishPointCloud(self):
-        pts = self.depthmap_.downloadPointCloud(denoised=True)
+    def publishPointCloud(self, pts=None):
+        """pts: the points of a collected asynchronous publication (default: computed now, synchronously)"""
+        if pts is None:
+            pts = self.depthmap_.downloadPointCloud(denoised=True)
         if len(pts):
             n0, n1 = len(self.pc_), len(self.pc_) + len(pts)
             if self.pc_.base is not self._pc_store or n1 > len(self._pc_store):  # (a caller may have replaced pc_: start from what it holds)
@@ -53,10 +56,13 @@ class Publisher:
         self.publishDepthmap()
         self.publishPointCloud()
 
-    def publishConvergenceMap(self):
+    def publishConvergenceMap(self, colored=None):
         """publisher.cpp:112-147.  The library's Depthmap colours the map on the device (rmd_hip_seeds_convergence_bgr8: 3 bytes per pixel
-        cross the bus); any other object with rmd::Depthmap's interface (the CPU tests drive the oracle) gets the reference's host loop."""
-        if hasattr(self.depthmap_, "convergenceBGR8"):
+        cross the bus); any other object with rmd::Depthmap's interface (the CPU tests drive the oracle) gets the reference's host loop.
+        colored: the map of a collected asynchronous publication."""
+        if colored is not None:
+            pass
+        elif hasattr(self.depthmap_, "convergenceBGR8"):
             colored = self.depthmap_.convergenceBGR8()
         else:
             conv = self.depthmap_.getConvergenceMap()
@@ -76,8 +82,15 @@ class DepthmapNode:
 
     def __init__(self, cam_width, cam_height, cam_fx, cam_fy, cam_cx, cam_cy, ref_compl_perc=10.0, max_dist_from_ref=0.5,
                  publish_conv_every_n=10, patch_side=5, max_extent=100, denoise_lambda=0.5, denoise_iterations=200,
-                 on_depthmap=None, on_pointcloud=None, on_convergence=None, verbose=False, distortion=None, depthmap=None):
+                 on_depthmap=None, on_pointcloud=None, on_convergence=None, verbose=False, distortion=None, depthmap=None, async_publish=False):
         # `depthmap`: an object with rmd::Depthmap's interface to drive instead of the library's (the CPU tests use one)
+        # `async_publish`: publication off the update stream (Depthmap.publishAsync).  The reference launches its publisher with std::async and
+        # discards the future, whose destructor waits (depthmap_node.cpp:170-172, 179-181): publication blocks the callback.  With this switch
+        # the callback only REQUESTS the products (a snapshot of the state, a few microseconds) and goes on; what is published is the same, bit
+        # for bit and in the same order, but it reaches the callbacks a few messages later: at the start of a later denseInput() once the
+        # device has finished it, or in flush().  Off by default: the default node publishes WHEN the reference does (tests/test_reference_host_sources.py).
+        self.async_publish_ = bool(async_publish) and depthmap is None
+        self.in_flight_ = []  # kinds ("results" / "convergence") of the publications requested and not yet delivered, oldest first
         self.depthmap_ = depthmap if depthmap is not None else api.Depthmap(cam_width, cam_height, cam_fx, cam_cx, cam_fy, cam_cy,
                                                                             patch_side=patch_side, max_extent=max_extent)
         if distortion is not None:  # remode/cam_k1, cam_k2, cam_r1, cam_r2 (depthmap_node.cpp:66-74)
@@ -97,6 +110,8 @@ class DepthmapNode:
         """One svo_msgs::DenseInput message: 8-bit image, camera pose in the world frame (an api.SE3, 12 floats, or
         (qw, qx, qy, qz, tx, ty, tz)), scene depth range.  Returns the state the node is in afterwards."""
         self.num_msgs_ += 1
+        if self.in_flight_:
+            self.deliver(wait=False)
         if not isinstance(T_world_curr, api.SE3):
             T_world_curr = api.SE3(*T_world_curr) if len(T_world_curr) == 7 else api.SE3(T_world_curr)
         if self.verbose:
@@ -123,10 +138,45 @@ class DepthmapNode:
         return self.state_
 
     def denoiseAndPublishResults(self):  # depthmap_node.cpp:165-173
+        if self.async_publish_:
+            self._request("results", api.PUBLISH_DEPTH | api.PUBLISH_CLOUD | api.PUBLISH_CONVERGENCE)
+            return
         self.depthmap_.downloadDenoisedDepthmap(self.lambda_, self.iterations_)
         self.depthmap_.downloadConvergenceMap()
         self.publisher_.publishDepthmapAndPointCloud()
 
     def publishConvergenceMap(self):  # :175-182
+        if self.async_publish_:
+            self._request("convergence", api.PUBLISH_CONVERGENCE_BGR | api.PUBLISH_CONVERGENCE)  # (the int32 plane: the host mirror of :177)
+            return
         self.depthmap_.downloadConvergenceMap()  # (:177: the host mirror is refreshed here whether or not the colouring needs it)
         self.publisher_.publishConvergenceMap()
+
+    # ---- publication off the update stream (async_publish) ----
+    MAX_IN_FLIGHT = 3  # RMD_HIP_PUBLISH_SLOTS
+
+    def _request(self, kind, what):
+        if len(self.in_flight_) >= self.MAX_IN_FLIGHT:
+            self.deliver(wait=True, at_most=1)  # the oldest one's slot is needed
+        self.depthmap_.publishAsync(what, self.lambda_, self.iterations_)
+        self.in_flight_.append(kind)
+
+    def deliver(self, wait=False, at_most=None):
+        """hand the finished publications to the callbacks, oldest first; wait=True blocks until they are.  Returns how many were delivered."""
+        n = 0
+        while self.in_flight_ and (at_most is None or n < at_most):
+            pub = self.depthmap_.collectPublication(wait)
+            if pub is None:
+                break
+            kind = self.in_flight_.pop(0)
+            if kind == "results":
+                self.publisher_.publishDepthmap(pub["depth"])
+                self.publisher_.publishPointCloud(pub["points"])
+            else:
+                self.publisher_.publishConvergenceMap(pub["bgr"])
+            n += 1
+        return n
+
+    def flush(self):
+        """everything requested has been published when this returns (a node that shuts down, or a caller that needs the last results now)"""
+        return self.deliver(wait=True)

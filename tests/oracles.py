@@ -32,10 +32,10 @@ def lib_path(kind, side):
         return os.path.join(ORACLE_DIR, f"libremode_oracle_s{side}.so")
     if kind == "port_libm":
         return os.path.join(ORACLE_DIR, f"libremode_oracle_libm_s{side}.so")
-    if kind == "port_e150":  # Oracle B / Oracle A (shared math) built with RMD_MAX_EXTENT_EPIPOLAR_SEARCH = 150 (side 9 only)
-        return os.path.join(ORACLE_DIR, f"libremode_oracle_e150_s{side}.so")
-    if kind == "ref_rmd_e150":
-        return os.path.join(ORACLE_DIR, "_ref", f"libremode_ref_rmd_e150_s{side}.so")
+    if kind in ("port_e150", "port_e178"):  # Oracle B / Oracle A (shared math) built with RMD_MAX_EXTENT_EPIPOLAR_SEARCH = 150 / 178 (side 9 only)
+        return os.path.join(ORACLE_DIR, f"libremode_oracle_{kind[5:]}_s{side}.so")
+    if kind in ("ref_rmd_e150", "ref_rmd_e178"):
+        return os.path.join(ORACLE_DIR, "_ref", f"libremode_ref_rmd_{kind[8:]}_s{side}.so")
     if kind in ("cudalike", "cudalike_fma"):  # Oracle B with run-time switches towards the reference's real CUDA build (side 9 only; remode_oracle.cpp)
         return os.path.join(ORACLE_DIR, f"libremode_oracle_{kind}_s{side}.so")
     raise ValueError(kind)

@@ -133,6 +133,16 @@ def test_tunables_are_set_and_read_in_one_place():
     env.pop("RMD_HIP_COPY_THREADS", None)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), check=True).stdout
     assert out.split() == ["3", "2", "4", "0"], out
+    # a preset passes the same range check as rmd_hip_set_tunable: values outside it, and strings that are no number / no mode name, are ignored
+    # with a line on stderr (a negative RMD_HIP_AHEAD_WGS once went straight into the search kernel's grid arithmetic)
+    code = "from rpg_open_remode_amd import api; print(api.getTunable(api.TUNE_AHEAD_WGS), api.getTunable(api.TUNE_HOST_FRAMES), api.getTunable(api.TUNE_COPY_THREADS), api.getTunable(api.TUNE_PACK_BACKOFF))"
+    env = dict(os.environ, RMD_HIP_AHEAD_WGS="-7", RMD_HIP_HOST_FRAMES="sideways", RMD_HIP_COPY_THREADS="0", RMD_HIP_PACK_BACKOFF="12x")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), check=True)
+    assert res.stdout.split() == ["128", "-1", "4", "15"], res.stdout
+    assert res.stderr.count("ignored") == 4, res.stderr
+    env = dict(os.environ, RMD_HIP_AHEAD_WGS="0")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), check=True)
+    assert res.stdout.split()[0] == "128" and "ignored" in res.stderr
     # the library reads its environment in ONE place
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rpg_open_remode_amd", "csrc")
     hits = [f for f in sorted(os.listdir(csrc)) if os.path.isfile(os.path.join(csrc, f)) and "getenv(" in open(os.path.join(csrc, f)).read()]

@@ -634,18 +634,21 @@ def test_float_frames_of_8bit_levels_travel_as_bytes_and_mix_with_other_floats(s
     assert_states_equal(res.state(), host.state(), "float host frames of mixed kinds")
 
 
+@pytest.mark.parametrize("extent", [150, 178])
 @pytest.mark.parametrize("matcher", MATCHERS)
-def test_max_extent_150_equals_the_reference_built_with_that_extent(matcher):
+def test_max_extent_equals_the_reference_built_with_that_extent(matcher, extent):
     """RMD_MAX_EXTENT_EPIPOLAR_SEARCH is a compile-time constant of the reference that its CMakeLists leaves to the user (CMakeLists.txt:52-53);
     here it is a constructor argument (1..178).  With the prior variance inflated (3 sigma beyond the depth range on both sides) every search is
-    capped: 150 pixels = 215 steps per seed, step numbers and counts far beyond the 143 of the default extent -- against Oracle B and the
-    reference's own sources, both built with -DRMD_MAX_EXTENT_EPIPOLAR_SEARCH=150.  A batch of two members takes the same argument."""
+    capped: 150 pixels = 215 steps per seed, 178 pixels = 255 steps -- the LIMIT: the step index and the step count fill their 8-bit fields
+    (rmd_matcher.hpp), a tile of 256 such seeds is 255 rounds of work, its units fill the unit writer -- against Oracle B and the reference's own
+    sources, both built with -DRMD_MAX_EXTENT_EPIPOLAR_SEARCH=<extent>.  A batch of two members takes the same argument."""
+    n_steps = {150: 215, 178: 255}[extent]
     full = sequence(320, 240, 41)
     rng = full.max_depth - full.min_depth
     wide = np.full((full.height, full.width), 4.0 * rng * rng, np.float32)
-    kinds = ["port_e150"] + (["ref_rmd_e150"] if O.available("ref_rmd_e150", 9) else [])
+    kinds = [f"port_e{extent}"] + ([f"ref_rmd_e{extent}"] if O.available(f"ref_rmd_e{extent}", 9) else [])
     for kind in kinds:
-        hip = api.SeedMatrix(full.width, full.height, api.PinholeCamera(*full.K), patch_side=9, max_extent=150)
+        hip = api.SeedMatrix(full.width, full.height, api.PinholeCamera(*full.K), patch_side=9, max_extent=extent)
         apply_matcher(hip, matcher)
         orc = _oracle_seeds(kind, full, 9)
         hip.setReferenceImage(full.images[0], full.T_curr_world[0], full.min_depth, full.max_depth)
@@ -655,12 +658,14 @@ def test_max_extent_150_equals_the_reference_built_with_that_extent(matcher):
         for n, k in enumerate((4, 8, 12, 16), 1):
             hip.update(full.images[k], full.T_curr_world[k])
             orc.update(full.images[k], full.T_curr_world[k])
-            assert_states_equal(orc.state(), hip.state(), f"max_extent 150, {kind}, matcher {matcher}, update {n}")
+            assert_states_equal(orc.state(), hip.state(), f"max_extent {extent}, {kind}, matcher {matcher}, update {n}")
             if kind.startswith("port"):
                 st = orc.last_stats()
-                assert st["steps"] == 215 * st["live_seeds"] and st["ncc_evals"] > 150 * st["live_seeds"], st  # every search capped at 150 px, most of it in the image
-    b = api.SeedMatrixBatch(2, full.width, full.height, api.PinholeCamera(*full.K), patch_side=9, max_extent=150)
-    orcs = [_oracle_seeds("port_e150", full, 9) for _ in range(2)]
+                assert st["steps"] == n_steps * st["live_seeds"] and st["ncc_evals"] > extent * st["live_seeds"], st  # every search capped, most of it in the image
+                if n == 1:  # the arg-max really lands on the last step indices somewhere (step numbers up to n_steps - 1 are decoded)
+                    assert st["live_seeds"] > 10000
+    b = api.SeedMatrixBatch(2, full.width, full.height, api.PinholeCamera(*full.K), patch_side=9, max_extent=extent)
+    orcs = [_oracle_seeds(f"port_e{extent}", full, 9) for _ in range(2)]
     for i in range(2):
         b[i].setReferenceImage(full.images[4 * i], full.T_curr_world[4 * i], full.min_depth, full.max_depth)
         orcs[i].set_reference(full.images[4 * i], full.T_curr_world[4 * i], full.min_depth, full.max_depth)
@@ -671,6 +676,6 @@ def test_max_extent_150_equals_the_reference_built_with_that_extent(matcher):
         orcs[0].update(full.images[k], full.T_curr_world[k])
         orcs[1].update(full.images[k + 4], full.T_curr_world[k + 4])
     for i in range(2):
-        assert_states_equal(orcs[i].state(), b[i].state(), f"batch member {i}, max_extent 150")
+        assert_states_equal(orcs[i].state(), b[i].state(), f"batch member {i}, max_extent {extent}")
     with pytest.raises(api.RmdHipError):
         api.SeedMatrix(64, 48, api.PinholeCamera(*full.K), patch_side=9, max_extent=179)

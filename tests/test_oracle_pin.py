@@ -252,3 +252,35 @@ def test_cudalike_model_with_every_switch_off_is_the_reference():
         moved[name] = O.count_mismatch(got[11][O.PLANE_MU], sw[11][O.PLANE_MU])
     assert all(v > 0 for v in moved.values()), moved
     assert not O.OracleLib("port_libm", 9).set_cudalike(1)  # the other builds have no such switch
+
+
+@needs_ref
+@pytest.mark.parametrize("extent", [150, 178])
+def test_port_equals_reference_at_other_search_extents(extent):
+    """RMD_MAX_EXTENT_EPIPOLAR_SEARCH (CMakeLists.txt:52-53, epipolar_match.cu:75) is compile time in the reference: B and the reference's sources
+    built with 150 and with 178 -- the library's limit, 255 steps per seed -- agree bit for bit when every search is capped (prior variance
+    inflated), and the step counts are the ones the extent implies."""
+    n_steps = {150: 215, 178: 255}[extent]
+    seq = sequence(200, 150, 9)
+    rng = seq.max_depth - seq.min_depth
+    st0 = [None] * 8
+
+    def run(kind):
+        s = O.Seeds(O.OracleLib(kind, 9), seq.width, seq.height, seq.K)
+        s.set_reference(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+        s.upload(O.PLANE_SIGMA_SQ, np.full((seq.height, seq.width), 4.0 * rng * rng, np.float32))
+        out = []
+        for k in (4, 8):
+            s.update(seq.images[k], seq.T_curr_world[k])
+            out.append(s.state())
+        return s, out
+
+    a, ref = run(f"ref_rmd_e{extent}")
+    b, port = run(f"port_e{extent}")
+    for k, (r, p) in enumerate(zip(ref, port)):
+        assert_states_equal(r, p, f"extent {extent} update {k + 1}")
+    st = b.last_stats()
+    assert st["steps"] == n_steps * st["live_seeds"] and st["live_seeds"] > 1000, st
+    # and the extent matters: the default build (100 px) gives another result on the same input
+    _, dflt = run("port")
+    assert not np.array_equal(dflt[-1][O.PLANE_MU], port[-1][O.PLANE_MU])
