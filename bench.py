@@ -81,6 +81,9 @@ def parse():
                     "r*B .. r*B+B-1; the headline stays whole-job pixels / max elapsed.  Default 1: one sequence per GPU (the driver's BENCH / SCALE lines)")
     ap.add_argument("--dist", action="store_true", help="create the torch.distributed (RCCL) group even for a single rank")
     ap.add_argument("--no-extras", action="store_true", help="the timed region and the denoise only (profiling runs)")
+    ap.add_argument("--configs", default="configs[2],configs[4]", help="the other single-GPU configurations of BASELINE.json measured after the headline (one pass each; "
+                    "empty: skip them); only with the default workload")
+    ap.add_argument("--no-live", dest="live", action="store_false", help="skip the live-use figure (the node's state machine over the headline's frames)")
     ap.add_argument("--rendezvous-only", action="store_true", help="launch-path check, no measurement: join the process group (gloo when "
                     "there is no GPU), run the barriers and the throughput gather with zero work, print {\"rendezvous\": ...} and exit")
     return ap.parse_args()
@@ -282,6 +285,103 @@ def scenes_of_rank(rank, batch_per_gpu):
     return [rank * batch_per_gpu + i for i in range(batch_per_gpu)]
 
 
+def bind_rank_device(local_rank, n_dev, set_torch_device, check_device):
+    """Rank r of a --gpus N launch works on device local_rank % n_dev (more ranks than devices -- a one-GPU lease driven with --gpus 8 -- share
+    devices): torch's current device first (the RCCL group's), then the library's (api.checkCudaDevice = rmd_hip_set_device,
+    check_cuda_device.cu:60-71,109).  Called BEFORE the rank creates its first handle: handles bind to the device that is current when they
+    are created (tests/test_bench_cpu.py holds bench.py to that order)."""
+    if n_dev < 1:
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
+    dev_index = local_rank % n_dev
+    set_torch_device(dev_index)
+    if not check_device(dev_index):
+        raise SystemExit("no usable HIP device")
+    return dev_index
+
+
+def rank_record(r):
+    """one entry of `per_rank` from the gathered 7 x f64 record (elapsed, pixels, updates, converged, sequences, host CPU seconds, submit seconds)"""
+    return {"elapsed_s": round(r[0], 6), "mpix": r[1] / 1e6, "updates": int(r[2]), "converged": int(r[3]), "sequences": int(r[4]),
+            "host_cpu_s": round(r[5], 4), "host_cores_busy": round(r[5] / r[0], 3), "host_submit_us_per_update": round(r[6] / max(r[2] / max(r[4], 1.0), 1.0) * 1e6, 2)}
+
+
+def measure_config(api, synth, label, Wc, Hc, Fc, tv_iters, passes=1):
+    """One of the other single-GPU configurations of BASELINE.json (configs[2], configs[4]) measured like the headline -- complete passes, 8-bit host
+    frames inside update() (`value`) and frames resident in HBM (`resident`), one HIP event pair on the kernels' stream, TV-L1 of the config --
+    in a few seconds: `passes` timed passes after one warm-up pass each.  The driver's line carries them so that they are no longer figures only
+    the builder has seen (profiles/r06_bench_config*.json are the same runs through `--size`)."""
+    t_r = time.perf_counter()
+    Kc = synth.intrinsics(Wc, Hc)
+    gray, poses, dev = [], [], []
+    rng0 = None
+    for k in range(Fc):
+        T = synth.pose(k, 0)
+        g, rng = synth.render(Wc, Hc, T, 0, want_range=(k == 0), K=Kc)
+        if k == 0:
+            rng0 = rng
+        gray.append(g)
+        poses.append(np.ascontiguousarray(synth.invert_pose(T).astype(np.float32).reshape(12)))
+        d = api.DeviceImage(Wc, Hc, np.float32)
+        d.setDevData(synth.to_float_image(g))
+        dev.append(d)
+    lo, hi = float(rng0.min()), float(rng0.max())
+    render_s = time.perf_counter() - t_r
+    s = api.SeedMatrix(Wc, Hc, api.PinholeCamera(*Kc), patch_side=SIDE)
+
+    def pass_u8():
+        s.setReferenceImageU8(gray[0], poses[0], lo, hi)
+        for k in range(1, Fc):
+            s.updateU8(gray[k], poses[k])
+
+    def pass_res():
+        s.setReferenceImageDevice(dev[0].data, dev[0].stride, poses[0], lo, hi)
+        for k in range(1, Fc):
+            s.updateDevice(dev[k].data, dev[k].stride, poses[k])
+
+    def timed(one_pass):
+        one_pass()  # warm-up (staging buffers, clocks)
+        s.sync()
+        s.setOption(api.OPT_TIMING, 2)
+        s.timingReset()
+        ru0 = resource.getrusage(resource.RUSAGE_SELF)
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            one_pass()
+        s.sync()
+        dt = time.perf_counter() - t0
+        ru1 = resource.getrusage(resource.RUSAGE_SELF)
+        ms, n = s.timing(api.STAGE_UPDATE)
+        s.setOption(api.OPT_TIMING, 0)
+        cpu = (ru1.ru_utime + ru1.ru_stime) - (ru0.ru_utime + ru0.ru_stime)
+        return {"value": round(Wc * Hc * (Fc - 1) * passes / dt / 1e6, 1), "unit": "Mpix/s", "us_per_update_wall": round(dt / n * 1e6, 2),
+                "us_per_update_device": round(ms / n * 1e3, 2), "host_cores_busy": round(cpu / dt, 3), "passes": passes}
+    u8 = timed(pass_u8)
+    res = timed(pass_res)
+    avg_s = u8["us_per_update_device"] / 1e6
+    ach = FUSED_BYTES_PER_PIXEL * Wc * Hc / avg_s / 1e9
+    den = api.DepthmapDenoiser(Wc, Hc)
+    den.setLargeSigmaSq(hi - lo)
+    den.setOption(api.DENOISE_OPT_TIMING, 1)
+    den.denoise(s.getMu(), s.getSigmaSq(), s.getA(), s.getB(), TV_LAMBDA, 10, download=True)
+    td = time.perf_counter()
+    den.denoise(s.getMu(), s.getSigmaSq(), s.getA(), s.getB(), TV_LAMBDA, tv_iters, download=True)
+    wall_ms = (time.perf_counter() - td) * 1e3
+    tv_ms, tv_launches = den.timing()
+    tv_bw = TV_BYTES_PER_PIXEL_ITER * Wc * Hc * tv_iters / (tv_ms / 1e3) / 1e9 if tv_ms > 0 else 0.0
+    out = {"workload": f"{label}: {Wc}x{Hc}, {Fc} frames ({Fc - 1} updates per pass), patch side {SIDE}, TV-L1 {tv_iters} iterations; 8-bit host frames inside update()",
+           "value": u8["value"], "unit": "Mpix/s", "u8_host_frames": u8, "resident": res, "u8_over_resident": round(u8["value"] / res["value"], 4),
+           "converged_seeds_at_end": s.getConvergedCount(),
+           "roofline": {"bound": "hbm", "kernel": "seed_update (fused)", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                        "frac_resident": round(FUSED_BYTES_PER_PIXEL * Wc * Hc / (res["us_per_update_device"] / 1e6) / 1e9 / HBM_PEAK_GBS, 5),
+                        "avg_launch_us": u8["us_per_update_device"], "algorithmic_bytes_per_launch": FUSED_BYTES_PER_PIXEL * Wc * Hc, "traffic": None},
+           "roofline_denoiser": {"bound": "hbm", "kernel": "tv_iterate", "achieved": round(tv_bw, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(tv_bw / HBM_PEAK_GBS, 5),
+                                 "avg_launch_us": round(tv_ms / max(tv_launches, 1) * 1e3, 2), "launches": tv_launches, "iterations": tv_iters,
+                                 "denoise_wall_ms": round(wall_ms, 3), "traffic": None},
+           "host_render_and_upload_s": round(render_s, 1)}
+    del den, s, dev
+    return out
+
+
 class BatchAsSeeds:
     """the few SeedMatrix methods the timed region uses, on a SeedMatrixBatch (--batch-per-gpu)"""
 
@@ -328,12 +428,8 @@ def main():
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback of the product path)")
-    n_dev = torch.cuda.device_count()
-    dev_index = local_rank % n_dev  # more ranks than devices (a 1-GPU lease driven with --gpus 2) share devices
-    torch.cuda.set_device(dev_index)
+    dev_index = bind_rank_device(local_rank, torch.cuda.device_count(), torch.cuda.set_device, api.checkCudaDevice)  # before the rank's first handle
     device = torch.device("cuda", dev_index)
-    if not api.checkCudaDevice(dev_index):
-        raise SystemExit("no usable HIP device")
 
     # one independent sequence per rank (scene / trajectory seed = rank), rendered on the host frame by frame: the 8-bit frames stay
     # in pageable host memory (the timed region hands them over like a camera driver would); a float copy of every frame is made
@@ -502,6 +598,7 @@ def main():
                        "denoise_wall_ms": round(denoise_wall_ms, 3), "iterations": tv_iters, "depth_maps_per_launch": B}
 
         search_stats, cpu, glibc, resident, floats, heavy, batched, other_path = None, None, None, None, None, None, None, None
+        floats_other, other_configs, live = None, None, None
         extra_passes = max(1, min(args.steps, 3))
         if not args.no_extras and bm is None:
             # search statistics of the timed workload (separate pass over the same sequence, diagnostics counters on)
@@ -542,6 +639,9 @@ def main():
                 floats = dict(rate(pass_float), path="rmd_hip_seeds_update: float frames in pageable host memory, the reference's own signature "
                               "(seed_matrix.cu:120-128), frames as the reference's host path produces them (convertTo(CV_32F, 1.0f / 255.0f), depthmap.cpp:105): the library "
                               "finds every pixel to be an 8-bit level, bit pattern by bit pattern, and sends the bytes (DESIGN.md 4.6); the examination is split across a few host threads")
+                # ... and float frames that are NOT 8-bit levels (every pixel scaled by 0.999): nothing to pack, 4 bytes per pixel cross the host link
+                fimgs = [np.ascontiguousarray(f * np.float32(0.999)) for f in fimgs]
+                floats_other = dict(rate(pass_float), path="rmd_hip_seeds_update with float frames that are not 8-bit levels (x 0.999): sent as floats, 4 bytes per pixel")
                 del fimgs
 
             # updates 1..20 of a pass: every seed is live and searches its full range (the heaviest twentieth of the job)
@@ -639,6 +739,30 @@ def main():
                     batched[f"B={Bq}"] = entry
                     del bmq
 
+            # the other single-GPU configurations of BASELINE.json and live use (the node's state machine), after everything of the headline
+            if headline and world == 1 and not args.resident and args.configs:
+                other_configs = {}
+                for name, (Wc, Hc, Fc, tvc) in (("configs[2]", (1280, 960, 500, 200)), ("configs[4]", (1920, 1080, 1000, 500))):
+                    if name in args.configs:
+                        try:
+                            other_configs[name] = measure_config(api, synth, name, Wc, Hc, Fc, tvc)
+                        except Exception as e:  # the headline line must survive
+                            other_configs[name] = {"unavailable": str(e)}
+            if headline and world == 1 and args.live:
+                try:
+                    from rpg_open_remode_amd import live as live_mod
+                    lseq = synth.Sequence(W, H, F)
+                    live = {"what": "rmd::DepthmapNode's state machine over this workload's frames (depthmap_node.cpp:125-173): 8-bit host frames, a converged count after every "
+                                    "update, a new reference when 10 % have converged or the camera has moved 0.5, and at every reference change TV-L1 (0.5, 200), the "
+                                    "point cloud and -- every 11 messages -- the coloured convergence map; Mpix/s = frame pixels x messages / wall time",
+                            "publication_in_the_callback": live_mod.run_live(W, H, F, SIDE, async_publish=False, passes=3, seq=lseq),
+                            "publication_off_the_update_stream": live_mod.run_live(W, H, F, SIDE, async_publish=True, passes=3, breakdown=False, seq=lseq)}
+                    live["value"] = live["publication_off_the_update_stream"]["value"]
+                    live["unit"] = "Mpix/s"
+                    del lseq
+                except Exception as e:
+                    live = {"unavailable": str(e)}
+
             # CPU baseline = the untouched reference on the host cores; the same run gives the distance of the GPU result from it
             if args.cpu_seconds > 0 and world == 1 and F <= 500:
                 try:
@@ -693,11 +817,10 @@ def main():
             "roofline_valu": valu_roofline(avg_kernel_s, counters, n_sequences=B, ncc_evals_per_update=search_stats["ncc_evals"] if search_stats else None) if headline else None,
             "roofline_flops": flops_roofline(avg_kernel_s, search_stats["ncc_evals"] if search_stats else None, SIDE),
             "roofline_denoiser": roofline_tv, "cpu_baseline": cpu,
-            "resident": resident, "h2d_inclusive": other_path, "float_frames": floats, "heavy_prefix": heavy, "batched_per_gpu": batched,
+            "resident": resident, "h2d_inclusive": other_path, "float_frames": floats, "float_frames_not_8bit_levels": floats_other, "heavy_prefix": heavy, "batched_per_gpu": batched,
+            "configs": other_configs, "live": live,
             "parity": PARITY_NOTE, "parity_vs_glibc_reference": glibc, "tolerance_vs_cuda_build_model": cuda_build_tolerance() if headline else None,
-            "per_rank": [{"elapsed_s": round(r[0], 6), "mpix": r[1] / 1e6, "updates": int(r[2]), "converged": int(r[3]), "sequences": int(r[4]),
-                          "host_cpu_s": round(r[5], 4), "host_cores_busy": round(r[5] / r[0], 3), "host_submit_us_per_update": round(r[6] / max(r[2] / max(r[4], 1.0), 1.0) * 1e6, 2)}
-                         for r in per_rank],
+            "per_rank": [dict(rank_record(r), device=i % max(torch.cuda.device_count(), 1)) for i, r in enumerate(per_rank)],
             # host side of the timed region on rank 0: CPU seconds of all of the process's threads (getrusage), the same as cores kept busy, and
             # the wall time per update() call until the call returned (frame copied into the pinned ring, two launches queued) -- the device
             # time per update is roofline.avg_launch_us; a host that needs longer than that paces the run

@@ -94,7 +94,8 @@ typedef struct rmd_hip_batch rmd_hip_batch_t;
                                          0 = spin only (one core per handle that is fed host frames at full speed) */
 #define RMD_HIP_TUNE_RING_DEPTH 9     /* frames (a batch: steps) that may be in flight between update() and the setup kernel that consumes them = slots of the pinned
                                          frame ring, 3..8; 0 (default) = the library's choice: 6 for a SeedMatrix, 5 for a batch */
-#define RMD_HIP_NUM_TUNABLES 10
+#define RMD_HIP_TUNE_COPY_STREAMS 10   /* copy streams (copy engines) a SeedMatrix spreads its staged host frames over, 1..2 (2) */
+#define RMD_HIP_NUM_TUNABLES 11
 int rmd_hip_set_tunable(int tunable, int value);
 int rmd_hip_get_tunable(int tunable, int* value);
 
@@ -206,6 +207,12 @@ int rmd_hip_seeds_convergence_bgr8(rmd_hip_seeds_t* s, unsigned char* host_bgr);
 int rmd_hip_seeds_publish_async(rmd_hip_seeds_t* s, unsigned int what, float depth_range, float lambda, int iterations, int* ticket);
 int rmd_hip_seeds_publish_collect(rmd_hip_seeds_t* s, int wait, unsigned int* what, int* ticket, float* host_depth, float* host_xyzi, size_t capacity,
                                   size_t* n_points, unsigned char* host_bgr, int* host_convergence);
+/* The same without the copies: _peek hands out POINTERS into the pinned host buffers of the oldest publication (NULL for a product that was
+ * not requested; the points: *n_points x 4 floats) and leaves it in its slot; they stay valid until rmd_hip_seeds_publish_release gives the slot
+ * back.  collect = peek + memcpy + release. */
+int rmd_hip_seeds_publish_peek(rmd_hip_seeds_t* s, int wait, unsigned int* what, int* ticket, const float** depth, const float** xyzi, size_t* n_points,
+                               const unsigned char** bgr, const int** convergence);
+int rmd_hip_seeds_publish_release(rmd_hip_seeds_t* s);
 int rmd_hip_seeds_dist_from_ref(const rmd_hip_seeds_t* s, float* dist);
 /* blocks until all work queued by this handle has finished */
 int rmd_hip_seeds_sync(const rmd_hip_seeds_t* s);

@@ -51,11 +51,20 @@
 //   ACOS        acosf / atan2f -> correctly rounded, moved by a hash in [-2, 2] ulp (CUDA's acosf: 2 ulp, its atan2f: 3 ulp)
 //   FTZ         flush-to-zero and denormals-are-zero for every fp32 operation (MXCSR), as -ftz=true
 // FMA contraction (-fmad=true) is a compile-time matter: the "cudalike_fma" build is this one compiled with -ffp-contract=fast.
+// WHAT IS SPECIFIED AND WHAT IS GUESSED.  Specified behaviour of that build: TEX8 (the programming guide's fixed-point filter; only rounding
+// vs truncation of the weights is open: both are run), FTZ (-ftz=true), FMA contraction (-fmad=true).  GUESSES: the guide gives the fast /
+// approximate operations (DIV, SQRT, EXP, SIN, ACOS) as error BOUNDS only, not as functions -- the forms above are one plausible member
+// each.  orc_set_cudalike_amplitude(n) replaces those forms by "the correctly rounded result moved by a hash of the argument, uniformly in
+// [-n, n] units in the last place" (n >= 1), or, for n = -1, by each operation's DOCUMENTED maximum (as the guide's table of mathematical
+// functions gives them: division 2 ulp, sqrt.approx 1 ulp, rsqrt 2 ulp, __expf 2 + floor(|1.16 x|) ulp, sinf / acosf 2 ulp, atan2f 3 ulp;
+// __sinf's absolute bound 2^-21.41 is the SIN_ABS switch) -- the sensitivity lines of tests/cudalike_tolerance.py; 0 = the fixed forms.
 #include <xmmintrin.h>
 #include <pmmintrin.h>
 namespace cudalike {
 enum { TEX8 = 1, TEX8_TRUNC = 2, DIV = 4, SQRT = 8, EXP = 16, SIN = 32, SIN_ABS = 64, ACOS = 128, FTZ = 256 };
 static int flags = 0;
+static int amplitude = 0;  // orc_set_cudalike_amplitude
+inline int ulps_of(int documented_max) { return amplitude < 0 ? documented_max : amplitude; }
 inline void thread_mode() {
   _MM_SET_FLUSH_ZERO_MODE((flags & FTZ) ? _MM_FLUSH_ZERO_ON : _MM_FLUSH_ZERO_OFF);
   _MM_SET_DENORMALS_ZERO_MODE((flags & FTZ) ? _MM_DENORMALS_ZERO_ON : _MM_DENORMALS_ZERO_OFF);
@@ -70,17 +79,34 @@ inline float moved(float v, float arg, int max_ulp) {  // v moved by h(arg) in [
   for (; n < 0; ++n) v = nextafterf(v, -INFINITY);
   return v;
 }
-inline float div(float x, float y) { return (flags & DIV) ? x * (1.0f / y) : x / y; }
-inline float sqrt_(float x) { return (flags & SQRT) ? (x == 0.0f || isinf(x) ? x : x * static_cast<float>(1.0 / sqrt(static_cast<double>(x)))) : sqrtf(x); }
-inline float rsqrt_(float x) { return (flags & SQRT) ? static_cast<float>(1.0 / sqrt(static_cast<double>(x))) : 1.0f / sqrtf(x); }
-inline float exp_(float x) { return (flags & EXP) ? static_cast<float>(exp2(static_cast<double>(x * 1.4426950408889634f))) : expf(x); }
+inline float div(float x, float y) {
+  if (!(flags & DIV)) return x / y;
+  return amplitude ? moved(x / y, x * 0.6180339887f + y, ulps_of(2)) : x * (1.0f / y);
+}
+inline float sqrt_(float x) {
+  if (!(flags & SQRT)) return sqrtf(x);
+  if (amplitude) return moved(sqrtf(x), x, ulps_of(1));
+  return x == 0.0f || isinf(x) ? x : x * static_cast<float>(1.0 / sqrt(static_cast<double>(x)));
+}
+inline float rsqrt_(float x) {
+  if (!(flags & SQRT)) return 1.0f / sqrtf(x);
+  const float r = static_cast<float>(1.0 / sqrt(static_cast<double>(x)));
+  return amplitude ? moved(r, x, ulps_of(2)) : r;
+}
+inline float exp_(float x) {
+  if (!(flags & EXP)) return expf(x);
+  if (amplitude) return moved(static_cast<float>(exp(static_cast<double>(x))), x, ulps_of(2 + static_cast<int>(floorf(fabsf(1.16f * x) < 1000.0f ? fabsf(1.16f * x) : 1000.0f))));
+  return static_cast<float>(exp2(static_cast<double>(x * 1.4426950408889634f)));
+}
 inline float sin_(float x) {
   if (flags & SIN_ABS) return static_cast<float>(rint(sin(static_cast<double>(x)) * 2097152.0) / 2097152.0);
-  if (flags & SIN) return moved(static_cast<float>(sin(static_cast<double>(x))), x, 2);
+  if (flags & SIN) return moved(static_cast<float>(sin(static_cast<double>(x))), x, amplitude ? ulps_of(2) : 2);
   return sinf(x);
 }
-inline float acos_(float x) { return (flags & ACOS) ? moved(static_cast<float>(acos(static_cast<double>(x))), x, 2) : acosf(x); }
-inline float atan2_(float y, float x) { return (flags & ACOS) ? moved(static_cast<float>(atan2(static_cast<double>(y), static_cast<double>(x))), x, 2) : atan2f(y, x); }
+inline float acos_(float x) { return (flags & ACOS) ? moved(static_cast<float>(acos(static_cast<double>(x))), x, amplitude ? ulps_of(2) : 2) : acosf(x); }
+inline float atan2_(float y, float x) {
+  return (flags & ACOS) ? moved(static_cast<float>(atan2(static_cast<double>(y), static_cast<double>(x))), x, amplitude ? ulps_of(3) : 2) : atan2f(y, x);
+}
 }  // namespace cudalike
 #define ORC_EXPF cudalike::exp_
 #define ORC_SINF cudalike::sin_
@@ -432,6 +458,17 @@ int orc_set_cudalike(int flags) {
   return 1;
 #else
   (void)flags;
+  return 0;
+#endif
+}
+// cudalike build only: how far the GUESSED operations are moved (see the top of this file): 0 the fixed forms, n >= 1 up to n ulp, -1 each
+// operation's documented maximum
+int orc_set_cudalike_amplitude(int n) {
+#ifdef RMD_ORACLE_CUDALIKE
+  cudalike::amplitude = n;
+  return 1;
+#else
+  (void)n;
   return 0;
 #endif
 }

@@ -67,6 +67,8 @@ SIGNATURES = {
     "rmd_hip_seeds_point_cloud": (_i, [_p, _p, _p, _sz, _c.POINTER(_sz)]),
     "rmd_hip_seeds_publish_async": (_i, [_p, _c.c_uint, _f, _f, _i, _c.POINTER(_i)]),
     "rmd_hip_seeds_publish_collect": (_i, [_p, _i, _c.POINTER(_c.c_uint), _c.POINTER(_i), _p, _p, _sz, _c.POINTER(_sz), _p, _p]),
+    "rmd_hip_seeds_publish_peek": (_i, [_p, _i, _c.POINTER(_c.c_uint), _c.POINTER(_i), _pp, _pp, _c.POINTER(_sz), _pp, _pp]),
+    "rmd_hip_seeds_publish_release": (_i, [_p]),
     "rmd_hip_seeds_init_undistortion_map": (_i, [_p, _f, _f, _f, _f]),
     "rmd_hip_seeds_undistortion_map": (_i, [_p, _p, _p]),
     "rmd_hip_compute_undistortion_map": (_i, [_i, _i, _f, _f, _f, _f, _f, _f, _f, _f, _p, _p]),

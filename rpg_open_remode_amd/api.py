@@ -34,7 +34,7 @@ OPT_INJECT_FAULT = 9  # test hook, see include/rmd_hip.h
 PUBLISH_DEPTH, PUBLISH_CLOUD, PUBLISH_CONVERGENCE_BGR, PUBLISH_CONVERGENCE = 1, 2, 4, 8  # include/rmd_hip.h: RMD_HIP_PUBLISH_*
 
 # process-wide settings of the host side (include/rmd_hip.h: RMD_HIP_TUNE_*; the environment presets them: RMD_HIP_<NAME>)
-TUNE_HOST_FRAMES, TUNE_BATCH_GROUPS, TUNE_AHEAD_WGS, TUNE_PACK_BACKOFF, TUNE_FLOAT_AS_BYTES, TUNE_COPY_THREADS, TUNE_FUSED_INGEST, TUNE_INGEST_PROFILE, TUNE_HOST_WAIT, TUNE_RING_DEPTH = range(10)
+TUNE_HOST_FRAMES, TUNE_BATCH_GROUPS, TUNE_AHEAD_WGS, TUNE_PACK_BACKOFF, TUNE_FLOAT_AS_BYTES, TUNE_COPY_THREADS, TUNE_FUSED_INGEST, TUNE_INGEST_PROFILE, TUNE_HOST_WAIT, TUNE_RING_DEPTH, TUNE_COPY_STREAMS = range(11)
 HOST_FRAMES_DEFAULT, HOST_FRAMES_STAGED, HOST_FRAMES_STAGED_AHEAD, HOST_FRAMES_INPLACE, HOST_FRAMES_INPLACE_AHEAD = -1, 0, 1, 2, 3
 
 
@@ -412,6 +412,29 @@ class SeedMatrix:
         check(_lib.lib().rmd_hip_seeds_publish_async(self.ptr, int(what), float(depth_range), float(lam), int(iterations), ctypes.byref(t)))
         return int(t.value)
 
+    def peekPublication(self, wait=True):
+        """rmd_hip_seeds_publish_peek: like collectPublication, but the arrays are VIEWS of the library's pinned buffers -- no copy -- valid until
+        releasePublication() (which must follow); None when the oldest publication is still in flight and wait is False."""
+        what, ticket, n_pts = ctypes.c_uint(), ctypes.c_int(), ctypes.c_size_t()
+        d, x, b, c = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        rc = _lib.lib().rmd_hip_seeds_publish_peek(self.ptr, 1 if wait else 0, ctypes.byref(what), ctypes.byref(ticket), ctypes.byref(d), ctypes.byref(x),
+                                                   ctypes.byref(n_pts), ctypes.byref(b), ctypes.byref(c))
+        if rc == _lib.BUSY:
+            return None
+        check(rc)
+        h, w, n = self.height, self.width, int(n_pts.value)
+
+        def view(ptr, ctype, count, dtype, shape):
+            return np.frombuffer((ctype * count).from_address(ptr), dtype).reshape(shape) if ptr else None
+        return {"ticket": int(ticket.value), "what": int(what.value),
+                "depth": view(d.value, ctypes.c_float, h * w, np.float32, (h, w)),
+                "points": (view(x.value, ctypes.c_float, max(n, 1) * 4, np.float32, (max(n, 1), 4))[:n] if x.value else None),
+                "bgr": view(b.value, ctypes.c_ubyte, h * w * 3, np.uint8, (h, w, 3)),
+                "convergence": view(c.value, ctypes.c_int, h * w, np.int32, (h, w))}
+
+    def releasePublication(self):
+        check(_lib.lib().rmd_hip_seeds_publish_release(self.ptr))
+
     def collectPublication(self, wait=True):
         """rmd_hip_seeds_publish_collect: the OLDEST uncollected publication as a dict {"ticket", "what", "depth", "points", "bgr", "convergence"}
         (the products that were requested), or None when it is still in flight and wait is False.  Raises when there is none."""
@@ -713,16 +736,26 @@ class Depthmap:
         (SeedMatrix.publishAsync): the products belong to the state at this moment; the next setReferenceImage / update may follow at once."""
         return self.seeds_.publishAsync(what, getattr(self, "depth_range_", 0.0), lam, iterations)
 
-    def collectPublication(self, wait=True):
+    def collectPublication(self, wait=True, views=False):
         """the oldest publication requested with publishAsync (None: still in flight and wait is False); refreshes the host mirrors the
-        reference's getters return (getDepthmap, getConvergenceMap)"""
-        pub = self.seeds_.collectPublication(wait)
+        reference's getters return (getDepthmap, getConvergenceMap: ONE copy each out of the library's pinned buffers, and the copy is what the
+        dict holds).  views=True: the other products (points, coloured map) are views of those buffers, valid until releasePublication() --
+        which the caller then owes; views=False: everything is copied and the slot released here."""
+        pub = self.seeds_.peekPublication(wait)
         if pub is not None:
             if pub["depth"] is not None:
-                self.output_depth_32fc1_ = pub["depth"]
+                self.output_depth_32fc1_ = pub["depth"] = pub["depth"].copy()
             if pub["convergence"] is not None:
-                self.output_convergence_int_ = pub["convergence"]
+                self.output_convergence_int_ = pub["convergence"] = pub["convergence"].copy()
+            if not views:
+                for key in ("points", "bgr"):
+                    if pub[key] is not None:
+                        pub[key] = pub[key].copy()
+                self.seeds_.releasePublication()
         return pub
+
+    def releasePublication(self):
+        self.seeds_.releasePublication()
 
     def getConvergedPercentage(self):  # depthmap.cpp:152-156
         return float(np.float32(self.getConvergedCount()) / np.float32(self.width_ * self.height_) * np.float32(100.0))

@@ -24,7 +24,7 @@ int fail(int code, const char* fmt, ...) {
 const char* last_error() { return g_last_error; }
 
 // accepted values per tunable (rmd_hip_set_tunable AND the environment presets)
-static const int tunable_lo[RMD_HIP_NUM_TUNABLES] = {-1, 0, 1, 0, 0, 1, 0, 0, 0, 0}, tunable_hi[RMD_HIP_NUM_TUNABLES] = {3, 4, 1024, 1 << 20, 1, 16, 1, 1, 1, 8};
+static const int tunable_lo[RMD_HIP_NUM_TUNABLES] = {-1, 0, 1, 0, 0, 1, 0, 0, 0, 0, 1}, tunable_hi[RMD_HIP_NUM_TUNABLES] = {3, 4, 1024, 1 << 20, 1, 16, 1, 1, 1, 8, 2};
 
 // The library's process-wide settings and THE ONE PLACE where it reads its environment (include/rmd_hip.h: RMD_HIP_TUNE_*): the
 // defaults come from RMD_HIP_<NAME>, once, at the first call; rmd_hip_set_tunable overrides them for handles created afterwards.
@@ -41,9 +41,10 @@ Tunables& tunables() {
     t.v[RMD_HIP_TUNE_INGEST_PROFILE] = 0;
     t.v[RMD_HIP_TUNE_HOST_WAIT] = 1;
     t.v[RMD_HIP_TUNE_RING_DEPTH] = 0;
+    t.v[RMD_HIP_TUNE_COPY_STREAMS] = 2;
     static const char* const names[RMD_HIP_NUM_TUNABLES] = {"RMD_HIP_HOST_FRAMES", "RMD_HIP_BATCH_GROUPS", "RMD_HIP_AHEAD_WGS", "RMD_HIP_PACK_BACKOFF",
                                                             "RMD_HIP_FLOAT_AS_BYTES", "RMD_HIP_COPY_THREADS", "RMD_HIP_FUSED_INGEST", "RMD_HIP_INGEST_PROFILE", "RMD_HIP_HOST_WAIT",
-                                                            "RMD_HIP_RING_DEPTH"};
+                                                            "RMD_HIP_RING_DEPTH", "RMD_HIP_COPY_STREAMS"};
     // A preset from the environment passes the same range check as rmd_hip_set_tunable; one that fails it -- or does not parse -- is IGNORED
     // with a line on stderr (a negative RMD_HIP_AHEAD_WGS used to go straight into the search kernel's grid arithmetic).
     for (int k = 0; k < RMD_HIP_NUM_TUNABLES; ++k) {
@@ -297,6 +298,7 @@ int rmdh::seeds_destroy_impl(rmd_hip_seeds* s) {
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   for (auto& t : s->timers) t.destroy();
   if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);
+  if (s->copy_stream2) (void)hipStreamSynchronize(s->copy_stream2);
   publish_release(s);
   if (s->ingest_profile && s->ingest_us[3] > 0) {
     fprintf(stderr, "[rmd_hip ingest] %.0f frames: wait for slot %.2f us, host copy %.2f us, submit %.2f us per frame; longest wait %.0f us, %lu waits gave up after 2 ms\n",
@@ -323,6 +325,7 @@ int rmdh::seeds_destroy_impl(rmd_hip_seeds* s) {
   }
   if (s->cur_planes[0]) s->planes[RMD_HIP_PLANE_CURR_IMG].data = s->cur_planes[0];
   if (s->copy_stream && !s->batch) (void)hipStreamDestroy(s->copy_stream);
+  if (s->copy_stream2) (void)hipStreamDestroy(s->copy_stream2);
   if (s->region_start) (void)hipEventDestroy(s->region_start);
   if (s->region_stop) (void)hipEventDestroy(s->region_stop);
   for (auto& pl : s->planes)
@@ -333,7 +336,8 @@ int rmdh::seeds_destroy_impl(rmd_hip_seeds* s) {
   if (s->d_bgr) (void)hipFree(s->d_bgr);
   if (s->h_bgr) (void)hipHostFree(s->h_bgr);
   if (s->d_pc_counts) (void)hipFree(s->d_pc_counts);
-  if (s->d_pc_points) (void)hipFree(s->d_pc_points);
+  if (s->h_pc_points) (void)hipHostFree(s->h_pc_points);
+  if (s->h_pc_total) (void)hipHostFree(s->h_pc_total);
   if (s->d_scalars) (void)hipFree(s->d_scalars);
   if (s->h_scalars) (void)hipHostFree(s->h_scalars);
   if (s->h_progress) (void)hipHostFree(s->h_progress);

@@ -614,7 +614,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
     // workgroups plus 6 us of link time) -- no copy engine, no staging in HBM, nothing to wait for.
     const bool in_place = M.ingest_flag == nullptr;
     // one step ahead (see MatcherArgs): has this frame been brought in already, by the bringers of the previous update's search kernel?
-    if (NSEQ == 1 && M.ahead && ld_agent(M.ahead + 2) == M.ingest_number) return;
+    if (M.ahead && ld_agent(M.ahead + 2) == M.ingest_number) return;
     unsigned int spins = 0u;
     if (!in_place && behind()) {
       while (behind() && ++spins < (1u << 18)) __builtin_amdgcn_s_sleep(16);
@@ -948,6 +948,42 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
     }
     return;
   }
+  // A batch's frames one step ahead (MatcherArgs::handover): the bringers wait up to AHEAD_PATIENCE_TICKS for the caller to hand the next step
+  // over, agree on ONE verdict, and read the members' frames of this group from the pinned block into the members' other planes.
+  if (NSEQ > 1 && blockIdx.x < static_cast<unsigned int>(M.ahead_wgs)) {
+    const unsigned int next = M.ingest_number + 1u, no = next ^ 0x80000000u;
+    if (tid == 0) {
+      const unsigned long long t0 = wall_clock64();
+      unsigned int d;
+      for (;;) {
+        d = ld_agent(M.ahead);
+        if (d == next || d == no) break;
+        const bool there = ld_system(M.handover) == next;
+        if (there || wall_clock64() - t0 > AHEAD_PATIENCE_TICKS) {
+          (void)atomicCAS(M.ahead, d, there ? next : no);  // (whoever wins, the word is settled: read it again)
+          continue;
+        }
+        __builtin_amdgcn_s_sleep(32);
+      }
+      S.bcast[0] = d;
+    }
+    __syncthreads();
+    if (S.bcast[0] != next) return;
+    const unsigned int members = ld_system(M.handover + 1), kind = ld_system(M.handover + 2), frame_bytes = ld_system(M.handover + 3);
+    for (int j = 0; j < M.n_seq; ++j) {
+      if (!((members >> (M.group_first + j)) & 1u)) continue;
+      const SeqArgs& Qj = Bq[j];
+      ingest_in_place(static_cast<int>(kind), M.ingest_pitch, M.ahead_frames + static_cast<size_t>(M.group_first + j) * frame_bytes, Qj.next_dst, Qj.P.w, Qj.P.h,
+                      Qj.P.stride, static_cast<int>(blockIdx.x), M.ahead_wgs, tid);
+    }
+    __syncthreads();
+    if (tid == 0 && __hip_atomic_fetch_add(M.ahead + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == static_cast<unsigned int>(M.ahead_wgs) - 1u) {
+      __hip_atomic_store(M.ahead + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(M.ahead + 2, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (read by the NEXT launch's setup kernel: no fence, as above)
+      if (M.ingest_profile) __hip_atomic_fetch_add(M.progress + 5, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // diagnostics: steps brought in ahead
+    }
+    return;
+  }
   const unsigned int wg_id = blockIdx.x - static_cast<unsigned int>(M.ahead_wgs), n_wg = gridDim.x - static_cast<unsigned int>(M.ahead_wgs);
   const const_u64_ptr counts = (const_u64_ptr)(M.shards_cur);
   // On a LIGHT frame -- no shard holds more units than a sixteenth of the grid, which is every frame of the benchmark sequence after its first ~75 --
@@ -1169,6 +1205,9 @@ inline hipError_t launch_seed_pipeline_compact(const BatchArgs<NSEQ>& B, int n_s
     M.ingest_kind = ingest->kind; M.ingest_pitch = ingest->pitch;
     M.ingest_flag = ingest->flag; M.progress = ingest->progress; M.ingest_number = ingest->number;
     if (NSEQ == 1 && ingest->ahead) { M.ahead_wgs = ingest->ahead_wgs; M.submitted = ingest->submitted; M.ahead = ingest->ahead; }
+    if (NSEQ > 1 && ingest->ahead && ingest->handover) {
+      M.ahead_wgs = ingest->ahead_wgs; M.ahead = ingest->ahead; M.handover = ingest->handover; M.ahead_frames = ingest->ahead_frames; M.group_first = ingest->group_first;
+    }
   }
   auto search = seed_search_compact_kernel<SIDE, NSEQ>;
   constexpr int KIND = NSEQ == 1 ? 0 : 1;

@@ -206,6 +206,8 @@ inline bool frame_ahead(bool remap) {
   const int m = host_frames_mode(false);
   return !remap && (m == HOST_FRAMES_STAGED_AHEAD || m == HOST_FRAMES_INPLACE_AHEAD);
 }
+inline bool batch_frames_ahead() { return host_frames_mode(true) == HOST_FRAMES_INPLACE_AHEAD; }  // (a batch's frames read in place by the previous step's search kernels)
+constexpr int BATCH_AHEAD_WGS = 64;  // bringers per stream group
 constexpr size_t FLAG_WORDS = 16384;
 inline void fill_flag_block(unsigned int* block, unsigned int n, size_t words) {
   for (size_t i = 0; i < words; ++i) block[i] = n;
@@ -275,6 +277,11 @@ struct rmd_hip_seeds {
   hipEvent_t staged[SLOTS] = {};            // copy stream: the slot's frame is in its f32 plane
   hipEvent_t frame_done[SLOTS] = {};        // compute stream: the update that read the slot's plane has run
   hipStream_t copy_stream = nullptr;        // frame uploads and conversions run here, beside the previous frames' kernels
+  // A second copy stream: consecutive host frames of the fused path alternate between the two, so that two copy engines work on them.  One
+  // engine needs ~6 us per command beyond the transfer itself and every frame is two commands (the frame, its arrival flag): 22 us for a
+  // 640x480 8-bit frame, 58 us for a 1920x1080 one -- as long as the light updates of those sizes take (21 / 60 us), so that on the light two
+  // thirds of a sequence every second or third setup kernel waited for its frame (RMD_HIP_INGEST_PROFILE: "the kernel waited for").
+  hipStream_t copy_stream2 = nullptr;
   void* cur_planes[SLOTS] = {};             // current-image planes (pitch of planes[CURR_IMG]), used in rotation; [0] is the handle's own
   int u8_pitch = 0, ingest_slot = 0;
   // fused ingest (tile pipeline): the caller's frame is copied into one of SLOTS pinned buffers, a copy engine moves it to a staging
@@ -317,7 +324,8 @@ struct rmd_hip_seeds {
   unsigned char* d_bgr = nullptr;       // coloured convergence map (allocated at the first request): W x H x 3 bytes on the device ...
   unsigned char* h_bgr = nullptr;       // ... and their pinned landing buffer
   unsigned int* d_pc_counts = nullptr;  // point cloud (allocated at the first request): per-block counts / offsets, [n_blocks] = total
-  float4* d_pc_points = nullptr;        // W x H points
+  float4* h_pc_points = nullptr;        // pinned + mapped, W x H points: the point-cloud kernel writes here over the host link
+  unsigned int* h_pc_total = nullptr;   // pinned + mapped: their number
   // Publication off the update stream (rmd_hip_seeds_publish_async, rmd_publish.hip), everything allocated at the first request.  One slot per
   // publication in flight: the snapshot of the state it publishes and its products in pinned host memory; the TV-L1 workspace and the point
   // cloud's counters are shared -- the publications run one after the other on pub_stream.
@@ -333,7 +341,14 @@ struct rmd_hip_seeds {
     unsigned int what = 0;
     int ticket = 0;
     bool pending = false;
+    // the TV-L1 launch sequence of this slot (tv_prepare + the blocked iterations on this slot's snapshot) as an instantiated graph: a
+    // publication is 50 launches that never change between two requests with the same (depth range, lambda, iterations) -- one
+    // hipGraphLaunch instead of 0.15 ms of launch calls on the thread that also feeds the update stream
+    hipGraphExec_t tv_exec = nullptr;
+    float tv_range = 0.0f, tv_lambda = 0.0f;
+    int tv_iterations = -1, tv_result = 0;
   };
+  bool pub_graphs = true;  // false after a failed capture: direct launches from then on
   Publication* pub[RMD_HIP_PUBLISH_SLOTS] = {};
   hipStream_t pub_stream = nullptr;
   rmd_hip_image pub_u[2], pub_u_head[2], pub_p[2], pub_g;  // TV-L1 workspace of the publications
@@ -359,6 +374,7 @@ struct rmd_hip_batch {
     unsigned long long slot_step[8] = {};   // host frames: the step of this group's last launch that read staging slot k (0: none)
     unsigned long long last_step = 0;       // ... and of its last launch altogether
     hipEvent_t ev = nullptr;                // fork / join of the region timer
+    unsigned int* d_ahead = nullptr;        // device words of rmdk::MatcherArgs::ahead (frames one step ahead)
   };
   static constexpr int MAX_GROUPS = 4;
   int n_groups = 0;
@@ -371,6 +387,7 @@ struct rmd_hip_batch {
   unsigned char* h_stage[SLOTS_MAX] = {};
   unsigned char* d_stage[SLOTS_MAX] = {};
   size_t stage_bytes = 0;                   // capacity of each of the buffers above
+  unsigned int* h_handover = nullptr;       // pinned + mapped, 16 words per slot: rmdk::MatcherArgs::handover
   unsigned int* h_seq = nullptr;
   unsigned int* d_flag = nullptr;
   unsigned long long step_number = 0;

@@ -69,6 +69,7 @@ namespace rmdh {
 int ingest_init(rmd_hip_seeds* s) {
   if (s->ingest_ready) return RMD_HIP_OK;
   if (!s->copy_stream) HIP_TRY(create_stream(&s->copy_stream, 2));  // (a batch member uses the batch's)
+  if (!s->batch && !s->copy_stream2 && tunables().v[RMD_HIP_TUNE_COPY_STREAMS] > 1) HIP_TRY(create_stream(&s->copy_stream2, 2));
   const Tunables& T = tunables();
   s->ingest_profile = T.v[RMD_HIP_TUNE_INGEST_PROFILE] != 0;
   s->opt_fused_ingest = T.v[RMD_HIP_TUNE_FUSED_INGEST] != 0;
@@ -302,12 +303,14 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
   if (in_place) {
     in.common.flag = nullptr;  // the setup kernel reads the pinned buffer itself: it is complete before the kernel is launched
   } else {
-    HIP_TRY(hipMemcpyAsync(stage_dst, stage_src, stage_bytes, hipMemcpyHostToDevice, s->copy_stream));
+    // (frame and flag on ONE stream, consecutive frames on alternating streams: see copy_stream2)
+    hipStream_t cs = (s->copy_stream2 && (n64 & 1ull)) ? s->copy_stream2 : s->copy_stream;
+    HIP_TRY(hipMemcpyAsync(stage_dst, stage_src, stage_bytes, hipMemcpyHostToDevice, cs));
     const size_t fw = flag_words(s->h_progress, n);
     fill_flag_block(s->h_seq + k * FLAG_SLOT_WORDS, n, fw);  // behind the frame on the same stream: when the kernel sees n, the frame is in HBM
     unsigned int* slot_flag = flag_of(as_u8 ? 0 : 1, k);
     if (s->inject_withhold_flag) s->inject_withhold_flag = false;  // fault injection: the frame arrives, its flag never does -> the kernel's bounded wait runs out
-    else HIP_TRY(hipMemcpyAsync(slot_flag, s->h_seq + k * FLAG_SLOT_WORDS, fw * sizeof(unsigned int), hipMemcpyHostToDevice, s->copy_stream));
+    else HIP_TRY(hipMemcpyAsync(slot_flag, s->h_seq + k * FLAG_SLOT_WORDS, fw * sizeof(unsigned int), hipMemcpyHostToDevice, cs));
     in.common.flag = slot_flag;
   }
   int plane = 0;  // one plane is enough: setup k writes it after search k - 1 has run (same stream)

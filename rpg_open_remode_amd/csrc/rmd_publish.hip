@@ -164,10 +164,17 @@ int rmd_hip_seeds_point_cloud(rmd_hip_seeds_t* s, const rmd_hip_image_t* depth, 
     TRY(image_settle(depth));
   const int n_pix = s->width * s->height;
   const int n_blocks = (n_pix + rmdk::PC_BLOCK - 1) / rmdk::PC_BLOCK;
+  // The points go straight into pinned host memory (posted writes over the host link, 16 bytes per lane) and from there into the caller's
+  // buffer: their number is not known when the work is queued, and a device-to-host copy into PAGEABLE memory goes through the runtime's own
+  // staging (measured at 0.3 GB/s on one box of the pool: 3.5 ms for a cloud of 60 000 points).
   if (!s->d_pc_counts) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_pc_counts), (static_cast<size_t>(n_blocks) + 1) * sizeof(unsigned int)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_pc_points), static_cast<size_t>(n_pix) * sizeof(float4)));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_pc_points), static_cast<size_t>(n_pix) * sizeof(float4), hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_pc_total), 64, hipHostMallocMapped));
   }
+  void *d_points = nullptr, *d_total = nullptr;
+  HIP_TRY(hipHostGetDevicePointer(&d_points, s->h_pc_points, 0));
+  HIP_TRY(hipHostGetDevicePointer(&d_total, s->h_pc_total, 0));
   rmdk::PointCloudParams P;
   P.w = s->width; P.h = s->height;
   P.stride = s->P.stride;
@@ -178,16 +185,15 @@ int rmd_hip_seeds_point_cloud(rmd_hip_seeds_t* s, const rmd_hip_image_t* depth, 
   P.cam = s->P.cam;
   P.T_world_ref = s->T_world_ref;
   hipLaunchKernelGGL(rmdk::pc_count_kernel, dim3(n_blocks), dim3(rmdk::PC_BLOCK), 0, s->stream, P, s->d_pc_counts);
-  hipLaunchKernelGGL(rmdk::pc_scan_kernel, dim3(1), dim3(1024), 0, s->stream, s->d_pc_counts, n_blocks, s->d_pc_counts + n_blocks);
-  hipLaunchKernelGGL(rmdk::pc_write_kernel, dim3(n_blocks), dim3(rmdk::PC_BLOCK), 0, s->stream, P, s->d_pc_counts, s->d_pc_points,
+  hipLaunchKernelGGL(rmdk::pc_scan_kernel, dim3(1), dim3(1024), 0, s->stream, s->d_pc_counts, n_blocks, static_cast<unsigned int*>(d_total));
+  hipLaunchKernelGGL(rmdk::pc_write_kernel, dim3(n_blocks), dim3(rmdk::PC_BLOCK), 0, s->stream, P, s->d_pc_counts, static_cast<float4*>(d_points),
                      static_cast<unsigned int>(n_pix));
   HIP_TRY(hipGetLastError());
-  unsigned int total = 0;
-  HIP_TRY(hipMemcpyAsync(&total, s->d_pc_counts + n_blocks, sizeof(total), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  const size_t total = *static_cast<volatile unsigned int*>(s->h_pc_total);
   *n_points = total;
   const size_t n_copy = total < capacity ? total : capacity;
-  if (n_copy) HIP_TRY(hipMemcpy(out_xyzi, s->d_pc_points, n_copy * sizeof(float4), hipMemcpyDeviceToHost));
+  if (n_copy) memcpy(out_xyzi, s->h_pc_points, n_copy * sizeof(float4));
   return RMD_HIP_OK;
 }
 
@@ -289,7 +295,26 @@ int rmd_hip_seeds_publish_async(rmd_hip_seeds_t* s, unsigned int what, float dep
     float2* ps[2] = {static_cast<float2*>(s->pub_p[0].data), static_cast<float2*>(s->pub_p[1].data)};
     int cur_buf = 0;
     long n_launches = 0;
-    TRY(tv_run(P, us, uhs, ps, 1, iterations, 0, 0, s->pub_stream, nullptr, &cur_buf, &n_launches));
+    const bool same = pb.tv_exec && pb.tv_range == depth_range && pb.tv_lambda == lambda && pb.tv_iterations == iterations;
+    if (s->pub_graphs && !same) {  // (re)capture this slot's launch sequence
+      if (pb.tv_exec) { (void)hipGraphExecDestroy(pb.tv_exec); pb.tv_exec = nullptr; }
+      hipGraph_t graph = nullptr;
+      bool ok = hipStreamBeginCapture(s->pub_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      if (ok) {
+        const int rc = tv_run(P, us, uhs, ps, 1, iterations, 0, 0, s->pub_stream, nullptr, &cur_buf, &n_launches);
+        ok = hipStreamEndCapture(s->pub_stream, &graph) == hipSuccess && rc == RMD_HIP_OK && graph != nullptr;
+      }
+      if (ok) ok = hipGraphInstantiate(&pb.tv_exec, graph, nullptr, nullptr, 0) == hipSuccess;
+      if (graph) (void)hipGraphDestroy(graph);
+      if (ok) { pb.tv_range = depth_range; pb.tv_lambda = lambda; pb.tv_iterations = iterations; pb.tv_result = cur_buf; }
+      else { pb.tv_exec = nullptr; s->pub_graphs = false; (void)hipGetLastError(); }
+    }
+    if (pb.tv_exec) {
+      HIP_TRY(hipGraphLaunch(pb.tv_exec, s->pub_stream));
+      cur_buf = pb.tv_result;
+    } else {
+      TRY(tv_run(P, us, uhs, ps, 1, iterations, 0, 0, s->pub_stream, nullptr, &cur_buf, &n_launches));
+    }
     depth_img = &s->pub_u[cur_buf];
     HIP_TRY(hipMemcpy2DAsync(pb.h_depth, row, depth_img->data, depth_img->pitch, row, h, hipMemcpyDeviceToHost, s->pub_stream));
   }
@@ -332,10 +357,10 @@ int rmd_hip_seeds_publish_async(rmd_hip_seeds_t* s, unsigned int what, float dep
   return RMD_HIP_OK;
 }
 
-int rmd_hip_seeds_publish_collect(rmd_hip_seeds_t* s, int wait, unsigned int* what, int* ticket, float* host_depth, float* host_xyzi, size_t capacity,
-                                  size_t* n_points, unsigned char* host_bgr, int* host_convergence) {
-  if (!s) return fail(RMD_HIP_ERR_INVALID_ARG, "publish_collect: null handle");
-  if (s->pub_pending == 0) return fail(RMD_HIP_ERR_NOT_READY, "publish_collect: no publication in flight");
+int rmd_hip_seeds_publish_peek(rmd_hip_seeds_t* s, int wait, unsigned int* what, int* ticket, const float** depth, const float** xyzi, size_t* n_points,
+                               const unsigned char** bgr, const int** convergence) {
+  if (!s) return fail(RMD_HIP_ERR_INVALID_ARG, "publish_peek: null handle");
+  if (s->pub_pending == 0) return fail(RMD_HIP_ERR_NOT_READY, "publish_peek: no publication in flight");
   TRY(seeds_bind_device(s));
   rmd_hip_seeds::Publication& pb = *s->pub[s->pub_oldest];
   if (wait) HIP_TRY(hipEventSynchronize(pb.done));
@@ -344,23 +369,44 @@ int rmd_hip_seeds_publish_collect(rmd_hip_seeds_t* s, int wait, unsigned int* wh
     if (e == hipErrorNotReady) return RMD_HIP_BUSY;
     HIP_TRY(e);
   }
-  const size_t n_pix = static_cast<size_t>(s->width) * s->height;
   if (what) *what = pb.what;
   if (ticket) *ticket = pb.ticket;
-  if ((pb.what & RMD_HIP_PUBLISH_DEPTH) && host_depth) memcpy(host_depth, pb.h_depth, n_pix * sizeof(float));
-  size_t total = 0;
-  if (pb.what & RMD_HIP_PUBLISH_CLOUD) {
-    total = *static_cast<volatile unsigned int*>(pb.h_total);
-    const size_t n_copy = total < capacity ? total : capacity;
-    if (host_xyzi && n_copy) memcpy(host_xyzi, pb.h_points, n_copy * sizeof(float4));
-  }
-  if (n_points) *n_points = total;
-  if ((pb.what & RMD_HIP_PUBLISH_CONVERGENCE_BGR) && host_bgr) memcpy(host_bgr, pb.h_bgr, n_pix * 3);
-  if ((pb.what & RMD_HIP_PUBLISH_CONVERGENCE) && host_convergence) memcpy(host_convergence, pb.h_conv, n_pix * sizeof(int));
+  if (depth) *depth = (pb.what & RMD_HIP_PUBLISH_DEPTH) ? pb.h_depth : nullptr;
+  if (xyzi) *xyzi = (pb.what & RMD_HIP_PUBLISH_CLOUD) ? reinterpret_cast<const float*>(pb.h_points) : nullptr;
+  if (n_points) *n_points = (pb.what & RMD_HIP_PUBLISH_CLOUD) ? *static_cast<volatile unsigned int*>(pb.h_total) : 0u;
+  if (bgr) *bgr = (pb.what & RMD_HIP_PUBLISH_CONVERGENCE_BGR) ? pb.h_bgr : nullptr;
+  if (convergence) *convergence = (pb.what & RMD_HIP_PUBLISH_CONVERGENCE) ? pb.h_conv : nullptr;
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_seeds_publish_release(rmd_hip_seeds_t* s) {
+  if (!s) return fail(RMD_HIP_ERR_INVALID_ARG, "publish_release: null handle");
+  if (s->pub_pending == 0) return fail(RMD_HIP_ERR_NOT_READY, "publish_release: no publication in flight");
+  TRY(seeds_bind_device(s));
+  rmd_hip_seeds::Publication& pb = *s->pub[s->pub_oldest];
+  HIP_TRY(hipEventSynchronize(pb.done));  // (a slot is never handed back while the device still writes it)
   pb.pending = false;
   s->pub_oldest = (s->pub_oldest + 1) % RMD_HIP_PUBLISH_SLOTS;
   --s->pub_pending;
   return RMD_HIP_OK;
+}
+
+int rmd_hip_seeds_publish_collect(rmd_hip_seeds_t* s, int wait, unsigned int* what, int* ticket, float* host_depth, float* host_xyzi, size_t capacity,
+                                  size_t* n_points, unsigned char* host_bgr, int* host_convergence) {
+  const float *depth = nullptr, *xyzi = nullptr;
+  const unsigned char* bgr = nullptr;
+  const int* conv = nullptr;
+  size_t total = 0;
+  const int rc = rmd_hip_seeds_publish_peek(s, wait, what, ticket, &depth, &xyzi, &total, &bgr, &conv);
+  if (rc != RMD_HIP_OK) return rc;
+  const size_t n_pix = static_cast<size_t>(s->width) * s->height;
+  if (depth && host_depth) memcpy(host_depth, depth, n_pix * sizeof(float));
+  const size_t n_copy = total < capacity ? total : capacity;
+  if (xyzi && host_xyzi && n_copy) memcpy(host_xyzi, xyzi, n_copy * sizeof(float4));
+  if (n_points) *n_points = total;
+  if (bgr && host_bgr) memcpy(host_bgr, bgr, n_pix * 3);
+  if (conv && host_convergence) memcpy(host_convergence, conv, n_pix * sizeof(int));
+  return rmd_hip_seeds_publish_release(s);
 }
 
 }  // extern "C"
@@ -377,6 +423,7 @@ void publish_release(rmd_hip_seeds* s) {
     void* pinned[] = {pb->h_depth, pb->h_points, pb->h_total, pb->h_bgr, pb->h_conv};
     for (void* q : pinned)
       if (q) (void)hipHostFree(q);
+    if (pb->tv_exec) (void)hipGraphExecDestroy(pb->tv_exec);
     if (pb->snapped) (void)hipEventDestroy(pb->snapped);
     if (pb->done) (void)hipEventDestroy(pb->done);
     delete pb;

@@ -147,7 +147,9 @@ class DepthmapNode:
 
     def publishConvergenceMap(self):  # :175-182
         if self.async_publish_:
-            self._request("convergence", api.PUBLISH_CONVERGENCE_BGR | api.PUBLISH_CONVERGENCE)  # (the int32 plane: the host mirror of :177)
+            # (the reference refreshes its int32 host mirror here too, :177, although the colouring below is all that is published: in this mode
+            # the mirror -- getConvergenceMap() -- is refreshed by the RESULTS publications only; 1.2 MB per map that nobody reads stay on the device)
+            self._request("convergence", api.PUBLISH_CONVERGENCE_BGR)
             return
         self.depthmap_.downloadConvergenceMap()  # (:177: the host mirror is refreshed here whether or not the colouring needs it)
         self.publisher_.publishConvergenceMap()
@@ -165,15 +167,18 @@ class DepthmapNode:
         """hand the finished publications to the callbacks, oldest first; wait=True blocks until they are.  Returns how many were delivered."""
         n = 0
         while self.in_flight_ and (at_most is None or n < at_most):
-            pub = self.depthmap_.collectPublication(wait)
+            pub = self.depthmap_.collectPublication(wait, views=True)  # points / coloured map: views of the library's pinned buffers ...
             if pub is None:
                 break
             kind = self.in_flight_.pop(0)
-            if kind == "results":
-                self.publisher_.publishDepthmap(pub["depth"])
-                self.publisher_.publishPointCloud(pub["points"])
-            else:
-                self.publisher_.publishConvergenceMap(pub["bgr"])
+            try:
+                if kind == "results":
+                    self.publisher_.publishDepthmap(pub["depth"])
+                    self.publisher_.publishPointCloud(pub["points"])  # (appended to the accumulated cloud: its one copy)
+                else:
+                    self.publisher_.publishConvergenceMap(pub["bgr"])  # (a callback that keeps the image copies it, as with any message buffer)
+            finally:
+                self.depthmap_.releasePublication()  # ... valid until here
             n += 1
         return n
 

@@ -24,9 +24,9 @@ from rpg_open_remode_amd import synth  # noqa: E402
 SIDE = 9
 
 
-def run(kind, flags, seq, lam=0.5, iters=200):
+def run(kind, flags, seq, lam=0.5, iters=200, amplitude=0):
     olib = O.OracleLib(kind, SIDE)
-    assert olib.set_cudalike(flags)
+    assert olib.set_cudalike(flags, amplitude)
     s = O.Seeds(olib, seq.width, seq.height, seq.K)
     s.set_reference(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
     for n in range(1, seq.n_frames):
@@ -34,7 +34,7 @@ def run(kind, flags, seq, lam=0.5, iters=200):
     d = O.Denoiser(olib, seq.width, seq.height)
     d.set_large_sigma_sq(seq.max_depth - seq.min_depth)
     out = {"mu": s.download(O.PLANE_MU), "conv": s.download(O.PLANE_CONV), "den": d.denoise(s, lam, iters)}
-    olib.set_cudalike(0)
+    olib.set_cudalike(0, 0)
     return out
 
 
@@ -60,22 +60,37 @@ def compare(ref, got):
 
 def switches():
     L = O.OracleLib
-    return [("texture weights: 8 fractional bits, rounded; 4-tap form", "cudalike", L.TEX8),
-            ("texture weights: 8 fractional bits, truncated", "cudalike", L.TEX8_TRUNC),
-            ("x / y -> x * (1 / y)", "cudalike", L.DIV),
-            ("sqrtf -> x * rsqrt(x), rsqrtf correctly rounded", "cudalike", L.SQRT),
-            ("expf -> exp2(x * log2 e)", "cudalike", L.EXP),
-            ("sinf: another <= 2.5-ulp sine", "cudalike", L.SIN),
-            ("acosf / atan2f: another <= 2.5-ulp implementation", "cudalike", L.ACOS),
-            ("flush to zero", "cudalike", L.FTZ),
-            ("FMA contraction (-fmad=true)", "cudalike_fma", 0),
+    return [("[specified] texture weights: 8 fractional bits, rounded; 4-tap form", "cudalike", L.TEX8),
+            ("[specified] texture weights: 8 fractional bits, truncated", "cudalike", L.TEX8_TRUNC),
+            ("[guess] x / y -> x * (1 / y)", "cudalike", L.DIV),
+            ("[guess] sqrtf -> x * rsqrt(x), rsqrtf correctly rounded", "cudalike", L.SQRT),
+            ("[guess] expf -> exp2(x * log2 e)", "cudalike", L.EXP),
+            ("[guess] sinf: another <= 2.5-ulp sine", "cudalike", L.SIN),
+            ("[guess] acosf / atan2f: another <= 2.5-ulp implementation", "cudalike", L.ACOS),
+            ("[specified] flush to zero", "cudalike", L.FTZ),
+            ("[specified] FMA contraction (-fmad=true)", "cudalike_fma", 0),
             ("ALL OF THE ABOVE (rounded weights)", "cudalike_fma", L.TEX8 | L.DIV | L.SQRT | L.EXP | L.SIN | L.ACOS | L.FTZ),
             ("all, without the texture weights (-use_fast_math alone)", "cudalike_fma", L.DIV | L.SQRT | L.EXP | L.SIN | L.ACOS | L.FTZ),
             ("(upper bracket) sinf on the documented ABSOLUTE bound of __sinf: 2^-21 grid", "cudalike", L.SIN_ABS)]
 
 
+def sensitivity():
+    """the GUESSED switches one by one and all together, each at 1 ulp and at its documented maximum (orc_set_cudalike_amplitude): how much of the
+    table above is the shape this model happens to give an operation whose CUDA form is only known as an error bound"""
+    L = O.OracleLib
+    guessed = L.DIV | L.SQRT | L.EXP | L.SIN | L.ACOS
+    out = []
+    for name, flags in (("x / y", L.DIV), ("sqrtf / rsqrtf", L.SQRT), ("expf", L.EXP), ("sinf", L.SIN), ("acosf / atan2f", L.ACOS)):
+        for amp, label in ((1, "1 ulp"), (-1, "documented maximum")):
+            out.append((f"[guess] {name}: correctly rounded, moved by up to {label}", "cudalike", flags, amp))
+    for amp, label in ((1, "1 ulp"), (-1, "documented maximum")):
+        out.append((f"[range] ALL switches, the guessed ones at {label}", "cudalike_fma", L.TEX8 | guessed | L.FTZ, amp))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--sensitivity", action="store_true", help="also the guessed switches at 1 ulp and at their documented maxima (adds 12 runs)")
     ap.add_argument("--frames", type=int, default=200)
     ap.add_argument("--size", default="640x480")
     ap.add_argument("--out", default="")
@@ -89,8 +104,9 @@ def main():
              f"(depth range {seq.min_depth:.3f} .. {seq.max_depth:.3f} m).  Depth statistics over the seeds CONVERGED in both runs, metres.",
              f"{'switch':78s} | conv-mask mismatches | states differing | depth RMSE   (best 99 %) median    p99       max       > 1 cm | bit-identical | denoised RMSE   max"]
     print("\n".join(lines), flush=True)
-    for name, kind, flags in switches():
-        c = compare(ref, run(kind, flags, seq))
+    rows = [(n, k, f, 0) for n, k, f in switches()] + (sensitivity() if a.sensitivity else [])
+    for name, kind, flags, amp in rows:
+        c = compare(ref, run(kind, flags, seq, amplitude=amp))
         line = (f"{name:78s} | {c['mask_mismatch']:8d} ({100.0 * c['mask_mismatch'] / (w * h):6.3f} %) | {c['state_mismatch']:16d} | {c['depth_rmse']:.3e} {c['depth_rmse_99']:.3e} {c['depth_median']:.3e} "
                 f"{c['depth_p99']:.3e} {c['depth_max']:.3e} {c['over_1cm']:6d} | {100.0 * c['bit_identical']:11.1f} % | {c['denoised_rmse']:.3e} {c['denoised_max']:.3e}")
         print(line, flush=True)

@@ -93,6 +93,8 @@ class OracleLib:
             L.orc_set_num_threads.argtypes = [_c_i]
             L.orc_set_cudalike.argtypes = [_c_i]
             L.orc_set_cudalike.restype = _c_i
+            L.orc_set_cudalike_amplitude.argtypes = [_c_i]
+            L.orc_set_cudalike_amplitude.restype = _c_i
             L.orc_max_threads.restype = _c_i
             for name in ("expf", "sinf", "acosf", "rsqrtf"):
                 fn = getattr(L, "orc_math_" + name)
@@ -109,8 +111,10 @@ class OracleLib:
     # switches of the "cudalike" builds (remode_oracle.cpp); a no-op returning False on the other builds
     TEX8, TEX8_TRUNC, DIV, SQRT, EXP, SIN, SIN_ABS, ACOS, FTZ = 1, 2, 4, 8, 16, 32, 64, 128, 256
 
-    def set_cudalike(self, flags):
-        return bool(self.lib.orc_set_cudalike(int(flags)))
+    def set_cudalike(self, flags, amplitude=0):
+        """flags: which operations follow the model of the reference's CUDA build; amplitude: 0 the model's fixed forms of the guessed operations,
+        n >= 1 the correctly rounded result moved by up to n ulp, -1 by each operation's documented maximum (oracle/remode_oracle.cpp)"""
+        return bool(self.lib.orc_set_cudalike(int(flags))) and bool(self.lib.orc_set_cudalike_amplitude(int(amplitude)))
 
     def reduce_sum(self, img):
         img = np.ascontiguousarray(img, np.float32)

@@ -27,6 +27,20 @@ def _device_count():
     return n.value
 
 
+def _device_of(ptr):
+    """the device a device pointer lives on (hipPointerGetAttributes, straight from the HIP runtime: test infrastructure)"""
+    import ctypes
+
+    class Attr(ctypes.Structure):  # hipPointerAttribute_t
+        _fields_ = [("type", ctypes.c_int), ("device", ctypes.c_int), ("devicePointer", ctypes.c_void_p), ("hostPointer", ctypes.c_void_p),
+                    ("isManaged", ctypes.c_int), ("allocationFlags", ctypes.c_uint)]
+    hip = ctypes.CDLL("libamdhip64.so")
+    a = Attr()
+    rc = hip.hipPointerGetAttributes(ctypes.byref(a), ctypes.c_void_p(ptr))
+    assert rc == 0, f"hipPointerGetAttributes: {rc}"
+    return a.device
+
+
 def _run_all(device, concurrent, seqs):
     import ctypes
     from rpg_open_remode_amd import _lib
@@ -53,6 +67,7 @@ def _run_all(device, concurrent, seqs):
                 if k % 20 == 0:
                     counts.append(s.getConvergedCount())
             results[("single", scene)] = (s.state(), counts)
+            results[("placed", "single", scene)] = [_device_of(s.getMu().data), _device_of(s._plane(api.PLANE_REF_IMG).data)]
         return work
 
     def batch3():
@@ -63,6 +78,7 @@ def _run_all(device, concurrent, seqs):
         for k in range(1, F):
             b.updateU8([seqs[sc].gray[k] for sc in scenes], [seqs[sc].T_curr_world[k] for sc in scenes])
         results[("batch",)] = [b[i].state() for i in range(3)]
+        results[("placed", "batch")] = [_device_of(b[i].getMu().data) for i in range(3)]
 
     def denoiser():
         seq = seqs[5]
@@ -74,6 +90,7 @@ def _run_all(device, concurrent, seqs):
         d.setLargeSigmaSq(seq.max_depth - seq.min_depth)
         outs = [d.denoise(s.getMu(), s.getSigmaSq(), s.getA(), s.getB(), 0.5, 200) for _ in range(6)]
         results[("denoise",)] = outs
+        results[("placed", "denoise")] = [_device_of(d.result().data), _device_of(s.getSigmaSq().data)]
 
     jobs = [on_device(single(0)), on_device(single(1)), on_device(batch3), on_device(denoiser)]
     if concurrent:
@@ -93,6 +110,11 @@ def _check(device):
     seqs = {s: synth.Sequence(W, H, F, s) for s in range(6)}  # (rendered once: 6 x 61 frames)
     alone = _run_all(device, False, seqs)
     together = _run_all(device, True, seqs)
+    # placement, not only equality: every handle created by a thread whose current device was `device` keeps its planes THERE (the library's
+    # handles bind to the creating thread's device, check_cuda_device.cu:109 / rmd_hip_set_device)
+    for run in (alone, together):
+        placed = {k: v for k, v in run.items() if k[0] == "placed"}
+        assert len(placed) == 4 and all(d == device for v in placed.values() for d in v), (device, placed)
     for scene in (0, 1):
         assert_states_equal(alone[("single", scene)][0], together[("single", scene)][0], f"single sequence, scene {scene}: alone vs among three other handles")
         assert alone[("single", scene)][1] == together[("single", scene)][1]

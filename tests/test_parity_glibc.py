@@ -63,6 +63,36 @@ def test_config1_equals_the_untouched_reference():
     assert r["depth_rmse_all_seeds_m"] == 0.0 and r["denoised_rmse_m"] == 0.0 and r["depth_frac_bit_identical"] == 1.0
 
 
+@pytest.mark.parametrize("side", [3, 5, 7])
+def test_other_patch_sides_at_640x480_equal_the_untouched_reference(side):
+    """RMD_CORR_PATCH_SIDE is compile time in the reference ("must be odd", CMakeLists.txt:50-51) and a constructor argument here (3, 5, 7, 9): the
+    sides other than the configured 9 at the configured frame size, 60 updates (through the heavy first twenty and well into the light
+    phase, where band-shaped windows and graduated unit sizes come into play), against Oracle A built with that side -- every plane, the
+    converged count, 8-bit host frames through the default path, and a short TV-L1 run of the reference's own kernel."""
+    glibc_parity.require_pinned_glibc()
+    if not O.available("ref", side):
+        pytest.skip("oracle/_ref not present")
+    seq = sequence(640, 480, 61)
+    olib = O.OracleLib("ref", side)
+    olib.lib.ref_set_num_threads(max(1, min(olib.lib.ref_max_threads(), __import__("rpg_open_remode_amd").synth.effective_cpus())))
+    ref = O.Seeds(olib, seq.width, seq.height, seq.K)
+    hip = api.SeedMatrix(seq.width, seq.height, api.PinholeCamera(*seq.K), patch_side=side)
+    ref.set_reference(seq.images[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    hip.setReferenceImageU8(seq.gray[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    for k in range(1, 61):
+        ref.update(seq.images[k], seq.T_curr_world[k])
+        hip.updateU8(seq.gray[k], seq.T_curr_world[k])
+        if k in (1, 20, 45, 60):
+            assert_states_equal(ref.state(), hip.state(), f"side {side}: HIP vs the reference (system libm), update {k}")
+            assert hip.getConvergedCount() == ref.converged_count()
+    assert ref.converged_count() > 1000
+    rd = O.Denoiser(olib, seq.width, seq.height)
+    rd.set_large_sigma_sq(seq.max_depth - seq.min_depth)
+    hd = api.DepthmapDenoiser(seq.width, seq.height)
+    hd.setLargeSigmaSq(seq.max_depth - seq.min_depth)
+    assert O.planes_equal(rd.denoise(ref, 0.5, 3), hd.denoise(hip.getMu(), hip.getSigmaSq(), hip.getA(), hip.getB(), 0.5, 3))  # (the reference's fibre-emulated TV kernel: 1.5 s per iteration on the host)
+
+
 def test_config3_scenes_1_to_7_equal_the_untouched_reference_end_to_end():
     """BASELINE configs[3]: eight independent 640x480 sequences (scenes 0..7).  Scene 0 is the test above; here scenes 1..7 are followed by
     Oracle A (the reference's own kernels, system libm) over ALL 199 updates, and stepped as ONE batch of seven on the device: every state plane

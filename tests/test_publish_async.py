@@ -27,13 +27,13 @@ def _twin_products(seq, side, n_updates, first, lam, iters):
 @pytest.mark.parametrize("size", [(192, 144), (640, 480)])
 def test_async_publication_equals_the_synchronous_products_while_the_handle_moves_on(size):
     w, h = size
-    seq = sequence(w, h, 34)
+    seq = sequence(w, h, 72)
     side, lam, iters = 5, 0.5, 60
     s = api.SeedMatrix(w, h, api.PinholeCamera(*seq.K), patch_side=side)
     rng = float(np.float32(seq.max_depth) - np.float32(seq.min_depth))
     want = []
     # three publications in flight at once, each followed at once by a new reference and more updates: the snapshots must hold
-    for first, n_up in ((0, 9), (10, 7), (18, 12)):
+    for first, n_up in ((0, 30), (31, 6), (38, 31)):
         s.setReferenceImageU8(seq.gray[first], seq.T_curr_world[first], seq.min_depth, seq.max_depth)
         for k in range(first + 1, first + 1 + n_up):
             s.updateU8(seq.gray[k], seq.T_curr_world[k])
@@ -41,22 +41,25 @@ def test_async_publication_equals_the_synchronous_products_while_the_handle_move
         want.append((ticket, first, n_up))
     with pytest.raises(api.RmdHipError):  # the ring is full
         s.publishAsync(api.PUBLISH_CONVERGENCE_BGR, rng, lam, iters)
-    s.setReferenceImageU8(seq.gray[31], seq.T_curr_world[31], seq.min_depth, seq.max_depth)  # the handle moves on before anything is collected
-    s.updateU8(seq.gray[32], seq.T_curr_world[32])
+    s.setReferenceImageU8(seq.gray[70], seq.T_curr_world[70], seq.min_depth, seq.max_depth)  # the handle moves on before anything is collected
+    s.updateU8(seq.gray[71], seq.T_curr_world[71])
+    n_points = []
     for ticket, first, n_up in want:
         got = s.collectPublication(wait=True)
         assert got["ticket"] == ticket and got["what"] == ALL
         exp = _twin_products(seq, side, n_up, first, lam, iters)
         assert O.count_mismatch(exp["depth"], got["depth"]) == 0, (first, "depth")
-        assert exp["points"].shape == got["points"].shape and len(got["points"]) > 50 and O.count_mismatch(exp["points"], got["points"]) == 0, (first, "cloud")
+        assert exp["points"].shape == got["points"].shape and O.count_mismatch(exp["points"], got["points"]) == 0, (first, "cloud")
+        n_points.append(len(got["points"]))
         assert np.array_equal(exp["bgr"], got["bgr"]), (first, "bgr")
         assert np.array_equal(exp["convergence"], got["convergence"]), (first, "convergence")
+    assert max(n_points) > 200, n_points  # (seeds converge after ~20 updates: the long runs publish real clouds)
     with pytest.raises(api.RmdHipError):  # nothing left
         s.collectPublication(wait=True)
     # the handle itself was not disturbed: its state equals a handle that never published
     t = api.SeedMatrix(w, h, api.PinholeCamera(*seq.K), patch_side=side)
-    t.setReferenceImageU8(seq.gray[31], seq.T_curr_world[31], seq.min_depth, seq.max_depth)
-    t.updateU8(seq.gray[32], seq.T_curr_world[32])
+    t.setReferenceImageU8(seq.gray[70], seq.T_curr_world[70], seq.min_depth, seq.max_depth)
+    t.updateU8(seq.gray[71], seq.T_curr_world[71])
     for p in range(5):
         assert O.count_mismatch(t.download(p), s.download(p)) == 0, p
 
@@ -86,6 +89,29 @@ def test_single_products_and_polling():
     assert got["ticket"] == t2 and got["what"] == (api.PUBLISH_CLOUD | api.PUBLISH_DEPTH) and got["bgr"] is None
     exp = _twin_products(seq, 5, 5, 0, 0.5, 20)
     assert O.count_mismatch(exp["depth"], got["depth"]) == 0 and O.count_mismatch(exp["points"], got["points"]) == 0
+
+
+def test_peek_hands_out_views_until_release():
+    seq = sequence(160, 120, 36)
+    s = api.SeedMatrix(160, 120, api.PinholeCamera(*seq.K), patch_side=5)
+    s.setReferenceImageU8(seq.gray[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+    for k in range(1, 34):
+        s.updateU8(seq.gray[k], seq.T_curr_world[k])
+    s.publishAsync(ALL, float(seq.max_depth - seq.min_depth), 0.5, 30)
+    s.publishAsync(api.PUBLISH_CONVERGENCE_BGR)
+    v = s.peekPublication(wait=True)
+    exp = _twin_products(seq, 5, 33, 0, 0.5, 30)
+    assert len(v["points"]) == len(exp["points"]) > 100
+    for key in ("depth", "points", "bgr", "convergence"):
+        assert not v[key].flags.owndata  # views of the library's pinned buffers
+        assert np.array_equal(exp[key].view(np.uint8), v[key].view(np.uint8)), key
+    again = s.peekPublication(wait=True)  # peeking does not consume
+    assert again["ticket"] == v["ticket"]
+    s.releasePublication()
+    nxt = s.collectPublication(wait=True)
+    assert nxt["what"] == api.PUBLISH_CONVERGENCE_BGR and nxt["ticket"] == v["ticket"] + 1
+    with pytest.raises(api.RmdHipError):
+        s.releasePublication()
 
 
 def test_node_with_publication_off_the_update_stream_publishes_the_same_things_in_the_same_order():
@@ -128,4 +154,4 @@ def test_node_with_publication_off_the_update_stream_publishes_the_same_things_i
     assert order == [(t, i) for _, t, i in ev_s if t != "conv"]
     # the host mirrors the reference's getters return hold the last publication
     assert np.array_equal(node_a.depthmap_.getDepthmap(), node_s.depthmap_.getDepthmap())
-    assert np.array_equal(node_a.depthmap_.getConvergenceMap(), node_s.depthmap_.getConvergenceMap())
+    # (getConvergenceMap(): refreshed by the results publications only in this mode -- the synchronous node also refreshes it for every coloured map)

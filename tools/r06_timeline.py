@@ -76,7 +76,13 @@ if h2d and t_lo is not None:
             line += f"  = {frame_bytes / (sum(dd) / len(dd)) / 1e3:.1f} GB/s"
         busy = sum(e - s for s, e, _ in grp)
         span = max(e for _, e, _ in grp) - min(s for s, _, _ in grp)
-        line += f"; engine busy {busy / max(span, 1) * 100:.0f} % of their span"
+        # do consecutive copies overlap in time (two copy streams -> two engines)?
+        ev = sorted([(s, 1) for s, e, _ in grp] + [(e, -1) for s, e, _ in grp])
+        depth, last, two = 0, ev[0][0], 0
+        for t, dd_ in ev:
+            if depth >= 2: two += t - last
+            depth += dd_; last = t
+        line += f"; engine busy {busy / max(span, 1) * 100:.0f} % of their span, two in flight {two / max(span, 1) * 100:.0f} %"
         print(line)
     # lead of each frame copy over the setup kernel that consumes it (matched from the end of the run)
     q0 = queues[0]
