@@ -259,25 +259,44 @@ def cpu_reference_run(frame_fn, width, height, K, n_frames, side, min_depth, max
 def cuda_build_tolerance():
     """north_star: "depth-map equality vs. the reference CUDA path ... within a stated float tolerance".  No CUDA device exists here; the distance to
     such a build (8-bit texture weights, -use_fast_math) is bounded with a MODEL of it -- Oracle B's "cudalike" build, tests/cudalike_tolerance.py,
-    CPU only -- and the table it wrote is quoted here (its "all switches" row), not re-measured: profiles/r05_cudalike_tolerance.txt."""
-    path = os.path.join(ROOT, "profiles", "r05_cudalike_tolerance.txt")
+    CPU only -- and the table it wrote is quoted here, not re-measured: profiles/r06_cudalike_tolerance.txt.  The model's switches are of two kinds:
+    SPECIFIED behaviour of that build (texture weights with 8 fractional bits -- the CUDA programming guide's linear-filtering formula --, flush to
+    zero, FMA contraction) and GUESSES (the approximate division / square roots and the fast or other-library expf / sinf / acosf, which the guide
+    gives as error BOUNDS only); the guessed ones are therefore run three ways -- the model's fixed forms, "correctly rounded moved by up to 1 ulp",
+    "moved by up to the documented maximum" -- and the figures below are the RANGE over the three "all switches" rows."""
+    path = os.path.join(ROOT, "profiles", "r06_cudalike_tolerance.txt")
+
+    def row(line):
+        f = [c.strip() for c in line.split("|")]
+        d = f[3].split()
+        return {"converged_mask_mismatches": int(f[1].split()[0]), "convergence_states_differing": int(f[2]), "depth_rmse_m": float(d[0]),
+                "depth_rmse_best_99pct_m": float(d[1]), "depth_median_abs_diff_m": float(d[2]), "depth_p99_abs_diff_m": float(d[3]), "depth_max_abs_diff_m": float(d[4]),
+                "seeds_off_by_more_than_1cm": int(d[5]), "denoised_rmse_m": float(f[5].split()[0])}
     try:
+        rows = {}
         for line in open(path):
             if line.startswith("ALL OF THE ABOVE"):
-                f = [c.strip() for c in line.split("|")]
-                d = f[3].split()
-                return {"source": "profiles/r05_cudalike_tolerance.txt (tests/cudalike_tolerance.py: configs[1] + TV-L1 on the CPU, plain Oracle A semantics against a model of "
-                                  "the reference's nvcc -use_fast_math build reading images through the texture unit: 8-bit filter weights, x * (1 / y), approximate sqrt / "
-                                  "rsqrt, __expf, other <= 2.5-ulp sinf / acosf, flush-to-zero, FMA contraction -- all switched on)",
-                        "converged_mask_mismatches": int(f[1].split()[0]), "convergence_states_differing": int(f[2]),
-                        "depth_rmse_m": float(d[0]), "depth_rmse_best_99pct_m": float(d[1]), "depth_median_abs_diff_m": float(d[2]), "depth_p99_abs_diff_m": float(d[3]),
-                        "depth_max_abs_diff_m": float(d[4]), "seeds_off_by_more_than_1cm": int(d[5]), "denoised_rmse_m": float(f[5].split()[0]),
-                        "reading": "against a physical CUDA run expect ~0.1 % of the convergence mask to differ, a median depth difference of ~1e-4 m and an RMSE of ~1e-3 m "
-                                   "(a handful of seeds lock onto another NCC peak); a last-ulp change of any single operation already gives 1e-3: north_star's 1e-4 holds -- "
-                                   "as exact equality -- against the reference's executable semantics (parity_vs_glibc_reference), and cannot hold against any build that rounds differently"}
+                rows["guessed operations in the model's fixed forms"] = row(line)
+            elif line.startswith("[range] ALL switches"):
+                rows["guessed operations moved by up to " + line.split("at ", 1)[1].split("|")[0].strip()] = row(line)
+        if not rows:
+            return None
+        keys = next(iter(rows.values())).keys()
+        rng = {k: [min(r[k] for r in rows.values()), max(r[k] for r in rows.values())] for k in keys}
+        px = 640 * 480
+        return {"source": "profiles/r06_cudalike_tolerance.txt (tests/cudalike_tolerance.py --sensitivity: configs[1] + TV-L1 on the CPU, plain Oracle A semantics against a model of the "
+                          "reference's nvcc -use_fast_math build reading images through the texture unit, every switch on)",
+                "specified_switches": "texture filter weights with 8 fractional bits (rounded; truncated also run), flush-to-zero, FMA contraction",
+                "guessed_switches": "x / y, sqrtf / rsqrtf, expf, sinf, acosf / atan2f: known as error bounds only; run as fixed forms, at 1 ulp and at their documented maxima",
+                "all_switches_rows": rows, "range": rng,
+                "reading": f"against a physical CUDA run expect {100.0 * rng['converged_mask_mismatches'][0] / px:.2f}-{100.0 * rng['converged_mask_mismatches'][1] / px:.2f} % of the convergence "
+                           f"mask to differ, a median depth difference of {rng['depth_median_abs_diff_m'][0]:.1e}-{rng['depth_median_abs_diff_m'][1]:.1e} m, a depth RMSE of "
+                           f"{rng['depth_rmse_m'][0]:.1e}-{rng['depth_rmse_m'][1]:.1e} m (a handful of seeds lock onto another NCC peak) and {rng['denoised_rmse_m'][0]:.1e}-"
+                           f"{rng['denoised_rmse_m'][1]:.1e} m on the denoised map -- an ESTIMATE from a model validated against no CUDA output; what it shows robustly is that a "
+                           "last-ulp change of any single operation already gives 1e-3: north_star's 1e-4 holds -- as exact equality -- against the reference's executable "
+                           "semantics (parity_vs_glibc_reference), and cannot hold against any build that rounds differently"}
     except Exception as e:  # the bench line must survive a missing file
         return {"source": path, "unavailable": str(e)}
-    return None
 
 
 def scenes_of_rank(rank, batch_per_gpu):

@@ -104,24 +104,6 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
   // sequence (batch of 8: 50 + 30 us against a 100-us step).  Frames read IN PLACE must be complete before the kernels that read them start.
   const bool overlap = !in_place && n_segs > 0;
   if (n_segs && !overlap) CopyPool::instance().copy_many(segs, n_segs, frame_bytes);
-  const bool ahead = in_place && batch_frames_ahead();
-  if (ahead) {
-    // every member gets a second current-image plane (step n lives in plane n % 2: the bringers of step n - 1 fill it while that step's search
-    // still reads the other one), and the step is HANDED OVER: the block the previous step's bringers are waiting for
-    for (int i = 0; i < b->n; ++i) {
-      rmd_hip_seeds* m = b->members[i];
-      if (!m->cur_planes[0]) m->cur_planes[0] = m->planes[RMD_HIP_PLANE_CURR_IMG].data;
-      if (!m->cur_planes[1]) {
-        const rmd_hip_image& im = m->planes[RMD_HIP_PLANE_CURR_IMG];
-        HIP_TRY(hipMalloc(&m->cur_planes[1], im.pitch * im.height));
-        HIP_TRY(hipMemset(m->cur_planes[1], 0, im.pitch * im.height));
-        HIP_TRY(hipStreamSynchronize(nullptr));
-      }
-    }
-    unsigned int* hb = b->h_handover + static_cast<size_t>(k) * 16;
-    hb[1] = active; hb[2] = as_u8 ? 1u : 2u; hb[3] = static_cast<unsigned int>(frame_bytes);
-    __atomic_store_n(&hb[0], n, __ATOMIC_RELEASE);
-  }
   if (overlap) CopyPool::instance().begin_copy_many(segs, n_segs, frame_bytes);
   const double t_c = b->ingest_profile ? host_now_us() : 0.0;
   const unsigned char* frames_dev = b->d_stage[k];
@@ -139,19 +121,9 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
   in.number = n;
   in.no_remap = packed;
   in.profile = b->ingest_profile;
-  if (ahead) {
-    const int k_next = static_cast<int>((n64 + 1) % static_cast<unsigned long long>(b->slots));
-    void* dev = nullptr;
-    HIP_TRY(hipHostGetDevicePointer(&dev, b->h_handover + static_cast<size_t>(k_next) * 16, 0));
-    in.handover = static_cast<const unsigned int*>(dev);
-    HIP_TRY(hipHostGetDevicePointer(&dev, b->h_stage[k_next], 0));
-    in.ahead_frames = static_cast<const unsigned char*>(dev);
-    in.ahead_wgs = BATCH_AHEAD_WGS;
-  }
   for (int i = 0; i < b->n; ++i) {
     if (!((active >> i) & 1u)) continue;
     rmd_hip_seeds* m = b->members[i];
-    if (ahead) m->planes[RMD_HIP_PLANE_CURR_IMG].data = m->cur_planes[n64 & 1ull];  // (step n lives in plane n % 2)
     m->P.cur = static_cast<const float*>(m->planes[RMD_HIP_PLANE_CURR_IMG].data);  // setup k writes it after search k - 1 has run (same stream)
     m->P.cur_stride = m->P.stride;
     seeds_frame_pose(m, T_curr_world + 12 * i);
@@ -196,8 +168,8 @@ int rmd_hip_batch_destroy(rmd_hip_batch_t* b) {
             g_progress_timeouts, b->ingest_lead[0], b->ingest_lead[1], b->ingest_lead[2], b->ingest_lead[3], b->ingest_lead[4]);
     for (int g = 0; g < b->n_groups; ++g)
       if (b->groups[g].h_progress)
-        fprintf(stderr, "[rmd_hip ingest]   group %d: steps whose setup kernel converted its frames %u, of which it waited for %u (%u polls); steps brought in one step ahead %u\n", g,
-                b->groups[g].h_progress[2], b->groups[g].h_progress[3], b->groups[g].h_progress[4], b->groups[g].h_progress[5]);
+        fprintf(stderr, "[rmd_hip ingest]   group %d: steps whose setup kernel converted its frames %u, of which it waited for %u (%u polls)\n", g,
+                b->groups[g].h_progress[2], b->groups[g].h_progress[3], b->groups[g].h_progress[4]);
   }
   for (int i = 0; i < rmdk::MAX_BATCH; ++i)
     if (b->members[i]) (void)seeds_destroy_impl(b->members[i]);
@@ -206,7 +178,6 @@ int rmd_hip_batch_destroy(rmd_hip_batch_t* b) {
     if (b->d_stage[q]) (void)hipFree(b->d_stage[q]);
   }
   if (b->h_seq) (void)hipHostFree(b->h_seq);
-  if (b->h_handover) (void)hipHostFree(b->h_handover);
   if (b->d_flag) (void)hipFree(b->d_flag);
   {
     rmd_hip_batch::Denoise& dn = b->dn;
@@ -225,7 +196,6 @@ int rmd_hip_batch_destroy(rmd_hip_batch_t* b) {
   for (auto& G : b->groups) {
     G.ws.release();
     if (G.h_progress) (void)hipHostFree(G.h_progress);
-    if (G.d_ahead) (void)hipFree(G.d_ahead);
     if (G.ev) (void)hipEventDestroy(G.ev);
   }
   if (b->copy_stream) (void)hipStreamDestroy(b->copy_stream);
@@ -268,7 +238,6 @@ int rmd_hip_batch_create(int n, int width, int height, float fx, float fy, float
     if (hipHostMalloc(reinterpret_cast<void**>(&G.h_progress), 64, hipHostMallocMapped) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: progress words"));
     for (int q = 0; q < 16; ++q) G.h_progress[q] = 0u;
     if (hipEventCreate(&G.ev) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: event"));
-    if (hipMalloc(reinterpret_cast<void**>(&G.d_ahead), 64) != hipSuccess || hipMemset(G.d_ahead, 0, 64) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: ahead words"));
   }
   if (create_stream(&b->copy_stream, 2) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: hipStreamCreate failed"));
   hipDeviceProp_t prop;
@@ -276,9 +245,6 @@ int rmd_hip_batch_create(int n, int width, int height, float fx, float fy, float
   if (hipHostMalloc(reinterpret_cast<void**>(&b->h_seq), rmd_hip_batch::SLOTS_MAX * FLAG_SLOT_WORDS * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&b->d_flag), FLAG_ALLOC_BYTES) != hipSuccess || hipMemset(b->d_flag, 0, FLAG_ALLOC_BYTES) != hipSuccess)
     return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: ingest words"));
-  if (hipHostMalloc(reinterpret_cast<void**>(&b->h_handover), rmd_hip_batch::SLOTS_MAX * 16 * sizeof(unsigned int), hipHostMallocMapped) != hipSuccess)
-    return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: hand-over words"));
-  memset(b->h_handover, 0, rmd_hip_batch::SLOTS_MAX * 16 * sizeof(unsigned int));
   b->n = n;  // (group_of needs it while the members are created)
   for (int i = 0; i < n; ++i) {
     const int rc = seeds_create_impl(width, height, fx, fy, cx, cy, patch_side, max_extent, b, i, &b->members[i]);

@@ -32,7 +32,7 @@
 namespace rmdk {
 
 constexpr int FR_MIN_WAVES = 3;   // __launch_bounds__ of the search kernel (five workgroups per CU at 96 VGPRs: measured, slower -- LAB.md)
-constexpr int FR_WIN_CAP = 5632;  // texels of the LDS window (22 KB); any shape with (width | 1) * height <= FR_WIN_CAP
+constexpr int FR_WIN_CAP = 5632;  // texels of the LDS window (22 KB); any shape with window_stride(width) * height <= FR_WIN_CAP
 constexpr int FR_UNIT_ROUNDS = 4, FR_UNIT_ITEMS = FR_UNIT_ROUNDS * TILE_PIX;
 constexpr int FR_MAX_ROWS = 255;   // rows of an LDS window (one entry of the row table each; 8 bits in a unit entry)
 constexpr int FR_MAX_WIDTH = 511;  // texels per window row (9 bits in a unit entry)
@@ -45,6 +45,9 @@ constexpr int FR_MAX_WIDTH = 511;  // texels per window row (9 bits in a unit en
 constexpr int FR_SHEAR_BITS = 11;
 constexpr unsigned int TILE_WANTS_BAND = 0x10000u;  // flag in a tile's word of MatcherArgs::tile_live (its low half: seeds in state UPDATE)
 RMDK_D int shear_of(int q, int m) { return (q * m) >> FR_SHEAR_BITS; }  // (arithmetic shift: floor, q may be negative)
+// Row stride of a window of `ww` texels per row: odd, so that the rows of a vertical bundle of samples start in different LDS banks.  (Lab
+// builds try others: LAB_WINDOW_STRIDE, rmd_lab.hpp; `ww | 3` and `(ww + 2) | 1` measured within the noise of `ww | 1`: profiles/r06_ab_window_stride.txt.)
+RMDK_D constexpr int window_stride(int ww) { return LAB_WINDOW_STRIDE(ww); }
 
 // ---- agent-scope accessors (global address space, sc1) ---------------------------------------------------------------
 RMDK_D unsigned int ld_agent(const unsigned int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -233,17 +236,17 @@ RMDK_D void block_bbox_read(const FrameSmem<SIDE>& S, int& x0, int& y0, int& x1,
 }
 RMDK_D bool window_fits(int u0, int y0, int u1, int y1) {  // inclusive band columns and rows
   const int ww = u1 - u0 + 1, rows = y1 - y0 + 1;
-  return u1 >= u0 && y1 >= y0 && rows <= FR_MAX_ROWS && ww <= FR_MAX_WIDTH && (ww | 1) * rows <= FR_WIN_CAP;
+  return u1 >= u0 && y1 >= y0 && rows <= FR_MAX_ROWS && ww <= FR_MAX_WIDTH && window_stride(ww) * rows <= FR_WIN_CAP;
 }
 
 // The LDS window of the current image, workgroup-uniform.
 struct FrameWindow {
   int x0, y0;    // window row q = image row y0 + q; its LDS column 0 = image column x0 + shear_of(y0 + q - yref, m)
   int ww, rows;  // texels per row, rows
-  int ws;        // row stride in LDS (ww | 1)
+  int ws;        // row stride in LDS (window_stride(ww))
   int m, yref;   // the band's shear (m / 2048 columns per row; 0: a box) and the image row it is counted from (the tile's first row)
   bool valid;    // staged and covering every sample of the tile in LDS
-  RMDK_D void set(int u0, int y0_, int u1, int y1) { x0 = u0; y0 = y0_; ww = u1 - u0 + 1; rows = y1 - y0_ + 1; ws = ww | 1; }
+  RMDK_D void set(int u0, int y0_, int u1, int y1) { x0 = u0; y0 = y0_; ww = u1 - u0 + 1; rows = y1 - y0_ + 1; ws = window_stride(ww); }
   RMDK_D void clear() { x0 = y0 = 0; ww = rows = 0; ws = 1; valid = false; }
 };
 
@@ -254,9 +257,9 @@ RMDK_D void clamp_window(FrameWindow& W) {
   constexpr int FLAT = 43;  // rows: (128 | 1) * 43 <= FR_WIN_CAP
   const int ww = W.ww, wh = W.rows;
   const int nw = wh > FLAT ? min(ww, 64) : min(ww, min((FR_WIN_CAP / wh - 1) | 1, FR_MAX_WIDTH));
-  const int nh = min(min(wh, FR_WIN_CAP / (nw | 1)), FR_MAX_ROWS);
+  const int nh = min(min(wh, FR_WIN_CAP / window_stride(nw)), FR_MAX_ROWS);
   W.x0 += (ww - nw) / 2; W.y0 += (wh - nh) / 2;  // (x0 is the band's column origin at ANY row: the shear is anchored at yref, not at y0)
-  W.ww = nw; W.rows = nh; W.ws = nw | 1;
+  W.ww = nw; W.rows = nh; W.ws = window_stride(nw);
 }
 
 // Stage the band W of the current image into the LDS window, ROW-WISE and LDS-DIRECT: wave v takes rows v, v + 4, ...; one
@@ -614,7 +617,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
     // workgroups plus 6 us of link time) -- no copy engine, no staging in HBM, nothing to wait for.
     const bool in_place = M.ingest_flag == nullptr;
     // one step ahead (see MatcherArgs): has this frame been brought in already, by the bringers of the previous update's search kernel?
-    if (M.ahead && ld_agent(M.ahead + 2) == M.ingest_number) return;
+    if (NSEQ == 1 && M.ahead && ld_agent(M.ahead + 2) == M.ingest_number) return;
     unsigned int spins = 0u;
     if (!in_place && behind()) {
       while (behind() && ++spins < (1u << 18)) __builtin_amdgcn_s_sleep(16);
@@ -932,55 +935,20 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
   }
   // One step ahead (MatcherArgs::ahead): the first ahead_wgs workgroups -- dispatched first, so they never queue behind the persistent
   // ones -- bring the next host frame into the other current-image plane if the setup kernel found it in the ring, and leave.
+  // (As the LAST workgroups of the grid instead they measure the same: profiles/r06_ab_split_frames.txt.)
   if (NSEQ == 1 && blockIdx.x < static_cast<unsigned int>(M.ahead_wgs)) {
     const unsigned int next = M.ingest_number + 1u;
     if (ld_agent(M.ahead) != next) return;
     const SeedParams& P = Bq[0].P;
-    if (M.ingest_flag == nullptr) ingest_in_place(M.ingest_kind, M.ingest_pitch, Bq[0].next_src, Bq[0].next_dst, P.w, P.h, P.stride, static_cast<int>(blockIdx.x), M.ahead_wgs, tid);
-    else ingest_staged(M.ingest_kind, M.ingest_pitch, Bq[0].next_src, Bq[0].next_dst, P.w, P.h, P.stride, static_cast<int>(blockIdx.x), M.ahead_wgs, tid,
-                       [](const unsigned int* p) { return *p; });
+    const int part = static_cast<int>(blockIdx.x);
+    if (M.ingest_flag == nullptr) ingest_in_place(M.ingest_kind, M.ingest_pitch, Bq[0].next_src, Bq[0].next_dst, P.w, P.h, P.stride, part, M.ahead_wgs, tid);
+    else ingest_staged(M.ingest_kind, M.ingest_pitch, Bq[0].next_src, Bq[0].next_dst, P.w, P.h, P.stride, part, M.ahead_wgs, tid, [](const unsigned int* p) { return *p; });
     // The last one to finish publishes the frame.  Plane and number are read by the NEXT kernels only, and a kernel's stores are all
     // visible to the kernels behind it on the stream: no fence here (an agent-scope fence writes back and invalidates the L2 the
     // searching workgroups live on -- a hundred of them made every update 20 us longer).
     if (tid == 0 && __hip_atomic_fetch_add(M.ahead + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == static_cast<unsigned int>(M.ahead_wgs) - 1u) {
       __hip_atomic_store(M.ahead + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(M.ahead + 2, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return;
-  }
-  // A batch's frames one step ahead (MatcherArgs::handover): the bringers wait up to AHEAD_PATIENCE_TICKS for the caller to hand the next step
-  // over, agree on ONE verdict, and read the members' frames of this group from the pinned block into the members' other planes.
-  if (NSEQ > 1 && blockIdx.x < static_cast<unsigned int>(M.ahead_wgs)) {
-    const unsigned int next = M.ingest_number + 1u, no = next ^ 0x80000000u;
-    if (tid == 0) {
-      const unsigned long long t0 = wall_clock64();
-      unsigned int d;
-      for (;;) {
-        d = ld_agent(M.ahead);
-        if (d == next || d == no) break;
-        const bool there = ld_system(M.handover) == next;
-        if (there || wall_clock64() - t0 > AHEAD_PATIENCE_TICKS) {
-          (void)atomicCAS(M.ahead, d, there ? next : no);  // (whoever wins, the word is settled: read it again)
-          continue;
-        }
-        __builtin_amdgcn_s_sleep(32);
-      }
-      S.bcast[0] = d;
-    }
-    __syncthreads();
-    if (S.bcast[0] != next) return;
-    const unsigned int members = ld_system(M.handover + 1), kind = ld_system(M.handover + 2), frame_bytes = ld_system(M.handover + 3);
-    for (int j = 0; j < M.n_seq; ++j) {
-      if (!((members >> (M.group_first + j)) & 1u)) continue;
-      const SeqArgs& Qj = Bq[j];
-      ingest_in_place(static_cast<int>(kind), M.ingest_pitch, M.ahead_frames + static_cast<size_t>(M.group_first + j) * frame_bytes, Qj.next_dst, Qj.P.w, Qj.P.h,
-                      Qj.P.stride, static_cast<int>(blockIdx.x), M.ahead_wgs, tid);
-    }
-    __syncthreads();
-    if (tid == 0 && __hip_atomic_fetch_add(M.ahead + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == static_cast<unsigned int>(M.ahead_wgs) - 1u) {
-      __hip_atomic_store(M.ahead + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(M.ahead + 2, next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (read by the NEXT launch's setup kernel: no fence, as above)
-      if (M.ingest_profile) __hip_atomic_fetch_add(M.progress + 5, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // diagnostics: steps brought in ahead
     }
     return;
   }
@@ -1094,7 +1062,7 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
       if (boxed) {
         W.x0 = static_cast<int>(static_cast<short>(box0 & 0xffffu)); W.y0 = static_cast<int>(box0 >> 16);
         W.rows = static_cast<int>(box1 & 0xffu); W.ww = static_cast<int>((box1 >> 8) & 0x1ffu);
-        W.ws = W.ww | 1;
+        W.ws = window_stride(W.ww);
         W.valid = true;
         frame_stage_window<SIDE>(P, S, tid, W);
       }
@@ -1205,9 +1173,6 @@ inline hipError_t launch_seed_pipeline_compact(const BatchArgs<NSEQ>& B, int n_s
     M.ingest_kind = ingest->kind; M.ingest_pitch = ingest->pitch;
     M.ingest_flag = ingest->flag; M.progress = ingest->progress; M.ingest_number = ingest->number;
     if (NSEQ == 1 && ingest->ahead) { M.ahead_wgs = ingest->ahead_wgs; M.submitted = ingest->submitted; M.ahead = ingest->ahead; }
-    if (NSEQ > 1 && ingest->ahead && ingest->handover) {
-      M.ahead_wgs = ingest->ahead_wgs; M.ahead = ingest->ahead; M.handover = ingest->handover; M.ahead_frames = ingest->ahead_frames; M.group_first = ingest->group_first;
-    }
   }
   auto search = seed_search_compact_kernel<SIDE, NSEQ>;
   constexpr int KIND = NSEQ == 1 ? 0 : 1;

@@ -206,8 +206,6 @@ inline bool frame_ahead(bool remap) {
   const int m = host_frames_mode(false);
   return !remap && (m == HOST_FRAMES_STAGED_AHEAD || m == HOST_FRAMES_INPLACE_AHEAD);
 }
-inline bool batch_frames_ahead() { return host_frames_mode(true) == HOST_FRAMES_INPLACE_AHEAD; }  // (a batch's frames read in place by the previous step's search kernels)
-constexpr int BATCH_AHEAD_WGS = 64;  // bringers per stream group
 constexpr size_t FLAG_WORDS = 16384;
 inline void fill_flag_block(unsigned int* block, unsigned int n, size_t words) {
   for (size_t i = 0; i < words; ++i) block[i] = n;
@@ -374,7 +372,6 @@ struct rmd_hip_batch {
     unsigned long long slot_step[8] = {};   // host frames: the step of this group's last launch that read staging slot k (0: none)
     unsigned long long last_step = 0;       // ... and of its last launch altogether
     hipEvent_t ev = nullptr;                // fork / join of the region timer
-    unsigned int* d_ahead = nullptr;        // device words of rmdk::MatcherArgs::ahead (frames one step ahead)
   };
   static constexpr int MAX_GROUPS = 4;
   int n_groups = 0;
@@ -387,7 +384,6 @@ struct rmd_hip_batch {
   unsigned char* h_stage[SLOTS_MAX] = {};
   unsigned char* d_stage[SLOTS_MAX] = {};
   size_t stage_bytes = 0;                   // capacity of each of the buffers above
-  unsigned int* h_handover = nullptr;       // pinned + mapped, 16 words per slot: rmdk::MatcherArgs::handover
   unsigned int* h_seq = nullptr;
   unsigned int* d_flag = nullptr;
   unsigned long long step_number = 0;

@@ -14,6 +14,15 @@
 #define LAB_WANT_BAND(flag) (flag)
 #endif
 
+// A/B of the LDS window's row stride (tools/ab_make.sh stride3 "-DRMD_LAB_STRIDE=3": ww | 3; stride5 "-DRMD_LAB_STRIDE=5": (ww + 2) | 1)
+#if defined(RMD_LAB_STRIDE) && RMD_LAB_STRIDE == 3
+#define LAB_WINDOW_STRIDE(ww) ((ww) | 3)
+#elif defined(RMD_LAB_STRIDE) && RMD_LAB_STRIDE == 5
+#define LAB_WINDOW_STRIDE(ww) (((ww) + 2) | 1)
+#else
+#define LAB_WINDOW_STRIDE(ww) ((ww) | 1)
+#endif
+
 #ifdef RMD_LAB_PROFILE_ROUNDS
 #define LAB_PROF(...) __VA_ARGS__
 namespace rmdk {

@@ -172,17 +172,7 @@ struct MatcherArgs {
   int ahead_wgs;
   const unsigned int* submitted;   // staged: the arrival flag of frame n + 1's staging buffer; in place: a pinned host word, the newest frame of this kind that is complete in the ring
   unsigned int* ahead;             // device words: [0] frame to bring in during this update's search kernel or 0, [1] bringers done, [2] newest frame brought in ahead
-  // The same for a BATCH whose frames are read in place (NSEQ > 1): the caller is rarely a whole step ahead of the device, so the verdict is not
-  // taken by the setup kernel but by the search kernel's bringers themselves, which WAIT a little (AHEAD_PATIENCE_TICKS) for the next step to be
-  // handed over: `handover` is the pinned block of the next step's ring slot -- [0] the step's number once its frames are complete in the
-  // pinned block, [1] members that have a frame (bits), [2] kind, [3] bytes per frame --, `ahead_frames` that slot's frames (member i at
-  // i x handover[3]); the first bringer to see the number (or the deadline) settles ahead[0] = step (bring it) / step ^ 2^31 (do not) with a
-  // compare-and-swap, and every bringer acts on the settled word.
-  const unsigned int* handover;
-  const unsigned char* ahead_frames;
-  int group_first;                 // index in the batch of this launch's sequence 0
 };
-constexpr unsigned long long AHEAD_PATIENCE_TICKS = 2000;  // 20 us of the 100 MHz wall clock
 
 // One sequence of a launch: the reference's mvs::DeviceData of that SeedMatrix for this frame plus what the deferred finalisation
 // of ITS previous frame and the ingest of ITS host frame need.
@@ -222,9 +212,6 @@ struct IngestArgs {
   int ahead_wgs = 0;  // see MatcherArgs::ahead
   const unsigned int* submitted = nullptr;
   unsigned int* ahead = nullptr;
-  const unsigned int* handover = nullptr;  // a batch's next step (MatcherArgs::handover)
-  const unsigned char* ahead_frames = nullptr;
-  int group_first = 0;
 };
 
 RMDK_D unsigned int orderable_f32(float f) {
@@ -476,7 +463,6 @@ inline MatcherArgs matcher_args(const MatcherWorkspace& ws) {
   M.shard_cap = ws.shard_cap;
   M.ingest_kind = 0; M.ingest_pitch = 0; M.ingest_wgs = 0; M.ingest_rows = 0; M.ingest_profile = 0; M.ingest_flag = nullptr; M.progress = nullptr; M.ingest_number = 0u;
   M.ahead_wgs = 0; M.submitted = nullptr; M.ahead = nullptr;
-  M.handover = nullptr; M.ahead_frames = nullptr; M.group_first = 0;
   return M;
 }
 

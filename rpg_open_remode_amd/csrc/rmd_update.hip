@@ -134,8 +134,6 @@ int batch_launch(rmd_hip_batch* b, unsigned int active, const rmdk::IngestArgs* 
         }
         B.seq[j].ingest_dst = const_cast<float*>(P.cur);
       }
-      // frames one step ahead (MatcherArgs::handover): the plane the NEXT step of this member lives in -- the one this step does not use
-      if (ingest && ingest->handover && m->cur_planes[1]) B.seq[j].next_dst = static_cast<float*>(m->cur_planes[(ingest->number + 1u) & 1u]);  // (step n lives in plane n % 2)
     }
     rmdk::IngestArgs in;
     if (ingest) {
@@ -143,7 +141,6 @@ int batch_launch(rmd_hip_batch* b, unsigned int active, const rmdk::IngestArgs* 
       void* dev_progress = nullptr;
       HIP_TRY(hipHostGetDevicePointer(&dev_progress, G.h_progress, 0));
       in.progress = static_cast<unsigned int*>(dev_progress);
-      if (in.handover) { in.ahead = G.d_ahead; in.group_first = G.first; }
     }
     const int rc = dispatch_side(b->members[0]->patch_side, [&](auto side) {
       constexpr int SIDE = decltype(side)::value;
