@@ -120,7 +120,7 @@ def _code_only(text):
     return " ".join("".join(out).split())
 
 
-KERNEL_SOURCES = ["rmd_device.hpp", "rmd_frame.hpp", "rmd_kernels.hpp", "rmd_lab.hpp", "rmd_matcher.hpp", "rmd_math.h", "rmd_tv_kernels.hpp"]  # the device code of librmd_hip.so (csrc/rmd_host.hpp and the .hip units are host code)
+KERNEL_SOURCES = ["rmd_device.hpp", "rmd_frame.hpp", "rmd_frame_window.hpp", "rmd_frame_ingest.hpp", "rmd_frame_setup.hpp", "rmd_frame_search.hpp", "rmd_kernels.hpp", "rmd_lab.hpp", "rmd_matcher.hpp", "rmd_math.h", "rmd_tv_kernels.hpp"]  # the device code of librmd_hip.so (csrc/rmd_host.hpp and the .hip units are host code)
 
 
 def kernel_source_sha256():

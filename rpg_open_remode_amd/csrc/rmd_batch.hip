@@ -1,4 +1,5 @@
-// librmd_hip.so -- rmd_hip_batch_*: several SeedMatrix objects of one size stepped by ONE launch pair per stream group, and TV-L1 for all of them in one launch sequence.
+// librmd_hip.so -- rmd_hip_batch_*: several SeedMatrix objects of one size stepped by ONE launch pair per stream group, and
+// TV-L1 for all of them in one launch sequence.
 #include "rmd_host.hpp"
 #include "rmd_copy_pool.hpp"
 
@@ -54,7 +55,8 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
     const int lead = static_cast<int>(n - *static_cast<volatile unsigned int*>(b->groups[0].h_progress));
     ++b->ingest_lead[lead < 0 ? 0 : lead > 4 ? 4 : lead];
   }
-  const size_t need = static_cast<size_t>(b->n) * static_cast<size_t>(m0->width) * m0->height * sizeof(float);  // float frames: the larger kind
+  // float frames: the larger kind
+  const size_t need = static_cast<size_t>(b->n) * static_cast<size_t>(m0->width) * m0->height * sizeof(float);
   if (b->stage_bytes < need) {
     for (int g = 0; g < b->n_groups; ++g) HIP_TRY(hipStreamSynchronize(b->groups[g].stream));
     HIP_TRY(hipStreamSynchronize(b->copy_stream));
@@ -73,7 +75,8 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
   else if (!gray && float_frames_as_bytes()) {
     packed = true;
     for (int i = 0; i < b->n && packed; ++i)
-      if ((active >> i) & 1u) packed = CopyPool::instance().pack(f32[i], b->h_stage[k] + static_cast<size_t>(i) * bytes_u8, m0->width, m0->height, u8_pitch);
+      if ((active >> i) & 1u) packed = CopyPool::instance().pack(f32[i], b->h_stage[k] + static_cast<size_t>(i) * bytes_u8, m0->width,
+          m0->height, u8_pitch);
     if (packed) frame_bytes = bytes_u8;
     else b->pack_backoff = 15;
   }
@@ -89,7 +92,8 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
     if (packed) continue;
     unsigned char* dst = b->h_stage[k] + static_cast<size_t>(i) * frame_bytes;
     if (gray && u8_pitch != m0->width) {
-      for (int y = 0; y < m0->height; ++y) memcpy(dst + static_cast<size_t>(y) * u8_pitch, gray[i] + static_cast<size_t>(y) * m0->width, m0->width);
+      for (int y = 0; y < m0->height; ++y) memcpy(dst + static_cast<size_t>(y) * u8_pitch, gray[i] + static_cast<size_t>(y) * m0->width,
+          m0->width);
     } else {
       segs[n_segs].dst = dst;
       segs[n_segs].src = gray ? static_cast<const void*>(gray[i]) : static_cast<const void*>(f32[i]);
@@ -97,11 +101,12 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
     }
   }
   const bool in_place = frame_in_place(true, any_maps);  // (the remap gathers single bytes: staged)
-  // The frames of the step go into the pinned block, spread over the copy threads.  STAGED frames are brought in by the copy engine and their
-  // setup kernels wait for the arrival flag themselves: nothing the host queues for the compute streams depends on the pinned block, so the
-  // step's launches are queued WHILE the helpers copy (the caller's share of the copy follows them) -- per step the host spends
+  // The frames of the step go into the pinned block, spread over the copy threads.  STAGED frames are brought in by the copy engine and
+  // their setup kernels wait for the arrival flag themselves: nothing the host queues for the compute streams depends on the pinned block,
+  // so the step's launches are queued WHILE the helpers copy (the caller's share of the copy follows them) -- per step the host spends
   // max(copy, launches) instead of their sum, which is what lets it stay a step or more ahead of the device on the light two thirds of a
-  // sequence (batch of 8: 50 + 30 us against a 100-us step).  Frames read IN PLACE must be complete before the kernels that read them start.
+  // sequence (batch of 8: 50 + 30 us against a 100-us step).  Frames read IN PLACE must be complete before the kernels that read them
+  // start.
   const bool overlap = !in_place && n_segs > 0;
   if (n_segs && !overlap) CopyPool::instance().copy_many(segs, n_segs, frame_bytes);
   if (overlap) CopyPool::instance().begin_copy_many(segs, n_segs, frame_bytes);
@@ -124,13 +129,15 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
   for (int i = 0; i < b->n; ++i) {
     if (!((active >> i) & 1u)) continue;
     rmd_hip_seeds* m = b->members[i];
-    m->P.cur = static_cast<const float*>(m->planes[RMD_HIP_PLANE_CURR_IMG].data);  // setup k writes it after search k - 1 has run (same stream)
+    // setup k writes it after search k - 1 has run (same stream)
+    m->P.cur = static_cast<const float*>(m->planes[RMD_HIP_PLANE_CURR_IMG].data);
     m->P.cur_stride = m->P.stride;
     seeds_frame_pose(m, T_curr_world + 12 * i);
   }
-  // The arrival flag of a batch always travels as the whole block, i.e. through the copy engine: the 4-byte form is a blit KERNEL, and a step's
-  // ingest workgroups -- up to 75 per member, dispatched ahead of the tiles -- may all be waiting for it while the other groups' persistent
-  // search workgroups hold the rest of the wave slots (batch of 16, staged: the blit never ran, the kernels' bounded wait expired after 0.13 s).
+  // The arrival flag of a batch always travels as the whole block, i.e. through the copy engine: the 4-byte form is a blit KERNEL, and a
+  // step's ingest workgroups -- up to 75 per member, dispatched ahead of the tiles -- may all be waiting for it while the other groups'
+  // persistent search workgroups hold the rest of the wave slots (batch of 16, staged: the blit never ran, the kernels' bounded wait
+  // expired after 0.13 s).
   const size_t fw = FLAG_WORDS;
   for (int g = 0; g < b->n_groups; ++g) {
     rmd_hip_batch::Group& G = b->groups[g];
@@ -141,7 +148,8 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
   if (rc == RMD_HIP_OK && !in_place) {
     const size_t off = static_cast<size_t>(first) * frame_bytes, len = static_cast<size_t>(last - first + 1) * frame_bytes;
     HIP_TRY(hipMemcpyAsync(b->d_stage[k] + off, b->h_stage[k] + off, len, hipMemcpyHostToDevice, b->copy_stream));
-    fill_flag_block(b->h_seq + k * FLAG_SLOT_WORDS, n, fw);  // behind the frames on the same stream: when the kernel sees n, they are in HBM
+    // behind the frames on the same stream: when the kernel sees n, they are in HBM
+    fill_flag_block(b->h_seq + k * FLAG_SLOT_WORDS, n, fw);
     HIP_TRY(hipMemcpyAsync(b->d_flag, b->h_seq + k * FLAG_SLOT_WORDS, fw * sizeof(unsigned int), hipMemcpyHostToDevice, b->copy_stream));
   }
   if (b->ingest_profile) {
@@ -162,13 +170,16 @@ int rmd_hip_batch_destroy(rmd_hip_batch_t* b) {
     if (G.stream) (void)hipStreamSynchronize(G.stream);
   if (b->copy_stream) (void)hipStreamSynchronize(b->copy_stream);
   if (b->ingest_profile && b->ingest_us[3] > 0) {
-    fprintf(stderr, "[rmd_hip ingest] batch of %d, %.0f steps: wait for slot %.2f us, host copy %.2f us, submit %.2f us per step; longest wait %.0f us, %lu waits gave up after 2 ms; "
+    fprintf(stderr, "[rmd_hip ingest] batch of %d, %.0f steps: wait for slot %.2f us, host copy %.2f us, submit %.2f us per step; "
+                    "longest wait %.0f us, %lu waits gave up after 2 ms; "
                     "steps handed over <=0 / 1 / 2 / 3 / >=4 ahead of group 0's newest started setup kernel: %lu / %lu / %lu / %lu / %lu\n",
-            b->n, b->ingest_us[3], b->ingest_us[0] / b->ingest_us[3], b->ingest_us[1] / b->ingest_us[3], b->ingest_us[2] / b->ingest_us[3], g_progress_max_wait_us,
+            b->n, b->ingest_us[3], b->ingest_us[0] / b->ingest_us[3], b->ingest_us[1] / b->ingest_us[3], b->ingest_us[2] / b->ingest_us[3],
+                g_progress_max_wait_us,
             g_progress_timeouts, b->ingest_lead[0], b->ingest_lead[1], b->ingest_lead[2], b->ingest_lead[3], b->ingest_lead[4]);
     for (int g = 0; g < b->n_groups; ++g)
       if (b->groups[g].h_progress)
-        fprintf(stderr, "[rmd_hip ingest]   group %d: steps whose setup kernel converted its frames %u, of which it waited for %u (%u polls)\n", g,
+        fprintf(stderr,
+            "[rmd_hip ingest]   group %d: steps whose setup kernel converted its frames %u, of which it waited for %u (%u polls)\n", g,
                 b->groups[g].h_progress[2], b->groups[g].h_progress[3], b->groups[g].h_progress[4]);
   }
   for (int i = 0; i < rmdk::MAX_BATCH; ++i)
@@ -205,7 +216,8 @@ int rmd_hip_batch_destroy(rmd_hip_batch_t* b) {
   return RMD_HIP_OK;
 }
 
-int rmd_hip_batch_create(int n, int width, int height, float fx, float fy, float cx, float cy, int patch_side, int max_extent, rmd_hip_batch_t** out) {
+int rmd_hip_batch_create(int n, int width, int height, float fx, float fy, float cx, float cy, int patch_side, int max_extent,
+    rmd_hip_batch_t** out) {
   if (!out) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_create: null output");
   *out = nullptr;
   if (n < 1 || n > rmdk::MAX_BATCH) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_create: %d sequences (1..%d)", n, rmdk::MAX_BATCH);
@@ -216,7 +228,8 @@ int rmd_hip_batch_create(int n, int width, int height, float fx, float fy, float
   if (!b) return fail(RMD_HIP_ERR_RUNTIME, "batch_create: out of host memory");
   (void)hipGetDevice(&b->device);
   auto bail = [&](int rc) { rmd_hip_batch_destroy(b); return rc; };
-  int want_groups = n >= 3 ? 3 : n;  // measured (profiles/r03_batch_ab.txt): three groups beat two by 3-9 %, a fourth shares a hardware-queue pool and loses 25 %
+  // measured (profiles/r03_batch_ab.txt): three groups beat two by 3-9 %, a fourth shares a hardware-queue pool and loses 25 %
+  int want_groups = n >= 3 ? 3 : n;
   if (tunables().v[RMD_HIP_TUNE_BATCH_GROUPS] > 0) want_groups = tunables().v[RMD_HIP_TUNE_BATCH_GROUPS];  // (A/B)
   if (want_groups < 1) want_groups = 1;
   if (want_groups > rmd_hip_batch::MAX_GROUPS) want_groups = rmd_hip_batch::MAX_GROUPS;
@@ -225,7 +238,8 @@ int rmd_hip_batch_create(int n, int width, int height, float fx, float fy, float
   while (want_groups * rmdk::MAX_GROUP_SEQ < n) ++want_groups;
   b->n_groups = want_groups;
   b->ingest_profile = tunables().v[RMD_HIP_TUNE_INGEST_PROFILE] != 0;
-  if (tunables().v[RMD_HIP_TUNE_RING_DEPTH] > 0) b->slots = tunables().v[RMD_HIP_TUNE_RING_DEPTH] < 3 ? 3 : tunables().v[RMD_HIP_TUNE_RING_DEPTH];
+  if (tunables().v[RMD_HIP_TUNE_RING_DEPTH] > 0) b->slots = tunables().v[RMD_HIP_TUNE_RING_DEPTH] < 3 ? 3
+      : tunables().v[RMD_HIP_TUNE_RING_DEPTH];
   b->opt_unit_target = 1;  // (2x / 3x as many, smaller units: +4 % with one group of 4, nothing with two groups)
   const size_t pitch = (static_cast<size_t>(width) * 4 + 255) / 256 * 256;  // as image_alloc lays the members' planes out
   for (int g = 0; g < b->n_groups; ++g) {
@@ -234,16 +248,20 @@ int rmd_hip_batch_create(int n, int width, int height, float fx, float fy, float
     G.n = n / b->n_groups + (g < n % b->n_groups ? 1 : 0);  // the larger groups first
     // (one priority level each, see create_stream; a fourth group shares the first one's pool)
     if (create_stream(&G.stream, g % 3) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: hipStreamCreate failed"));
-    if (G.ws.allocate(width, height, static_cast<int>(pitch / 4), G.n, max_extent) != 0) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: update workspace"));
-    if (hipHostMalloc(reinterpret_cast<void**>(&G.h_progress), 64, hipHostMallocMapped) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: progress words"));
+    if (G.ws.allocate(width, height, static_cast<int>(pitch / 4), G.n, max_extent) != 0) return bail(fail(RMD_HIP_ERR_RUNTIME,
+        "batch_create: update workspace"));
+    if (hipHostMalloc(reinterpret_cast<void**>(&G.h_progress), 64, hipHostMallocMapped) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME,
+        "batch_create: progress words"));
     for (int q = 0; q < 16; ++q) G.h_progress[q] = 0u;
     if (hipEventCreate(&G.ev) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: event"));
   }
   if (create_stream(&b->copy_stream, 2) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: hipStreamCreate failed"));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, b->device) == hipSuccess && prop.multiProcessorCount > 0) b->num_cus = prop.multiProcessorCount;
-  if (hipHostMalloc(reinterpret_cast<void**>(&b->h_seq), rmd_hip_batch::SLOTS_MAX * FLAG_SLOT_WORDS * sizeof(unsigned int), hipHostMallocDefault) != hipSuccess ||
-      hipMalloc(reinterpret_cast<void**>(&b->d_flag), FLAG_ALLOC_BYTES) != hipSuccess || hipMemset(b->d_flag, 0, FLAG_ALLOC_BYTES) != hipSuccess)
+  if (hipHostMalloc(reinterpret_cast<void**>(&b->h_seq), rmd_hip_batch::SLOTS_MAX * FLAG_SLOT_WORDS * sizeof(unsigned int),
+      hipHostMallocDefault) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&b->d_flag), FLAG_ALLOC_BYTES) != hipSuccess || hipMemset(b->d_flag, 0,
+          FLAG_ALLOC_BYTES) != hipSuccess)
     return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: ingest words"));
   b->n = n;  // (group_of needs it while the members are created)
   for (int i = 0; i < n; ++i) {
@@ -276,7 +294,8 @@ int rmd_hip_batch_update_device(rmd_hip_batch_t* b, const float* const* dev_imgs
     if (!dev_imgs[i]) continue;
     rmd_hip_seeds* m = b->members[i];
     if (!m->has_reference) return fail(RMD_HIP_ERR_NOT_READY, "batch_update_device: member %d has no reference image", i);
-    if (stride_elems[i] < static_cast<size_t>(m->width)) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_update_device: stride < width (member %d)", i);
+    if (stride_elems[i] < static_cast<size_t>(m->width)) return fail(RMD_HIP_ERR_INVALID_ARG,
+        "batch_update_device: stride < width (member %d)", i);
     active |= 1u << i;
   }
   if (!active) return RMD_HIP_OK;
@@ -374,19 +393,22 @@ int rmd_hip_batch_denoise(rmd_hip_batch_t* b, const float* depth_range, float la
   // setLargeSigmaSq(), not a map of the prior
   for (int i = 0; i < n; ++i)
     if (!b->members[i]->has_reference) return fail(RMD_HIP_ERR_NOT_READY, "batch_denoise: member %d has no reference image", i);
-  if (!dn.ready) {  // (a call that fails half-way allocates only what is still missing when it is repeated; batch_destroy releases whatever exists)
+  // (a call that fails half-way allocates only what is still missing when it is repeated; batch_destroy releases whatever exists)
+  if (!dn.ready) {
     rmd_hip_image* f32[] = {&dn.u[0], &dn.u[1], &dn.u_head[0], &dn.u_head[1], &dn.g};
     for (auto* im : f32)
       if (!im->data) TRY(image_alloc(im, RMD_HIP_KIND_F32, w, h * n));
     for (int k = 0; k < 2; ++k)
       if (!dn.p[k].data) TRY(image_alloc(&dn.p[k], RMD_HIP_KIND_F32X2, w, h * n));
-    if (!dn.d_table) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dn.d_table), static_cast<size_t>(rmdk::MAX_BATCH) * rmdk::TV_MEMBER_WORDS * sizeof(unsigned long long)));
+    if (!dn.d_table) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dn.d_table), static_cast<size_t>(rmdk::MAX_BATCH) * rmdk::TV_MEMBER_WORDS
+        * sizeof(unsigned long long)));
     if (!dn.h_staging) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&dn.h_staging), static_cast<size_t>(n) * w * h * sizeof(float)));
     if (!dn.stream) HIP_TRY(hipStreamCreateWithFlags(&dn.stream, hipStreamNonBlocking));
     HIP_TRY(hipDeviceSynchronize());
     dn.ready = true;
   }
-  // the members' state must be final and at rest: deferred finalisations, then every group's stream (the members' last kernels are left in flight)
+  // the members' state must be final and at rest: deferred finalisations, then every group's stream (the members' last kernels are left in
+  // flight)
   for (int i = 0; i < n; ++i) TRY(seeds_flush(b->members[i]));
   for (int g = 0; g < b->n_groups; ++g) HIP_TRY(hipStreamSynchronize(b->groups[g].stream));
   for (int g = 0; g < b->n_groups; ++g) TRY(ingest_error_check(b->groups[g].h_progress));
@@ -394,7 +416,8 @@ int rmd_hip_batch_denoise(rmd_hip_batch_t* b, const float* depth_range, float la
   unsigned long long table[rmdk::MAX_BATCH * rmdk::TV_MEMBER_WORDS] = {};
   for (int i = 0; i < n; ++i) {
     const rmd_hip_seeds* m = b->members[i];
-    const float large_sigma_sq = depth_range[i] * depth_range[i] / 72.0f;  // DepthmapDenoiser::setLargeSigmaSq, depthmap_denoiser.cu:226-229
+    // DepthmapDenoiser::setLargeSigmaSq, depthmap_denoiser.cu:226-229
+    const float large_sigma_sq = depth_range[i] * depth_range[i] / 72.0f;
     unsigned int bits;
     memcpy(&bits, &large_sigma_sq, 4);
     unsigned long long* t = table + static_cast<size_t>(i) * rmdk::TV_MEMBER_WORDS;
@@ -452,7 +475,8 @@ int rmd_hip_batch_denoise(rmd_hip_batch_t* b, const float* depth_range, float la
 int rmd_hip_batch_denoise_result(const rmd_hip_batch_t* b, int index, const rmd_hip_image_t** view) {
   if (!b || !view) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_denoise_result: null argument");
   if (index < 0 || index >= b->n) return fail(RMD_HIP_ERR_INVALID_ARG, "batch_denoise_result: index %d outside [0, %d)", index, b->n);
-  if (!b->dn.ready || !b->dn.result[index].data) return fail(RMD_HIP_ERR_NOT_READY, "batch_denoise_result: rmd_hip_batch_denoise has not run");
+  if (!b->dn.ready || !b->dn.result[index].data) return fail(RMD_HIP_ERR_NOT_READY,
+      "batch_denoise_result: rmd_hip_batch_denoise has not run");
   *view = &b->dn.result[index];
   return RMD_HIP_OK;
 }

@@ -1,9 +1,8 @@
-// librmd_hip.so: C ABI (include/rmd_hip.h) over the HIP kernels -- library, device selection, rmd::DeviceImage, rmd::SeedMatrix (everything but
-// the sources of its frames, rmd_ingest.hip, and its kernel launches, rmd_update.hip); the other units are listed in rmd_host.hpp.  Host orchestration of
-// rmd::SeedMatrix (seed_matrix.cu:28-230), rmd::DepthmapDenoiser (depthmap_denoiser.cu:124-229),
-// rmd::ImageReducer (reduction.cu) and rmd::DeviceImage (device_image.cuh), redesigned around
-// per-handle HIP streams, kernarg parameter blocks and pinned staging instead of the reference's
-// default stream, device-resident descriptor structs and global texture references.
+// librmd_hip.so: C ABI (include/rmd_hip.h) over the HIP kernels -- library, device selection, rmd::DeviceImage, rmd::SeedMatrix (everything
+// but the sources of its frames, rmd_ingest.hip, and its kernel launches, rmd_update.hip); the other units are listed in rmd_host.hpp.
+// Host orchestration of rmd::SeedMatrix (seed_matrix.cu:28-230), rmd::DepthmapDenoiser (depthmap_denoiser.cu:124-229), rmd::ImageReducer
+// (reduction.cu) and rmd::DeviceImage (device_image.cuh), redesigned around per-handle HIP streams, kernarg parameter blocks and pinned
+// staging instead of the reference's default stream, device-resident descriptor structs and global texture references.
 #include "rmd_host.hpp"
 
 using namespace rmdh;
@@ -24,7 +23,8 @@ int fail(int code, const char* fmt, ...) {
 const char* last_error() { return g_last_error; }
 
 // accepted values per tunable (rmd_hip_set_tunable AND the environment presets)
-static const int tunable_lo[RMD_HIP_NUM_TUNABLES] = {-1, 0, 1, 0, 0, 1, 0, 0, 0, 0, 1}, tunable_hi[RMD_HIP_NUM_TUNABLES] = {3, 4, 1024, 1 << 20, 1, 16, 1, 1, 1, 8, 2};
+static const int tunable_lo[RMD_HIP_NUM_TUNABLES] = {-1, 0, 1, 0, 0, 1, 0, 0, 0, 0, 1}, tunable_hi[RMD_HIP_NUM_TUNABLES] = {3, 4, 1024,
+    1 << 20, 1, 16, 1, 1, 1, 8, 2};
 
 // The library's process-wide settings and THE ONE PLACE where it reads its environment (include/rmd_hip.h: RMD_HIP_TUNE_*): the
 // defaults come from RMD_HIP_<NAME>, once, at the first call; rmd_hip_set_tunable overrides them for handles created afterwards.
@@ -42,11 +42,13 @@ Tunables& tunables() {
     t.v[RMD_HIP_TUNE_HOST_WAIT] = 1;
     t.v[RMD_HIP_TUNE_RING_DEPTH] = 0;
     t.v[RMD_HIP_TUNE_COPY_STREAMS] = 2;
-    static const char* const names[RMD_HIP_NUM_TUNABLES] = {"RMD_HIP_HOST_FRAMES", "RMD_HIP_BATCH_GROUPS", "RMD_HIP_AHEAD_WGS", "RMD_HIP_PACK_BACKOFF",
-                                                            "RMD_HIP_FLOAT_AS_BYTES", "RMD_HIP_COPY_THREADS", "RMD_HIP_FUSED_INGEST", "RMD_HIP_INGEST_PROFILE", "RMD_HIP_HOST_WAIT",
+    static const char* const names[RMD_HIP_NUM_TUNABLES] = {"RMD_HIP_HOST_FRAMES", "RMD_HIP_BATCH_GROUPS", "RMD_HIP_AHEAD_WGS",
+        "RMD_HIP_PACK_BACKOFF",
+                                                            "RMD_HIP_FLOAT_AS_BYTES", "RMD_HIP_COPY_THREADS", "RMD_HIP_FUSED_INGEST",
+                                                                "RMD_HIP_INGEST_PROFILE", "RMD_HIP_HOST_WAIT",
                                                             "RMD_HIP_RING_DEPTH", "RMD_HIP_COPY_STREAMS"};
-    // A preset from the environment passes the same range check as rmd_hip_set_tunable; one that fails it -- or does not parse -- is IGNORED
-    // with a line on stderr (a negative RMD_HIP_AHEAD_WGS used to go straight into the search kernel's grid arithmetic).
+    // A preset from the environment passes the same range check as rmd_hip_set_tunable; one that fails it -- or does not parse -- is
+    // IGNORED with a line on stderr (a negative RMD_HIP_AHEAD_WGS used to go straight into the search kernel's grid arithmetic).
     for (int k = 0; k < RMD_HIP_NUM_TUNABLES; ++k) {
       const char* e = getenv(names[k]);
       if (!e || !e[0]) continue;
@@ -63,7 +65,8 @@ Tunables& tunables() {
         parsed = end != e && *end == '\0';
       }
       if (!parsed || v < tunable_lo[k] || v > tunable_hi[k]) {
-        fprintf(stderr, "[rmd_hip] %s=%s ignored: %s [%d, %d]\n", names[k], e, parsed ? "outside" : "not a number in", tunable_lo[k], tunable_hi[k]);
+        fprintf(stderr, "[rmd_hip] %s=%s ignored: %s [%d, %d]\n", names[k], e, parsed ? "outside" : "not a number in", tunable_lo[k],
+            tunable_hi[k]);
         continue;
       }
       t.v[k] = static_cast<int>(v);
@@ -104,7 +107,8 @@ int image_alloc(rmd_hip_image* img, int kind, int width, int height) {
 int ingest_error_check(unsigned int* h_progress) {
   if (h_progress && h_progress[1] != 0u) {
     h_progress[1] = 0u;
-    return fail(RMD_HIP_ERR_RUNTIME, "seed update: the staging copy of a host frame did not complete within the kernel's bounded wait (about "
+    return fail(RMD_HIP_ERR_RUNTIME,
+        "seed update: the staging copy of a host frame did not complete within the kernel's bounded wait (about "
                                      "0.1 s); the seed state is invalid until the next setReferenceImage");
   }
   return RMD_HIP_OK;
@@ -180,7 +184,8 @@ int rmd_hip_version(void) { return RMD_HIP_VERSION_NUMBER; }
 int rmd_hip_set_tunable(int tunable, int value) {
   if (tunable < 0 || tunable >= RMD_HIP_NUM_TUNABLES) return fail(RMD_HIP_ERR_INVALID_ARG, "set_tunable: unknown tunable %d", tunable);
   if (value < tunable_lo[tunable] || value > tunable_hi[tunable])
-    return fail(RMD_HIP_ERR_INVALID_ARG, "set_tunable: value %d of tunable %d outside [%d, %d]", value, tunable, tunable_lo[tunable], tunable_hi[tunable]);
+    return fail(RMD_HIP_ERR_INVALID_ARG, "set_tunable: value %d of tunable %d outside [%d, %d]", value, tunable, tunable_lo[tunable],
+        tunable_hi[tunable]);
   tunables().v[tunable] = value;
   return RMD_HIP_OK;
 }
@@ -288,7 +293,8 @@ int rmd_hip_image_info(const rmd_hip_image_t* img, int* kind, int* width, int* h
 
 // ---- SeedMatrix -----------------------------------------------------------------------------
 int rmd_hip_seeds_destroy(rmd_hip_seeds_t* s) {
-  if (s && s->batch) return fail(RMD_HIP_ERR_INVALID_ARG, "seeds_destroy: this SeedMatrix belongs to a batch (rmd_hip_batch_destroy releases it)");
+  if (s && s->batch) return fail(RMD_HIP_ERR_INVALID_ARG,
+      "seeds_destroy: this SeedMatrix belongs to a batch (rmd_hip_batch_destroy releases it)");
   return seeds_destroy_impl(s);
 }
 }  // extern "C"
@@ -301,13 +307,17 @@ int rmdh::seeds_destroy_impl(rmd_hip_seeds* s) {
   if (s->copy_stream2) (void)hipStreamSynchronize(s->copy_stream2);
   publish_release(s);
   if (s->ingest_profile && s->ingest_us[3] > 0) {
-    fprintf(stderr, "[rmd_hip ingest] %.0f frames: wait for slot %.2f us, host copy %.2f us, submit %.2f us per frame; longest wait %.0f us, %lu waits gave up after 2 ms\n",
-            s->ingest_us[3], s->ingest_us[0] / s->ingest_us[3], s->ingest_us[1] / s->ingest_us[3], s->ingest_us[2] / s->ingest_us[3], g_progress_max_wait_us,
+    fprintf(stderr, "[rmd_hip ingest] %.0f frames: wait for slot %.2f us, host copy %.2f us, submit %.2f us per frame; "
+                    "longest wait %.0f us, %lu waits gave up after 2 ms\n",
+            s->ingest_us[3], s->ingest_us[0] / s->ingest_us[3], s->ingest_us[1] / s->ingest_us[3], s->ingest_us[2] / s->ingest_us[3],
+                g_progress_max_wait_us,
             g_progress_timeouts);
     if (s->h_progress)
-      fprintf(stderr, "[rmd_hip ingest] frames handed over <=0 / 1 / 2 / 3 / >=4 ahead of the newest setup kernel that had started: %lu / %lu / %lu / %lu / %lu; "
+      fprintf(stderr, "[rmd_hip ingest] frames handed over <=0 / 1 / 2 / 3 / >=4 ahead of the newest setup kernel that had started: "
+                      "%lu / %lu / %lu / %lu / %lu; "
                       "converted by their own setup kernel (not one step ahead) %u, of which the kernel waited for %u (%u polls)\n",
-              s->ingest_lead[0], s->ingest_lead[1], s->ingest_lead[2], s->ingest_lead[3], s->ingest_lead[4], s->h_progress[2], s->h_progress[3], s->h_progress[4]);
+              s->ingest_lead[0], s->ingest_lead[1], s->ingest_lead[2], s->ingest_lead[3], s->ingest_lead[4], s->h_progress[2],
+                  s->h_progress[3], s->h_progress[4]);
   }
   for (int k = 0; k < rmd_hip_seeds::RING_MAX; ++k) {
     if (s->h_zc_u8[k]) (void)hipHostFree(s->h_zc_u8[k]);
@@ -359,7 +369,8 @@ int rmd_hip_seeds_create(int width, int height, float fx, float fy, float cx, fl
 
 }  // extern "C"
 // batch != null: member `seq` of that batch -- the batch's streams and update workspace instead of its own
-int rmdh::seeds_create_impl(int width, int height, float fx, float fy, float cx, float cy, int patch_side, int max_extent, rmd_hip_batch* batch, int seq,
+int rmdh::seeds_create_impl(int width, int height, float fx, float fy, float cx, float cy, int patch_side, int max_extent,
+    rmd_hip_batch* batch, int seq,
                             rmd_hip_seeds** out) {
   if (!out) return fail(RMD_HIP_ERR_INVALID_ARG, "seeds_create: null output");
   *out = nullptr;
@@ -367,7 +378,8 @@ int rmdh::seeds_create_impl(int width, int height, float fx, float fy, float cx,
   if (!side_supported(patch_side))
     return fail(RMD_HIP_ERR_INVALID_ARG, "seeds_create: unsupported patch side %d (3, 5, 7, 9)", patch_side);
   if (max_extent <= 0 || max_extent > rmdk::MAX_EXTENT_LIMIT)
-    return fail(RMD_HIP_ERR_INVALID_ARG, "seeds_create: max_extent %d outside (0, %d] (a seed's search steps are numbered in 8 bits: 255 steps of 0.7 pixels)", max_extent,
+    return fail(RMD_HIP_ERR_INVALID_ARG,
+        "seeds_create: max_extent %d outside (0, %d] (a seed's search steps are numbered in 8 bits: 255 steps of 0.7 pixels)", max_extent,
                 rmdk::MAX_EXTENT_LIMIT);
   int ndev = 0;
   TRY(rmd_hip_device_count(&ndev));
@@ -394,7 +406,8 @@ int rmdh::seeds_create_impl(int width, int height, float fx, float fy, float cx,
   if (hipMalloc(reinterpret_cast<void**>(&s->d_scalars), 17 * sizeof(unsigned long long)) != hipSuccess ||
       hipHostMalloc(reinterpret_cast<void**>(&s->h_scalars), 17 * sizeof(unsigned long long)) != hipSuccess)
     return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: scalar buffers"));
-  if (hipMemset(s->d_scalars, 0, 17 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: scalar buffers"));
+  if (hipMemset(s->d_scalars, 0, 17 * sizeof(unsigned long long)) != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME,
+      "seeds_create: scalar buffers"));
   memset(s->h_scalars, 0, 17 * sizeof(unsigned long long));
   rmdk::SeedParams& P = s->P;
   memset(&P, 0, sizeof(P));
@@ -415,14 +428,18 @@ int rmdh::seeds_create_impl(int width, int height, float fx, float fy, float cx,
   P.cam = rmdk::Cam{fx, fy, cx, cy};
   P.one_pix_angle = atan2f(1.0f, 2.0f * fx) * 2.0f;  // pinhole_camera.cuh:56-59
   P.max_extent = static_cast<float>(max_extent);
-  if (!batch && s->matcher_ws.allocate(width, height, P.stride, 1, max_extent) != 0) return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: update workspace"));
-  if (batch && (grp->ws.stride != P.stride || grp->ws.tiles_x != (width + rmdk::TILE_W - 1) / rmdk::TILE_W || grp->ws.tiles_y != (height + rmdk::TILE_H - 1) / rmdk::TILE_H))
+  if (!batch && s->matcher_ws.allocate(width, height, P.stride, 1, max_extent) != 0) return bail(fail(RMD_HIP_ERR_RUNTIME,
+      "seeds_create: update workspace"));
+  if (batch && (grp->ws.stride != P.stride || grp->ws.tiles_x != (width + rmdk::TILE_W - 1) / rmdk::TILE_W
+      || grp->ws.tiles_y != (height + rmdk::TILE_H - 1) / rmdk::TILE_H))
     return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: the batch's workspace has another geometry"));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount > 0) s->num_cus = prop.multiProcessorCount;
   int lds = 0;
-  if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, s->device) == hipSuccess && lds > 0) s->mws->lds_bytes = lds;
-  if (hipDeviceSynchronize() != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: device synchronisation failed"));  // all fills done
+  if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor,
+      s->device) == hipSuccess && lds > 0) s->mws->lds_bytes = lds;
+  // all fills done
+  if (hipDeviceSynchronize() != hipSuccess) return bail(fail(RMD_HIP_ERR_RUNTIME, "seeds_create: device synchronisation failed"));
   // the copy stream is created right next to the compute stream.  A batch member's updates go through the BATCH's staging buffers and
   // progress words: it gets its own (the staging slots of set_reference*) lazily, at its first host reference frame (ingest_reference)
   if (!batch && ingest_init(s) != RMD_HIP_OK) return bail(RMD_HIP_ERR_RUNTIME);
@@ -445,7 +462,8 @@ int rmd_hip_seeds_set_reference_device(rmd_hip_seeds_t* s, const float* dev_img,
 
 int rmd_hip_seeds_update_device(rmd_hip_seeds_t* s, const float* dev_img, size_t stride_elems, const float* T_curr_world) {
   if (!s || !dev_img || !T_curr_world) return fail(RMD_HIP_ERR_INVALID_ARG, "update_device: null argument");
-  if (s->batch) return fail(RMD_HIP_ERR_INVALID_ARG, "update_device: this SeedMatrix is a member of a batch; its updates are issued with rmd_hip_batch_update*");
+  if (s->batch) return fail(RMD_HIP_ERR_INVALID_ARG,
+      "update_device: this SeedMatrix is a member of a batch; its updates are issued with rmd_hip_batch_update*");
   if (!s->has_reference) return fail(RMD_HIP_ERR_NOT_READY, "update_device: setReferenceImage has not been called");
   if (stride_elems < static_cast<size_t>(s->width)) return fail(RMD_HIP_ERR_INVALID_ARG, "update_device: stride < width");
   TRY(seeds_bind_device(s));
@@ -546,7 +564,8 @@ int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value) {
   // pairs, eager finalisation or unit targets: accepting such a setting and then ignoring it would leave last_stats / timing stale
   if (s->batch && ((option == RMD_HIP_OPT_COLLECT_STATS && value != 0) || (option == RMD_HIP_OPT_TIMING && value != 0) ||
                    (option == RMD_HIP_OPT_LAZY_FINALIZE && value == 0) || option == RMD_HIP_OPT_UNIT_TARGET))
-    return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: option %d has no effect on a member of a batch (rmd_hip_batch_set_option sets the batch's timing and unit "
+    return fail(RMD_HIP_ERR_INVALID_ARG,
+        "set_option: option %d has no effect on a member of a batch (rmd_hip_batch_set_option sets the batch's timing and unit "
                                          "target)", option);
   switch (option) {
     case RMD_HIP_OPT_MATCHER:
@@ -574,7 +593,8 @@ int rmd_hip_seeds_set_option(rmd_hip_seeds_t* s, int option, int value) {
       s->opt_lazy = value != 0;
       return RMD_HIP_OK;
     case RMD_HIP_OPT_INJECT_FAULT:
-      if (value != 0 && value != 1) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: fault %d (1 = withhold the arrival flag of the next staged host frame)", value);
+      if (value != 0 && value != 1) return fail(RMD_HIP_ERR_INVALID_ARG,
+          "set_option: fault %d (1 = withhold the arrival flag of the next staged host frame)", value);
       if (s->batch) return fail(RMD_HIP_ERR_INVALID_ARG, "set_option: fault injection is for plain SeedMatrix handles");
       s->inject_withhold_flag = value == 1;
       return RMD_HIP_OK;
@@ -656,7 +676,8 @@ int rmd_hip_seeds_trace_download(rmd_hip_seeds_t* s, int frame, unsigned long lo
     if (capacity < fn) return fail(RMD_HIP_ERR_INVALID_ARG, "trace_download: buffer too small (%zu words needed)", fn);
     TRY(seeds_bind_device(s));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    HIP_TRY(hipMemcpy(out, ws.d_wg_trace + static_cast<size_t>(frame % rmdk::FR_TRACE_FRAMES) * fn, fn * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, ws.d_wg_trace + static_cast<size_t>(frame % rmdk::FR_TRACE_FRAMES) * fn, fn * sizeof(unsigned long long),
+        hipMemcpyDeviceToHost));
     *written = fn;
     return RMD_HIP_OK;
   }

@@ -1,5 +1,6 @@
-// Host threads that copy (and examine) callers' frames into pinned staging buffers; shared by the frame sources of a SeedMatrix (rmd_ingest.hip), of a
-// batch (rmd_batch.hip) and the self test (rmd_reduce.hip).  One pool per process (the instance lives in an inline function).
+// Host threads that copy (and examine) callers' frames into pinned staging buffers; shared by the frame sources of a SeedMatrix
+// (rmd_ingest.hip), of a batch (rmd_batch.hip) and the self test (rmd_reduce.hip).  One pool per process (the instance lives in an inline
+// function).
 #ifndef RMD_COPY_POOL_HPP
 #define RMD_COPY_POOL_HPP
 
@@ -9,9 +10,9 @@
 // not the GPU, the bound of update(float*) -- the reference's own signature (seed_matrix.cu:120-128).  Frames of 256 KB and more are
 // split across a few persistent helper threads (created at the first such copy, parked on a condition variable in between).
 namespace rmdh {
-// Float frames whose every pixel is an 8-bit level -- what the reference's own host path produces: Depthmap::inputImage converts the
-// 8-bit camera image with convertTo(CV_32F, 1.0f / 255.0f) and hands the floats to SeedMatrix::update (depthmap.cpp:105, 75-77) -- travel to
-// the device as bytes: a quarter of the copy-engine time, which is what bounds float frames (1.2 MB at the engine's 23 GB/s take longer than
+// Float frames whose every pixel is an 8-bit level -- what the reference's own host path produces: Depthmap::inputImage converts the 8-bit
+// camera image with convertTo(CV_32F, 1.0f / 255.0f) and hands the floats to SeedMatrix::update (depthmap.cpp:105, 75-77) -- travel to the
+// device as bytes: a quarter of the copy-engine time, which is what bounds float frames (1.2 MB at the engine's 23 GB/s take longer than
 // the update).  The device multiplies by the same 1.0f / 255.0f, and a row is only accepted if that product has the caller's BIT PATTERN in
 // every pixel, so the current image is the caller's image bit for bit.  Rows [y0, y1) of a w-wide image; false at the first other pixel.
 #if defined(__HIP_DEVICE_COMPILE__) || !defined(__x86_64__)
@@ -61,9 +62,9 @@ class CopyPool {
     wait();
     segs_ = nullptr; n_segs_ = 0;
   }
-  // The same in two halves, so that the caller can do something else while the helpers copy (rmd_batch.hip queues a step's kernel launches in
-  // between): begin_copy_many wakes the helpers and returns; finish_copy_many copies the caller's share and waits for theirs.  `segs` must
-  // stay valid in between; every begin is followed by exactly one finish on the same thread (the pool is held in between).
+  // The same in two halves, so that the caller can do something else while the helpers copy (rmd_batch.hip queues a step's kernel launches
+  // in between): begin_copy_many wakes the helpers and returns; finish_copy_many copies the caller's share and waits for theirs.  `segs`
+  // must stay valid in between; every begin is followed by exactly one finish on the same thread (the pool is held in between).
   void begin_copy_many(const Segment* segs, int n, size_t bytes) {
     call_mutex_.lock();
     split_ = n_workers_ != 0 && n > 1 && bytes * static_cast<size_t>(n) >= kMinBytes;
@@ -82,7 +83,8 @@ class CopyPool {
   }
   // pack_float_rows_u8 over the rows of one frame, split over the participants; true if every row was accepted
   bool pack(const float* src, unsigned char* dst, int w, int h, int pitch) {
-    if (!pack_float_rows_u8(src, dst, w, pitch, h / 2, h / 2 + 1)) return false;  // an image of other floats is turned down before anybody is woken
+    // an image of other floats is turned down before anybody is woken
+    if (!pack_float_rows_u8(src, dst, w, pitch, h / 2, h / 2 + 1)) return false;
     if (n_workers_ == 0 || static_cast<size_t>(w) * h * sizeof(float) < kMinBytes) return pack_float_rows_u8(src, dst, w, pitch, 0, h);
     std::lock_guard<std::mutex> one_copy_at_a_time(call_mutex_);
     const int parts = n_workers_ + 1, rows = (h + parts - 1) / parts;
@@ -158,7 +160,8 @@ class CopyPool {
         if ((++spins & 63u) == 0u && host_now_us() - t0 > kPollUs) {
           std::unique_lock<std::mutex> lk(m_);
           __atomic_fetch_add(&parked_, 1, __ATOMIC_SEQ_CST);
-          cv_.wait(lk, [&] { return __atomic_load_n(&stop_, __ATOMIC_ACQUIRE) || __atomic_load_n(&generation_, __ATOMIC_SEQ_CST) != seen; });
+          cv_.wait(lk, [&] { return __atomic_load_n(&stop_, __ATOMIC_ACQUIRE) || __atomic_load_n(&generation_,
+              __ATOMIC_SEQ_CST) != seen; });
           __atomic_fetch_sub(&parked_, 1, __ATOMIC_SEQ_CST);
         }
       }
@@ -166,7 +169,8 @@ class CopyPool {
       seen = __atomic_load_n(&generation_, __ATOMIC_ACQUIRE);
       if (pack_src_) {
         const int y0 = index * pack_rows_, y1 = y0 + pack_rows_ < pack_h_ ? y0 + pack_rows_ : pack_h_;
-        if (y0 < y1 && !pack_float_rows_u8(pack_src_, pack_dst_, pack_w_, pack_pitch_, y0, y1)) __atomic_store_n(&pack_ok_, 0, __ATOMIC_RELAXED);
+        if (y0 < y1 && !pack_float_rows_u8(pack_src_, pack_dst_, pack_w_, pack_pitch_, y0, y1)) __atomic_store_n(&pack_ok_, 0,
+            __ATOMIC_RELAXED);
       } else if (segs_) {
         for (int i = index; i < n_segs_; i += n_workers_ + 1) memcpy(segs_[i].dst, segs_[i].src, bytes_);
       } else {

@@ -1,4 +1,5 @@
-// librmd_hip.so -- rmd::DepthmapDenoiser (depthmap_denoiser.cu:124-229): rmd_hip_denoiser_*, and the launch sequence shared with rmd_hip_batch_denoise.
+// librmd_hip.so -- rmd::DepthmapDenoiser (depthmap_denoiser.cu:124-229): rmd_hip_denoiser_*, and the launch sequence shared with
+// rmd_hip_batch_denoise.
 #include "rmd_host.hpp"
 #include "rmd_tv_kernels.hpp"
 
@@ -9,7 +10,8 @@ namespace rmdh {
 // tv_prepare + `iterations` primal-dual iterations of TvParams P for `n_z` depth maps (grid z; 1 = the single denoiser, P.members null) on
 // `stream`, ping-ponging between the two sets of iterate planes; *result_index = the set that holds the result.  ev0 (may be null) is
 // recorded between the preparation and the first iteration.
-int tv_run(const rmdk::TvParams& P, float* const u[2], float* const uh[2], float2* const p[2], int n_z, int iterations, int opt_iters_per_launch, int opt_geometry,
+int tv_run(const rmdk::TvParams& P, float* const u[2], float* const uh[2], float2* const p[2], int n_z, int iterations,
+    int opt_iters_per_launch, int opt_geometry,
            hipStream_t stream, hipEvent_t ev0, int* result_index, long* launches) {
   const unsigned int nz = static_cast<unsigned int>(n_z);
   {

@@ -1,7 +1,8 @@
 // Host side of librmd_hip.so shared by its translation units: the handle structs behind the opaque types of include/rmd_hip.h, error
 // plumbing, and the functions one unit needs from another.  Who owns what:
 //   rmd_capi.hip     library / device / rmd::DeviceImage / rmd::SeedMatrix entry points (everything but the frame sources), observers
-//   rmd_update.hip   the ONLY unit that instantiates the seed kernels: seed_init, the two-launch update pipeline for one sequence or a batch,
+//   rmd_update.hip   the ONLY unit that instantiates the seed kernels: seed_init, the two-launch update pipeline for one sequence or a
+//   batch,
 //                    the stand-alone finalisation, the per-pixel A/B baseline
 //   rmd_ingest.hip   frames handed over in host memory: pinned ring, staging copies and arrival flags, conversion one step ahead,
 //                    float frames that travel as bytes, lens-undistortion maps
@@ -180,7 +181,8 @@ struct rmd_hip_image {
 // update); a batch uses in place -- its setup kernels are long enough to hide the link time and the copy engine's 25-30 us of fixed
 // cost per copy is what bounds a step of 4..8 frames (8 sequences: 10 470 -> 12 740 Mpix/s).  Frames that go through the lens-
 // undistortion maps are always staged, without ahead (the remap gathers single bytes).  A/B: RMD_HIP_TUNE_HOST_FRAMES.
-enum { HOST_FRAMES_DEFAULT = -1, HOST_FRAMES_STAGED = 0, HOST_FRAMES_STAGED_AHEAD = 1, HOST_FRAMES_INPLACE = 2, HOST_FRAMES_INPLACE_AHEAD = 3 };
+enum { HOST_FRAMES_DEFAULT = -1, HOST_FRAMES_STAGED = 0, HOST_FRAMES_STAGED_AHEAD = 1, HOST_FRAMES_INPLACE = 2,
+    HOST_FRAMES_INPLACE_AHEAD = 3 };
 constexpr int AHEAD_WGS = 128;  // workgroups of the search kernel that bring the next frame in (MatcherArgs::ahead)
 
 // Process-wide settings of the host side (rmd_hip_set_tunable; include/rmd_hip.h lists them).  None changes results.  THE ONE PLACE where
@@ -248,8 +250,9 @@ struct rmd_hip_seeds {
   hipStream_t stream = nullptr;
   unsigned long long* d_scalars = nullptr;  // [0] count result, [1..16] diagnostics
   unsigned long long* h_scalars = nullptr;  // pinned mirror
-  // (unit target 2: a single sequence's search is a latency chain with a tail; units of half the size shorten the tail now that a unit's staging is cheap:
-  // 45.4 -> 44.3 us per update, profiles/r04_unit_target.txt; a batch keeps 1, its tails are filled by the other stream groups)
+  // (unit target 2: a single sequence's search is a latency chain with a tail; units of half the size shorten the tail now that a unit's
+  // staging is cheap: 45.4 -> 44.3 us per update, profiles/r04_unit_target.txt; a batch keeps 1, its tails are filled by the other stream
+  // groups)
   int opt_matcher = 3, opt_timing = 0, opt_stats = 0, opt_unit_target = 2;
   // a SeedMatrix that is a member of a batch (rmd_hip_batch_*) shares the batch's streams and update workspace: its update
   // kernels are launched by the batch, for all members at once; everything else (reference frames, observers) works per member
@@ -277,21 +280,20 @@ struct rmd_hip_seeds {
   hipStream_t copy_stream = nullptr;        // frame uploads and conversions run here, beside the previous frames' kernels
   // A second copy stream: consecutive host frames of the fused path alternate between the two, so that two copy engines work on them.  One
   // engine needs ~6 us per command beyond the transfer itself and every frame is two commands (the frame, its arrival flag): 22 us for a
-  // 640x480 8-bit frame, 58 us for a 1920x1080 one -- as long as the light updates of those sizes take (21 / 60 us), so that on the light two
-  // thirds of a sequence every second or third setup kernel waited for its frame (RMD_HIP_INGEST_PROFILE: "the kernel waited for").
+  // 640x480 8-bit frame, 58 us for a 1920x1080 one -- as long as the light updates of those sizes take (21 / 60 us), so that on the light
+  // two thirds of a sequence every second or third setup kernel waited for its frame (RMD_HIP_INGEST_PROFILE: "the kernel waited for").
   hipStream_t copy_stream2 = nullptr;
   void* cur_planes[SLOTS] = {};             // current-image planes (pitch of planes[CURR_IMG]), used in rotation; [0] is the handle's own
   int u8_pitch = 0, ingest_slot = 0;
-  // fused ingest (tile pipeline): the caller's frame is copied into one of SLOTS pinned buffers, a copy engine moves it to a staging
-  // buffer in HBM and then writes the frame's number next to it (copy stream); the setup kernel waits for that number itself,
-  // converts the frame into the current-image plane and tells the host through `h_progress` which frames it has consumed.
-  // No events, no cross-stream waits: neither queue ever holds a barrier packet for the other.
-  // RING slots: the caller may be RING - 1 frames ahead of the setup kernel that has started last.  With three, frame n was handed over
-  // when setup n - 2 started and reached HBM 55-60 us later (host copy, submission, 35-45 us of copy engine) -- after setup n - 1 had
-  // looked for it, so it was rarely converted one step ahead (rmdk::MatcherArgs::ahead); with four it always is.
-  // Round 6: the depth is a run-time value (RMD_HIP_TUNE_RING_DEPTH; default 6).  At 1920x1080 a light update takes 60 us and a frame needs
-  // 130 us from the moment its slot is free to its arrival in HBM (the caller's wake-up, 2 MB into the pinned slot, two submissions, 50 us of
-  // copy engine): with four slots every fourth frame missed its step-ahead conversion.
+  // fused ingest (tile pipeline): the caller's frame is copied into one of SLOTS pinned buffers, a copy engine moves it to a staging buffer
+  // in HBM and then writes the frame's number next to it (copy stream); the setup kernel waits for that number itself, converts the frame
+  // into the current-image plane and tells the host through `h_progress` which frames it has consumed. No events, no cross-stream waits:
+  // neither queue ever holds a barrier packet for the other. RING slots: the caller may be RING - 1 frames ahead of the setup kernel that
+  // has started last.  With three, frame n was handed over when setup n - 2 started and reached HBM 55-60 us later (host copy, submission,
+  // 35-45 us of copy engine) -- after setup n - 1 had looked for it, so it was rarely converted one step ahead (rmdk::MatcherArgs::ahead);
+  // with four it always is. Round 6: the depth is a run-time value (RMD_HIP_TUNE_RING_DEPTH; default 6).  At 1920x1080 a light update takes
+  // 60 us and a frame needs 130 us from the moment its slot is free to its arrival in HBM (the caller's wake-up, 2 MB into the pinned slot,
+  // two submissions, 50 us of copy engine): with four slots every fourth frame missed its step-ahead conversion.
   static constexpr int RING_MAX = 8;
   int ring = 6;
   unsigned char* h_zc_u8[RING_MAX] = {};
@@ -299,17 +301,24 @@ struct rmd_hip_seeds {
   unsigned char* d_zc_u8[RING_MAX] = {};
   float* d_zc_f32[RING_MAX] = {};
   unsigned int* h_seq = nullptr;            // pinned, one block per slot: the frame number the copy stream writes into d_zc_flag
-  unsigned int* d_zc_flag = nullptr;        // device, one block per ring slot: number of the last frame whose copy into that slot's staging buffer has completed
-  unsigned int* h_submitted = nullptr;      // pinned, [kind * RING + slot]: number of the newest 8-bit (kind 0) / float (kind 1) frame that is complete in that ring slot (frames read in place, one step ahead)
+  // device, one block per ring slot: number of the last frame whose copy into that slot's staging buffer has completed
+  unsigned int* d_zc_flag = nullptr;
+  // pinned, [kind * RING + slot]: number of the newest 8-bit (kind 0) / float (kind 1) frame that is complete in that ring slot (frames
+  // read in place, one step ahead)
+  unsigned int* h_submitted = nullptr;
   unsigned int* d_ahead = nullptr;          // device: the words of rmdk::MatcherArgs::ahead
-  int pack_backoff = 0, pack_backoff_len = 15;  // float frames that are not 8-bit levels: the next pack_backoff_len frames are not examined (pack_float_rows_u8)
+  // float frames that are not 8-bit levels: the next pack_backoff_len frames are not examined (pack_float_rows_u8)
+  int pack_backoff = 0, pack_backoff_len = 15;
   unsigned int* h_progress = nullptr;       // pinned: [0] number of the ingested frame whose setup kernel has started, [1] error bits
   unsigned long long zc_number = 0;         // ingested frames so far (the device sees the low 32 bits and compares modulo 2^32)
   int opt_fused_ingest = 1;                 // RMD_HIP_TUNE_FUSED_INGEST = 0 switches back to the copy-stream pipeline (A/B)
   bool ingest_ready = false;                // ingest_init has run
-  bool inject_withhold_flag = false;        // test hook (RMD_HIP_OPT_INJECT_FAULT): the arrival flag of the next staged host frame is not sent
+  // test hook (RMD_HIP_OPT_INJECT_FAULT): the arrival flag of the next staged host frame is not sent
+  bool inject_withhold_flag = false;
   double ingest_us[4] = {0, 0, 0, 0};  // diagnostics (RMD_HIP_INGEST_PROFILE): host time waiting for a slot, copying, submitting; frames
-  unsigned long ingest_lead[5] = {0, 0, 0, 0, 0};  // ... and how many frames the caller was ahead of the newest setup kernel that had started when it handed a frame over (<= 0, 1, 2, 3, >= 4)
+  // ... and how many frames the caller was ahead of the newest setup kernel that had started when it handed a frame over (<= 0, 1, 2, 3, >=
+  // 4)
+  unsigned long ingest_lead[5] = {0, 0, 0, 0, 0};
   bool ingest_profile = false;
   rmdh::StageTimer timers[RMD_HIP_NUM_SEED_STAGES];
   long long last_stats[16] = {0};
@@ -324,9 +333,9 @@ struct rmd_hip_seeds {
   unsigned int* d_pc_counts = nullptr;  // point cloud (allocated at the first request): per-block counts / offsets, [n_blocks] = total
   float4* h_pc_points = nullptr;        // pinned + mapped, W x H points: the point-cloud kernel writes here over the host link
   unsigned int* h_pc_total = nullptr;   // pinned + mapped: their number
-  // Publication off the update stream (rmd_hip_seeds_publish_async, rmd_publish.hip), everything allocated at the first request.  One slot per
-  // publication in flight: the snapshot of the state it publishes and its products in pinned host memory; the TV-L1 workspace and the point
-  // cloud's counters are shared -- the publications run one after the other on pub_stream.
+  // Publication off the update stream (rmd_hip_seeds_publish_async, rmd_publish.hip), everything allocated at the first request.  One slot
+  // per publication in flight: the snapshot of the state it publishes and its products in pinned host memory; the TV-L1 workspace and the
+  // point cloud's counters are shared -- the publications run one after the other on pub_stream.
   struct Publication {
     rmd_hip_image mu, sigma_sq, a, b, conv, ref;  // snapshot (written by the update stream, read by pub_stream)
     rmdk::Pose T_world_ref;
@@ -380,7 +389,8 @@ struct rmd_hip_batch {
   // frames handed over in host memory: the frames of one step, back to back, through SLOTS pinned buffers and SLOTS staging buffers
   // (see ingest_current_fused: the same protocol, one sequence number per step)
   static constexpr int SLOTS_MAX = 8;
-  int slots = 5;                            // steps in flight between the caller and the setup kernels (RMD_HIP_TUNE_RING_DEPTH; 3 until round 5)
+  // steps in flight between the caller and the setup kernels (RMD_HIP_TUNE_RING_DEPTH; 3 until round 5)
+  int slots = 5;
   unsigned char* h_stage[SLOTS_MAX] = {};
   unsigned char* d_stage[SLOTS_MAX] = {};
   size_t stage_bytes = 0;                   // capacity of each of the buffers above
@@ -389,9 +399,11 @@ struct rmd_hip_batch {
   unsigned long long step_number = 0;
   int opt_timing = 0, opt_unit_target = 1;
   int pack_backoff = 0;
-  bool ingest_profile = false;              // diagnostics (RMD_HIP_INGEST_PROFILE), as for a single SeedMatrix: host time per step waiting for a slot, copying, submitting; steps
+  // diagnostics (RMD_HIP_INGEST_PROFILE), as for a single SeedMatrix: host time per step waiting for a slot, copying, submitting; steps
+  bool ingest_profile = false;
   double ingest_us[4] = {0, 0, 0, 0};
-  unsigned long ingest_lead[5] = {0, 0, 0, 0, 0};  // steps handed over <= 0, 1, 2, 3, >= 4 ahead of the newest setup kernel of the first group that had started
+  // steps handed over <= 0, 1, 2, 3, >= 4 ahead of the newest setup kernel of the first group that had started
+  unsigned long ingest_lead[5] = {0, 0, 0, 0, 0};
   hipEvent_t region_start = nullptr, region_stop = nullptr;
   long region_updates = 0;
   // TV-L1 for all members in one launch sequence (rmd_hip_batch_denoise), allocated at the first request: the denoiser's planes hold the
@@ -426,7 +438,8 @@ struct rmd_hip_denoiser {
   float* h_staging = nullptr;  // pinned, W x H: device -> pinned (async DMA) -> caller's pageable buffer
   int opt_timing = 0, opt_iters_per_launch = 0, opt_geometry = 0;
   rmdh::StageTimer timer;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;  // around the iteration loop when opt_timing is set; created at first use, destroyed with the handle
+  // around the iteration loop when opt_timing is set; created at first use, destroyed with the handle
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
 namespace rmdh {
@@ -460,13 +473,15 @@ inline void cpu_relax() {  // a polite spin, whatever the host architecture
 // rmd_capi.hip
 int image_settle(const rmd_hip_image* img);  // wait until the owner of an image (if any) has settled it
 int image_alloc(rmd_hip_image* img, int kind, int width, int height);
-int seeds_sync(const rmd_hip_seeds* s);      // every observer of the seed state goes through here: settle deferred work, then wait for the stream
+// every observer of the seed state goes through here: settle deferred work, then wait for the stream
+int seeds_sync(const rmd_hip_seeds* s);
 int seeds_bind_device(const rmd_hip_seeds* s);
 int ingest_error_check(unsigned int* h_progress);
 int seeds_after_reference(rmd_hip_seeds* s, const float* T_curr_world, float min_depth, float max_depth);
 void seeds_frame_pose(rmd_hip_seeds* s, const float* T_curr_world);
 int seeds_after_frame(rmd_hip_seeds* s, const float* T_curr_world, const PendingIngest* ingest = nullptr);
-int seeds_create_impl(int width, int height, float fx, float fy, float cx, float cy, int patch_side, int max_extent, rmd_hip_batch* batch, int seq, rmd_hip_seeds** out);
+int seeds_create_impl(int width, int height, float fx, float fy, float cx, float cy, int patch_side, int max_extent, rmd_hip_batch* batch,
+    int seq, rmd_hip_seeds** out);
 int seeds_destroy_impl(rmd_hip_seeds* s);
 // rmd_update.hip
 int seeds_flush(rmd_hip_seeds* s);           // the deferred finalisation of this handle's last update, as a kernel of its own
@@ -476,16 +491,19 @@ int batch_launch(rmd_hip_batch* b, unsigned int active, const rmdk::IngestArgs* 
 // rmd_ingest.hip
 int ingest_init(rmd_hip_seeds* s);
 int ingest_current(rmd_hip_seeds* s, const unsigned char* host_gray, const float* host_f32, const float* T_curr_world);
-int ingest_reference(rmd_hip_seeds* s, const unsigned char* host_gray, const float* host_f32, const float* T_curr_world, float min_depth, float max_depth);
+int ingest_reference(rmd_hip_seeds* s, const unsigned char* host_gray, const float* host_f32, const float* T_curr_world, float min_depth,
+    float max_depth);
 int wait_for_progress(volatile unsigned int* progress, unsigned int need, hipStream_t stream);
 // rmd_batch.hip
 int batch_bind_device(const rmd_hip_batch* b);
 // rmd_publish.hip
-void publish_release(rmd_hip_seeds* s);      // waits for the publications in flight and releases everything rmd_hip_seeds_publish_async allocated
+// waits for the publications in flight and releases everything rmd_hip_seeds_publish_async allocated
+void publish_release(rmd_hip_seeds* s);
 // rmd_reduce.hip
 void launch_count_eq(const int* img, int w, int h, int stride, int value, unsigned long long* out_dev, hipStream_t stream);
 // rmd_denoise.hip
-int tv_run(const rmdk::TvParams& P, float* const u[2], float* const uh[2], float2* const p[2], int n_z, int iterations, int opt_iters_per_launch, int opt_geometry,
+int tv_run(const rmdk::TvParams& P, float* const u[2], float* const uh[2], float2* const p[2], int n_z, int iterations,
+    int opt_iters_per_launch, int opt_geometry,
            hipStream_t stream, hipEvent_t ev0, int* result_index, long* launches);
 
 }  // namespace rmdh

@@ -1,5 +1,6 @@
-// librmd_hip.so -- frames handed over in host memory (SeedMatrix::setReferenceImage / update with host pointers, seed_matrix.cu:87-158; Depthmap::inputImage,
-// depthmap.cpp:95-106): pinned ring, staging copies and arrival flags, conversion one step ahead, lens-undistortion maps.
+// librmd_hip.so -- frames handed over in host memory (SeedMatrix::setReferenceImage / update with host pointers, seed_matrix.cu:87-158;
+// Depthmap::inputImage, depthmap.cpp:95-106): pinned ring, staging copies and arrival flags, conversion one step ahead, lens-undistortion
+// maps.
 #include "rmd_host.hpp"
 #include "rmd_copy_pool.hpp"
 
@@ -12,7 +13,8 @@ namespace rmdk {  // (kernels of this unit only: each kernel of the library has 
 // Frame ingest (reference: Depthmap::inputImage, src/depthmap.cpp:95-106 -- cv::Mat::convertTo(CV_32F, 1.0f/255.0f) on the
 // host): 8-bit gray -> f32 plane on the device.  One fp32 multiply per pixel, identical bits to the host conversion.
 // 4 pixels per lane: one 32-bit load, one 128-bit store.
-static __global__ __launch_bounds__(256) void ingest_u8_kernel(const unsigned char* __restrict__ src, int src_pitch, float* __restrict__ dst,
+static __global__ __launch_bounds__(256) void ingest_u8_kernel(const unsigned char* __restrict__ src, int src_pitch,
+    float* __restrict__ dst,
                                                         int dst_stride, int w, int h) {
   const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const int y = blockIdx.y * blockDim.y + threadIdx.y;
@@ -41,7 +43,8 @@ static __global__ __launch_bounds__(256) void ingest_u8_remap_kernel(const unsig
   if (x >= w || y >= h) return;
   const short2 m = map1[static_cast<size_t>(y) * w + x];
   const int f = map2[static_cast<size_t>(y) * w + x] & 1023;
-  dst[static_cast<size_t>(y) * dst_stride + x] = remap_u8_pixel(src, src_pitch, m, f, w, h, [](const unsigned char* p) { return static_cast<int>(*p); });
+  dst[static_cast<size_t>(y) * dst_stride + x] = remap_u8_pixel(src, src_pitch, m, f, w, h, [](const unsigned char* p) {
+      return static_cast<int>(*p); });
 }
 
 }  // namespace rmdk
@@ -79,7 +82,8 @@ int ingest_init(rmd_hip_seeds* s) {
     const int depth = T.v[RMD_HIP_TUNE_RING_DEPTH];
     if (depth > 0) s->ring = depth < 3 ? 3 : depth;  // (three: the caller's slot, the copy engine's, the one the kernels read)
   }
-  if (s->batch) {  // a member only ever stages REFERENCE frames (ingest_frame: pinned slot -> plane on the copy stream): events, nothing else
+  // a member only ever stages REFERENCE frames (ingest_frame: pinned slot -> plane on the copy stream): events, nothing else
+  if (s->batch) {
     s->cur_planes[0] = s->planes[RMD_HIP_PLANE_CURR_IMG].data;
     s->u8_pitch = (s->width + 3) / 4 * 4;
     for (int k = 0; k < rmd_hip_seeds::SLOTS; ++k) {
@@ -92,8 +96,10 @@ int ingest_init(rmd_hip_seeds* s) {
   }
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_progress), 64, hipHostMallocMapped));
   for (int q = 0; q < 16; ++q) s->h_progress[q] = 0u;
-  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_seq), rmd_hip_seeds::RING_MAX * FLAG_SLOT_WORDS * sizeof(unsigned int), hipHostMallocDefault));
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_flag), 2 * rmd_hip_seeds::RING_MAX * FLAG_ALLOC_BYTES));  // one flag block per ring slot and kind of frame
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_seq), rmd_hip_seeds::RING_MAX * FLAG_SLOT_WORDS * sizeof(unsigned int),
+      hipHostMallocDefault));
+  // one flag block per ring slot and kind of frame
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_zc_flag), 2 * rmd_hip_seeds::RING_MAX * FLAG_ALLOC_BYTES));
   HIP_TRY(hipMemset(s->d_zc_flag, 0, 2 * rmd_hip_seeds::RING_MAX * FLAG_ALLOC_BYTES));
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_submitted), 64, hipHostMallocMapped));
   static_assert(2 * rmd_hip_seeds::RING_MAX * sizeof(unsigned int) <= 64, "h_submitted");
@@ -121,7 +127,8 @@ int ingest_init(rmd_hip_seeds* s) {
   return RMD_HIP_OK;
 }
 
-static int ingest_frame(rmd_hip_seeds* s, const unsigned char* host_gray, const float* host_f32, void* dst, size_t dst_pitch, bool dst_is_ref, int k) {
+static int ingest_frame(rmd_hip_seeds* s, const unsigned char* host_gray, const float* host_f32, void* dst, size_t dst_pitch,
+    bool dst_is_ref, int k) {
   const double t_a = s->ingest_profile ? host_now_us() : 0.0;
   HIP_TRY(hipEventSynchronize(s->staged[k]));  // the upload that last used this slot's staging buffers has run
   const double t_b = s->ingest_profile ? host_now_us() : 0.0;
@@ -150,11 +157,13 @@ static int ingest_frame(rmd_hip_seeds* s, const unsigned char* host_gray, const 
     const int dst_stride = static_cast<int>(dst_pitch / 4);
     if (s->d_undist_map1) {
       const dim3 block(64, 4), grid((s->width + 63) / 64, (s->height + 3) / 4);
-      hipLaunchKernelGGL(rmdk::ingest_u8_remap_kernel, grid, block, 0, s->copy_stream, s->d_u8[k], s->u8_pitch, s->d_undist_map1, s->d_undist_map2,
+      hipLaunchKernelGGL(rmdk::ingest_u8_remap_kernel, grid, block, 0, s->copy_stream, s->d_u8[k], s->u8_pitch, s->d_undist_map1,
+          s->d_undist_map2,
                          static_cast<float*>(dst), dst_stride, s->width, s->height);
     } else {
       const dim3 block(64, 4), grid((s->width + 255) / 256, (s->height + 3) / 4);
-      hipLaunchKernelGGL(rmdk::ingest_u8_kernel, grid, block, 0, s->copy_stream, s->d_u8[k], s->u8_pitch, static_cast<float*>(dst), dst_stride,
+      hipLaunchKernelGGL(rmdk::ingest_u8_kernel, grid, block, 0, s->copy_stream, s->d_u8[k], s->u8_pitch, static_cast<float*>(dst),
+          dst_stride,
                          s->width, s->height);
     }
     HIP_TRY(hipGetLastError());
@@ -173,16 +182,15 @@ static int ingest_frame(rmd_hip_seeds* s, const unsigned char* host_gray, const 
   return RMD_HIP_OK;
 }
 
-// a host frame becomes the current image: stage it into the plane that is NOT being read by the update in flight
-// The fused path: frame n goes through pinned buffer and staging buffer n % SLOTS, last read by the copy engine / the setup kernel of
-// frame n - SLOTS.  That kernel has completed once the setup kernel of frame n - SLOTS + 1 has STARTED (same stream), which is
-// what h_progress reports.
-// Wait (on the host, without touching the device) until the setup kernel of step `need` has started, as reported through the pinned word
-// `progress`: the staging buffers of SLOTS steps ago are free then.  Numbers are compared modulo 2^32 like the kernel's test.
-// The word is written by the DEVICE (a store of the setup kernel into pinned memory): there is nothing a futex or a condition variable could
-// be woken by.  So: a polite spin for the first 2 us (the usual wait when the host is barely ahead), then short sleeps -- the caller is up
-// to three frames (>= 100 us of device work) ahead of the kernel it waits for, an overslept wake-up of a few microseconds stalls nothing, and a
-// rank's host thread no longer burns a whole core while the device works (eight ranks share the 16 CPUs of the measurement box's quota:
+// a host frame becomes the current image: stage it into the plane that is NOT being read by the update in flight The fused path: frame n
+// goes through pinned buffer and staging buffer n % SLOTS, last read by the copy engine / the setup kernel of frame n - SLOTS.  That kernel
+// has completed once the setup kernel of frame n - SLOTS + 1 has STARTED (same stream), which is what h_progress reports. Wait (on the
+// host, without touching the device) until the setup kernel of step `need` has started, as reported through the pinned word `progress`: the
+// staging buffers of SLOTS steps ago are free then.  Numbers are compared modulo 2^32 like the kernel's test. The word is written by the
+// DEVICE (a store of the setup kernel into pinned memory): there is nothing a futex or a condition variable could be woken by.  So: a
+// polite spin for the first 2 us (the usual wait when the host is barely ahead), then short sleeps -- the caller is up to three frames (>=
+// 100 us of device work) ahead of the kernel it waits for, an overslept wake-up of a few microseconds stalls nothing, and a rank's host
+// thread no longer burns a whole core while the device works (eight ranks share the 16 CPUs of the measurement box's quota:
 // profiles/r05_nranks/).  Linux rounds a sleep up by the thread's timer slack (50 us by default): the slack is 2 us WHILE THIS FUNCTION
 // SLEEPS and the caller's own value again when it returns (a library does not leave a scheduling attribute of the application's thread
 // changed -- threads created later would inherit it); if the slack cannot be read or set the wait goes on with the caller's slack, in
@@ -198,7 +206,8 @@ int wait_for_progress(volatile unsigned int* progress, unsigned int need, hipStr
       const double waited = host_now_us() - t0;
       if (waited > 2000.0) {  // far behind (or another matcher ran the frames in between): an idle stream has read everything
         ++g_progress_timeouts;
-        if (hipStreamSynchronize(stream) != hipSuccess) rc = fail(RMD_HIP_ERR_RUNTIME, "waiting for a free slot of the frame ring: hipStreamSynchronize failed");
+        if (hipStreamSynchronize(stream) != hipSuccess) rc = fail(RMD_HIP_ERR_RUNTIME,
+            "waiting for a free slot of the frame ring: hipStreamSynchronize failed");
         break;
       }
       if (may_sleep && waited > 2.0) {
@@ -229,15 +238,18 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
   const int k = static_cast<int>(n64 % ring);
   if (n64 > static_cast<unsigned long long>(ring)) TRY(wait_for_progress(s->h_progress, n - ring + 1u, s->stream));
   const double t_b = s->ingest_profile ? host_now_us() : 0.0;
-  if (s->ingest_profile) {  // how far ahead of the device is the caller?  frame n is handed over while setup `started` is the newest that has begun
+  // how far ahead of the device is the caller?  frame n is handed over while setup `started` is the newest that has begun
+  if (s->ingest_profile) {
     const int lead = static_cast<int>(n - *static_cast<volatile unsigned int*>(s->h_progress));
     ++s->ingest_lead[lead < 0 ? 0 : lead > 4 ? 4 : lead];
   }
   PendingIngest in;
   bool in_place = false;
   // every ring slot has its own arrival flag, one per kind of frame (8-bit / float: they use different staging buffers): the setup kernel
-  // of frame n asks for frame n's; its verdict for frame n + 1 reads the flag of that slot for ITS kind, which a frame of the other kind never sets
-  auto flag_of = [&](int kind, int slot) { return s->d_zc_flag + (static_cast<size_t>(kind) * rmd_hip_seeds::RING_MAX + slot) * (FLAG_ALLOC_BYTES / sizeof(unsigned int)); };
+  // of frame n asks for frame n's; its verdict for frame n + 1 reads the flag of that slot for ITS kind, which a frame of the other kind
+  // never sets
+  auto flag_of = [&](int kind, int slot) {
+      return s->d_zc_flag + (static_cast<size_t>(kind) * rmd_hip_seeds::RING_MAX + slot) * (FLAG_ALLOC_BYTES / sizeof(unsigned int)); };
   void* stage_src = nullptr; void* stage_dst = nullptr; size_t stage_bytes = 0;
   auto ensure_u8_ring = [&]() -> int {
     const size_t bytes = static_cast<size_t>(s->u8_pitch) * s->height;
@@ -307,9 +319,11 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
     hipStream_t cs = (s->copy_stream2 && (n64 & 1ull)) ? s->copy_stream2 : s->copy_stream;
     HIP_TRY(hipMemcpyAsync(stage_dst, stage_src, stage_bytes, hipMemcpyHostToDevice, cs));
     const size_t fw = flag_words(s->h_progress, n);
-    fill_flag_block(s->h_seq + k * FLAG_SLOT_WORDS, n, fw);  // behind the frame on the same stream: when the kernel sees n, the frame is in HBM
+    // behind the frame on the same stream: when the kernel sees n, the frame is in HBM
+    fill_flag_block(s->h_seq + k * FLAG_SLOT_WORDS, n, fw);
     unsigned int* slot_flag = flag_of(as_u8 ? 0 : 1, k);
-    if (s->inject_withhold_flag) s->inject_withhold_flag = false;  // fault injection: the frame arrives, its flag never does -> the kernel's bounded wait runs out
+    // fault injection: the frame arrives, its flag never does -> the kernel's bounded wait runs out
+    if (s->inject_withhold_flag) s->inject_withhold_flag = false;
     else HIP_TRY(hipMemcpyAsync(slot_flag, s->h_seq + k * FLAG_SLOT_WORDS, fw * sizeof(unsigned int), hipMemcpyHostToDevice, cs));
     in.common.flag = slot_flag;
   }
@@ -318,8 +332,8 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
     const int kind = as_u8 ? 0 : 1, k_next = static_cast<int>((n64 + 1) % ring);
     void* dev = nullptr;
     if (in_place) {
-      // frame n is complete in ITS slot, for ITS kind: the verdict of setup n - 1 read this very word, and setup n's verdict for frame n + 1
-      // reads the word of slot k_next for this kind -- which a frame of the other kind, or a frame two steps ahead, never sets (one word
+      // frame n is complete in ITS slot, for ITS kind: the verdict of setup n - 1 read this very word, and setup n's verdict for frame n +
+      // 1 reads the word of slot k_next for this kind -- which a frame of the other kind, or a frame two steps ahead, never sets (one word
       // per kind for the whole ring let setup n take "frame n + 2 of this kind is there" for "frame n + 1 is", and convert stale bytes)
       __atomic_store_n(&s->h_submitted[kind * rmd_hip_seeds::RING_MAX + k], n, __ATOMIC_RELEASE);
       HIP_TRY(hipHostGetDevicePointer(&dev, s->h_submitted, 0));
@@ -397,7 +411,8 @@ int rmd_hip_seeds_set_reference(rmd_hip_seeds_t* s, const float* host_img, const
 
 int rmd_hip_seeds_update(rmd_hip_seeds_t* s, const float* host_img, const float* T_curr_world) {
   if (!s || !host_img || !T_curr_world) return fail(RMD_HIP_ERR_INVALID_ARG, "update: null argument");
-  if (s->batch) return fail(RMD_HIP_ERR_INVALID_ARG, "update: this SeedMatrix is a member of a batch; its updates are issued with rmd_hip_batch_update*");
+  if (s->batch) return fail(RMD_HIP_ERR_INVALID_ARG,
+      "update: this SeedMatrix is a member of a batch; its updates are issued with rmd_hip_batch_update*");
   if (!s->has_reference) return fail(RMD_HIP_ERR_NOT_READY, "update: setReferenceImage has not been called");
   TRY(seeds_bind_device(s));
   // the frame is copied into pinned memory here (the caller's buffer is free on return, as after the reference's blocking
@@ -414,7 +429,8 @@ int rmd_hip_seeds_set_reference_u8(rmd_hip_seeds_t* s, const unsigned char* host
 
 int rmd_hip_seeds_update_u8(rmd_hip_seeds_t* s, const unsigned char* host_gray, const float* T_curr_world) {
   if (!s || !host_gray || !T_curr_world) return fail(RMD_HIP_ERR_INVALID_ARG, "update_u8: null argument");
-  if (s->batch) return fail(RMD_HIP_ERR_INVALID_ARG, "update_u8: this SeedMatrix is a member of a batch; its updates are issued with rmd_hip_batch_update*");
+  if (s->batch) return fail(RMD_HIP_ERR_INVALID_ARG,
+      "update_u8: this SeedMatrix is a member of a batch; its updates are issued with rmd_hip_batch_update*");
   if (!s->has_reference) return fail(RMD_HIP_ERR_NOT_READY, "update_u8: setReferenceImage has not been called");
   TRY(seeds_bind_device(s));
   return ingest_current(s, host_gray, nullptr, T_curr_world);

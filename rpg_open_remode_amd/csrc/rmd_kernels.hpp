@@ -136,7 +136,8 @@ RMDK_D Segment epipolar_segment(const SeedParams& P, int x, int y, float mu, flo
 // Returns 0: nothing changes, 1: (mu, sigma_sq, a, b) have been replaced by the posterior, 2: only b has changed (NO_MATCH).
 // T_ref_curr: the pose of the frame the match was found in (P.T_ref_curr, or the previous frame's when that frame's finalisation runs
 // fused into the next frame's setup kernel).
-RMDK_D int seed_fuse_values(const SeedParams& P, const Pose& T_ref_curr, int x, int y, int state, float& mu, float& sigma_sq, float& a, float& b, F2 match) {
+RMDK_D int seed_fuse_values(const SeedParams& P, const Pose& T_ref_curr, int x, int y, int state, float& mu, float& sigma_sq, float& a,
+    float& b, F2 match) {
   if (state == ST_UPDATE) {
     const F3 f_ref = normalize3(cam2world(P.cam, static_cast<float>(x), static_cast<float>(y)));
     const F3 f_epi = normalize3(cam2world(P.cam, match.x, match.y));

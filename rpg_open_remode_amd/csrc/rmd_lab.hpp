@@ -7,7 +7,8 @@
 #ifndef RMD_LAB_HPP
 #define RMD_LAB_HPP
 
-// A/B of the round-5 sheared window (tools/ab_make.sh noshear "-DRMD_LAB_NO_SHEAR"): no tile ever asks for a band, i.e. all windows are boxes
+// A/B of the round-5 sheared window (tools/ab_make.sh noshear "-DRMD_LAB_NO_SHEAR"): no tile ever asks for a band, i.e. all windows are
+// boxes
 #ifdef RMD_LAB_NO_SHEAR
 #define LAB_WANT_BAND(flag) false
 #else

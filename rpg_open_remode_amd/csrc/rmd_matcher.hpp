@@ -31,19 +31,24 @@ constexpr int TILE_W = 16, TILE_H = 16, TILE_PIX = TILE_W * TILE_H;
 constexpr int MAX_UNIT_ROUNDS = 4;  // a work unit is 1..4 rounds of the 256 lanes (chosen per frame from the previous frame's work)
 constexpr int MIN_UNIT_ITEMS = TILE_PIX;
 // Search steps of one seed: l = -half; l <= half; l += 0.7f with half <= max_extent / 2 (epipolar_match.cu:75,88), i.e. at most
-// floor(max_extent / 0.7) + 1.  Step numbers and counts live in 8-bit fields (the search kernel's descriptors, FrameSmem::packed): 255 steps,
-// i.e. max_extent <= 178 -- the reference's RMD_MAX_EXTENT_EPIPOLAR_SEARCH is an unbounded compile-time constant with default 100
+// floor(max_extent / 0.7) + 1.  Step numbers and counts live in 8-bit fields (the search kernel's descriptors, FrameSmem::packed): 255
+// steps, i.e. max_extent <= 178 -- the reference's RMD_MAX_EXTENT_EPIPOLAR_SEARCH is an unbounded compile-time constant with default 100
 // (CMakeLists.txt:52-53); beyond 178 the fields would have to be widened.
 constexpr int MAX_EXTENT_LIMIT = 178;
 inline int max_search_steps(int max_extent) { return static_cast<int>(static_cast<float>(max_extent) / 0.7f) + 2; }
 static_assert(static_cast<int>(MAX_EXTENT_LIMIT / 0.7f) + 1 <= 255, "step numbers of a seed fit 8 bits");
-constexpr int UNIT_SHARDS = 16;  // unit lists / counters, tile t -> shard t % UNIT_SHARDS; hand-out counters of the search, workgroup b -> b % UNIT_SHARDS
+// unit lists / counters, tile t -> shard t % UNIT_SHARDS; hand-out counters of the search, workgroup b -> b % UNIT_SHARDS
+constexpr int UNIT_SHARDS = 16;
 constexpr int HANDOUT_STRIDE = 32;  // words between two hand-out counters (128 B: one L2 line each)
-constexpr unsigned int UNIT_TILE_BOX = 0x80000000u;  // flag in a unit's first-item word: words 2, 3 hold the texel box of ALL samples of the unit's tile, and it fits the LDS window
-constexpr int FR_TRACE_FRAMES = 256, FR_TRACE_WORDS = 8;  // timeline of the tile pipeline, per workgroup: start, setup done, own tile done, exit (10 ns ticks), work items, units searched
+// flag in a unit's first-item word: words 2, 3 hold the texel box of ALL samples of the unit's tile, and it fits the LDS window
+constexpr unsigned int UNIT_TILE_BOX = 0x80000000u;
+// timeline of the tile pipeline, per workgroup: start, setup done, own tile done, exit (10 ns ticks), work items, units searched
+constexpr int FR_TRACE_FRAMES = 256, FR_TRACE_WORDS = 8;
 
-constexpr int MAX_GROUP_SEQ = 8;  // sequences ONE launch pair can carry (the per-sequence parameter blocks travel as kernel arguments: 4 KB)
-constexpr int MAX_BATCH = 3 * MAX_GROUP_SEQ;  // sequences of a batch: it steps its members in up to three stream groups, one launch pair each (rmd_hip_batch)
+// sequences ONE launch pair can carry (the per-sequence parameter blocks travel as kernel arguments: 4 KB)
+constexpr int MAX_GROUP_SEQ = 8;
+// sequences of a batch: it steps its members in up to three stream groups, one launch pair each (rmd_hip_batch)
+constexpr int MAX_BATCH = 3 * MAX_GROUP_SEQ;
 
 // Workspace of the update pipeline for `n_seq` independent sequences of one size that are updated by ONE launch pair (a plain
 // SeedMatrix is the case n_seq = 1).  Per-seed planes hold the sequences back to back (`seq_plane` elements each), tiles are
@@ -56,20 +61,23 @@ struct MatcherWorkspace {
   float* d_lfirst = nullptr;  // per seed: accumulated l at the first in-image step
   unsigned int* d_packed = nullptr;      // per seed: first in-image step << 16 | number of in-image steps
   unsigned long long* d_best = nullptr;  // per seed: arg-max key
-  unsigned int* d_tile_live = nullptr;   // per tile: seeds in state UPDATE after the last frame's check (0: the tile is dead until the next reference frame)
+  // per tile: seeds in state UPDATE after the last frame's check (0: the tile is dead until the next reference frame)
+  unsigned int* d_tile_live = nullptr;
   unsigned int* d_tile_conv = nullptr;   // per tile: seeds that seed_check found CONVERGED in this frame
   uint4* d_units = nullptr;         // work units: (tile, first item | UNIT_TILE_BOX, the tile's sample box x0 | y0 << 16, x1 | y1 << 16)
   unsigned int* d_handout = nullptr;  // UNIT_SHARDS hand-out counters of the search kernel, HANDOUT_STRIDE words apart
   // counters of the current frame: [0] work units (round-1 plan kernel), [1] units handed out beyond the static first round,
   // [5] items per unit
   unsigned long long* d_shards = nullptr;  // 3 sets (frame % 3) of UNIT_SHARDS counters {work items << 32 | units}
-  unsigned long long* h_conv = nullptr;    // pinned, one word per sequence: {update number << 32 | CONVERGED seeds at the start of that update}
+  // pinned, one word per sequence: {update number << 32 | CONVERGED seeds at the start of that update}
+  unsigned long long* h_conv = nullptr;
   unsigned long long* d_conv = nullptr;    // its device address
   long long frame = 0;                     // updates since the last reference (which set of shard counters is current)
   unsigned int update_number = 0;          // launch pairs so far (modulo 2^32), stamped into h_conv
   int shard_cap = 0;                       // unit-list entries per shard
   int lds_bytes = 160 * 1024;              // LDS per CU of the handle's device (gfx950: 160 KB)
-  unsigned long long* d_wg_trace = nullptr;  // diagnostics, allocated on demand: FR_TRACE_FRAMES slices of wg_trace_slice_u64() words (probes of the search workgroups)
+  // diagnostics, allocated on demand: FR_TRACE_FRAMES slices of wg_trace_slice_u64() words (probes of the search workgroups)
+  unsigned long long* d_wg_trace = nullptr;
   int max_units = 0;
   bool attr_set_small = false, attr_set_large = false;
   bool attr_set_compact[4][2] = {{false, false}, {false, false}, {false, false}, {false, false}};  // per patch side, {one sequence, batch}
@@ -97,7 +105,8 @@ struct MatcherWorkspace {
     if (hipMalloc(reinterpret_cast<void**>(&d_handout), UNIT_SHARDS * HANDOUT_STRIDE * sizeof(unsigned int)) != hipSuccess) return -1;
     if (hipMemset(d_handout, 0, UNIT_SHARDS * HANDOUT_STRIDE * sizeof(unsigned int)) != hipSuccess) return -1;
     if (hipMalloc(reinterpret_cast<void**>(&d_shards), 3 * UNIT_SHARDS * sizeof(unsigned long long)) != hipSuccess) return -1;
-    if (hipHostMalloc(reinterpret_cast<void**>(&h_conv), MAX_GROUP_SEQ * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) return -1;
+    if (hipHostMalloc(reinterpret_cast<void**>(&h_conv), MAX_GROUP_SEQ * sizeof(unsigned long long),
+        hipHostMallocMapped) != hipSuccess) return -1;
     for (int q = 0; q < MAX_GROUP_SEQ; ++q) h_conv[q] = 0ull;
     void* dev = nullptr;
     if (hipHostGetDevicePointer(&dev, h_conv, 0) != hipSuccess) return -1;
@@ -152,12 +161,14 @@ struct MatcherArgs {
   // -- the next launch -- reads.  IN PLACE (ingest_flag == null): those workgroups read the frames straight from the pinned host
   // buffers over the host link (ingest_in_place); the buffers were complete before the kernel was launched, nothing to wait for.
   // The frames and their destinations are per sequence (SeqArgs).  ingest_kind 0: the frames are resident already.
-  int ingest_kind;                 // 1: 8-bit rows of ingest_pitch bytes (a multiple of 4), four pixels per dword; 2: float rows of P.w elements, unpadded
+  // 1: 8-bit rows of ingest_pitch bytes (a multiple of 4), four pixels per dword; 2: float rows of P.w elements, unpadded
+  int ingest_kind;
   int ingest_pitch;
   int ingest_wgs;                  // workgroups (per sequence) that do the conversion: the first ones of the setup grid ...
   int ingest_rows;                 // ... which occupy this many grid rows IN FRONT of the tile grid (tile row = blockIdx.y - ingest_rows)
   int ingest_profile;              // diagnostics (RMD_HIP_INGEST_PROFILE): count into progress[2..4]
-  const unsigned int* ingest_flag; // device word: number of the last step whose staging copy (into this step's buffers) has completed; null: in place
+  // device word: number of the last step whose staging copy (into this step's buffers) has completed; null: in place
+  const unsigned int* ingest_flag;
   unsigned int* progress;          // pinned host words: [0] <- ingest_number when this setup starts (everything before it has
                                    // completed: the host may reuse that step's buffers), [1] |= 1 if the flag never came;
                                    // diagnostics: [2] frames converted by their own setup kernel (not one step ahead), [3] of those, frames
@@ -170,8 +181,11 @@ struct MatcherArgs {
   // plane and set ahead[2] = n + 1, and the ingest workgroups of setup n + 1 find nothing left to do.  Nobody waits for a frame on this
   // path: one that was not there in time is handled by its own setup kernel as without it.
   int ahead_wgs;
-  const unsigned int* submitted;   // staged: the arrival flag of frame n + 1's staging buffer; in place: a pinned host word, the newest frame of this kind that is complete in the ring
-  unsigned int* ahead;             // device words: [0] frame to bring in during this update's search kernel or 0, [1] bringers done, [2] newest frame brought in ahead
+  // staged: the arrival flag of frame n + 1's staging buffer; in place: a pinned host word, the newest frame of this kind that is complete
+  // in the ring
+  const unsigned int* submitted;
+  // device words: [0] frame to bring in during this update's search kernel or 0, [1] bringers done, [2] newest frame brought in ahead
+  unsigned int* ahead;
 };
 
 // One sequence of a launch: the reference's mvs::DeviceData of that SeedMatrix for this frame plus what the deferred finalisation
@@ -198,7 +212,8 @@ struct BatchArgs {
   SeqArgs seq[NSEQ];
 };
 static_assert(sizeof(BatchArgs<MAX_GROUP_SEQ>) + sizeof(MatcherArgs) + 64 <= 4096, "kernel arguments are limited to 4 KB");
-RMDK_D const SeqArgs* seq_table() { return (const SeqArgs*)__builtin_amdgcn_kernarg_segment_ptr(); }  // (C cast: from the constant address space)
+// (C cast: from the constant address space)
+RMDK_D const SeqArgs* seq_table() { return (const SeqArgs*)__builtin_amdgcn_kernarg_segment_ptr(); }
 
 // what the caller of the pipeline hands over when the frames came from host memory
 struct IngestArgs {
@@ -393,23 +408,26 @@ RMDK_D void ncc_sums_regular(const float* __restrict__ base, int rt_stride, cons
 }
 
 // Sums of one NCC evaluation over a regular footprint in the LDS window (the hot block of the whole path): the arithmetic of
-// ncc_sums_regular, software-pipelined by hand.  The texel row r + 1 and the template row r are requested from the LDS BEFORE
-// the filter / accumulate work on row r, and scheduling barriers keep the compiler from sinking the reads back to their first
-// use (left alone it issues every read a few instructions before an s_waitcnt: ~60 exposed LDS latencies per evaluation, which
-// is most of a round's time when a wave has its SIMD to itself, i.e. on every frame but the first twenty).
-// With four waves per SIMD the block is bound by VALU issue, not by the LDS: builds that leave out 28 % or 72 % of its LDS reads run
-// the heaviest updates in the same time (+-1 %), and the kernel issues one VALU instruction per 2.9 cycles and SIMD there, the rate of a
-// pure v_fma_f32 stream on this part (profiles/r03_lds_ceiling.txt).  Keeping the two product sums as a register pair for v_pk_add_f32
-// (4.3 cycles against 2 x 2.7 in isolation) was tried: as a vector-typed expression the optimiser sinks the chain of packed adds below the
-// last row with all 81 products alive (168 VGPRs + scratch); pinned by volatile inline assembly it costs 125 VGPRs, is bit-identical and
-// gains nothing on the heaviest updates (490 -> 494 us for a batch of 8); pairs of columns through the vertical filter cost 114 extra moves.
+// ncc_sums_regular, software-pipelined by hand.  The texel row r + 1 and the template row r are requested from the LDS BEFORE the filter /
+// accumulate work on row r, and scheduling barriers keep the compiler from sinking the reads back to their first use (left alone it issues
+// every read a few instructions before an s_waitcnt: ~60 exposed LDS latencies per evaluation, which is most of a round's time when a wave
+// has its SIMD to itself, i.e. on every frame but the first twenty). With four waves per SIMD the block is bound by VALU issue, not by the
+// LDS: builds that leave out 28 % or 72 % of its LDS reads run the heaviest updates in the same time (+-1 %), and the kernel issues one
+// VALU instruction per 2.9 cycles and SIMD there, the rate of a pure v_fma_f32 stream on this part (profiles/r03_lds_ceiling.txt).  Keeping
+// the two product sums as a register pair for v_pk_add_f32 (4.3 cycles against 2 x 2.7 in isolation) was tried: as a vector-typed
+// expression the optimiser sinks the chain of packed adds below the last row with all 81 products alive (168 VGPRs + scratch); pinned by
+// volatile inline assembly it costs 125 VGPRs, is bit-identical and gains nothing on the heaviest updates (490 -> 494 us for a batch of 8);
+// pairs of columns through the vertical filter cost 114 extra moves.
 template <int SIDE>
-RMDK_D void ncc_sums_lds_pipelined(const float* __restrict__ win_x, const int* __restrict__ row_start, int off_first, int off_second, const float (&ax)[SIDE],
-                                   const float (&ay)[SIDE], const float* __restrict__ ref_patch, int ref_stride, float& sum_img, float& sum_img_sq,
+RMDK_D void ncc_sums_lds_pipelined(const float* __restrict__ win_x, const int* __restrict__ row_start, int off_first, int off_second,
+    const float (&ax)[SIDE],
+                                   const float (&ay)[SIDE], const float* __restrict__ ref_patch, int ref_stride, float& sum_img,
+                                       float& sum_img_sq,
                                    float& sum_img_templ) {
-  // win_x = the window + the footprint's first image column; row_start = the window's row table at the footprint's first row: texel row r of
-  // the footprint starts at win_x[row_start[r]] (a sheared window has no constant row stride).  Entries 0 and 1 come from the caller; entry
-  // r + 2 is requested while row r is worked on -- two rows ahead of the texel reads that need it, so that it costs no wait and two registers.
+  // win_x = the window + the footprint's first image column; row_start = the window's row table at the footprint's first row: texel row r
+  // of the footprint starts at win_x[row_start[r]] (a sheared window has no constant row stride).  Entries 0 and 1 come from the caller;
+  // entry r + 2 is requested while row r is worked on -- two rows ahead of the texel reads that need it, so that it costs no wait and two
+  // registers.
   float t[2][SIDE + 1], tm[2][SIDE], hprev[SIDE], hcur[SIDE];
   int off_next = off_second, off_after = 0;
 #pragma unroll
@@ -461,7 +479,8 @@ inline MatcherArgs matcher_args(const MatcherWorkspace& ws) {
   M.conv_out = ws.d_conv;
   M.update_number = ws.update_number;
   M.shard_cap = ws.shard_cap;
-  M.ingest_kind = 0; M.ingest_pitch = 0; M.ingest_wgs = 0; M.ingest_rows = 0; M.ingest_profile = 0; M.ingest_flag = nullptr; M.progress = nullptr; M.ingest_number = 0u;
+  M.ingest_kind = 0; M.ingest_pitch = 0; M.ingest_wgs = 0; M.ingest_rows = 0; M.ingest_profile = 0; M.ingest_flag = nullptr; M.progress =
+      nullptr; M.ingest_number = 0u;
   M.ahead_wgs = 0; M.submitted = nullptr; M.ahead = nullptr;
   return M;
 }

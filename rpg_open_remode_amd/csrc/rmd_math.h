@@ -54,13 +54,13 @@ RMD_HD float rmd_nanf() {
 // ------------------------------------------------------------------------------------------------------------------------
 // expf / sinf / acosf: the functions of GNU libc 2.35 (x86-64), restated operation for operation.
 //
-// The reference calls expf (seed_update.cu:36), sinf and acosf (triangulation.cu:63-66).  Its CUDA build gets NVIDIA's
-// fast-math intrinsics, which nothing but that build can reproduce; the only executable form of the reference -- its own
-// kernels compiled for the host (the test suite's "Oracle A") -- gets the C library's.  So the contract is pinned to that library: the three
-// functions below return, for EVERY float argument, the bits glibc 2.35 returns on an x86-64 host with FMA (the variants its
-// ifunc resolvers select on every current CPU: __expf_fma, __sinf_fma; acosf has a single variant).  oracle/libm_exhaustive.cpp
-// checks all 2^32 arguments of each against the host's libm (tests/test_math_contract.py runs a sample of it every time).
-// With that, the reference built unmodified against the system's libm and the HIP kernels agree bit for bit.
+// The reference calls expf (seed_update.cu:36), sinf and acosf (triangulation.cu:63-66).  Its CUDA build gets NVIDIA's fast-math
+// intrinsics, which nothing but that build can reproduce; the only executable form of the reference -- its own kernels compiled for the
+// host (the test suite's "Oracle A") -- gets the C library's.  So the contract is pinned to that library: the three functions below return,
+// for EVERY float argument, the bits glibc 2.35 returns on an x86-64 host with FMA (the variants its ifunc resolvers select on every
+// current CPU: __expf_fma, __sinf_fma; acosf has a single variant).  oracle/libm_exhaustive.cpp checks all 2^32 arguments of each against
+// the host's libm (tests/test_math_contract.py runs a sample of it every time). With that, the reference built unmodified against the
+// system's libm and the HIP kernels agree bit for bit.
 //
 // The algorithms are the published ones: expf and sinf are Szabolcs Nagy's / Wilco Dijkstra's routines from ARM's
 // optimized-routines as adopted by glibc 2.27 / 2.28 (sysdeps/ieee754/flt-32/e_expf.c, s_sinf.c, sincosf.h, sincosf_data.c,
@@ -75,11 +75,16 @@ RMD_HD double rmd_u2d(uint64_t u) { double d; memcpy(&d, &u, sizeof(d)); return 
 
 // e_exp2f_data.c: T[i] = bits(2^(i/32)) - (i << 52) / 32
 static const uint64_t RMD_EXP2F_T[32] = {
-    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull,
-    0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
-    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull,
-    0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
-    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull,
+        0x3fef54873168b9aaull,
+    0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull,
+        0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull,
+        0x3fee9f75e8ec5f74ull,
+    0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull,
+        0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull,
+        0x3fef7c97337b9b5full,
     0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
 
 // T[i]: from the table on the host; on the device from immediates through a binary tree of selects on the five index bits -- a
@@ -110,10 +115,12 @@ RMD_HD float rmd_expf(float x) {
     if (abstop >= 0x7f8u) return x + x;                                  // +Inf, NaN
     if (x > 88.7228317f) return INFINITY;                              // x > log(0x1p128): overflow  [0x1.62e42ep6f]
     if (x < -103.972076f) return 0.0f;                                 // x < log(0x1p-150): underflow  [-0x1.9fe368p6f]
-    if (x < -103.278923f) return 3.30872245e-23f * 3.30872245e-23f;              // x < log(0x1p-149): may underflow (rounds to the smallest denormal)  [-0x1.9d1d9ep6f 0x1.4p-75f 0x1.4p-75f]
+    // x < log(0x1p-149): may underflow (rounds to the smallest denormal)  [-0x1.9d1d9ep6f 0x1.4p-75f 0x1.4p-75f]
+    if (x < -103.278923f) return 3.30872245e-23f * 3.30872245e-23f;
   }
   const double InvLn2N = 46.166241308446828, SHIFT = 6755399441055744.0;  // 0x1.71547652b82fep+5 0x1.8p+52
-  const double C0 = 1.6938359250920212e-06, C1 = 0.00023459809789509004, C2 = 0.021660849396613134;  // 0x1.c6af84b912394p-20 0x1.ebfce50fac4f3p-13 0x1.62e42ff0c52d6p-6
+  // 0x1.c6af84b912394p-20 0x1.ebfce50fac4f3p-13 0x1.62e42ff0c52d6p-6
+  const double C0 = 1.6938359250920212e-06, C1 = 0.00023459809789509004, C2 = 0.021660849396613134;
   // x * N / ln2 = k + r with r in [-1/2, 1/2] and integer k
   double kd = fma(InvLn2N, xd, SHIFT);
   const uint64_t ki = rmd_d2u(kd);
@@ -144,9 +151,12 @@ RMD_HD float rmd_expf(float x) {
 #define RMD_SC_S2 0.0083321781461388536  // 0x1.1107605230bc4p-7
 #define RMD_SC_S3 (-0.00019517298981385725)  // -0x1.994eb3774cf24p-13
 // 4/pi as a 768-bit fraction in overlapping 32-bit words (__inv_pio4)
-static const uint32_t RMD_INV_PIO4[24] = {0xa2u,       0xa2f9u,     0xa2f983u,   0xa2f9836eu, 0xf9836e4eu, 0x836e4e44u, 0x6e4e4415u, 0x4e441529u,
-                                          0x441529fcu, 0x1529fc27u, 0x29fc2757u, 0xfc2757d1u, 0x2757d1f5u, 0x57d1f534u, 0xd1f534ddu, 0xf534ddc0u,
-                                          0x34ddc0dbu, 0xddc0db62u, 0xc0db6295u, 0xdb629599u, 0x6295993cu, 0x95993c43u, 0x993c4390u, 0x3c439041u};
+static const uint32_t RMD_INV_PIO4[24] = {0xa2u,       0xa2f9u,     0xa2f983u,   0xa2f9836eu, 0xf9836e4eu, 0x836e4e44u, 0x6e4e4415u,
+    0x4e441529u,
+                                          0x441529fcu, 0x1529fc27u, 0x29fc2757u, 0xfc2757d1u, 0x2757d1f5u, 0x57d1f534u, 0xd1f534ddu,
+                                              0xf534ddc0u,
+                                          0x34ddc0dbu, 0xddc0db62u, 0xc0db6295u, 0xdb629599u, 0x6295993cu, 0x95993c43u, 0x993c4390u,
+                                              0x3c439041u};
 
 // sincosf.h sinf_poly on quadrant q = n + (sign of a large argument): sine polynomial for even n on x * sign[q & 3], cosine
 // polynomial (of table q & 2) for odd n; rounded to float

@@ -1,5 +1,5 @@
-// librmd_hip.so -- the two steps AFTER the path that the reference runs on the host over downloaded images: the CONVERGED-masked
-// world-frame point cloud (Publisher::publishPointCloud, src/publisher.cpp:54-104) and the coloured convergence map
+// librmd_hip.so -- the two steps AFTER the path that the reference runs on the host over downloaded images: the
+// CONVERGED-masked world-frame point cloud (Publisher::publishPointCloud, src/publisher.cpp:54-104) and the coloured convergence map
 // (Publisher::publishConvergenceMap, src/publisher.cpp:112-147), with their kernels.
 #include "rmd_host.hpp"
 
@@ -103,7 +103,8 @@ static __global__ __launch_bounds__(PC_BLOCK) void pc_write_kernel(PointCloudPar
 // reference image comes back from the float plane the path works on (rint(v * 255) is exact for v = k * (1/255)f, like pc_write_kernel).
 // Four pixels per lane: twelve output bytes = three dwords (rows of the packed W x 3 output need not be dword-aligned: the output is
 // addressed as ONE array of W * H * 3 bytes, groups of four pixels counted over the whole image, the last group may be short).
-static __global__ __launch_bounds__(256) void convergence_bgr8_kernel(const float* __restrict__ ref, const int* __restrict__ conv, int w, int h, int stride,
+static __global__ __launch_bounds__(256) void convergence_bgr8_kernel(const float* __restrict__ ref, const int* __restrict__ conv, int w,
+    int h, int stride,
                                                                unsigned char* __restrict__ out) {
   const long long n = static_cast<long long>(w) * h;
   const long long p0 = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) * 4;
@@ -114,7 +115,8 @@ static __global__ __launch_bounds__(256) void convergence_bgr8_kernel(const floa
     const long long p = p0 + q < n ? p0 + q : n - 1;
     const int y = static_cast<int>(p / w), x = static_cast<int>(p - static_cast<long long>(y) * w);
     const size_t i = static_cast<size_t>(y) * stride + x;
-    const unsigned int g = static_cast<unsigned int>(fminf(fmaxf(rintf(ref[i] * 255.0f), 0.0f), 255.0f));  // saturates like cv::saturate_cast<uchar>
+    // saturates like cv::saturate_cast<uchar>
+    const unsigned int g = static_cast<unsigned int>(fminf(fmaxf(rintf(ref[i] * 255.0f), 0.0f), 255.0f));
     const int st = conv[i];
     b[3 * q] = st == ST_CONVERGED ? 255u : g;
     b[3 * q + 1] = g;
@@ -130,9 +132,9 @@ static __global__ __launch_bounds__(256) void convergence_bgr8_kernel(const floa
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// The snapshot a publication works on (rmd_hip_seeds_publish_async): up to six planes of one pitch copied as flat arrays of 16-byte vectors --
-// the planes' rows are padded to 256 bytes, padding travels along.  One launch on the update stream: 24 + 24 bytes per pixel at most.
+// ------------------------------------------------------------------------------------------ The snapshot a publication works on
+// (rmd_hip_seeds_publish_async): up to six planes of one pitch copied as flat arrays of 16-byte vectors -- the planes' rows are padded to
+// 256 bytes, padding travels along.  One launch on the update stream: 24 + 24 bytes per pixel at most.
 typedef unsigned int snap_vec_t __attribute__((ext_vector_type(4)));
 struct SnapshotArgs {
   const snap_vec_t* src[6];
@@ -141,7 +143,8 @@ struct SnapshotArgs {
   unsigned int n_vec;  // 16-byte vectors per plane
 };
 static __global__ __launch_bounds__(256) void snapshot_kernel(SnapshotArgs A) {
-  const SnapshotArgs* const a = (const SnapshotArgs*)__builtin_amdgcn_kernarg_segment_ptr();  // (indexed in place: no copy of the pointer arrays into scratch)
+  // (indexed in place: no copy of the pointer arrays into scratch)
+  const SnapshotArgs* const a = (const SnapshotArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   (void)A;
   const unsigned int step = gridDim.x * blockDim.x;
   for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < a->n_vec; i += step) {
@@ -165,8 +168,8 @@ int rmd_hip_seeds_point_cloud(rmd_hip_seeds_t* s, const rmd_hip_image_t* depth, 
   const int n_pix = s->width * s->height;
   const int n_blocks = (n_pix + rmdk::PC_BLOCK - 1) / rmdk::PC_BLOCK;
   // The points go straight into pinned host memory (posted writes over the host link, 16 bytes per lane) and from there into the caller's
-  // buffer: their number is not known when the work is queued, and a device-to-host copy into PAGEABLE memory goes through the runtime's own
-  // staging (measured at 0.3 GB/s on one box of the pool: 3.5 ms for a cloud of 60 000 points).
+  // buffer: their number is not known when the work is queued, and a device-to-host copy into PAGEABLE memory goes through the runtime's
+  // own staging (measured at 0.3 GB/s on one box of the pool: 3.5 ms for a cloud of 60 000 points).
   if (!s->d_pc_counts) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_pc_counts), (static_cast<size_t>(n_blocks) + 1) * sizeof(unsigned int)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_pc_points), static_cast<size_t>(n_pix) * sizeof(float4), hipHostMallocMapped));
@@ -185,8 +188,10 @@ int rmd_hip_seeds_point_cloud(rmd_hip_seeds_t* s, const rmd_hip_image_t* depth, 
   P.cam = s->P.cam;
   P.T_world_ref = s->T_world_ref;
   hipLaunchKernelGGL(rmdk::pc_count_kernel, dim3(n_blocks), dim3(rmdk::PC_BLOCK), 0, s->stream, P, s->d_pc_counts);
-  hipLaunchKernelGGL(rmdk::pc_scan_kernel, dim3(1), dim3(1024), 0, s->stream, s->d_pc_counts, n_blocks, static_cast<unsigned int*>(d_total));
-  hipLaunchKernelGGL(rmdk::pc_write_kernel, dim3(n_blocks), dim3(rmdk::PC_BLOCK), 0, s->stream, P, s->d_pc_counts, static_cast<float4*>(d_points),
+  hipLaunchKernelGGL(rmdk::pc_scan_kernel, dim3(1), dim3(1024), 0, s->stream, s->d_pc_counts, n_blocks,
+      static_cast<unsigned int*>(d_total));
+  hipLaunchKernelGGL(rmdk::pc_write_kernel, dim3(n_blocks), dim3(rmdk::PC_BLOCK), 0, s->stream, P, s->d_pc_counts,
+      static_cast<float4*>(d_points),
                      static_cast<unsigned int>(n_pix));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s->stream));
@@ -209,7 +214,8 @@ int rmd_hip_seeds_convergence_bgr8(rmd_hip_seeds_t* s, unsigned char* host_bgr) 
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_bgr), bytes));
   }
   const long long groups = (static_cast<long long>(s->width) * s->height + 3) / 4;
-  hipLaunchKernelGGL(rmdk::convergence_bgr8_kernel, dim3(static_cast<unsigned int>((groups + 255) / 256)), dim3(256), 0, s->stream, s->P.ref, s->P.conv, s->width,
+  hipLaunchKernelGGL(rmdk::convergence_bgr8_kernel, dim3(static_cast<unsigned int>((groups + 255) / 256)), dim3(256), 0, s->stream,
+      s->P.ref, s->P.conv, s->width,
                      s->height, s->P.stride, s->d_bgr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(s->h_bgr, s->d_bgr, bytes, hipMemcpyDeviceToHost, s->stream));
@@ -228,12 +234,14 @@ int rmd_hip_seeds_publish_async(rmd_hip_seeds_t* s, unsigned int what, float dep
   if ((what & RMD_HIP_PUBLISH_DEPTH) && iterations < 0) return fail(RMD_HIP_ERR_INVALID_ARG, "publish_async: negative iteration count");
   if (!s->has_reference) return fail(RMD_HIP_ERR_NOT_READY, "publish_async: no reference image set");
   if (s->pub_pending >= RMD_HIP_PUBLISH_SLOTS)
-    return fail(RMD_HIP_ERR_NOT_READY, "publish_async: %d publications are waiting to be collected (rmd_hip_seeds_publish_collect)", s->pub_pending);
+    return fail(RMD_HIP_ERR_NOT_READY, "publish_async: %d publications are waiting to be collected (rmd_hip_seeds_publish_collect)",
+        s->pub_pending);
   TRY(seeds_bind_device(s));
   const int w = s->width, h = s->height;
   const size_t n_pix = static_cast<size_t>(w) * h;
   if (!s->pub_stream) {
-    HIP_TRY(create_stream(&s->pub_stream, 1));  // its own priority level: never on the hardware queue of the update or the copy stream (create_stream)
+    // its own priority level: never on the hardware queue of the update or the copy stream (create_stream)
+    HIP_TRY(create_stream(&s->pub_stream, 1));
     rmd_hip_image* f32[] = {&s->pub_u[0], &s->pub_u[1], &s->pub_u_head[0], &s->pub_u_head[1], &s->pub_g};
     for (auto* im : f32) TRY(image_alloc(im, RMD_HIP_KIND_F32, w, h));
     for (int k = 0; k < 2; ++k) TRY(image_alloc(&s->pub_p[k], RMD_HIP_KIND_F32X2, w, h));
@@ -265,12 +273,14 @@ int rmd_hip_seeds_publish_async(rmd_hip_seeds_t* s, unsigned int what, float dep
   if (want_depth || want_conv) TRY(seeds_flush(s));
   rmdk::SnapshotArgs A;
   memset(&A, 0, sizeof(A));
-  auto add = [&](const void* src, rmd_hip_image& dst) { A.src[A.n_planes] = static_cast<const rmdk::snap_vec_t*>(src); A.dst[A.n_planes] = static_cast<rmdk::snap_vec_t*>(dst.data); ++A.n_planes; };
+  auto add = [&](const void* src, rmd_hip_image& dst) { A.src[A.n_planes] = static_cast<const rmdk::snap_vec_t*>(src); A.dst[A.n_planes] =
+      static_cast<rmdk::snap_vec_t*>(dst.data); ++A.n_planes; };
   if (want_depth) { add(s->P.mu, pb.mu); add(s->P.sigma_sq, pb.sigma_sq); add(s->P.a, pb.a); add(s->P.b, pb.b); }
   if (want_cloud || want_bgr || want_conv) add(s->P.conv, pb.conv);
   if (want_cloud || want_bgr) add(s->P.ref, pb.ref);
   A.n_vec = static_cast<unsigned int>(pb.mu.pitch * static_cast<size_t>(h) / 16);  // (every f32 / i32 plane of the handle has this pitch)
-  hipLaunchKernelGGL(rmdk::snapshot_kernel, dim3((A.n_vec + 255) / 256 < 2048u ? (A.n_vec + 255) / 256 : 2048u), dim3(256), 0, s->stream, A);
+  hipLaunchKernelGGL(rmdk::snapshot_kernel, dim3((A.n_vec + 255) / 256 < 2048u ? (A.n_vec + 255) / 256 : 2048u), dim3(256), 0, s->stream,
+      A);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(pb.snapped, s->stream));
   pb.T_world_ref = s->T_world_ref;
@@ -333,17 +343,20 @@ int rmd_hip_seeds_publish_async(rmd_hip_seeds_t* s, unsigned int what, float dep
     HIP_TRY(hipHostGetDevicePointer(&d_points, pb.h_points, 0));
     HIP_TRY(hipHostGetDevicePointer(&d_total, pb.h_total, 0));
     hipLaunchKernelGGL(rmdk::pc_count_kernel, dim3(n_blocks), dim3(rmdk::PC_BLOCK), 0, s->pub_stream, P, s->pub_pc_counts);
-    hipLaunchKernelGGL(rmdk::pc_scan_kernel, dim3(1), dim3(1024), 0, s->pub_stream, s->pub_pc_counts, n_blocks, static_cast<unsigned int*>(d_total));
-    // the points go straight into pinned host memory (posted writes over the host link, 16 bytes per lane): their number is not known when the
-    // transfers are queued, and a copy of all W x H slots would move the unconverged ones too
-    hipLaunchKernelGGL(rmdk::pc_write_kernel, dim3(n_blocks), dim3(rmdk::PC_BLOCK), 0, s->pub_stream, P, s->pub_pc_counts, static_cast<float4*>(d_points),
+    hipLaunchKernelGGL(rmdk::pc_scan_kernel, dim3(1), dim3(1024), 0, s->pub_stream, s->pub_pc_counts, n_blocks,
+        static_cast<unsigned int*>(d_total));
+    // the points go straight into pinned host memory (posted writes over the host link, 16 bytes per lane): their number is not known when
+    // the transfers are queued, and a copy of all W x H slots would move the unconverged ones too
+    hipLaunchKernelGGL(rmdk::pc_write_kernel, dim3(n_blocks), dim3(rmdk::PC_BLOCK), 0, s->pub_stream, P, s->pub_pc_counts,
+        static_cast<float4*>(d_points),
                        static_cast<unsigned int>(n_pix));
     HIP_TRY(hipGetLastError());
   }
   if (want_bgr) {
     const long long groups = (static_cast<long long>(n_pix) + 3) / 4;
     hipLaunchKernelGGL(rmdk::convergence_bgr8_kernel, dim3(static_cast<unsigned int>((groups + 255) / 256)), dim3(256), 0, s->pub_stream,
-                       static_cast<const float*>(pb.ref.data), static_cast<const int*>(pb.conv.data), w, h, static_cast<int>(pb.conv.stride), s->pub_d_bgr);
+                       static_cast<const float*>(pb.ref.data), static_cast<const int*>(pb.conv.data), w, h,
+                           static_cast<int>(pb.conv.stride), s->pub_d_bgr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(pb.h_bgr, s->pub_d_bgr, n_pix * 3, hipMemcpyDeviceToHost, s->pub_stream));
   }
@@ -357,7 +370,8 @@ int rmd_hip_seeds_publish_async(rmd_hip_seeds_t* s, unsigned int what, float dep
   return RMD_HIP_OK;
 }
 
-int rmd_hip_seeds_publish_peek(rmd_hip_seeds_t* s, int wait, unsigned int* what, int* ticket, const float** depth, const float** xyzi, size_t* n_points,
+int rmd_hip_seeds_publish_peek(rmd_hip_seeds_t* s, int wait, unsigned int* what, int* ticket, const float** depth, const float** xyzi,
+    size_t* n_points,
                                const unsigned char** bgr, const int** convergence) {
   if (!s) return fail(RMD_HIP_ERR_INVALID_ARG, "publish_peek: null handle");
   if (s->pub_pending == 0) return fail(RMD_HIP_ERR_NOT_READY, "publish_peek: no publication in flight");
@@ -391,7 +405,8 @@ int rmd_hip_seeds_publish_release(rmd_hip_seeds_t* s) {
   return RMD_HIP_OK;
 }
 
-int rmd_hip_seeds_publish_collect(rmd_hip_seeds_t* s, int wait, unsigned int* what, int* ticket, float* host_depth, float* host_xyzi, size_t capacity,
+int rmd_hip_seeds_publish_collect(rmd_hip_seeds_t* s, int wait, unsigned int* what, int* ticket, float* host_depth, float* host_xyzi,
+    size_t capacity,
                                   size_t* n_points, unsigned char* host_bgr, int* host_convergence) {
   const float *depth = nullptr, *xyzi = nullptr;
   const unsigned char* bgr = nullptr;

@@ -1,4 +1,5 @@
-// librmd_hip.so -- rmd::ImageReducer<T> (reduction.cu), the self tests of the wave primitives / the float-frame examination / the device side of the arithmetic contract.
+// librmd_hip.so -- rmd::ImageReducer<T> (reduction.cu), the self tests of the wave primitives / the float-frame examination / the device
+// side of the arithmetic contract.
 #include "rmd_host.hpp"
 #include "rmd_copy_pool.hpp"
 
@@ -43,12 +44,14 @@ static __global__ __launch_bounds__(256) void sum_partial_kernel(const float* __
 }
 // integer image sum (ImageReducer<int>::sum, reduction.cu:186): exact in 64 bits, the caller truncates to int like the
 // reference's int accumulation wraps
-static __global__ __launch_bounds__(256) void sum_i32_kernel(const int* __restrict__ img, int w, int h, int stride, unsigned long long* __restrict__ out) {
+static __global__ __launch_bounds__(256) void sum_i32_kernel(const int* __restrict__ img, int w, int h, int stride,
+    unsigned long long* __restrict__ out) {
   __shared__ unsigned long long wave_part[4];
   unsigned long long acc = 0;
   for (int y = blockIdx.y; y < h; y += gridDim.y) {
     const int* row = img + static_cast<size_t>(y) * stride;
-    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < w; x += gridDim.x * blockDim.x) acc += static_cast<unsigned long long>(static_cast<long long>(row[x]));
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < w; x += gridDim.x * blockDim.x) acc += static_cast<unsigned long
+        long>(static_cast<long long>(row[x]));
   }
   acc = wave_sum_u64(acc);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -143,7 +146,8 @@ int reduce_scratch(ReduceScratch** out) {
 }
 
 int reduce_sum_f32_dev(const float* data, size_t stride, size_t width, size_t height, float* sum) {
-  if (width == 0 || height == 0 || width > 0x7fffffff || height > 0x7fffffff || stride > 0x7fffffff) return fail(RMD_HIP_ERR_INVALID_ARG, "reduce_sum: bad shape");
+  if (width == 0 || height == 0 || width > 0x7fffffff || height > 0x7fffffff || stride > 0x7fffffff) return fail(RMD_HIP_ERR_INVALID_ARG,
+      "reduce_sum: bad shape");
   std::lock_guard<std::mutex> lock(g_reduce_mutex);
   ReduceScratch* r = nullptr;
   TRY(reduce_scratch(&r));
@@ -157,7 +161,8 @@ int reduce_sum_f32_dev(const float* data, size_t stride, size_t width, size_t he
 }
 
 int reduce_u64_dev(bool count_eq, const int* data, size_t stride, size_t width, size_t height, int value, unsigned long long* result) {
-  if (width == 0 || height == 0 || width > 0x7fffffff || height > 0x7fffffff || stride > 0x7fffffff) return fail(RMD_HIP_ERR_INVALID_ARG, "reduce: bad shape");
+  if (width == 0 || height == 0 || width > 0x7fffffff || height > 0x7fffffff || stride > 0x7fffffff) return fail(RMD_HIP_ERR_INVALID_ARG,
+      "reduce: bad shape");
   std::lock_guard<std::mutex> lock(g_reduce_mutex);
   ReduceScratch* r = nullptr;
   TRY(reduce_scratch(&r));
@@ -244,7 +249,8 @@ int rmd_hip_selftest_wave_primitives(int* mismatching_lanes) {
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), sizeof(unsigned int)));
   hipError_t e = hipMemset(d, 0, sizeof(unsigned int));
   if (e == hipSuccess) {
-    for (unsigned int seed = 1; seed <= 8; ++seed) hipLaunchKernelGGL(rmdk::wave_primitives_selftest_kernel, dim3(64), dim3(64), 0, nullptr, seed, d);
+    for (unsigned int seed = 1; seed <= 8; ++seed) hipLaunchKernelGGL(rmdk::wave_primitives_selftest_kernel, dim3(64), dim3(64), 0, nullptr,
+        seed, d);
     e = hipGetLastError();
   }
   unsigned int bad = 0;

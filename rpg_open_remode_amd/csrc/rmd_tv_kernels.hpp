@@ -1,6 +1,6 @@
 // TV-L1 kernels (src/depthmap_denoiser.cu:45-118): tv_prepare_kernel <- :45-59 + :215-217, tv_iterate_kernel <- :61-118 (one iteration per
-// launch), tv_iterate_blocked_kernel (K iterations per launch in LDS).  Included by ONE translation unit, rmd_denoise.hip: the kernels exist in
-// one code object (TvParams and the member table live in rmd_kernels.hpp, which the host units share).
+// launch), tv_iterate_blocked_kernel (K iterations per launch in LDS).  Included by ONE translation unit, rmd_denoise.hip: the kernels
+// exist in one code object (TvParams and the member table live in rmd_kernels.hpp, which the host units share).
 #ifndef RMD_TV_KERNELS_HPP
 #define RMD_TV_KERNELS_HPP
 
@@ -12,7 +12,8 @@ namespace rmdk {
 static __global__ __launch_bounds__(256) void tv_prepare_kernel(TvParams P, float* __restrict__ u, float* __restrict__ u_head,
                                                          float2* __restrict__ p) {
   tv_select_member(P);
-  u = tv_member_plane(P, u, P.member_stride); u_head = tv_member_plane(P, u_head, P.member_stride); p = tv_member_plane(P, p, P.member_stride2);
+  u = tv_member_plane(P, u, P.member_stride); u_head = tv_member_plane(P, u_head, P.member_stride); p = tv_member_plane(P, p,
+      P.member_stride2);
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x >= P.w || y >= P.h) return;
@@ -56,8 +57,10 @@ static __global__ __launch_bounds__(TV_TX * TV_TY) void tv_iterate_kernel(TvPara
                                                                   float* __restrict__ uh_out, float2* __restrict__ p_out) {
   __shared__ float2 sp[TV_TY + 1][TV_TX + 1];
   tv_select_member(P);
-  u_in = tv_member_plane(P, u_in, P.member_stride); uh_in = tv_member_plane(P, uh_in, P.member_stride); p_in = tv_member_plane(P, p_in, P.member_stride2);
-  u_out = tv_member_plane(P, u_out, P.member_stride); uh_out = tv_member_plane(P, uh_out, P.member_stride); p_out = tv_member_plane(P, p_out, P.member_stride2);
+  u_in = tv_member_plane(P, u_in, P.member_stride); uh_in = tv_member_plane(P, uh_in, P.member_stride); p_in = tv_member_plane(P, p_in,
+      P.member_stride2);
+  u_out = tv_member_plane(P, u_out, P.member_stride); uh_out = tv_member_plane(P, uh_out, P.member_stride); p_out = tv_member_plane(P,
+      p_out, P.member_stride2);
   const int tx = threadIdx.x, ty = threadIdx.y;
   const int x0 = blockIdx.x * TV_TX, y0 = blockIdx.y * TV_TY;
   const int x = x0 + tx, y = y0 + ty;
@@ -115,8 +118,10 @@ __global__ __launch_bounds__(256) void tv_iterate_blocked_kernel(TvParams P, con
   using G = TvBlocked<BX_, BY_, KMAX>;
   __shared__ float su[G::EN], suh[G::EN], spx[G::EN], spy[G::EN], sg[G::EN], smu[G::EN];
   tv_select_member(P);
-  u_in = tv_member_plane(P, u_in, P.member_stride); uh_in = tv_member_plane(P, uh_in, P.member_stride); p_in = tv_member_plane(P, p_in, P.member_stride2);
-  u_out = tv_member_plane(P, u_out, P.member_stride); uh_out = tv_member_plane(P, uh_out, P.member_stride); p_out = tv_member_plane(P, p_out, P.member_stride2);
+  u_in = tv_member_plane(P, u_in, P.member_stride); uh_in = tv_member_plane(P, uh_in, P.member_stride); p_in = tv_member_plane(P, p_in,
+      P.member_stride2);
+  u_out = tv_member_plane(P, u_out, P.member_stride); uh_out = tv_member_plane(P, uh_out, P.member_stride); p_out = tv_member_plane(P,
+      p_out, P.member_stride2);
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x * G::BX, y0 = blockIdx.y * G::BY;
   const int ex0 = max(x0 - iters, 0), ey0 = max(y0 - iters, 0);

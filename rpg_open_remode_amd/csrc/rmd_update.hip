@@ -1,5 +1,6 @@
-// librmd_hip.so -- the one translation unit that instantiates the seed kernels (seed_init.cu, seed_check.cu, epipolar_match.cu, seed_update.cu of the
-// reference as seed_init_kernel + the two-launch pipeline of rmd_frame.hpp): launches for one SeedMatrix and for the stream groups of a batch.
+// librmd_hip.so -- the one translation unit that instantiates the seed kernels (seed_init.cu, seed_check.cu, epipolar_match.cu,
+// seed_update.cu of the reference as seed_init_kernel + the two-launch pipeline of rmd_frame.hpp): launches for one SeedMatrix and for the
+// stream groups of a batch.
 #include "rmd_host.hpp"
 #include "rmd_frame.hpp"
 
@@ -50,7 +51,8 @@ int seeds_launch_init(rmd_hip_seeds* s) {
 }
 
 int seeds_launch_update(rmd_hip_seeds* s, const PendingIngest* ingest) {
-  if (s->batch) return fail(RMD_HIP_ERR_INVALID_ARG, "update: this SeedMatrix is a member of a batch; its updates are issued with rmd_hip_batch_update*");
+  if (s->batch) return fail(RMD_HIP_ERR_INVALID_ARG,
+      "update: this SeedMatrix is a member of a batch; its updates are issued with rmd_hip_batch_update*");
   rmdk::SeedParams P = s->P;
   P.stats = nullptr;
   P.trace = nullptr;
@@ -72,7 +74,8 @@ int seeds_launch_update(rmd_hip_seeds* s, const PendingIngest* ingest) {
       } else {
         rmdk::SeedParams Pt = P;
         if (s->opt_stats == 2 && s->matcher_ws.d_wg_trace) {  // timeline probes of the setup tiles and the search workgroups
-          Pt.trace = s->matcher_ws.d_wg_trace + static_cast<size_t>(s->trace_frame % rmdk::FR_TRACE_FRAMES) * s->matcher_ws.wg_trace_slice_u64();
+          Pt.trace = s->matcher_ws.d_wg_trace + static_cast<size_t>(s->trace_frame % rmdk::FR_TRACE_FRAMES)
+              * s->matcher_ws.wg_trace_slice_u64();
           ++s->trace_frame;
         }
         rmdk::BatchArgs<1> B;
@@ -84,7 +87,8 @@ int seeds_launch_update(rmd_hip_seeds* s, const PendingIngest* ingest) {
           B.seq[0].ingest_map2 = ingest->u8 && !ingest->no_remap ? s->d_undist_map2 : nullptr;
           B.seq[0].next_src = ingest->next_src; B.seq[0].next_dst = ingest->next_dst;
         }
-        HIP_TRY((rmdk::launch_seed_pipeline_compact<SIDE, 1>(B, 1, s->matcher_ws, s->stream, s->num_cus, s->opt_unit_target, ingest ? &ingest->common : nullptr)));
+        HIP_TRY((rmdk::launch_seed_pipeline_compact<SIDE, 1>(B, 1, s->matcher_ws, s->stream, s->num_cus, s->opt_unit_target,
+            ingest ? &ingest->common : nullptr)));
         s->P_pending = P;
         s->P_pending.stats = nullptr;
         s->P_pending.trace = nullptr;
@@ -147,9 +151,11 @@ int batch_launch(rmd_hip_batch* b, unsigned int active, const rmdk::IngestArgs* 
       if (G.n == 1) {
         rmdk::BatchArgs<1> B1;
         B1.seq[0] = B.seq[0];
-        HIP_TRY((rmdk::launch_seed_pipeline_compact<SIDE, 1>(B1, 1, G.ws, G.stream, b->num_cus, b->opt_unit_target, ingest ? &in : nullptr)));
+        HIP_TRY((rmdk::launch_seed_pipeline_compact<SIDE, 1>(B1, 1, G.ws, G.stream, b->num_cus, b->opt_unit_target,
+            ingest ? &in : nullptr)));
       } else {
-        HIP_TRY((rmdk::launch_seed_pipeline_compact<SIDE, rmdk::MAX_GROUP_SEQ>(B, G.n, G.ws, G.stream, b->num_cus, b->opt_unit_target, ingest ? &in : nullptr)));
+        HIP_TRY((rmdk::launch_seed_pipeline_compact<SIDE, rmdk::MAX_GROUP_SEQ>(B, G.n, G.ws, G.stream, b->num_cus, b->opt_unit_target,
+            ingest ? &in : nullptr)));
       }
       return RMD_HIP_OK;
     });

@@ -65,6 +65,7 @@ def break_code(code, limit, indent):
         def score(i):
             before, after = code[:i], code[i + 1:]
             if before.endswith(","): return 5
+            if before.endswith("{") and after.startswith("return"): return 6
             if after.startswith(("&& ", "|| ")): return 4
             if after.startswith(("? ", ": ")): return 3
             if before.endswith((" =", "return")): return 2 if before.endswith(" =") else 0
@@ -79,10 +80,60 @@ def break_code(code, limit, indent):
     return lines
 
 
+BULLET = re.compile(r"^\s*([*\-]|\d+\.|\([a-z0-9]\)|[A-Za-z_]+\s{2,})\s*")
+
+
+def reflow_comment_blocks(src, limit):
+    """re-flows, paragraph by paragraph, every block of whole-line comments in which some line is too long (a paragraph: consecutive comment lines of
+    one indentation up to an empty comment line, a bullet or a line that is indented further than the one before it)"""
+    out, i, changed = [], 0, False
+    while i < len(src):
+        m = re.match(r"^(\s*)//(.*)$", src[i])
+        if not m:
+            out.append(src[i]); i += 1
+            continue
+        indent = m.group(1)
+        j = i
+        block = []
+        while j < len(src):
+            mm = re.match(r"^(\s*)//(.*)$", src[j])
+            if not mm or mm.group(1) != indent:
+                break
+            block.append(mm.group(2))
+            j += 1
+        # paragraphs
+        paras, cur = [], []
+        for t in block:
+            lead = len(t) - len(t.lstrip(" "))
+            starts_new = (not t.strip()) or BULLET.match(t) is not None and lead >= 1 and (t.lstrip()[:1] in "*-" or lead >= 2) or (cur and lead > (len(cur[-1]) - len(cur[-1].lstrip(" "))) + 1)
+            if starts_new and cur:
+                paras.append(cur); cur = []
+            if not t.strip():
+                paras.append([t])
+            else:
+                cur.append(t)
+        if cur:
+            paras.append(cur)
+        for para in paras:
+            if all(len(indent) + 2 + len(t) <= limit for t in para) or not para[0].strip():
+                out += [f"{indent}//{t}" for t in para]
+                continue
+            first_lead = para[0][:len(para[0]) - len(para[0].lstrip(" "))]
+            hang = para[1][:len(para[1]) - len(para[1].lstrip(" "))] if len(para) > 1 else (first_lead if not BULLET.match(para[0]) else first_lead + "  ")
+            text = " ".join(t.strip() for t in para)
+            # keep double spaces after full stops as the sources write them
+            width = limit - len(indent) - 2
+            wrapped = textwrap.wrap(text, width=width, initial_indent=first_lead or " ", subsequent_indent=hang or " ", break_long_words=False, break_on_hyphens=False)
+            out += [f"{indent}//{t}" for t in wrapped]
+            changed = True
+        i = j
+    return out, changed
+
+
 left = 0
 for path in a.files:
-    src = open(path).read().split("\n")
-    out, changed = [], False
+    src, block_changed = reflow_comment_blocks(open(path).read().split("\n"), a.limit)
+    out, changed = [], block_changed
     for n, line in enumerate(src, 1):
         if len(line) <= a.limit or line.rstrip().endswith("\\"):
             out.append(line)
