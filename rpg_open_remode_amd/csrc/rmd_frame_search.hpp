@@ -221,7 +221,6 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
   }
   // One step ahead (MatcherArgs::ahead): the first ahead_wgs workgroups -- dispatched first, so they never queue behind the persistent
   // ones -- bring the next host frame into the other current-image plane if the setup kernel found it in the ring, and leave.
-  // (As the LAST workgroups of the grid instead they measure the same: profiles/r06_ab_split_frames.txt.)
   if (NSEQ == 1 && blockIdx.x < static_cast<unsigned int>(M.ahead_wgs)) {
     const unsigned int next = M.ingest_number + 1u;
     if (ld_agent(M.ahead) != next) return;
@@ -293,10 +292,8 @@ __global__ __launch_bounds__(TILE_PIX, FR_MIN_WAVES) void seed_search_compact_ke
   W.clear(); W.m = 0; W.yref = 0;
   // Unit wg_id is ours for free.  When there are more units than workgroups the rest is handed out by sixteen counters (workgroup b draws
   // from counter b % 16, which deals the units n_wg + b % 16 + 16 k: one counter word for a thousand workgroups serialises their returning
-  // atomics for 12 us).  Claiming the next unit while the current one is searched was measured twice and lost twice: throughout (round 3: a
-  // unit claimed one unit-time earlier is a unit the fastest workgroup cannot take, profiles/r03_batch_ab.txt) and only while two more
-  // units per workgroup were left, with the claimed entry fetched by a scalar load during the rounds (round 4: batch of 4 -3 %, batch of 8
-  // -1 %, profiles/r04_early_claim_ab.txt) -- the two round trips it hides are not what a unit waits for.
+  // atomics for 12 us).  A unit is claimed only when the current one is done: a unit claimed earlier is a unit the fastest workgroup cannot
+  // take (LAB.md, "early claim").
   const bool handout = n_units > n_wg;
   const unsigned int cls = wg_id & (UNIT_SHARDS - 1);
   // the unit entries were written by the setup kernel, the launch before this one: scalar loads (the address is uniform, the words land in

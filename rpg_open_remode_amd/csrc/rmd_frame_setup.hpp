@@ -53,8 +53,7 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
   const int seq = NSEQ == 1 ? 0 : static_cast<int>(blockIdx.z);
   // one sequence: the named argument, which the compiler fetches with a few wide scalar loads at the top of the kernel; several: the
   // argument segment indexed by the sequence number (see BatchArgs), copied once so that its loads are issued here too and not one
-  // by one where the values are used (every one of those was a scalar-cache round trip on this kernel's dependent chain)
-  // (a batch's block read by reference instead: +0.5 %, within the noise: profiles/r04_ab_setup_args.txt)
+  // by one where the values are used (every one of those is a scalar-cache round trip on this kernel's dependent chain)
   const SeqArgs Q = NSEQ == 1 ? B.seq[0] : seq_table()[seq];
   const SeedParams& P = Q.P;
   if (NSEQ > 1 && !Q.active) return;  // this sequence has no frame in this launch
@@ -72,11 +71,10 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
   // frame ingest (see MatcherArgs): the workgroups IN FRONT of the tile grid (blockIdx.y < ingest_rows, at most INGEST_WGS of them per
   // sequence, launched only when host frames are pending) wait for the staging copy's flag and convert the staged frame into the
   // current-image plane.  They are dispatched first: the conversion runs beside the tiles' latency chains instead of behind the last of
-  // them (below the tile grid, as until round 5, a 1920x1080 frame's conversion started when the last of 8 160 tile workgroups had been
-  // placed and made the kernel 15 us longer).  Only these few workgroups ever wait: if every tile workgroup did, a device filled with
+  // them.  Only these few workgroups ever wait: if every tile workgroup did, a device filled with
   // waiting waves could keep a copy that is carried out by a blit kernel from ever running.  The wait is bounded; a copy that never
-  // arrives is reported through progress[1].  The flag is read with agent-scope acquire loads and the staged frame with agent-scope
-  // loads: the copy may finish after this kernel has started.
+  // arrives is reported through progress[1].  Flag and staged frame are read with agent-scope loads: the copy may finish after this kernel
+  // has started.
   const int wg = tile_by * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x);
   if (tile_by < 0 || tile_by >= M.tiles_y) {
     // One step ahead: the verdict for the NEXT frame -- has it been handed over (a pinned host word, frames read in place) / arrived in HBM
@@ -96,9 +94,8 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
     // step numbers are compared modulo 2^32 (a live system never stops counting): "behind" = the signed difference is negative.
     // The flag and the staged frame are read with RELAXED agent-scope loads and NO acquire fence: on this part an agent-scope acquire is a
     // cache invalidation (buffer_inv sc1: the vector L1 AND the lines of this XCD's L2 that other agents may have written), issued by every
-    // wave that executes it -- two per ingest wave until round 5, a few hundred of them at the head of every setup kernel with host frames,
-    // thrown at the L2 the tile workgroups are loading their seeds' state through (1920x1080, conversion left to the setup kernel: 147 us
-    // per update with them, profiles/r06_*).  What the acquire was there for holds without it: the frame's loads are agent-scope loads
+    // wave that executes it, thrown at the L2 the tile workgroups are loading their seeds' state through.  What an acquire would be there
+    // for holds without it: the frame's loads are agent-scope loads
     // themselves (they never hit a stale line), and they are issued after the branch that consumed the flag -- the hardware issues a
     // wave's instructions in order and does not speculate; the compiler is kept from moving them by the barrier below.
     auto behind = [&]() { return static_cast<int>(ld_agent(M.ingest_flag) - M.ingest_number) < 0; };
@@ -161,16 +158,15 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
   const int tile_g = (NSEQ == 1 ? 0 : seq * M.n_tiles) + tile;               // within the launch
   // A tile in which the previous frame's check left no seed in state UPDATE is DEAD until the next reference frame: BORDER / CONVERGED /
   // DIVERGED are absorbing (nothing but the finalisation of an UPDATE seed ever changes sigma_sq, a, b), so every plane, the tile's
-  // CONVERGED count and its empty descriptors already hold what this launch would write.  Its workgroup leaves after one scalar load -- on
-  // the ~170 light frames of the benchmark sequence that is four tiles in five, which used to fetch 44 bytes per pixel and run the check
-  // for nothing. (tile_live: written at the end of this kernel by the tile's own workgroup, read here one launch later; fuse_prev = nobody
-  // touched the planes in between.  The launch's housekeeping below must not depend on tile 0 being alive.) (the tile's word: seeds in
-  // state UPDATE after the previous frame's check | TILE_WANTS_BAND, see below)
+  // CONVERGED count and its empty descriptors already hold what this launch would write.  Its workgroup leaves after one scalar load (on
+  // the ~170 light frames of the benchmark sequence: four tiles in five). (tile_live: written at the end of this kernel by the tile's own
+  // workgroup, read here one launch later; fuse_prev = nobody touched the planes in between.  The launch's housekeeping below must not
+  // depend on tile 0 being alive.) (the tile's word: seeds in state UPDATE after the previous frame's check | TILE_WANTS_BAND, see below)
   const unsigned int tile_word = *(const __attribute__((address_space(4))) unsigned int*)(M.tile_live + tile_g);
   const bool dead_tile = Q.fuse_prev && (tile_word & 0xffffu) == 0u;
   // A tile whose samples did not fit a BOX-shaped window one frame ago (a bundle of long diagonal segments) gets a sheared band this frame;
   // everybody else -- nearly every tile of nearly every frame -- pays nothing for the machinery: no slope, no second pair of reductions.
-  // (The first frame on which a tile's box does not fit goes to the search kernel's own window policy, as before round 5.)
+  // (The first frame on which a tile's box does not fit goes to the search kernel's own window policy.)
   const bool want_band = LAB_WANT_BAND((tile_word & TILE_WANTS_BAND) != 0u);
   // the seed's state: requested before anything else, so that the scalar-load chains below (kernel arguments, the previous frame's
   // counters) run while these are in flight
@@ -188,8 +184,6 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
       __HIP_MEMORY_SCOPE_SYSTEM);
   // (computed here, at the top, so that its scalar loads travel with the kernel arguments)
   // unit size: 1..4 rounds of 256 evaluations, from the previous frame's work (a frame differs little from the one before)
-  // (capped at 3 / 2 rounds -- a shorter tail on the heaviest updates, more staging --: update 1 +6 %, batch of 8 -2 % / -8 %:
-  // profiles/r04_ab_unit_cap.txt)
   int unit_rounds = MAX_UNIT_ROUNDS;
   if (M.shards_prev) {
     // the previous frame's counters are not written by anybody while this kernel runs: read them through the scalar path (constant
@@ -200,7 +194,6 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
     unsigned long long items = 0;
 #pragma unroll
     for (int q = 0; q < UNIT_SHARDS; ++q) items += prev[q] >> 32;
-    // (rounding to nearest instead of up, or aiming at 2x / 3x as many units, changes nothing measurable: 48.2 - 49.0 us per update)
     const unsigned long long per_round = static_cast<unsigned long long>(target_units) * TILE_PIX;
     static_assert(MAX_UNIT_ROUNDS == 4, "the ladder below is ceil(items / per_round) clamped to 1..4");
     unit_rounds = items > 3 * per_round ? 4 : items > 2 * per_round ? 3 : items > per_round ? 2 : 1;  // no 64-bit division
@@ -209,9 +202,8 @@ __global__ __launch_bounds__(TILE_PIX) void seed_setup_compact_kernel(BatchArgs<
   // units of the last shards are the last to be searched, and while the last unit runs every other workgroup waits: up to one unit's time,
   // a fifth of the kernel on the frames that have two to five units per workgroup.  The tiles of shards 12, 13 cut their work into units of
   // half the frame's size, those of shards 14, 15 into quarters (at least one round): 12 % more units, the wait at the end a quarter as
-  // long -- update 1 96 -> 92.5 us, a sequence 38.2 -> 37.6 us per update (profiles/r05_ab_unit_tail.txt).  In a batch the other stream
-  // groups' kernels fill that wait already and the smaller units only cost their staging: -3 ... -4 % with every graduation tried; there
-  // all units of a frame have one size.
+  // long.  In a batch the other stream groups' kernels fill that wait already and the smaller units only cost their staging: there all
+  // units of a frame have one size.
   if (NSEQ == 1) unit_rounds = max(1, unit_rounds >> unit_tail_shift(tile_g % UNIT_SHARDS));
   // what the planes hold now (known only when the previous frame's values were loaded for its finalisation): a seed that has
   // converged or diverged keeps writing the same state and an empty descriptor, a third of this kernel's stores -- skipped

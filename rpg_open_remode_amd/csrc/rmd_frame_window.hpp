@@ -30,8 +30,7 @@ constexpr int FR_SHEAR_BITS = 11;
 constexpr unsigned int TILE_WANTS_BAND = 0x10000u;  // flag in a tile's word of MatcherArgs::tile_live (its low half: seeds in state UPDATE)
 RMDK_D int shear_of(int q, int m) { return (q * m) >> FR_SHEAR_BITS; }  // (arithmetic shift: floor, q may be negative)
 // Row stride of a window of `ww` texels per row: odd, so that the rows of a vertical bundle of samples start in different LDS banks.  (Lab
-// builds try others: LAB_WINDOW_STRIDE, rmd_lab.hpp; `ww | 3` and `(ww + 2) | 1` measured within the noise of `ww | 1`:
-// profiles/r06_ab_window_stride.txt.)
+// builds try others: LAB_WINDOW_STRIDE, rmd_lab.hpp.)
 RMDK_D constexpr int window_stride(int ww) { return LAB_WINDOW_STRIDE(ww); }
 
 // ---- agent-scope accessors (global address space, sc1) ---------------------------------------------------------------
@@ -136,9 +135,7 @@ RMDK_D float ncc_at_dyn(const SeedParams& P, F2 px, const float* __restrict__ wi
   } else if (irregular_in_window<SIDE>(px, row_start, ws, wy0, rows, ww)) {
     // An irregular footprint (the replayed roundings moved a column or a row by a texel: ~1e-6 of the steps) whose neighbourhood lies
     // inside the window: sample by sample like the path below, but from the LDS.  From L2 such an evaluation is 81 x 4 dependent round
-    // trips -- 15-20 us in ONE lane, and with a quarter of a million evaluations per light update every third or fourth update had one: its
-    // workgroup ended at 30 us where the others ended at 17 (profiles/r04_timeline_light_frames.txt: the "slowest workgroups" of updates
-    // 31, 34).
+    // trips -- 15-20 us in ONE lane, and with a quarter of a million evaluations per light update every third or fourth update has one.
 #pragma unroll 1
     for (int m = 0; m < SIDE; ++m) {
       const float cy = px.y + static_cast<float>(OFFSET + m) + 0.5f;
@@ -258,9 +255,7 @@ RMDK_D void clamp_window(FrameWindow& W) {
 // wave-uniform LDS base + lane x 4 bytes: exactly a row of the window; lanes past the row's end -- or outside the image, where a band may
 // reach but no footprint does -- are masked out), no vector register and no ds_write in between -- so ALL rows of a wave are in flight
 // together and the window arrives in ONE memory round trip whatever its shape; the row's first column is scalar arithmetic.  Also writes
-// the window's row table.  History: element-wise staging (a division of the element index by the run-time width per texel: 25 vector
-// instructions per texel row) -> row-wise through registers, 12 rows per lane in flight (a full 64 x 86 window: two round trips, 4-7 us of
-// an unboxed unit's 23) -> LDS-direct boxes (round 4: one sequence 43.4 -> 40.0 us per update) -> sheared bands (round 5).
+// the window's row table.
 // No barrier; the loads are still in flight when this returns.  A wave reads window rows that OTHER waves transferred, so every wave drains
 // its own transfers (drain_vmem: s_waitcnt vmcnt(0)) before the workgroup barrier that precedes the first read: a workgroup-scope release
 // only guarantees lgkmcnt(0), and the compiler tracks LDS-direct transfers per wave.  tests/test_kernel_budget.py checks the disassembly.

@@ -389,7 +389,7 @@ struct rmd_hip_batch {
   // frames handed over in host memory: the frames of one step, back to back, through SLOTS pinned buffers and SLOTS staging buffers
   // (see ingest_current_fused: the same protocol, one sequence number per step)
   static constexpr int SLOTS_MAX = 8;
-  // steps in flight between the caller and the setup kernels (RMD_HIP_TUNE_RING_DEPTH; 3 until round 5)
+  // steps in flight between the caller and the setup kernels (RMD_HIP_TUNE_RING_DEPTH)
   int slots = 5;
   unsigned char* h_stage[SLOTS_MAX] = {};
   unsigned char* d_stage[SLOTS_MAX] = {};
