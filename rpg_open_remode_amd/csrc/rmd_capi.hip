@@ -41,7 +41,7 @@ Tunables& tunables() {
     t.v[RMD_HIP_TUNE_INGEST_PROFILE] = 0;
     t.v[RMD_HIP_TUNE_HOST_WAIT] = 1;
     t.v[RMD_HIP_TUNE_RING_DEPTH] = 0;
-    t.v[RMD_HIP_TUNE_COPY_STREAMS] = 2;
+    t.v[RMD_HIP_TUNE_COPY_STREAMS] = 1;
     static const char* const names[RMD_HIP_NUM_TUNABLES] = {"RMD_HIP_HOST_FRAMES", "RMD_HIP_BATCH_GROUPS", "RMD_HIP_AHEAD_WGS",
         "RMD_HIP_PACK_BACKOFF",
                                                             "RMD_HIP_FLOAT_AS_BYTES", "RMD_HIP_COPY_THREADS", "RMD_HIP_FUSED_INGEST",
@@ -312,6 +312,12 @@ int rmdh::seeds_destroy_impl(rmd_hip_seeds* s) {
             s->ingest_us[3], s->ingest_us[0] / s->ingest_us[3], s->ingest_us[1] / s->ingest_us[3], s->ingest_us[2] / s->ingest_us[3],
                 g_progress_max_wait_us,
             g_progress_timeouts);
+    fprintf(stderr,
+        "[rmd_hip ingest] longest single phase of an update() call: ring wait %.0f us (frame %llu), copy into the slot %.0f us (%llu), "
+                    "copy-engine commands %.0f us (%llu), launches %.0f us (%llu)\n",
+            s->ingest_max_us[0], s->ingest_max_at[0], s->ingest_max_us[1], s->ingest_max_at[1], s->ingest_max_us[2], s->ingest_max_at[2],
+                s->ingest_max_us[3],
+            s->ingest_max_at[3]);
     if (s->h_progress)
       fprintf(stderr, "[rmd_hip ingest] frames handed over <=0 / 1 / 2 / 3 / >=4 ahead of the newest setup kernel that had started: "
                       "%lu / %lu / %lu / %lu / %lu; "

@@ -278,10 +278,12 @@ struct rmd_hip_seeds {
   hipEvent_t staged[SLOTS] = {};            // copy stream: the slot's frame is in its f32 plane
   hipEvent_t frame_done[SLOTS] = {};        // compute stream: the update that read the slot's plane has run
   hipStream_t copy_stream = nullptr;        // frame uploads and conversions run here, beside the previous frames' kernels
-  // A second copy stream: consecutive host frames of the fused path alternate between the two, so that two copy engines work on them.  One
-  // engine needs ~6 us per command beyond the transfer itself and every frame is two commands (the frame, its arrival flag): 22 us for a
-  // 640x480 8-bit frame, 58 us for a 1920x1080 one -- as long as the light updates of those sizes take (21 / 60 us), so that on the light
-  // two thirds of a sequence every second or third setup kernel waited for its frame (RMD_HIP_INGEST_PROFILE: "the kernel waited for").
+  // A second copy stream (RMD_HIP_TUNE_COPY_STREAMS = 2; OFF by default): consecutive host frames of the fused path alternate between the
+  // two. The runtime serves both with ONE copy engine, but one copy's submission overlaps the other's transfer: 640x480 39.1 -> 38.5 us per
+  // update (an engine needs ~6 us per command beyond the transfer and every frame is two commands: 22 us per VGA frame, as long as a light
+  // update). Off because with it one update() call in ~5 000 -- update 4..7 of a pass -- takes 9-10 ms: 8 of 17 runs of 80 passes against 2
+  // of 38 with one stream (profiles/r06_stall_hunt.txt; where the phase timers caught such a call it sat in the memcpy into the pinned
+  // slot). A 1.5 % gain is not worth one 17-ms pass in forty.
   hipStream_t copy_stream2 = nullptr;
   void* cur_planes[SLOTS] = {};             // current-image planes (pitch of planes[CURR_IMG]), used in rotation; [0] is the handle's own
   int u8_pitch = 0, ingest_slot = 0;
@@ -291,11 +293,10 @@ struct rmd_hip_seeds {
   // neither queue ever holds a barrier packet for the other. RING slots: the caller may be RING - 1 frames ahead of the setup kernel that
   // has started last.  With three, frame n was handed over when setup n - 2 started and reached HBM 55-60 us later (host copy, submission,
   // 35-45 us of copy engine) -- after setup n - 1 had looked for it, so it was rarely converted one step ahead (rmdk::MatcherArgs::ahead);
-  // with four it always is. Round 6: the depth is a run-time value (RMD_HIP_TUNE_RING_DEPTH; default 6).  At 1920x1080 a light update takes
-  // 60 us and a frame needs 130 us from the moment its slot is free to its arrival in HBM (the caller's wake-up, 2 MB into the pinned slot,
-  // two submissions, 50 us of copy engine): with four slots every fourth frame missed its step-ahead conversion.
+  // with four it always is.  The depth is a run-time value (RMD_HIP_TUNE_RING_DEPTH, 3..8; default 4): deeper rings bought nothing at any
+  // size (what a late frame waits for is the copy engine, not the caller).
   static constexpr int RING_MAX = 8;
-  int ring = 6;
+  int ring = 4;
   unsigned char* h_zc_u8[RING_MAX] = {};
   float* h_zc_f32[RING_MAX] = {};
   unsigned char* d_zc_u8[RING_MAX] = {};
@@ -318,6 +319,10 @@ struct rmd_hip_seeds {
   double ingest_us[4] = {0, 0, 0, 0};  // diagnostics (RMD_HIP_INGEST_PROFILE): host time waiting for a slot, copying, submitting; frames
   // ... and how many frames the caller was ahead of the newest setup kernel that had started when it handed a frame over (<= 0, 1, 2, 3, >=
   // 4)
+  // ... the longest single ring wait / copy into the slot / queueing of the copy-engine commands / pair of launches, and the frame it
+  // happened at
+  double ingest_max_us[4] = {0, 0, 0, 0};
+  unsigned long long ingest_max_at[4] = {0, 0, 0, 0};
   unsigned long ingest_lead[5] = {0, 0, 0, 0, 0};
   bool ingest_profile = false;
   rmdh::StageTimer timers[RMD_HIP_NUM_SEED_STAGES];
@@ -389,8 +394,8 @@ struct rmd_hip_batch {
   // frames handed over in host memory: the frames of one step, back to back, through SLOTS pinned buffers and SLOTS staging buffers
   // (see ingest_current_fused: the same protocol, one sequence number per step)
   static constexpr int SLOTS_MAX = 8;
-  // steps in flight between the caller and the setup kernels (RMD_HIP_TUNE_RING_DEPTH)
-  int slots = 5;
+  // steps in flight between the caller and the setup kernels (RMD_HIP_TUNE_RING_DEPTH; more than three bought nothing)
+  int slots = 3;
   unsigned char* h_stage[SLOTS_MAX] = {};
   unsigned char* d_stage[SLOTS_MAX] = {};
   size_t stage_bytes = 0;                   // capacity of each of the buffers above

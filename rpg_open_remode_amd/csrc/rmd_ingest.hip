@@ -312,6 +312,7 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
     in.common.kind = 2;
   }
   const bool ahead = frame_ahead(remap);
+  const double t_copied = s->ingest_profile ? host_now_us() : 0.0;
   if (in_place) {
     in.common.flag = nullptr;  // the setup kernel reads the pinned buffer itself: it is complete before the kernel is launched
   } else {
@@ -368,6 +369,10 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
   if (s->ingest_profile) {
     const double t_d = host_now_us();
     s->ingest_us[0] += t_b - t_a; s->ingest_us[1] += t_c - t_b; s->ingest_us[2] += t_d - t_c; s->ingest_us[3] += 1.0;
+    // ring wait, copy into the slot, copy-engine commands, launches
+    const double phase[4] = {t_b - t_a, t_copied - t_b, t_c - t_copied, t_d - t_c};
+    for (int q = 0; q < 4; ++q)
+      if (phase[q] > s->ingest_max_us[q]) { s->ingest_max_us[q] = phase[q]; s->ingest_max_at[q] = n64; }
   }
   return rc;
 }
