@@ -90,10 +90,11 @@ typedef struct rmd_hip_batch rmd_hip_batch_t;
 #define RMD_HIP_TUNE_FUSED_INGEST 6   /* 1 (default): host frames are converted by the update's own kernels; 0: upload + conversion kernel on the copy stream */
 #define RMD_HIP_TUNE_INGEST_PROFILE 7 /* 1: a handle prints the host time per frame it spent waiting / copying / submitting when it is destroyed */
 #define RMD_HIP_TUNE_HOST_WAIT 8      /* how update() waits for a free slot of its pinned frame ring (the device is up to three frames behind the caller): 1
-                                         (default) = spin for 2 us, then sleep in steps of ~15 us (the waiting thread's timer slack is set to 2 us);
+                                         (default) = spin for 2 us, then sleep in steps of ~15 us (the calling thread's timer slack is lowered to 2 us for the duration of
+                                         the wait and put back before update() returns; if it cannot be changed the steps are coarser);
                                          0 = spin only (one core per handle that is fed host frames at full speed) */
 #define RMD_HIP_TUNE_RING_DEPTH 9     /* frames (a batch: steps) that may be in flight between update() and the setup kernel that consumes them = slots of the pinned
-                                         frame ring, 3..8; 0 (default) = the library's choice: 6 for a SeedMatrix, 5 for a batch */
+                                         frame ring, 3..8; 0 (default) = the library's choice: 4 for a SeedMatrix, 3 for a batch */
 #define RMD_HIP_TUNE_COPY_STREAMS 10   /* copy streams a SeedMatrix spreads its staged host frames over, 1..2 (1; 2 is 1.5 % faster at 640x480 and stalls one update() in ~5 000 for 9 ms) */
 #define RMD_HIP_NUM_TUNABLES 11
 int rmd_hip_set_tunable(int tunable, int value);

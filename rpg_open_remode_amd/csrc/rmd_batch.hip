@@ -171,7 +171,7 @@ int rmd_hip_batch_destroy(rmd_hip_batch_t* b) {
   if (b->copy_stream) (void)hipStreamSynchronize(b->copy_stream);
   if (b->ingest_profile && b->ingest_us[3] > 0) {
     fprintf(stderr, "[rmd_hip ingest] batch of %d, %.0f steps: wait for slot %.2f us, host copy %.2f us, submit %.2f us per step; "
-                    "longest wait %.0f us, %lu waits gave up after 2 ms; "
+                    "longest wait %.0f us, %lu waits gave up (stream idle, word not reached); "
                     "steps handed over <=0 / 1 / 2 / 3 / >=4 ahead of group 0's newest started setup kernel: %lu / %lu / %lu / %lu / %lu\n",
             b->n, b->ingest_us[3], b->ingest_us[0] / b->ingest_us[3], b->ingest_us[1] / b->ingest_us[3], b->ingest_us[2] / b->ingest_us[3],
                 g_progress_max_wait_us,

@@ -308,7 +308,7 @@ int rmdh::seeds_destroy_impl(rmd_hip_seeds* s) {
   publish_release(s);
   if (s->ingest_profile && s->ingest_us[3] > 0) {
     fprintf(stderr, "[rmd_hip ingest] %.0f frames: wait for slot %.2f us, host copy %.2f us, submit %.2f us per frame; "
-                    "longest wait %.0f us, %lu waits gave up after 2 ms\n",
+                    "longest wait %.0f us, %lu waits gave up (stream idle, word not reached)\n",
             s->ingest_us[3], s->ingest_us[0] / s->ingest_us[3], s->ingest_us[1] / s->ingest_us[3], s->ingest_us[2] / s->ingest_us[3],
                 g_progress_max_wait_us,
             g_progress_timeouts);

@@ -236,7 +236,8 @@ inline hipError_t create_stream(hipStream_t* out, int level) {
   return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio);
 }
 
-extern unsigned long g_progress_timeouts;  // diagnostics (RMD_HIP_INGEST_PROFILE): waits for a staging slot that gave up after 2 ms
+// diagnostics (RMD_HIP_INGEST_PROFILE): waits for a staging slot that ended because the stream was idle before the word was reached
+extern unsigned long g_progress_timeouts;
 extern double g_progress_max_wait_us;   // ... and the longest such wait
 
 // ---- rmd::SeedMatrix ------------------------------------------------------------------------

@@ -49,7 +49,8 @@ static __global__ __launch_bounds__(256) void ingest_u8_remap_kernel(const unsig
 
 }  // namespace rmdk
 
-unsigned long g_progress_timeouts = 0;  // diagnostics (RMD_HIP_INGEST_PROFILE): waits for a staging slot that gave up after 2 ms
+// diagnostics (RMD_HIP_INGEST_PROFILE): waits for a staging slot that ended because the stream was idle before the word was reached
+unsigned long g_progress_timeouts = 0;
 double g_progress_max_wait_us = 0.0;    // ... and the longest such wait
 
 namespace rmdh {
@@ -202,13 +203,23 @@ int wait_for_progress(volatile unsigned int* progress, unsigned int need, hipStr
     const bool may_sleep = tunables().v[RMD_HIP_TUNE_HOST_WAIT] != 0;
     long saved_slack = -1;  // >= 0: the caller's timer slack, to be restored
     int rc = RMD_HIP_OK;
+    double next_query = 2000.0;
     while (behind()) {
       const double waited = host_now_us() - t0;
-      if (waited > 2000.0) {  // far behind (or another matcher ran the frames in between): an idle stream has read everything
-        ++g_progress_timeouts;
-        if (hipStreamSynchronize(stream) != hipSuccess) rc = fail(RMD_HIP_ERR_RUNTIME,
-            "waiting for a free slot of the frame ring: hipStreamSynchronize failed");
-        break;
+      // A long wait is either a long kernel (the first update of a 1920x1080 sequence takes 7-9 ms: keep waiting, in longer sleeps) or a
+      // word that will never move because nothing this wait is for is queued any more (another matcher ran the frames in between): then the
+      // stream is idle and has read everything.  Looked at twice per millisecond; counted as "gave up" only in the second case.
+      if (waited > next_query) {
+        next_query = waited + 500.0;
+        const hipError_t q = hipStreamQuery(stream);
+        if (q == hipSuccess) {
+          if (behind()) ++g_progress_timeouts;
+          break;
+        }
+        if (q != hipErrorNotReady) {
+          rc = fail(RMD_HIP_ERR_RUNTIME, "waiting for a free slot of the frame ring: hipStreamQuery failed: %s", hipGetErrorString(q));
+          break;
+        }
       }
       if (may_sleep && waited > 2.0) {
         if (saved_slack < 0) {
@@ -216,7 +227,7 @@ int wait_for_progress(volatile unsigned int* progress, unsigned int need, hipStr
           if (cur > 2000 && prctl(PR_SET_TIMERSLACK, 2000UL, 0UL, 0UL, 0UL) == 0) saved_slack = cur;
           else saved_slack = 0;  // (already fine, or not ours to change: nothing to restore)
         }
-        timespec ts = {0, 8000};  // 8 us + the slack + the scheduler's wake-up: 15-20 us in practice
+        timespec ts = {0, waited > 2000.0 ? 50000 : 8000};  // 8 us + the slack + the scheduler's wake-up: 15-20 us in practice
         (void)nanosleep(&ts, nullptr);
       } else {
         cpu_relax();

@@ -81,6 +81,28 @@ int main(int argc, char** argv) {
   fwrite(&n_points, 8, 1, out);
   fwrite(cloud.data(), 16, n_points, out);
   fclose(out);
+  // extension: the same products off the update stream (publishAsync / collectPublication), requested while the handle moves on -- they must be
+  // the synchronous ones above, bit for bit
+  {
+    std::vector<float> depth2(px), cloud2(static_cast<size_t>(px) * 4);
+    std::vector<unsigned char> bgr(static_cast<size_t>(px) * 3), bgr2(static_cast<size_t>(px) * 3);
+    std::vector<int> conv2(px);
+    seeds.downloadConvergenceBGR8(bgr.data());
+    const int ticket = seeds.publishAsync(RMD_HIP_PUBLISH_DEPTH | RMD_HIP_PUBLISH_CLOUD | RMD_HIP_PUBLISH_CONVERGENCE_BGR | RMD_HIP_PUBLISH_CONVERGENCE,
+                                          range[1] - range[0], 0.5f, 30);
+    unsigned int what = 0;
+    int got_ticket = 0;
+    size_t n2 = 0;
+    while (!seeds.collectPublication(false, &what, &got_ticket, depth2.data(), cloud2.data(), px, &n2, bgr2.data(), conv2.data())) {}  // polling: false = still in flight
+    if (got_ticket != ticket || n2 != n_points) return 11;
+    if (memcmp(depth2.data(), den.data(), sizeof(float) * px) != 0) return 12;
+    if (memcmp(cloud2.data(), cloud.data(), 16 * n_points) != 0) return 13;
+    if (memcmp(bgr2.data(), bgr.data(), bgr.size()) != 0) return 14;
+    if (memcmp(conv2.data(), conv.data(), sizeof(int) * px) != 0) return 15;
+    bool threw = false;
+    try { seeds.collectPublication(true, &what, &got_ticket, NULL, NULL, 0, &n2, NULL, NULL); } catch (const rmd::CudaException&) { threw = true; }  // nothing left
+    if (!threw) return 16;
+  }
   printf("facade_check OK: %dx%d, %d frames, converged %llu\n", w, h, n, n_conv);
   return 0;
 }
