@@ -375,6 +375,7 @@ def measure_config(api, synth, label, Wc, Hc, Fc, tv_iters, passes=1):
         return {"value": round(Wc * Hc * (Fc - 1) * passes / dt / 1e6, 1), "unit": "Mpix/s", "us_per_update_wall": round(dt / n * 1e6, 2),
                 "us_per_update_device": round(ms / n * 1e3, 2), "host_cores_busy": round(cpu / dt, 3), "passes": passes}
     u8 = timed(pass_u8)
+    u8["frames_on_copy_engines_addressed_directly"], u8["frames_on_the_copy_stream"] = s.stagedFrames()
     res = timed(pass_res)
     avg_s = u8["us_per_update_device"] / 1e6
     ach = FUSED_BYTES_PER_PIXEL * Wc * Hc / avg_s / 1e9
@@ -563,6 +564,13 @@ def main():
     kernel_ms, kernel_updates = seeds.timing(api.STAGE_UPDATE)  # device time of the region / update() calls in it
     seeds.setOption(api.OPT_TIMING, 0)
     converged = seeds.getConvergedCount()
+    # which way the host frames of this handle went (warm-up + timed passes): the library falls back to its copy stream by itself where it cannot
+    # address the copy engines (csrc/rmd_engines.hip)
+    staged_route = None
+    if hasattr(seeds, "stagedFrames") and not args.resident:
+        by_engines, by_stream = seeds.stagedFrames()
+        staged_route = {"RMD_HIP_TUNE_COPY_ENGINES": api.getTunable(api.TUNE_COPY_ENGINES), "frames_on_copy_engines_addressed_directly": by_engines,
+                        "frames_on_the_copy_stream": by_stream}
     n_updates = (F - 1) * args.steps          # update() calls of ONE sequence; a batch steps B sequences per call
     units = float(W * H * n_updates * B)
     max_elapsed, total_units, per_rank = batch.gather_throughput(elapsed, units, device, extra=(float(n_updates * B), float(converged), float(B), host_cpu_s, host_submit_s))
@@ -844,6 +852,7 @@ def main():
             # the wall time per update() call until the call returned (frame copied into the pinned ring, two launches queued) -- the device
             # time per update is roofline.avg_launch_us; a host that needs longer than that paces the run
             "host_cpu_s": round(host_cpu_s, 4), "host_cores_busy": round(host_cpu_s / elapsed, 3), "host_submit_us_per_update": round(host_submit_s / n_updates * 1e6, 2),
+            "host_frame_route": staged_route,
             # spread inside the timed region (rank 0): the K passes one by one, as the caller sees them -- the time between the returns of the last
             # update() of consecutive passes; the caller runs at most three frames ahead of the device, so a pass is its device time +- 0.1 ms
             "pass_ms": ({"first": round((pass_marks[1] - pass_marks[0]) * 1e3, 4), "min": round(min(b - a for a, b in zip(pass_marks, pass_marks[1:])) * 1e3, 4),

@@ -80,8 +80,9 @@ typedef struct rmd_hip_batch rmd_hip_batch_t;
  * this library, tools/ab_make.sh.) */
 #define RMD_HIP_TUNE_HOST_FRAMES 0    /* how a frame handed over in host memory reaches the current-image plane: 0 staged (a copy engine fills a staging
                                          buffer in HBM), 1 staged_ahead (... and the frame is converted during the previous update's search kernel), 2 inplace
-                                         (the kernels read the pinned ring themselves), 3 inplace_ahead; -1 (default) = staged_ahead for a SeedMatrix,
-                                         inplace for a batch; frames with lens undistortion are always staged.  Environment: the names or the numbers */
+                                         (the kernels read the pinned ring themselves), 3 inplace_ahead; -1 (default) = staged for a SeedMatrix (staged_ahead
+                                         when RMD_HIP_TUNE_COPY_ENGINES is 0), inplace for a batch; frames with lens undistortion are always staged.
+                                         Environment: the names or the numbers */
 #define RMD_HIP_TUNE_BATCH_GROUPS 1   /* stream groups of a batch, 1..4; 0 (default) = min(n, 3) */
 #define RMD_HIP_TUNE_AHEAD_WGS 2      /* workgroups that convert a host frame one step ahead (128) */
 #define RMD_HIP_TUNE_PACK_BACKOFF 3   /* after a float frame that is not made of 8-bit levels the next n frames are not examined (15; tests use 0) */
@@ -96,7 +97,13 @@ typedef struct rmd_hip_batch rmd_hip_batch_t;
 #define RMD_HIP_TUNE_RING_DEPTH 9     /* frames (a batch: steps) that may be in flight between update() and the setup kernel that consumes them = slots of the pinned
                                          frame ring, 3..8; 0 (default) = the library's choice: 4 for a SeedMatrix, 3 for a batch */
 #define RMD_HIP_TUNE_COPY_STREAMS 10   /* copy streams a SeedMatrix spreads its staged host frames over, 1..2 (1; 2 is 1.5 % faster at 640x480 and stalls one update() in ~5 000 for 9 ms) */
-#define RMD_HIP_NUM_TUNABLES 11
+#define RMD_HIP_TUNE_COPY_ENGINES 11  /* how a SeedMatrix's staged host frames travel: 0 = hipMemcpyAsync on the handle's copy stream (one engine for every
+                                         host-to-device copy of the process; the arrival flag a second, 64-KB command behind the frame); 1..3 = on copy
+                                         engines addressed directly (csrc/rmd_engines.hip), the flag a 4-byte dependent copy: 1 = one engine, 2 (default) =
+                                         frames alternate between two engines, each flag behind its frame, 3 = ... the flags on two engines of their own
+                                         (fastest alone, slowest when processes share a device).  Falls back to 0 by itself where the engines cannot be
+                                         addressed */
+#define RMD_HIP_NUM_TUNABLES 12
 int rmd_hip_set_tunable(int tunable, int value);
 int rmd_hip_get_tunable(int tunable, int* value);
 
@@ -215,6 +222,9 @@ int rmd_hip_seeds_publish_peek(rmd_hip_seeds_t* s, int wait, unsigned int* what,
                                const unsigned char** bgr, const int** convergence);
 int rmd_hip_seeds_publish_release(rmd_hip_seeds_t* s);
 int rmd_hip_seeds_dist_from_ref(const rmd_hip_seeds_t* s, float* dist);
+/* diagnostics (not in the reference): how this handle's staged host frames have travelled so far -- counts[0] on copy engines addressed directly
+ * (RMD_HIP_TUNE_COPY_ENGINES 1..3), counts[1] on the handle's copy stream (route 0, and the fallback where the engines cannot be addressed) */
+int rmd_hip_seeds_staged_frames(const rmd_hip_seeds_t* s, unsigned long long counts[2]);
 /* blocks until all work queued by this handle has finished */
 int rmd_hip_seeds_sync(const rmd_hip_seeds_t* s);
 

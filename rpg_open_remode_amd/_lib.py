@@ -57,6 +57,7 @@ SIGNATURES = {
     "rmd_hip_seeds_converged_count": (_i, [_p, _c.POINTER(_sz)]),
     "rmd_hip_seeds_convergence_bgr8": (_i, [_p, _p]),
     "rmd_hip_seeds_dist_from_ref": (_i, [_p, _c.POINTER(_f)]),
+    "rmd_hip_seeds_staged_frames": (_i, [_p, _c.POINTER(_c.c_ulonglong)]),
     "rmd_hip_seeds_sync": (_i, [_p]),
     "rmd_hip_seeds_set_option": (_i, [_p, _i, _i]),
     "rmd_hip_seeds_timing": (_i, [_p, _i, _c.POINTER(_c.c_double), _c.POINTER(_c.c_long)]),

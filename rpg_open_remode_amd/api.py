@@ -34,7 +34,7 @@ OPT_INJECT_FAULT = 9  # test hook, see include/rmd_hip.h
 PUBLISH_DEPTH, PUBLISH_CLOUD, PUBLISH_CONVERGENCE_BGR, PUBLISH_CONVERGENCE = 1, 2, 4, 8  # include/rmd_hip.h: RMD_HIP_PUBLISH_*
 
 # process-wide settings of the host side (include/rmd_hip.h: RMD_HIP_TUNE_*; the environment presets them: RMD_HIP_<NAME>)
-TUNE_HOST_FRAMES, TUNE_BATCH_GROUPS, TUNE_AHEAD_WGS, TUNE_PACK_BACKOFF, TUNE_FLOAT_AS_BYTES, TUNE_COPY_THREADS, TUNE_FUSED_INGEST, TUNE_INGEST_PROFILE, TUNE_HOST_WAIT, TUNE_RING_DEPTH, TUNE_COPY_STREAMS = range(11)
+TUNE_HOST_FRAMES, TUNE_BATCH_GROUPS, TUNE_AHEAD_WGS, TUNE_PACK_BACKOFF, TUNE_FLOAT_AS_BYTES, TUNE_COPY_THREADS, TUNE_FUSED_INGEST, TUNE_INGEST_PROFILE, TUNE_HOST_WAIT, TUNE_RING_DEPTH, TUNE_COPY_STREAMS, TUNE_COPY_ENGINES = range(12)
 HOST_FRAMES_DEFAULT, HOST_FRAMES_STAGED, HOST_FRAMES_STAGED_AHEAD, HOST_FRAMES_INPLACE, HOST_FRAMES_INPLACE_AHEAD = -1, 0, 1, 2, 3
 
 
@@ -403,6 +403,12 @@ class SeedMatrix:
         out = ctypes.c_float()
         check(_lib.lib().rmd_hip_seeds_dist_from_ref(self.ptr, ctypes.byref(out)))
         return float(out.value)
+
+    def stagedFrames(self):
+        """(frames staged on copy engines addressed directly, frames staged on the copy stream) so far: which way RMD_HIP_TUNE_COPY_ENGINES really went"""
+        out = (ctypes.c_ulonglong * 2)()
+        check(_lib.lib().rmd_hip_seeds_staged_frames(self.ptr, out))
+        return int(out[0]), int(out[1])
 
     def publishAsync(self, what, depth_range=0.0, lam=0.5, iterations=200):
         """rmd_hip_seeds_publish_async: snapshot the state and queue its publication products (PUBLISH_* bits: TV-L1 denoised depth map, point

@@ -54,7 +54,7 @@ def hipcc_path():
     raise RuntimeError("hipcc not found")
 
 
-HIP_UNITS = ["rmd_capi", "rmd_update", "rmd_ingest", "rmd_batch", "rmd_denoise", "rmd_reduce", "rmd_publish"]  # translation units of librmd_hip.so (csrc/rmd_host.hpp says who owns what)
+HIP_UNITS = ["rmd_capi", "rmd_update", "rmd_ingest", "rmd_batch", "rmd_denoise", "rmd_reduce", "rmd_publish", "rmd_engines"]  # translation units of librmd_hip.so (csrc/rmd_host.hpp says who owns what)
 
 
 def build_hip(force=False, verbose=False, extra_flags=(), out=None):
@@ -90,7 +90,8 @@ def build_hip(force=False, verbose=False, extra_flags=(), out=None):
     objs = [os.path.join(obj_dir, u + tag + ".o") for u in units]
     linked = False
     if force or compiled or _newer(out, objs):
-        _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out], verbose=verbose)
+        # (libhsa-runtime64: the runtime libamdhip64 itself sits on -- rmd_engines.hip addresses the copy engines through it)
+        _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out, "-lhsa-runtime64"], verbose=verbose)
         linked = True
     build_hip.last_report = {"library": out, "compiled": compiled, "reused": reused, "linked": linked}
     return out

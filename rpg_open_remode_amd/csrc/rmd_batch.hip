@@ -147,6 +147,8 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
   if (overlap) CopyPool::instance().finish_copy_many();  // (also after a failed launch: the pool must be released)
   if (rc == RMD_HIP_OK && !in_place) {
     const size_t off = static_cast<size_t>(first) * frame_bytes, len = static_cast<size_t>(last - first + 1) * frame_bytes;
+    // (on the copy stream: a batch's default is in place; its staged steps gained nothing from the engines addressed directly --
+    // profiles/r06_ab_copy_engines.txt)
     HIP_TRY(hipMemcpyAsync(b->d_stage[k] + off, b->h_stage[k] + off, len, hipMemcpyHostToDevice, b->copy_stream));
     // behind the frames on the same stream: when the kernel sees n, they are in HBM
     fill_flag_block(b->h_seq + k * FLAG_SLOT_WORDS, n, fw);

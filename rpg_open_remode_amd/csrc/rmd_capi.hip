@@ -23,8 +23,8 @@ int fail(int code, const char* fmt, ...) {
 const char* last_error() { return g_last_error; }
 
 // accepted values per tunable (rmd_hip_set_tunable AND the environment presets)
-static const int tunable_lo[RMD_HIP_NUM_TUNABLES] = {-1, 0, 1, 0, 0, 1, 0, 0, 0, 0, 1}, tunable_hi[RMD_HIP_NUM_TUNABLES] = {3, 4, 1024,
-    1 << 20, 1, 16, 1, 1, 1, 8, 2};
+static const int tunable_lo[RMD_HIP_NUM_TUNABLES] = {-1, 0, 1, 0, 0, 1, 0, 0, 0, 0, 1, 0}, tunable_hi[RMD_HIP_NUM_TUNABLES] = {3, 4, 1024,
+    1 << 20, 1, 16, 1, 1, 1, 8, 2, 3};
 
 // The library's process-wide settings and THE ONE PLACE where it reads its environment (include/rmd_hip.h: RMD_HIP_TUNE_*): the
 // defaults come from RMD_HIP_<NAME>, once, at the first call; rmd_hip_set_tunable overrides them for handles created afterwards.
@@ -42,11 +42,12 @@ Tunables& tunables() {
     t.v[RMD_HIP_TUNE_HOST_WAIT] = 1;
     t.v[RMD_HIP_TUNE_RING_DEPTH] = 0;
     t.v[RMD_HIP_TUNE_COPY_STREAMS] = 1;
+    t.v[RMD_HIP_TUNE_COPY_ENGINES] = 2;  // (3 loses a quarter when eight processes share a device: profiles/r06_ab_copy_engines.txt)
     static const char* const names[RMD_HIP_NUM_TUNABLES] = {"RMD_HIP_HOST_FRAMES", "RMD_HIP_BATCH_GROUPS", "RMD_HIP_AHEAD_WGS",
         "RMD_HIP_PACK_BACKOFF",
                                                             "RMD_HIP_FLOAT_AS_BYTES", "RMD_HIP_COPY_THREADS", "RMD_HIP_FUSED_INGEST",
                                                                 "RMD_HIP_INGEST_PROFILE", "RMD_HIP_HOST_WAIT",
-                                                            "RMD_HIP_RING_DEPTH", "RMD_HIP_COPY_STREAMS"};
+                                                            "RMD_HIP_RING_DEPTH", "RMD_HIP_COPY_STREAMS", "RMD_HIP_COPY_ENGINES"};
     // A preset from the environment passes the same range check as rmd_hip_set_tunable; one that fails it -- or does not parse -- is
     // IGNORED with a line on stderr (a negative RMD_HIP_AHEAD_WGS used to go straight into the search kernel's grid arithmetic).
     for (int k = 0; k < RMD_HIP_NUM_TUNABLES; ++k) {
@@ -305,6 +306,7 @@ int rmdh::seeds_destroy_impl(rmd_hip_seeds* s) {
   for (auto& t : s->timers) t.destroy();
   if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);
   if (s->copy_stream2) (void)hipStreamSynchronize(s->copy_stream2);
+  ingest_release_engines(s);
   publish_release(s);
   if (s->ingest_profile && s->ingest_us[3] > 0) {
     fprintf(stderr, "[rmd_hip ingest] %.0f frames: wait for slot %.2f us, host copy %.2f us, submit %.2f us per frame; "
@@ -318,12 +320,15 @@ int rmdh::seeds_destroy_impl(rmd_hip_seeds* s) {
             s->ingest_max_us[0], s->ingest_max_at[0], s->ingest_max_us[1], s->ingest_max_at[1], s->ingest_max_us[2], s->ingest_max_at[2],
                 s->ingest_max_us[3],
             s->ingest_max_at[3]);
-    if (s->h_progress)
+    if (s->h_progress) {
+      fprintf(stderr, "[rmd_hip ingest] staged frames: %lu on copy engines addressed directly (route %d), %lu on the copy stream\n",
+              s->staged_by_engines, s->engine_route, s->staged_by_stream);
       fprintf(stderr, "[rmd_hip ingest] frames handed over <=0 / 1 / 2 / 3 / >=4 ahead of the newest setup kernel that had started: "
                       "%lu / %lu / %lu / %lu / %lu; "
                       "converted by their own setup kernel (not one step ahead) %u, of which the kernel waited for %u (%u polls)\n",
               s->ingest_lead[0], s->ingest_lead[1], s->ingest_lead[2], s->ingest_lead[3], s->ingest_lead[4], s->h_progress[2],
                   s->h_progress[3], s->h_progress[4]);
+    }
   }
   for (int k = 0; k < rmd_hip_seeds::RING_MAX; ++k) {
     if (s->h_zc_u8[k]) (void)hipHostFree(s->h_zc_u8[k]);
@@ -555,6 +560,13 @@ int rmd_hip_seeds_converged_count(const rmd_hip_seeds_t* s, size_t* count) {
 int rmd_hip_seeds_dist_from_ref(const rmd_hip_seeds_t* s, float* dist) {
   if (!s || !dist) return fail(RMD_HIP_ERR_INVALID_ARG, "dist_from_ref: null argument");
   *dist = s->dist_from_ref;
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_seeds_staged_frames(const rmd_hip_seeds_t* s, unsigned long long counts[2]) {
+  if (!s || !counts) return fail(RMD_HIP_ERR_INVALID_ARG, "staged_frames: null argument");
+  counts[0] = s->staged_by_engines;
+  counts[1] = s->staged_by_stream;
   return RMD_HIP_OK;
 }
 

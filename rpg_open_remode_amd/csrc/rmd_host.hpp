@@ -147,6 +147,9 @@ struct ScopedStage {
 
 }  // namespace rmdh
 
+namespace rmdh { class CopyEngines; }
+using rmdh::CopyEngines;
+
 // ---- rmd::DeviceImage<T> -------------------------------------------------------------------
 struct rmd_hip_image {
   int kind = 0, width = 0, height = 0, device = 0;
@@ -176,10 +179,11 @@ struct rmd_hip_image {
 //   in place  the ingest workgroups read the pinned ring themselves over the host link: no copy engine, no staging, no flag.
 // "+ ahead" (single sequences): frame n + 1 is converted during the SEARCH kernel of frame n whenever it has arrived (staged) or been
 // handed over (in place) by the time setup n runs (rmdk::MatcherArgs::ahead); setup n + 1 then finds nothing left to do.
-// Defaults (measured, profiles/r03_h2d.txt): a single sequence uses staged + ahead -- the copy engine does not touch the CUs, whereas
-// link reads issued by a CU delay the loads of the workgroups it shares its memory pipeline with (in place + ahead: search +4.5 us per
-// update); a batch uses in place -- its setup kernels are long enough to hide the link time and the copy engine's 25-30 us of fixed
-// cost per copy is what bounds a step of 4..8 frames (8 sequences: 10 470 -> 12 740 Mpix/s).  Frames that go through the lens-
+// Defaults (measured): a single sequence uses STAGED on copy engines addressed directly (rmd_engines.hpp; profiles/r06_ab_copy_engines.txt) and
+// staged + ahead where its frames travel on the copy stream (RMD_HIP_TUNE_COPY_ENGINES = 0; profiles/r03_h2d.txt) -- the copy engines do not
+// touch the CUs, whereas link reads issued by a CU delay the loads of the workgroups it shares its memory pipeline with (in place + ahead:
+// search +4.5 us per update); a batch uses in place -- its setup kernels are long enough to hide most of the link time, and its caller is
+// never far enough ahead of the device for a copy engine (8 sequences: 10 470 -> 12 740 Mpix/s).  Frames that go through the lens-
 // undistortion maps are always staged, without ahead (the remap gathers single bytes).  A/B: RMD_HIP_TUNE_HOST_FRAMES.
 enum { HOST_FRAMES_DEFAULT = -1, HOST_FRAMES_STAGED = 0, HOST_FRAMES_STAGED_AHEAD = 1, HOST_FRAMES_INPLACE = 2,
     HOST_FRAMES_INPLACE_AHEAD = 3 };
@@ -198,7 +202,9 @@ Tunables& tunables();
 inline int host_frames_mode(bool batch) {
   const int forced = rmdh::tunables().v[RMD_HIP_TUNE_HOST_FRAMES];
   if (forced != HOST_FRAMES_DEFAULT) return forced;
-  return batch ? HOST_FRAMES_INPLACE : HOST_FRAMES_STAGED_AHEAD;
+  // (a single sequence: with the frames on copy engines addressed directly they arrive early enough for the frame's OWN setup kernel, whose
+  // ingest workgroups convert beside the tiles' latency chains for nothing; one step ahead costs the search kernel its bringers)
+  return batch ? HOST_FRAMES_INPLACE : rmdh::tunables().v[RMD_HIP_TUNE_COPY_ENGINES] > 0 ? HOST_FRAMES_STAGED : HOST_FRAMES_STAGED_AHEAD;
 }
 inline bool frame_in_place(bool batch, bool remap) {
   const int m = host_frames_mode(batch);
@@ -286,6 +292,14 @@ struct rmd_hip_seeds {
   // of 38 with one stream (profiles/r06_stall_hunt.txt; where the phase timers caught such a call it sat in the memcpy into the pinned
   // slot). A 1.5 % gain is not worth one 17-ms pass in forty.
   hipStream_t copy_stream2 = nullptr;
+  // Staged frames on copy engines addressed directly (rmd_engines.hpp; RMD_HIP_TUNE_COPY_ENGINES: 0 = the copy stream above, 1 = one
+  // engine, 2 = frames alternate between two engines, 3 = ... and their flags between two more): one completion signal per ring slot for
+  // the frame, one for its flag.  engines == nullptr: they cannot be used in this process (or a submission was refused once): the copy
+  // stream carries the frames.
+  CopyEngines* engines = nullptr;
+  int engine_route = 0;
+  uint64_t sig_frame[8] = {}, sig_flag[8] = {};  // [RING_MAX]
+  unsigned long staged_by_engines = 0, staged_by_stream = 0;  // diagnostics (RMD_HIP_INGEST_PROFILE)
   void* cur_planes[SLOTS] = {};             // current-image planes (pitch of planes[CURR_IMG]), used in rotation; [0] is the handle's own
   int u8_pitch = 0, ingest_slot = 0;
   // fused ingest (tile pipeline): the caller's frame is copied into one of SLOTS pinned buffers, a copy engine moves it to a staging buffer
@@ -500,6 +514,7 @@ int ingest_current(rmd_hip_seeds* s, const unsigned char* host_gray, const float
 int ingest_reference(rmd_hip_seeds* s, const unsigned char* host_gray, const float* host_f32, const float* T_curr_world, float min_depth,
     float max_depth);
 int wait_for_progress(volatile unsigned int* progress, unsigned int need, hipStream_t stream);
+void ingest_release_engines(rmd_hip_seeds* s);  // waits for what the copy engines still hold of this handle; destroys its signals
 // rmd_batch.hip
 int batch_bind_device(const rmd_hip_batch* b);
 // rmd_publish.hip

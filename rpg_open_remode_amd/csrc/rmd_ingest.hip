@@ -3,6 +3,7 @@
 // maps.
 #include "rmd_host.hpp"
 #include "rmd_copy_pool.hpp"
+#include "rmd_engines.hpp"
 
 #include <sys/prctl.h>
 
@@ -70,6 +71,24 @@ namespace rmdh {
 //   copy      wait until the update that read the slot's plane (SLOTS frames ago) has run -> H2D -> [u8: x(1/255) / remap kernel]
 //   compute   wait until the slot's plane is staged -> this frame's kernels -> mark the slot's plane free
 //     The current image rotates through SLOTS planes; planes[CURR_IMG] always names the one of the latest frame.
+void ingest_release_engines(rmd_hip_seeds* s) {
+  bool any = false;
+  for (int q = 0; q < rmd_hip_seeds::RING_MAX; ++q) any = any || s->sig_frame[q] || s->sig_flag[q];
+  s->engines = nullptr;
+  if (!any) return;
+  CopyEngines* e = CopyEngines::for_device(s->device);  // (not s->engines: it may have been given up while copies were in flight)
+  for (int q = 0; q < rmd_hip_seeds::RING_MAX; ++q) {
+    for (uint64_t* sig : {&s->sig_frame[q], &s->sig_flag[q]}) {
+      if (!*sig || !e) continue;
+      // an engine that still owes this signal its completion writes it -- and the staging buffer -- when it gets there: neither is freed
+      // under it (a withheld flag leaves no copy behind: its signal was never raised)
+      if (e->wait_idle(*sig, 2e6)) e->destroy_signal(*sig);
+      *sig = 0;
+    }
+  }
+  s->engines = nullptr;
+}
+
 int ingest_init(rmd_hip_seeds* s) {
   if (s->ingest_ready) return RMD_HIP_OK;
   if (!s->copy_stream) HIP_TRY(create_stream(&s->copy_stream, 2));  // (a batch member uses the batch's)
@@ -79,6 +98,14 @@ int ingest_init(rmd_hip_seeds* s) {
   s->opt_fused_ingest = T.v[RMD_HIP_TUNE_FUSED_INGEST] != 0;
   s->pack_backoff_len = T.v[RMD_HIP_TUNE_PACK_BACKOFF];  // (tests: 0 examines every float frame)
   s->ingest_ready = true;
+  s->engine_route = s->batch ? 0 : T.v[RMD_HIP_TUNE_COPY_ENGINES];
+  if (s->engine_route > 0 && (s->engines = CopyEngines::for_device(s->device)) != nullptr) {
+    for (int q = 0; q < rmd_hip_seeds::RING_MAX; ++q) {
+      s->sig_frame[q] = s->engines->create_signal();
+      s->sig_flag[q] = s->engines->create_signal();
+      if (!s->sig_frame[q] || !s->sig_flag[q]) { ingest_release_engines(s); break; }
+    }
+  }
   {
     const int depth = T.v[RMD_HIP_TUNE_RING_DEPTH];
     if (depth > 0) s->ring = depth < 3 ? 3 : depth;  // (three: the caller's slot, the copy engine's, the one the kernels read)
@@ -327,16 +354,40 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
   if (in_place) {
     in.common.flag = nullptr;  // the setup kernel reads the pinned buffer itself: it is complete before the kernel is launched
   } else {
-    // (frame and flag on ONE stream, consecutive frames on alternating streams: see copy_stream2)
-    hipStream_t cs = (s->copy_stream2 && (n64 & 1ull)) ? s->copy_stream2 : s->copy_stream;
-    HIP_TRY(hipMemcpyAsync(stage_dst, stage_src, stage_bytes, hipMemcpyHostToDevice, cs));
-    const size_t fw = flag_words(s->h_progress, n);
-    // behind the frame on the same stream: when the kernel sees n, the frame is in HBM
-    fill_flag_block(s->h_seq + k * FLAG_SLOT_WORDS, n, fw);
     unsigned int* slot_flag = flag_of(as_u8 ? 0 : 1, k);
     // fault injection: the frame arrives, its flag never does -> the kernel's bounded wait runs out
-    if (s->inject_withhold_flag) s->inject_withhold_flag = false;
-    else HIP_TRY(hipMemcpyAsync(slot_flag, s->h_seq + k * FLAG_SLOT_WORDS, fw * sizeof(unsigned int), hipMemcpyHostToDevice, cs));
+    const bool withhold = s->inject_withhold_flag;
+    s->inject_withhold_flag = false;
+    bool sent = false;
+    if (s->engines) {
+      // The frame on a data engine, its flag -- one word -- on a flag engine that waits for the frame's completion in hardware
+      // (rmd_engines.hpp).  The slot's signals are idle: the slot was consumed, so its flag had landed; what may be a few microseconds
+      // behind is the flag engine's own completion signal.
+      if (!s->engines->wait_idle(s->sig_frame[k], 2e6) || !s->engines->wait_idle(s->sig_flag[k], 2e6))
+        return fail(RMD_HIP_ERR_RUNTIME, "a copy engine has not completed ring slot %d's previous frame after 2 s", k);
+      s->h_seq[k * FLAG_SLOT_WORDS] = n;
+      // 1: one engine; 2: frames alternate between two engines, a frame's flag is the next command of its own engine; 3: ... and the flags
+      // go to two engines of their own
+      const unsigned de = s->engine_route > 1 ? static_cast<unsigned>(n64 & 1ull) : 0u, fe = s->engine_route > 2 ? 2u + de : de;
+      sent = s->engines->submit(de, fe, stage_dst, stage_src, stage_bytes,
+                                s->sig_frame[k], withhold ? nullptr : slot_flag, s->h_seq + k * FLAG_SLOT_WORDS, sizeof(unsigned int),
+                                s->sig_flag[k]);
+      if (!sent) {  // refused: this frame and every later one take the copy stream
+        if (s->ingest_profile) fprintf(stderr, "[rmd_hip ingest] copy engines given up: %s\n", s->engines->last_error());
+        s->engines = nullptr;
+      }
+    }
+    ++(sent ? s->staged_by_engines : s->staged_by_stream);
+    if (!sent) {
+      // (frame and flag on ONE stream, consecutive frames on alternating streams: see copy_stream2)
+      hipStream_t cs = (s->copy_stream2 && (n64 & 1ull)) ? s->copy_stream2 : s->copy_stream;
+      HIP_TRY(hipMemcpyAsync(stage_dst, stage_src, stage_bytes, hipMemcpyHostToDevice, cs));
+      const size_t fw = flag_words(s->h_progress, n);
+      // behind the frame on the same stream: when the kernel sees n, the frame is in HBM
+      fill_flag_block(s->h_seq + k * FLAG_SLOT_WORDS, n, fw);
+      if (!withhold)
+        HIP_TRY(hipMemcpyAsync(slot_flag, s->h_seq + k * FLAG_SLOT_WORDS, fw * sizeof(unsigned int), hipMemcpyHostToDevice, cs));
+    }
     in.common.flag = slot_flag;
   }
   int plane = 0;  // one plane is enough: setup k writes it after search k - 1 has run (same stream)

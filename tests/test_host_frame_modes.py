@@ -65,6 +65,37 @@ def test_every_host_frame_mode_equals_the_resident_path(mode):
     assert res.returncode == 0 and "MODES-OK" in res.stdout, res.stdout[-2000:]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["staged", "staged_ahead"])
+@pytest.mark.parametrize("engines", [0, 1, 2, 3])
+def test_staged_frames_by_every_copy_route_equal_the_resident_path(engines, mode):
+    """RMD_HIP_COPY_ENGINES: staged frames on copy engines addressed directly (one engine, two, two + two for the flags) or on the copy stream -- the same bits,
+    and the route asked for is the route taken (the library falls back to the copy stream by itself where the engines cannot be addressed: on this box they can)."""
+    env = dict(os.environ, RMD_HIP_HOST_FRAMES=mode, RMD_HIP_PACK_BACKOFF="0", RMD_HIP_COPY_ENGINES=str(engines), RMD_HIP_INGEST_PROFILE="1")
+    res = subprocess.run([sys.executable, "-c", CHILD, ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert res.returncode == 0 and "MODES-OK" in res.stdout, res.stdout[-2000:]
+    import re
+    routes = [(int(a), int(b)) for a, b in re.findall(r"staged frames: (\d+) on copy engines addressed directly \(route \d\), (\d+) on the copy stream", res.stdout)]
+    assert len(routes) >= 3, res.stdout[-2000:]  # (the three single-sequence runs with host frames)
+    for by_engines, by_stream in routes:
+        assert by_engines + by_stream == 11 and (by_stream == 0 if engines else by_engines == 0), (engines, routes, res.stdout[-1500:])
+
+
+@pytest.mark.gpu
+def test_the_default_route_of_host_frames_is_the_copy_engines():
+    """no environment: a SeedMatrix's 8-bit host frames travel on copy engines addressed directly (rmd_hip_seeds_staged_frames says so) -- a silent fall-back to
+    the copy stream on a box where the engines can be addressed would be a regression nobody sees in the parity tests"""
+    code = ("import sys; sys.path.insert(0, sys.argv[1])\n"
+            "from rpg_open_remode_amd import api, synth\n"
+            "seq = synth.Sequence(320, 240, 8, 0); s = api.SeedMatrix(320, 240, api.PinholeCamera(*seq.K), patch_side=5)\n"
+            "s.setReferenceImageU8(seq.gray[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)\n"
+            "for k in range(1, 8): s.updateU8(seq.gray[k], seq.T_curr_world[k])\n"
+            "s.sync(); print('ROUTE', s.stagedFrames(), api.getTunable(api.TUNE_COPY_ENGINES), api.getTunable(api.TUNE_HOST_FRAMES))\n")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("RMD_HIP_") or k == "RMD_HIP_LIB"}
+    res = subprocess.run([sys.executable, "-c", code, ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert res.returncode == 0 and "ROUTE (7, 0) 2 -1" in res.stdout, res.stdout[-2000:]
+
+
 GROUPS_CHILD = r'''
 import sys, numpy as np
 sys.path.insert(0, sys.argv[1])
