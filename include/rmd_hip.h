@@ -98,11 +98,11 @@ typedef struct rmd_hip_batch rmd_hip_batch_t;
                                          frame ring, 3..8; 0 (default) = the library's choice: 4 for a SeedMatrix, 3 for a batch */
 #define RMD_HIP_TUNE_COPY_STREAMS 10   /* copy streams a SeedMatrix spreads its staged host frames over, 1..2 (1; 2 is 1.5 % faster at 640x480 and stalls one update() in ~5 000 for 9 ms) */
 #define RMD_HIP_TUNE_COPY_ENGINES 11  /* how a SeedMatrix's staged host frames travel: 0 = hipMemcpyAsync on the handle's copy stream (one engine for every
-                                         host-to-device copy of the process; the arrival flag a second, 64-KB command behind the frame); 1..3 = on copy
-                                         engines addressed directly (csrc/rmd_engines.hip), the flag a 4-byte dependent copy: 1 = one engine, 2 (default) =
-                                         frames alternate between two engines, each flag behind its frame, 3 = ... the flags on two engines of their own
-                                         (fastest alone, slowest when processes share a device).  Falls back to 0 by itself where the engines cannot be
-                                         addressed */
+                                         host-to-device copy of the process; the arrival flag a second, 64-KB command behind the frame); 1..4 = on that many
+                                         copy engines addressed directly (csrc/rmd_engines.hip), consecutive frames on consecutive engines, each frame's
+                                         flag a 4-byte dependent copy behind it on its own engine; -1 (default) = two engines, three for frames of 1.5
+                                         Mpixel or more.  Falls back to 0 by itself where the engines cannot be addressed (rmd_hip_seeds_staged_frames
+                                         tells) */
 #define RMD_HIP_NUM_TUNABLES 12
 int rmd_hip_set_tunable(int tunable, int value);
 int rmd_hip_get_tunable(int tunable, int* value);

@@ -23,8 +23,8 @@ int fail(int code, const char* fmt, ...) {
 const char* last_error() { return g_last_error; }
 
 // accepted values per tunable (rmd_hip_set_tunable AND the environment presets)
-static const int tunable_lo[RMD_HIP_NUM_TUNABLES] = {-1, 0, 1, 0, 0, 1, 0, 0, 0, 0, 1, 0}, tunable_hi[RMD_HIP_NUM_TUNABLES] = {3, 4, 1024,
-    1 << 20, 1, 16, 1, 1, 1, 8, 2, 3};
+static const int tunable_lo[RMD_HIP_NUM_TUNABLES] = {-1, 0, 1, 0, 0, 1, 0, 0, 0, 0, 1, -1}, tunable_hi[RMD_HIP_NUM_TUNABLES] = {3, 4, 1024,
+    1 << 20, 1, 16, 1, 1, 1, 8, 2, 4};
 
 // The library's process-wide settings and THE ONE PLACE where it reads its environment (include/rmd_hip.h: RMD_HIP_TUNE_*): the
 // defaults come from RMD_HIP_<NAME>, once, at the first call; rmd_hip_set_tunable overrides them for handles created afterwards.
@@ -42,7 +42,7 @@ Tunables& tunables() {
     t.v[RMD_HIP_TUNE_HOST_WAIT] = 1;
     t.v[RMD_HIP_TUNE_RING_DEPTH] = 0;
     t.v[RMD_HIP_TUNE_COPY_STREAMS] = 1;
-    t.v[RMD_HIP_TUNE_COPY_ENGINES] = 2;  // (3 loses a quarter when eight processes share a device: profiles/r06_ab_copy_engines.txt)
+    t.v[RMD_HIP_TUNE_COPY_ENGINES] = -1;
     static const char* const names[RMD_HIP_NUM_TUNABLES] = {"RMD_HIP_HOST_FRAMES", "RMD_HIP_BATCH_GROUPS", "RMD_HIP_AHEAD_WGS",
         "RMD_HIP_PACK_BACKOFF",
                                                             "RMD_HIP_FLOAT_AS_BYTES", "RMD_HIP_COPY_THREADS", "RMD_HIP_FUSED_INGEST",

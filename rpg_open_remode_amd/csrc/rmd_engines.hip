@@ -56,28 +56,29 @@ bool g_engines_tried[MAX_DEVICES] = {false};
 
 }  // namespace
 
-CopyEngines* CopyEngines::for_device(int hip_device) {
+CopyEngines* CopyEngines::for_device(int hip_device, int n_engines) {
   if (hip_device < 0 || hip_device >= MAX_DEVICES) return nullptr;
   std::lock_guard<std::mutex> lock(g_engines_mutex);
   if (!g_engines_tried[hip_device]) {
     g_engines_tried[hip_device] = true;
     CopyEngines* e = new CopyEngines();
-    if (e->init(hip_device)) g_engines[hip_device] = e;
+    if (e->find_agents(hip_device)) g_engines[hip_device] = e;
     else {
       if (tunables().v[RMD_HIP_TUNE_INGEST_PROFILE]) fprintf(stderr, "[rmd_hip ingest] copy engines not used: %s\n", e->err_);
       delete e;
     }
   }
-  return g_engines[hip_device];
+  CopyEngines* e = g_engines[hip_device];
+  if (e && n_engines > e->n_ready_ && !e->first_copies(n_engines)) {
+    if (tunables().v[RMD_HIP_TUNE_INGEST_PROFILE]) fprintf(stderr, "[rmd_hip ingest] copy engines not used: %s\n", e->err_);
+    return nullptr;
+  }
+  return e;
 }
 
-bool CopyEngines::init(int hip_device) {
-  auto no = [&](const char* what, hsa_status_t st) {
-    snprintf(err_, sizeof err_, "%s: %s", what, status_text(st));
-    return false;
-  };
+bool CopyEngines::find_agents(int hip_device) {
   hsa_status_t st = hsa_init();  // (reference-counted: HIP holds the runtime open already)
-  if (st != HSA_STATUS_SUCCESS) return no("hsa_init", st);
+  if (st != HSA_STATUS_SUCCESS) { snprintf(err_, sizeof err_, "hsa_init: %s", status_text(st)); return false; }
   int bus = 0, dev = 0, domain = 0;
   if (hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, hip_device) != hipSuccess ||
       hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, hip_device) != hipSuccess ||
@@ -89,19 +90,25 @@ bool CopyEngines::init(int hip_device) {
   S.want_domain = static_cast<uint32_t>(domain);
   S.want_bdf = (static_cast<uint32_t>(bus) << 8) | (static_cast<uint32_t>(dev) << 3);
   st = hsa_iterate_agents(visit_agent, &S);
-  if (st != HSA_STATUS_SUCCESS) return no("hsa_iterate_agents", st);
+  if (st != HSA_STATUS_SUCCESS) { snprintf(err_, sizeof err_, "hsa_iterate_agents: %s", status_text(st)); return false; }
   if (!S.have_gpu && S.n_gpus == 1) { S.gpu = S.only_gpu; S.have_gpu = true; }  // (one GPU in the process: no address needed to tell it)
   if (!S.have_gpu || !S.have_cpu) {
     snprintf(err_, sizeof err_, "no HSA agent at PCI %04x:%02x:%02x (HIP device %d)", domain, bus, dev, hip_device);
     return false;
   }
   gpu_ = S.gpu.handle; cpu_ = S.cpu.handle;
-  // Each engine is tried once with a word of its own -- which also makes the runtime create the engine's queue here and not inside the
-  // first update() that uses it (2-4 ms).
-  // Engines [0] and [1] carry frames: 0x1 and 0x4, not 0x1 and 0x2 -- two frames in flight with their flags behind them take 41 us per
-  // 1920x1080 frame on the former pair and 48 us on the latter (as on 0x4 / 0x8: neighbours share something; tools/link_probe.cpp, route G).
-  const unsigned want[4] = {HSA_AMD_SDMA_ENGINE_0, HSA_AMD_SDMA_ENGINE_2, HSA_AMD_SDMA_ENGINE_1, HSA_AMD_SDMA_ENGINE_3};
-  const int n_want = tunables().v[RMD_HIP_TUNE_COPY_ENGINES] >= 3 ? 4 : 2;
+  // The order frames rotate in: 0x1, 0x4, 0x2, 0x8 -- not 0x1, 0x2: two frames in flight with their flags behind them take 41 us per
+  // 1920x1080 frame on 0x1 / 0x4 and 48 us on 0x1 / 0x2 (as on 0x4 / 0x8: neighbours share something; tools/link_probe.cpp, route G).
+  engine_[0] = HSA_AMD_SDMA_ENGINE_0; engine_[1] = HSA_AMD_SDMA_ENGINE_2; engine_[2] = HSA_AMD_SDMA_ENGINE_1; engine_[3] =
+      HSA_AMD_SDMA_ENGINE_3;
+  return true;
+}
+
+// Engines [n_ready_, n) are tried once with a word of their own -- which also makes the runtime create each engine's queue here and not
+// inside the first update() that uses it (2-4 ms).  Under g_engines_mutex.
+bool CopyEngines::first_copies(int n) {
+  if (n > 4) n = 4;
+  const hsa_agent_t gpu = as_agent(gpu_), cpu = as_agent(cpu_);
   unsigned int* h_word = nullptr; unsigned int* d_word = nullptr;
   if (hipHostMalloc(reinterpret_cast<void**>(&h_word), 64, hipHostMallocDefault) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&d_word), 64) != hipSuccess) {
@@ -114,25 +121,25 @@ bool CopyEngines::init(int hip_device) {
   const uint64_t sig = create_signal();
   bool ok = sig != 0;
   if (!ok) snprintf(err_, sizeof err_, "hsa_signal_create failed");
-  for (int q = 0; ok && q < n_want; ++q) {
+  for (int q = n_ready_; ok && q < n; ++q) {
     hsa_signal_store_relaxed(as_signal(sig), 1);
-    st = hsa_amd_memory_async_copy_on_engine(d_word, S.gpu, h_word, S.cpu, 4, 0, nullptr, as_signal(sig),
-                                             static_cast<hsa_amd_sdma_engine_id_t>(want[q]), false);
+    const hsa_status_t st = hsa_amd_memory_async_copy_on_engine(d_word, gpu, h_word, cpu, 4, 0, nullptr, as_signal(sig),
+                                                                static_cast<hsa_amd_sdma_engine_id_t>(engine_[q]), false);
     if (st != HSA_STATUS_SUCCESS) {
       hsa_signal_store_relaxed(as_signal(sig), 0);
-      ok = no("hsa_amd_memory_async_copy_on_engine (first copy)", st);
+      snprintf(err_, sizeof err_, "hsa_amd_memory_async_copy_on_engine (first copy, engine 0x%x): %s", engine_[q], status_text(st));
+      ok = false;
     } else if (!wait_idle(sig, 2e6)) {
-      snprintf(err_, sizeof err_, "engine 0x%x did not complete its first copy within 2 s", want[q]);
+      snprintf(err_, sizeof err_, "engine 0x%x did not complete its first copy within 2 s", engine_[q]);
       return false;  // (signal and words stay allocated: the engine may still write them)
+    } else {
+      n_ready_ = q + 1;
     }
   }
   if (sig) destroy_signal(sig);
   (void)hipFree(d_word);
   (void)hipHostFree(h_word);
-  if (!ok) return false;
-  for (int q = 0; q < 4; ++q) engine_[q] = want[q];
-  n_ready_ = n_want;
-  return true;
+  return ok;
 }
 
 uint64_t CopyEngines::create_signal() {
@@ -160,10 +167,12 @@ bool CopyEngines::wait_idle(uint64_t sig, double timeout_us) const {
 bool CopyEngines::submit(unsigned data_engine, unsigned flag_engine, void* dst, const void* src, size_t bytes, uint64_t frame_sig,
                          void* flag_dst, const void* flag_src, size_t flag_bytes, uint64_t flag_sig) {
   const hsa_agent_t gpu = as_agent(gpu_), cpu = as_agent(cpu_);
-  const unsigned de = engine_[data_engine % static_cast<unsigned>(n_ready_)], fe = engine_[flag_engine % static_cast<unsigned>(n_ready_)];
+  const unsigned n_ready = static_cast<unsigned>(n_ready_ > 0 ? n_ready_ : 1);
+  const unsigned de = engine_[data_engine % n_ready], fe = engine_[flag_engine % n_ready];
   const hsa_signal_t fs = as_signal(frame_sig);
   hsa_signal_store_relaxed(fs, 1);
-  hsa_status_t st = hsa_amd_memory_async_copy_on_engine(dst, gpu, src, cpu, bytes, 0, nullptr, fs, static_cast<hsa_amd_sdma_engine_id_t>(de),
+  hsa_status_t st = hsa_amd_memory_async_copy_on_engine(dst, gpu, src, cpu, bytes, 0, nullptr, fs,
+      static_cast<hsa_amd_sdma_engine_id_t>(de),
                                                         false);
   if (st != HSA_STATUS_SUCCESS) {
     hsa_signal_store_relaxed(fs, 0);

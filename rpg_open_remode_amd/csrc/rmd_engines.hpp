@@ -20,10 +20,9 @@ namespace rmdh {
 
 class CopyEngines {
  public:
-  // The engines of a HIP device, or nullptr when they cannot be used (agents not found, an engine refused its first copy): the caller
-  // stays on its copy stream.  The object lives as long as the process; the first call decides how many engines it holds (2, or 4 when
-  // RMD_HIP_TUNE_COPY_ENGINES is 3 at that time).
-  static CopyEngines* for_device(int hip_device);
+  // The engines of a HIP device with (at least) the first n_engines of them (1..4) ready, or nullptr when they cannot be used (agents not
+  // found, an engine refused its first copy): the caller stays on its copy stream.  The object lives as long as the process.
+  static CopyEngines* for_device(int hip_device, int n_engines);
 
   // a completion signal (0 = idle); 0 on failure
   uint64_t create_signal();
@@ -32,11 +31,11 @@ class CopyEngines {
   // until the engine has completed what the signal stands for; false after `timeout_us`
   bool wait_idle(uint64_t sig, double timeout_us) const;
 
-  // dst <- src (bytes) on engine `data_engine` (0..3); then, once that has landed, flag_dst <- flag_src (flag_bytes) on engine
-  // `flag_engine` -- the same engine: the next command in its queue; another one: that engine waits for the frame's completion signal in
-  // hardware, i.e. it is busy polling until then.  flag_dst == nullptr: no flag (fault injection: the frame arrives, its flag never does).
-  // Both signals must be idle.  false: the runtime refused (last_error() says why) -- the frame copy may be in flight all the same:
-  // frame_sig tells.
+  // dst <- src (bytes) on engine `data_engine` (0..3, modulo the engines that are ready); then, once that has landed, flag_dst <- flag_src
+  // (flag_bytes) on engine `flag_engine` -- the same engine: the next command in its queue; another one: that engine waits for the frame's
+  // completion signal in hardware, i.e. it is busy polling until then (fastest for one process, -26 % when eight share a device).  flag_dst
+  // == nullptr: no flag (fault injection: the frame arrives, its flag never does). Both signals must be idle.  false: the runtime refused
+  // (last_error() says why) -- the frame copy may be in flight all the same: frame_sig tells.
   bool submit(unsigned data_engine, unsigned flag_engine, void* dst, const void* src, size_t bytes, uint64_t frame_sig, void* flag_dst,
               const void* flag_src, size_t flag_bytes, uint64_t flag_sig);
   int engines_ready() const { return n_ready_; }
@@ -45,7 +44,8 @@ class CopyEngines {
 
  private:
   CopyEngines() = default;
-  bool init(int hip_device);
+  bool find_agents(int hip_device);
+  bool first_copies(int n);
   uint64_t gpu_ = 0, cpu_ = 0;          // hsa_agent_t handles
   unsigned engine_[4] = {0, 0, 0, 0};  // hsa_amd_sdma_engine_id_t bits
   int n_ready_ = 0;                    // engines [0, n_ready_) have carried a first copy

@@ -175,16 +175,16 @@ struct rmd_hip_image {
 // caller may reuse it when update() returns); from there
 //   staged    the copy engine brings it into a staging buffer in HBM, followed by its arrival flag, with no ordering against the compute
 //             stream; the ingest workgroups of the frame's setup kernel wait for the flag and convert the frame into the current-image
-//             plane (rmdk::MatcherArgs);
-//   in place  the ingest workgroups read the pinned ring themselves over the host link: no copy engine, no staging, no flag.
-// "+ ahead" (single sequences): frame n + 1 is converted during the SEARCH kernel of frame n whenever it has arrived (staged) or been
-// handed over (in place) by the time setup n runs (rmdk::MatcherArgs::ahead); setup n + 1 then finds nothing left to do.
-// Defaults (measured): a single sequence uses STAGED on copy engines addressed directly (rmd_engines.hpp; profiles/r06_ab_copy_engines.txt) and
-// staged + ahead where its frames travel on the copy stream (RMD_HIP_TUNE_COPY_ENGINES = 0; profiles/r03_h2d.txt) -- the copy engines do not
-// touch the CUs, whereas link reads issued by a CU delay the loads of the workgroups it shares its memory pipeline with (in place + ahead:
-// search +4.5 us per update); a batch uses in place -- its setup kernels are long enough to hide most of the link time, and its caller is
-// never far enough ahead of the device for a copy engine (8 sequences: 10 470 -> 12 740 Mpix/s).  Frames that go through the lens-
-// undistortion maps are always staged, without ahead (the remap gathers single bytes).  A/B: RMD_HIP_TUNE_HOST_FRAMES.
+//             plane (rmdk::MatcherArgs); in place  the ingest workgroups read the pinned ring themselves over the host link: no copy
+//             engine, no staging, no flag. "+ ahead" (single sequences): frame n + 1 is converted during the SEARCH kernel of frame n
+//             whenever it has arrived (staged) or been handed over (in place) by the time setup n runs (rmdk::MatcherArgs::ahead); setup n
+//             + 1 then finds nothing left to do. Defaults (measured): a single sequence uses STAGED on copy engines addressed directly
+//             (rmd_engines.hpp; profiles/r06_ab_copy_engines.txt) and staged + ahead where its frames travel on the copy stream
+//             (RMD_HIP_TUNE_COPY_ENGINES = 0; profiles/r03_h2d.txt) -- the copy engines do not touch the CUs, whereas link reads issued by
+//             a CU delay the loads of the workgroups it shares its memory pipeline with (in place + ahead: search +4.5 us per update); a
+//             batch uses in place -- its setup kernels are long enough to hide most of the link time, and its caller is never far enough
+//             ahead of the device for a copy engine (8 sequences: 10 470 -> 12 740 Mpix/s).  Frames that go through the lens- undistortion
+//             maps are always staged, without ahead (the remap gathers single bytes).  A/B: RMD_HIP_TUNE_HOST_FRAMES.
 enum { HOST_FRAMES_DEFAULT = -1, HOST_FRAMES_STAGED = 0, HOST_FRAMES_STAGED_AHEAD = 1, HOST_FRAMES_INPLACE = 2,
     HOST_FRAMES_INPLACE_AHEAD = 3 };
 constexpr int AHEAD_WGS = 128;  // workgroups of the search kernel that bring the next frame in (MatcherArgs::ahead)
@@ -204,7 +204,7 @@ inline int host_frames_mode(bool batch) {
   if (forced != HOST_FRAMES_DEFAULT) return forced;
   // (a single sequence: with the frames on copy engines addressed directly they arrive early enough for the frame's OWN setup kernel, whose
   // ingest workgroups convert beside the tiles' latency chains for nothing; one step ahead costs the search kernel its bringers)
-  return batch ? HOST_FRAMES_INPLACE : rmdh::tunables().v[RMD_HIP_TUNE_COPY_ENGINES] > 0 ? HOST_FRAMES_STAGED : HOST_FRAMES_STAGED_AHEAD;
+  return batch ? HOST_FRAMES_INPLACE : rmdh::tunables().v[RMD_HIP_TUNE_COPY_ENGINES] != 0 ? HOST_FRAMES_STAGED : HOST_FRAMES_STAGED_AHEAD;
 }
 inline bool frame_in_place(bool batch, bool remap) {
   const int m = host_frames_mode(batch);
@@ -292,10 +292,9 @@ struct rmd_hip_seeds {
   // of 38 with one stream (profiles/r06_stall_hunt.txt; where the phase timers caught such a call it sat in the memcpy into the pinned
   // slot). A 1.5 % gain is not worth one 17-ms pass in forty.
   hipStream_t copy_stream2 = nullptr;
-  // Staged frames on copy engines addressed directly (rmd_engines.hpp; RMD_HIP_TUNE_COPY_ENGINES: 0 = the copy stream above, 1 = one
-  // engine, 2 = frames alternate between two engines, 3 = ... and their flags between two more): one completion signal per ring slot for
-  // the frame, one for its flag.  engines == nullptr: they cannot be used in this process (or a submission was refused once): the copy
-  // stream carries the frames.
+  // Staged frames on copy engines addressed directly (rmd_engines.hpp; RMD_HIP_TUNE_COPY_ENGINES: 0 = the copy stream above, 1..4 = that
+  // many engines in rotation): one completion signal per ring slot for the frame, one for its flag.  engines == nullptr: they cannot be
+  // used in this process (or a submission was refused once): the copy stream carries the frames.
   CopyEngines* engines = nullptr;
   int engine_route = 0;
   uint64_t sig_frame[8] = {}, sig_flag[8] = {};  // [RING_MAX]

@@ -76,7 +76,7 @@ void ingest_release_engines(rmd_hip_seeds* s) {
   for (int q = 0; q < rmd_hip_seeds::RING_MAX; ++q) any = any || s->sig_frame[q] || s->sig_flag[q];
   s->engines = nullptr;
   if (!any) return;
-  CopyEngines* e = CopyEngines::for_device(s->device);  // (not s->engines: it may have been given up while copies were in flight)
+  CopyEngines* e = CopyEngines::for_device(s->device, 0);  // (not s->engines: it may have been given up while copies were in flight)
   for (int q = 0; q < rmd_hip_seeds::RING_MAX; ++q) {
     for (uint64_t* sig : {&s->sig_frame[q], &s->sig_flag[q]}) {
       if (!*sig || !e) continue;
@@ -98,8 +98,12 @@ int ingest_init(rmd_hip_seeds* s) {
   s->opt_fused_ingest = T.v[RMD_HIP_TUNE_FUSED_INGEST] != 0;
   s->pack_backoff_len = T.v[RMD_HIP_TUNE_PACK_BACKOFF];  // (tests: 0 examines every float frame)
   s->ingest_ready = true;
+  // engines in rotation; -1: the library's choice -- two, three for frames of 1.5 Mpixel or more (1920x1080: 41 -> 37 us of engine time per
+  // frame against a 45-us light update, +10 %; smaller frames gain nothing from a third engine and lose 6 % with it when eight processes
+  // share a device: profiles/r06_ab_copy_engines.txt)
   s->engine_route = s->batch ? 0 : T.v[RMD_HIP_TUNE_COPY_ENGINES];
-  if (s->engine_route > 0 && (s->engines = CopyEngines::for_device(s->device)) != nullptr) {
+  if (s->engine_route < 0) s->engine_route = static_cast<long long>(s->width) * s->height >= 1500000ll ? 3 : 2;
+  if (s->engine_route > 0 && (s->engines = CopyEngines::for_device(s->device, s->engine_route)) != nullptr) {
     for (int q = 0; q < rmd_hip_seeds::RING_MAX; ++q) {
       s->sig_frame[q] = s->engines->create_signal();
       s->sig_flag[q] = s->engines->create_signal();
@@ -366,9 +370,8 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
       if (!s->engines->wait_idle(s->sig_frame[k], 2e6) || !s->engines->wait_idle(s->sig_flag[k], 2e6))
         return fail(RMD_HIP_ERR_RUNTIME, "a copy engine has not completed ring slot %d's previous frame after 2 s", k);
       s->h_seq[k * FLAG_SLOT_WORDS] = n;
-      // 1: one engine; 2: frames alternate between two engines, a frame's flag is the next command of its own engine; 3: ... and the flags
-      // go to two engines of their own
-      const unsigned de = s->engine_route > 1 ? static_cast<unsigned>(n64 & 1ull) : 0u, fe = s->engine_route > 2 ? 2u + de : de;
+      // frames rotate over engine_route engines (1..4); a frame's flag is the next command of its own engine
+      const unsigned de = static_cast<unsigned>(n64 % static_cast<unsigned long long>(s->engine_route)), fe = de;
       sent = s->engines->submit(de, fe, stage_dst, stage_src, stage_bytes,
                                 s->sig_frame[k], withhold ? nullptr : slot_flag, s->h_seq + k * FLAG_SLOT_WORDS, sizeof(unsigned int),
                                 s->sig_flag[k]);

@@ -77,7 +77,7 @@ int main(int argc, char** argv) {
 
   if (hsa_ok) {  // the runtime creates an engine's queue at its first use: not inside a timed loop
     hsa_signal_t w; HSA(hsa_signal_create(1, 0, nullptr, &w));
-    for (uint32_t b = 1; b <= 0x10u; b <<= 1) {
+    for (uint32_t b = 1; b <= 0x40u; b <<= 1) {
       hsa_signal_store_relaxed(w, 1);
       if (hsa_amd_memory_async_copy_on_engine(d, A.gpu, h, A.cpu, 1 << 20, 0, nullptr, w, static_cast<hsa_amd_sdma_engine_id_t>(b), false) == HSA_STATUS_SUCCESS)
         while (hsa_signal_wait_scacquire(w, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_ACTIVE) >= 1) {}
@@ -213,6 +213,28 @@ int main(int argc, char** argv) {
         run_f(2, 4, 0xffffu, "G  frames alternating 0x2 / 0x4, a frame's flag on its own");
         run_f(4, 8, 0xffffu, "G  frames alternating 0x4 / 0x8, a frame's flag on its own");
         run_f(1, 0x10, 0xffffu, "G  frames alternating 0x1 / 0x10, a frame's flag on its own");
+        // G with any number of engines: frame i and its flag on engine list[i % n]
+        auto run_g = [&](std::vector<uint32_t> list, const char* what) -> int {
+          for (auto& s : sig) hsa_signal_store_relaxed(s, 1);
+          for (auto& s : fsig) hsa_signal_store_relaxed(s, 1);
+          CHECK(hipDeviceSynchronize());
+          const double t0 = now_us();
+          for (int i = 0; i < n; ++i) {
+            const hsa_amd_sdma_engine_id_t e = static_cast<hsa_amd_sdma_engine_id_t>(list[i % list.size()]);
+            hsa_status_t st = hsa_amd_memory_async_copy_on_engine(slot_d(i), A.gpu, slot_h(i), A.cpu, bytes, 0, nullptr, sig[i], e, false);
+            if (st == HSA_STATUS_SUCCESS)
+              st = hsa_amd_memory_async_copy_on_engine(dflag + (i % SLOTS) * 64, A.gpu, hflag + (i % SLOTS) * 64, A.cpu, 4, 1, &sig[i], fsig[i], e, false);
+            if (st != HSA_STATUS_SUCCESS) { const char* m = nullptr; hsa_status_string(st, &m); printf("  %-14s %s: refused (%s)\n", names[si], what, m ? m : "?"); return 0; }
+          }
+          for (int i = 0; i < n; ++i)
+            while (hsa_signal_wait_scacquire(fsig[i], HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_ACTIVE) >= 1) {}
+          report(what, now_us() - t0, n);
+          return 0;
+        };
+        run_g({1, 4, 0x10}, "G  frames over 0x1 / 0x4 / 0x10, a frame's flag on its own");
+        run_g({1, 4, 2}, "G  frames over 0x1 / 0x4 / 0x2, a frame's flag on its own");
+        run_g({1, 4, 2, 8}, "G  frames over 0x1 / 0x4 / 0x2 / 0x8, a frame's flag on its own");
+        run_g({1, 4, 0x10, 0x40}, "G  frames over 0x1 / 0x4 / 0x10 / 0x40, a frame's flag on its own");
         // latency of one frame + flag on an idle link (submit -> flag landed)
         {
           double worst = 0, sum = 0;
