@@ -144,7 +144,9 @@ bool CopyEngines::first_copies(int n) {
 
 uint64_t CopyEngines::create_signal() {
   hsa_signal_t s;
-  if (hsa_signal_create(0, 0, nullptr, &s) != HSA_STATUS_SUCCESS) return 0;
+  // Consumed by the device's engines only (a dependent copy waits for it) and READ by the host (idle()): no interrupt and no event of the
+  // kernel driver behind it (an interrupt signal changed neither rate nor host time: gpurun r06_y).
+  if (hsa_amd_signal_create(0, 0, nullptr, HSA_AMD_SIGNAL_AMD_GPU_ONLY, &s) != HSA_STATUS_SUCCESS) return 0;
   return s.handle;
 }
 
