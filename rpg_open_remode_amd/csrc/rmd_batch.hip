@@ -2,6 +2,7 @@
 // TV-L1 for all of them in one launch sequence.
 #include "rmd_host.hpp"
 #include "rmd_copy_pool.hpp"
+#include "rmd_engines.hpp"
 
 using namespace rmdh;
 
@@ -39,7 +40,42 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
   const double t_a = b->ingest_profile ? host_now_us() : 0.0;
   const unsigned long long n64 = ++b->step_number;
   const unsigned int n = static_cast<unsigned int>(n64);
-  const int k = static_cast<int>(n64 % static_cast<unsigned long long>(b->slots));
+  // Staged on a copy engine addressed directly (b->engines): the pinned block of a step is free as soon as the engine has read it, and what
+  // the kernels read is a staging buffer in HBM -- of which there are SLOTS_MAX, so that the caller may hand steps over that far ahead of
+  // the slowest stream group (the groups drift apart; with one ring for both, the fastest group ran into the newest step's frames while
+  // the host was held back by the slowest: 70-97 % of its setup kernels waited for their copy).  kp: pinned slot, k: staging slot.
+  bool any_maps = false;
+  int n_active = 0;
+  for (int i = 0; i < b->n; ++i) {
+    if (!((active >> i) & 1u)) continue;
+    ++n_active;
+    any_maps = any_maps || (gray && b->members[i]->d_undist_map1);
+  }
+  // In place or staged?  What RMD_HIP_TUNE_HOST_FRAMES says; left alone (-1): staged on the engine while a step is at most 3 MB (eight
+  // 640x480 frames: 16 180-16 380 against 14 980-15 020 Mpix/s in place, four: 14 780-14 990 against 13 100-13 570; sixteen: 15 150-15 190
+  // against 15 630-16 070 -- 4.9 MB are 180 us on one engine and 80 us of memcpy in front of it), else in place.  Frames that go through
+  // the lens-undistortion maps are always staged (the remap gathers single bytes).
+  const bool in_place = [&] {
+    if (any_maps) return false;
+    const int forced = tunables().v[RMD_HIP_TUNE_HOST_FRAMES];
+    if (forced != HOST_FRAMES_DEFAULT) return forced == HOST_FRAMES_INPLACE || forced == HOST_FRAMES_INPLACE_AHEAD;
+    return !(b->engines && static_cast<size_t>(n_active) * (gray ? bytes_u8 : frame_bytes) <= (size_t(3) << 20));
+  }();
+  const bool deep = b->engines != nullptr && !in_place;
+  const int kp = static_cast<int>(n64 % static_cast<unsigned long long>(b->slots));
+  const int k = deep ? static_cast<int>(n64 % static_cast<unsigned long long>(rmd_hip_batch::SLOTS_MAX)) : kp;
+  // The pinned block kp: an engine may still be reading it (its last step was staged on the engine), or kernels (it was read in place).
+  if (b->engines_used && (!b->engines_used->wait_idle(b->sig_frame[kp], 2e6) || !b->engines_used->wait_idle(b->sig_flag[kp], 2e6)))
+    return fail(RMD_HIP_ERR_RUNTIME, "a copy engine has not completed pinned slot %d's previous step after 2 s", kp);
+  if (deep && b->pinned_in_place[kp]) {  // (a change of mode: the only time a staged step waits for kernels on behalf of its PINNED block)
+    const unsigned long long used = b->pinned_in_place[kp];
+    for (int g = 0; g < b->n_groups; ++g) {
+      rmd_hip_batch::Group& G = b->groups[g];
+      if (G.last_step > used) TRY(wait_for_progress(G.h_progress, static_cast<unsigned int>(used) + 1u, G.stream));
+      else HIP_TRY(hipStreamSynchronize(G.stream));
+    }
+  }
+  b->pinned_in_place[kp] = in_place ? n64 : 0ull;
   // Slot k was last read by the setup kernels of the step recorded in slot_step[k]; such a kernel is done once a LATER setup kernel of
   // the same group has started (the progress word), or, if the group has not been launched since, once its stream is idle.
   static_assert(rmd_hip_batch::SLOTS_MAX <= 8, "Group::slot_step");
@@ -60,12 +96,15 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
   if (b->stage_bytes < need) {
     for (int g = 0; g < b->n_groups; ++g) HIP_TRY(hipStreamSynchronize(b->groups[g].stream));
     HIP_TRY(hipStreamSynchronize(b->copy_stream));
-    for (int q = 0; q < b->slots; ++q) {
+    for (int q = 0; b->engines_used && q < rmd_hip_batch::SLOTS_MAX; ++q)
+      if (!b->engines_used->wait_idle(b->sig_frame[q], 2e6) || !b->engines_used->wait_idle(b->sig_flag[q], 2e6))
+        return fail(RMD_HIP_ERR_RUNTIME, "a copy engine has not completed slot %d's step after 2 s", q);
+    for (int q = 0; q < rmd_hip_batch::SLOTS_MAX; ++q) {
       if (b->h_stage[q]) (void)hipHostFree(b->h_stage[q]);
       if (b->d_stage[q]) (void)hipFree(b->d_stage[q]);
       b->h_stage[q] = nullptr; b->d_stage[q] = nullptr;
-      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_stage[q]), need + 16, hipHostMallocDefault));
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_stage[q]), need));
+      if (q < b->slots) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_stage[q]), need + 16, hipHostMallocDefault));
+      if (q < b->slots || b->engines_used) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_stage[q]), need));
     }
     b->stage_bytes = need;
   }
@@ -75,14 +114,12 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
   else if (!gray && float_frames_as_bytes()) {
     packed = true;
     for (int i = 0; i < b->n && packed; ++i)
-      if ((active >> i) & 1u) packed = CopyPool::instance().pack(f32[i], b->h_stage[k] + static_cast<size_t>(i) * bytes_u8, m0->width,
+      if ((active >> i) & 1u) packed = CopyPool::instance().pack(f32[i], b->h_stage[kp] + static_cast<size_t>(i) * bytes_u8, m0->width,
           m0->height, u8_pitch);
     if (packed) frame_bytes = bytes_u8;
     else b->pack_backoff = 15;
   }
   const bool as_u8 = gray != nullptr || packed;
-  bool any_maps = false;
-  for (int i = 0; i < b->n; ++i) any_maps = any_maps || (gray && ((active >> i) & 1u) && b->members[i]->d_undist_map1);
   int first = -1, last = -1, n_segs = 0;
   CopyPool::Segment segs[rmdk::MAX_BATCH];
   for (int i = 0; i < b->n; ++i) {
@@ -90,7 +127,7 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
     if (first < 0) first = i;
     last = i;
     if (packed) continue;
-    unsigned char* dst = b->h_stage[k] + static_cast<size_t>(i) * frame_bytes;
+    unsigned char* dst = b->h_stage[kp] + static_cast<size_t>(i) * frame_bytes;
     if (gray && u8_pitch != m0->width) {
       for (int y = 0; y < m0->height; ++y) memcpy(dst + static_cast<size_t>(y) * u8_pitch, gray[i] + static_cast<size_t>(y) * m0->width,
           m0->width);
@@ -100,7 +137,6 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
       ++n_segs;
     }
   }
-  const bool in_place = frame_in_place(true, any_maps);  // (the remap gathers single bytes: staged)
   // The frames of the step go into the pinned block, spread over the copy threads.  STAGED frames are brought in by the copy engine and
   // their setup kernels wait for the arrival flag themselves: nothing the host queues for the compute streams depends on the pinned block,
   // so the step's launches are queued WHILE the helpers copy (the caller's share of the copy follows them) -- per step the host spends
@@ -115,7 +151,7 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
   rmdk::IngestArgs in;
   if (in_place) {  // the setup kernels read the pinned block themselves
     void* dev = nullptr;
-    HIP_TRY(hipHostGetDevicePointer(&dev, b->h_stage[k], 0));
+    HIP_TRY(hipHostGetDevicePointer(&dev, b->h_stage[kp], 0));
     frames_dev = static_cast<const unsigned char*>(dev);
     in.flag = nullptr;
   } else {
@@ -147,12 +183,22 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
   if (overlap) CopyPool::instance().finish_copy_many();  // (also after a failed launch: the pool must be released)
   if (rc == RMD_HIP_OK && !in_place) {
     const size_t off = static_cast<size_t>(first) * frame_bytes, len = static_cast<size_t>(last - first + 1) * frame_bytes;
-    // (on the copy stream: a batch's default is in place; its staged steps gained nothing from the engines addressed directly --
-    // profiles/r06_ab_copy_engines.txt)
-    HIP_TRY(hipMemcpyAsync(b->d_stage[k] + off, b->h_stage[k] + off, len, hipMemcpyHostToDevice, b->copy_stream));
-    // behind the frames on the same stream: when the kernel sees n, they are in HBM
-    fill_flag_block(b->h_seq + k * FLAG_SLOT_WORDS, n, fw);
-    HIP_TRY(hipMemcpyAsync(b->d_flag, b->h_seq + k * FLAG_SLOT_WORDS, fw * sizeof(unsigned int), hipMemcpyHostToDevice, b->copy_stream));
+    bool sent = false;
+    if (deep) {
+      // ONE engine for the batch, block and flag in its order: the batch has one flag word, and the steps' numbers must reach it in order
+      b->h_seq[kp * FLAG_SLOT_WORDS] = n;
+      sent = b->engines->submit(0u, 0u, b->d_stage[k] + off, b->h_stage[kp] + off, len, b->sig_frame[kp], b->d_flag,
+                                b->h_seq + kp * FLAG_SLOT_WORDS, sizeof(unsigned int), b->sig_flag[kp]);
+      if (!sent) b->engines = nullptr;  // refused: the copy stream from here on (this step's block may be in flight: sent again below)
+    }
+    if (!sent) {
+      HIP_TRY(hipMemcpyAsync(b->d_stage[k] + off, b->h_stage[kp] + off, len, hipMemcpyHostToDevice, b->copy_stream));
+      // behind the frames on the same stream: when the kernel sees n, they are in HBM
+      fill_flag_block(b->h_seq + kp * FLAG_SLOT_WORDS, n, fw);
+      HIP_TRY(hipMemcpyAsync(b->d_flag, b->h_seq + kp * FLAG_SLOT_WORDS, fw * sizeof(unsigned int), hipMemcpyHostToDevice, b->copy_stream));
+      // (the step in which the engines were given up: its pinned block is not in the books the copy-stream path keeps)
+      if (deep) HIP_TRY(hipStreamSynchronize(b->copy_stream));
+    }
   }
   if (b->ingest_profile) {
     const double t_d = host_now_us();
@@ -171,6 +217,17 @@ int rmd_hip_batch_destroy(rmd_hip_batch_t* b) {
   for (auto& G : b->groups)
     if (G.stream) (void)hipStreamSynchronize(G.stream);
   if (b->copy_stream) (void)hipStreamSynchronize(b->copy_stream);
+  {
+    bool any = false;
+    for (int q = 0; q < rmd_hip_batch::SLOTS_MAX; ++q) any = any || b->sig_frame[q] || b->sig_flag[q];
+    if (CopyEngines* e = any ? b->engines_used : nullptr) {  // (not b->engines: it may have been given up)
+      for (int q = 0; q < rmd_hip_batch::SLOTS_MAX; ++q)
+        for (uint64_t* sig : {&b->sig_frame[q], &b->sig_flag[q]}) {
+          if (*sig && e->wait_idle(*sig, 2e6)) e->destroy_signal(*sig);  // (an engine that still owes a signal keeps it)
+          *sig = 0;
+        }
+    }
+  }
   if (b->ingest_profile && b->ingest_us[3] > 0) {
     fprintf(stderr, "[rmd_hip ingest] batch of %d, %.0f steps: wait for slot %.2f us, host copy %.2f us, submit %.2f us per step; "
                     "longest wait %.0f us, %lu waits gave up (stream idle, word not reached); "
@@ -265,6 +322,14 @@ int rmd_hip_batch_create(int n, int width, int height, float fx, float fy, float
       hipMalloc(reinterpret_cast<void**>(&b->d_flag), FLAG_ALLOC_BYTES) != hipSuccess || hipMemset(b->d_flag, 0,
           FLAG_ALLOC_BYTES) != hipSuccess)
     return bail(fail(RMD_HIP_ERR_RUNTIME, "batch_create: ingest words"));
+  if (tunables().v[RMD_HIP_TUNE_COPY_ENGINES] != 0 && (b->engines = CopyEngines::for_device(b->device, 1)) != nullptr) {
+    b->engines_used = b->engines;
+    for (int q = 0; q < rmd_hip_batch::SLOTS_MAX && b->engines; ++q) {
+      b->sig_frame[q] = b->engines->create_signal();
+      b->sig_flag[q] = b->engines->create_signal();
+      if (!b->sig_frame[q] || !b->sig_flag[q]) b->engines = nullptr;  // (what was created is destroyed with the batch)
+    }
+  }
   b->n = n;  // (group_of needs it while the members are created)
   for (int i = 0; i < n; ++i) {
     const int rc = seeds_create_impl(width, height, fx, fy, cx, cy, patch_side, max_extent, b, i, &b->members[i]);

@@ -415,6 +415,12 @@ struct rmd_hip_batch {
   size_t stage_bytes = 0;                   // capacity of each of the buffers above
   unsigned int* h_seq = nullptr;
   unsigned int* d_flag = nullptr;
+  // staged steps on ONE copy engine addressed directly (rmd_engines.hpp; the batch has one flag word and the steps' numbers must reach it
+  // in order): the pinned blocks [0, slots) are free when the engine has read them, the staging buffers in HBM are SLOTS_MAX deep
+  CopyEngines* engines = nullptr;       // to submit to: given up (nullptr) after a refusal
+  CopyEngines* engines_used = nullptr;  // ... whose signals are still waited for
+  uint64_t sig_frame[SLOTS_MAX] = {}, sig_flag[SLOTS_MAX] = {};
+  unsigned long long pinned_in_place[SLOTS_MAX] = {};  // step whose kernels read pinned block [q] in place, 0: its last step was staged
   unsigned long long step_number = 0;
   int opt_timing = 0, opt_unit_target = 1;
   int pack_backoff = 0;

@@ -96,6 +96,51 @@ def test_the_default_route_of_host_frames_is_the_copy_engines():
     assert res.returncode == 0 and "ROUTE (7, 0) -1 -1" in res.stdout, res.stdout[-2000:]
 
 
+MIXED_CHILD = r'''
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from rpg_open_remode_amd import api, synth
+w, h, side, n, B = 320, 240, 7, 26, 3
+seq = synth.Sequence(w, h, n, 0)
+cam = api.PinholeCamera(*seq.K)
+def bits(st): return [np.ascontiguousarray(st[p]).view(np.uint32).copy() for p in sorted(st)]
+s = api.SeedMatrix(w, h, cam, patch_side=side)
+pl = []
+for im in seq.images:
+    d = api.DeviceImage(w, h, np.float32); d.setDevData(im); pl.append(d)
+s.setReferenceImageDevice(pl[0].data, pl[0].stride, seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+for k in range(1, n): s.updateDevice(pl[k].data, pl[k].stride, seq.T_curr_world[k])
+want = bits(s.state())
+b = api.SeedMatrixBatch(B, w, h, cam, patch_side=side)
+for m in b.members: m.setReferenceImageU8(seq.gray[0], seq.T_curr_world[0], seq.min_depth, seq.max_depth)
+# the way a step's frames travel changes from step to step, in runs of 1, 2, 3 ... steps: every transition between "kernels read the pinned
+# block" and "an engine copies it into one of eight staging buffers" in both directions, at every phase of the two rings
+modes, k = [api.getTunable(api.TUNE_HOST_FRAMES)], 1
+run = 1
+while k < n:
+    mode = 2 if (run % 2) else 0   # inplace / staged
+    for _ in range(run):
+        if k >= n: break
+        api.setTunable(api.TUNE_HOST_FRAMES, mode)
+        b.updateU8([seq.gray[k]] * B, [seq.T_curr_world[k]] * B)
+        k += 1
+    run += 1
+api.setTunable(api.TUNE_HOST_FRAMES, -1)
+for i in range(B):
+    got = bits(b[i].state())
+    assert all(np.array_equal(x, y) for x, y in zip(want, got)), f"batch member {i}"
+print("MIXED-OK")
+'''
+
+
+@pytest.mark.gpu
+def test_a_batch_that_changes_between_in_place_and_staged_steps():
+    """steps read in place by the kernels and steps staged by a copy engine into the deep staging ring, alternating in runs of 1, 2, 3 ... steps:
+    the pinned blocks are protected by the kernels' progress words in one mode and by the engine's signals in the other"""
+    res = subprocess.run([sys.executable, "-c", MIXED_CHILD, ROOT], env=dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert res.returncode == 0 and "MIXED-OK" in res.stdout, res.stdout[-2000:]
+
+
 GROUPS_CHILD = r'''
 import sys, numpy as np
 sys.path.insert(0, sys.argv[1])
