@@ -178,13 +178,15 @@ struct rmd_hip_image {
 //             plane (rmdk::MatcherArgs); in place  the ingest workgroups read the pinned ring themselves over the host link: no copy
 //             engine, no staging, no flag. "+ ahead" (single sequences): frame n + 1 is converted during the SEARCH kernel of frame n
 //             whenever it has arrived (staged) or been handed over (in place) by the time setup n runs (rmdk::MatcherArgs::ahead); setup n
-//             + 1 then finds nothing left to do. Defaults (measured): a single sequence uses STAGED on copy engines addressed directly
-//             (rmd_engines.hpp; profiles/r06_ab_copy_engines.txt) and staged + ahead where its frames travel on the copy stream
-//             (RMD_HIP_TUNE_COPY_ENGINES = 0; profiles/r03_h2d.txt) -- the copy engines do not touch the CUs, whereas link reads issued by
-//             a CU delay the loads of the workgroups it shares its memory pipeline with (in place + ahead: search +4.5 us per update); a
-//             batch uses in place -- its setup kernels are long enough to hide most of the link time, and its caller is never far enough
-//             ahead of the device for a copy engine (8 sequences: 10 470 -> 12 740 Mpix/s).  Frames that go through the lens- undistortion
-//             maps are always staged, without ahead (the remap gathers single bytes).  A/B: RMD_HIP_TUNE_HOST_FRAMES.
+//             + 1 then finds nothing left to do.
+//
+// Defaults (measured): a single sequence uses STAGED on copy engines addressed directly (rmd_engines.hpp; profiles/r06_ab_copy_engines.txt)
+// and staged + ahead where its frames travel on the copy stream (RMD_HIP_TUNE_COPY_ENGINES = 0; profiles/r03_h2d.txt) -- the copy engines do
+// not touch the CUs, whereas link reads issued by a CU delay the loads of the workgroups it shares its memory pipeline with (in place +
+// ahead: search +4.5 us per update).  A batch (rmd_batch.hip decides per step) is staged on one engine, eight staging buffers deep, while
+// a step is at most 3 MB, and read in place beyond that or without the engines -- its setup kernels are long enough to hide most of the
+// link time.  Frames that go through the lens-undistortion maps are always staged, without ahead (the remap gathers single bytes).
+// A/B: RMD_HIP_TUNE_HOST_FRAMES.
 enum { HOST_FRAMES_DEFAULT = -1, HOST_FRAMES_STAGED = 0, HOST_FRAMES_STAGED_AHEAD = 1, HOST_FRAMES_INPLACE = 2,
     HOST_FRAMES_INPLACE_AHEAD = 3 };
 constexpr int AHEAD_WGS = 128;  // workgroups of the search kernel that bring the next frame in (MatcherArgs::ahead)
