@@ -170,23 +170,28 @@ struct rmd_hip_image {
 // writes first or last, a reader of word 0 sees either the old number or the new one, and the new one only after the frame copy in
 // front of it (same stream) has completed.  The 64 KB form costs the copy engine 7 us more per frame, all of it latency when the
 // device is waiting for the frame (live use: the node asks for the converged count after every update, so the host never runs ahead):
-// there the 4-byte form is used -- the device has caught up, so the shader copy finds an empty chip (flag_words()).
+// there the 4-byte form is used -- the device has caught up, so the shader copy finds an empty chip (flag_words()).  (On copy engines
+// addressed directly -- rmd_engines.hpp, the default -- the flag is one word, copied by the engine itself behind the frame.)
+//
 // How a frame that was handed over in host memory reaches the device.  The caller's buffer is always copied into a pinned ring first (the
 // caller may reuse it when update() returns); from there
-//   staged    the copy engine brings it into a staging buffer in HBM, followed by its arrival flag, with no ordering against the compute
-//             stream; the ingest workgroups of the frame's setup kernel wait for the flag and convert the frame into the current-image
-//             plane (rmdk::MatcherArgs); in place  the ingest workgroups read the pinned ring themselves over the host link: no copy
-//             engine, no staging, no flag. "+ ahead" (single sequences): frame n + 1 is converted during the SEARCH kernel of frame n
-//             whenever it has arrived (staged) or been handed over (in place) by the time setup n runs (rmdk::MatcherArgs::ahead); setup n
-//             + 1 then finds nothing left to do.
+//
+//   staged:   a copy engine brings it into a staging buffer in HBM, followed by its arrival flag, with no ordering against the compute
+//   stream; the ingest workgroups of the frame's setup kernel wait for the flag and convert the frame into the current-image plane
+//   (rmdk::MatcherArgs);
+//
+//   in place: the ingest workgroups read the pinned ring themselves over the host link: no copy engine, no staging, no flag;
+//
+//   "+ ahead" (single sequences): frame n + 1 is converted during the SEARCH kernel of frame n whenever it has arrived (staged) or been
+//   handed over (in place) by the time setup n runs (rmdk::MatcherArgs::ahead); setup n + 1 then finds nothing left to do.
 //
 // Defaults (measured): a single sequence uses STAGED on copy engines addressed directly (rmd_engines.hpp; profiles/r06_ab_copy_engines.txt)
-// and staged + ahead where its frames travel on the copy stream (RMD_HIP_TUNE_COPY_ENGINES = 0; profiles/r03_h2d.txt) -- the copy engines do
-// not touch the CUs, whereas link reads issued by a CU delay the loads of the workgroups it shares its memory pipeline with (in place +
-// ahead: search +4.5 us per update).  A batch (rmd_batch.hip decides per step) is staged on one engine, eight staging buffers deep, while
-// a step is at most 3 MB, and read in place beyond that or without the engines -- its setup kernels are long enough to hide most of the
-// link time.  Frames that go through the lens-undistortion maps are always staged, without ahead (the remap gathers single bytes).
-// A/B: RMD_HIP_TUNE_HOST_FRAMES.
+// and staged + ahead where its frames travel on the copy stream (RMD_HIP_TUNE_COPY_ENGINES = 0; profiles/r03_h2d.txt) -- the copy engines
+// do not touch the CUs, whereas link reads issued by a CU delay the loads of the workgroups it shares its memory pipeline with (in place +
+// ahead: search +4.5 us per update).  A batch (rmd_batch.hip decides per step) is staged on one engine, eight staging buffers deep, while a
+// step is at most 3 MB, and read in place beyond that or without the engines -- its setup kernels are long enough to hide most of the link
+// time.  Frames that go through the lens-undistortion maps are always staged, without ahead (the remap gathers single bytes). A/B:
+// RMD_HIP_TUNE_HOST_FRAMES.
 enum { HOST_FRAMES_DEFAULT = -1, HOST_FRAMES_STAGED = 0, HOST_FRAMES_STAGED_AHEAD = 1, HOST_FRAMES_INPLACE = 2,
     HOST_FRAMES_INPLACE_AHEAD = 3 };
 constexpr int AHEAD_WGS = 128;  // workgroups of the search kernel that bring the next frame in (MatcherArgs::ahead)
