@@ -91,12 +91,17 @@ bool CopyEngines::find_agents(int hip_device) {
   S.want_bdf = (static_cast<uint32_t>(bus) << 8) | (static_cast<uint32_t>(dev) << 3);
   st = hsa_iterate_agents(visit_agent, &S);
   if (st != HSA_STATUS_SUCCESS) { snprintf(err_, sizeof err_, "hsa_iterate_agents: %s", status_text(st)); return false; }
+  const bool by_address = S.have_gpu;
   if (!S.have_gpu && S.n_gpus == 1) { S.gpu = S.only_gpu; S.have_gpu = true; }  // (one GPU in the process: no address needed to tell it)
   if (!S.have_gpu || !S.have_cpu) {
     snprintf(err_, sizeof err_, "no HSA agent at PCI %04x:%02x:%02x (HIP device %d)", domain, bus, dev, hip_device);
     return false;
   }
   gpu_ = S.gpu.handle; cpu_ = S.cpu.handle;
+  // (one process per GPU on a node of eight: an engine of the WRONG agent would write this device's memory from another one)
+  if (tunables().v[RMD_HIP_TUNE_INGEST_PROFILE])
+    fprintf(stderr, "[rmd_hip ingest] copy engines of HIP device %d: the HSA agent at PCI %04x:%02x:%02x, %s (%d GPU agent%s in the process)\n",
+            hip_device, domain, bus, dev, by_address ? "matched by address" : "the only GPU agent", S.n_gpus, S.n_gpus == 1 ? "" : "s");
   // The order frames rotate in: 0x1, 0x4, 0x2, 0x8 -- not 0x1, 0x2: two frames in flight with their flags behind them take 41 us per
   // 1920x1080 frame on 0x1 / 0x4 and 48 us on 0x1 / 0x2 (as on 0x4 / 0x8: neighbours share something; tools/link_probe.cpp, route G).
   engine_[0] = HSA_AMD_SDMA_ENGINE_0; engine_[1] = HSA_AMD_SDMA_ENGINE_2; engine_[2] = HSA_AMD_SDMA_ENGINE_1; engine_[3] =

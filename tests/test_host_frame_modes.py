@@ -92,8 +92,12 @@ def test_the_default_route_of_host_frames_is_the_copy_engines():
             "for k in range(1, 8): s.updateU8(seq.gray[k], seq.T_curr_world[k])\n"
             "s.sync(); print('ROUTE', s.stagedFrames(), api.getTunable(api.TUNE_COPY_ENGINES), api.getTunable(api.TUNE_HOST_FRAMES))\n")
     env = {k: v for k, v in os.environ.items() if not k.startswith("RMD_HIP_") or k == "RMD_HIP_LIB"}
+    env["RMD_HIP_INGEST_PROFILE"] = "1"
     res = subprocess.run([sys.executable, "-c", code, ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert res.returncode == 0 and "ROUTE (7, 0) -1 -1" in res.stdout, res.stdout[-2000:]
+    # the device's HSA agent is found by its PCI address, not by being the only one: on a node of eight that is what keeps a rank's frames off
+    # the engines of another rank's device
+    assert "matched by address" in res.stdout, res.stdout[-2000:]
 
 
 MIXED_CHILD = r'''
