@@ -49,6 +49,9 @@ const char* status_text(hsa_status_t st) {
 hsa_signal_t as_signal(uint64_t h) { hsa_signal_t s; s.handle = h; return s; }
 hsa_agent_t as_agent(uint64_t h) { hsa_agent_t a; a.handle = h; return a; }
 
+// handles of several threads submit to one CopyEngines object: a refusal is reported to the thread that met it
+thread_local char tl_submit_error[160] = {0};
+
 std::mutex g_engines_mutex;
 constexpr int MAX_DEVICES = 32;
 CopyEngines* g_engines[MAX_DEVICES] = {nullptr};
@@ -171,6 +174,8 @@ bool CopyEngines::wait_idle(uint64_t sig, double timeout_us) const {
   return true;
 }
 
+const char* CopyEngines::last_error() const { return tl_submit_error; }
+
 bool CopyEngines::submit(unsigned data_engine, unsigned flag_engine, void* dst, const void* src, size_t bytes, uint64_t frame_sig,
                          void* flag_dst, const void* flag_src, size_t flag_bytes, uint64_t flag_sig) {
   const hsa_agent_t gpu = as_agent(gpu_), cpu = as_agent(cpu_);
@@ -183,7 +188,7 @@ bool CopyEngines::submit(unsigned data_engine, unsigned flag_engine, void* dst, 
                                                         false);
   if (st != HSA_STATUS_SUCCESS) {
     hsa_signal_store_relaxed(fs, 0);
-    snprintf(err_, sizeof err_, "hsa_amd_memory_async_copy_on_engine (frame, engine 0x%x): %s", de, status_text(st));
+    snprintf(tl_submit_error, sizeof tl_submit_error, "hsa_amd_memory_async_copy_on_engine (frame, engine 0x%x): %s", de, status_text(st));
     return false;
   }
   if (!flag_dst) return true;
@@ -194,7 +199,7 @@ bool CopyEngines::submit(unsigned data_engine, unsigned flag_engine, void* dst, 
                                            false);
   if (st != HSA_STATUS_SUCCESS) {
     hsa_signal_store_relaxed(gs, 0);
-    snprintf(err_, sizeof err_, "hsa_amd_memory_async_copy_on_engine (flag, engine 0x%x): %s", fe, status_text(st));
+    snprintf(tl_submit_error, sizeof tl_submit_error, "hsa_amd_memory_async_copy_on_engine (flag, engine 0x%x): %s", fe, status_text(st));
     // (the frame is in flight: the caller sends it again its other way -- the same bytes to the same place -- and waits for frame_sig
     // before the slot's next frame)
     return false;

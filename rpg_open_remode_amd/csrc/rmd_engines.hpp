@@ -40,7 +40,7 @@ class CopyEngines {
               const void* flag_src, size_t flag_bytes, uint64_t flag_sig);
   int engines_ready() const { return n_ready_; }
 
-  const char* last_error() const { return err_; }
+  const char* last_error() const;  // of the calling thread's last refused submit()
 
  private:
   CopyEngines() = default;
@@ -49,7 +49,7 @@ class CopyEngines {
   uint64_t gpu_ = 0, cpu_ = 0;          // hsa_agent_t handles
   unsigned engine_[4] = {0, 0, 0, 0};  // hsa_amd_sdma_engine_id_t bits
   int n_ready_ = 0;                    // engines [0, n_ready_) have carried a first copy
-  char err_[160] = {0};
+  char err_[160] = {0};  // why the engines could not be had (written under the mutex of for_device)
 };
 
 }  // namespace rmdh
