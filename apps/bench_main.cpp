@@ -7,7 +7,8 @@
 //           device time = ONE HIP event pair on the handle's stream around the region (RMD_HIP_OPT_TIMING = 2)
 //
 // in three frame modes: "u8" (the headline: every frame an 8-bit image in pageable host memory, rmd_hip_seeds_update_u8), "resident" (frames in
-// HBM, read in place, rmd_hip_seeds_update_device) and "float" (rmd::SeedMatrix::update(float*), the reference's own signature).  Prints one
+// HBM, read in place, rmd_hip_seeds_update_device), "float" (rmd::SeedMatrix::update(float*), the reference's own signature) and "pinned" (8-bit
+// frames the caller keeps in pinned host memory, rmd_hip_seeds_update_u8_pinned: no copy into the library's ring).  Prints one
 // JSON line per mode: Mpix/s, us per update (wall and device), host CPU seconds of the process over the region (getrusage: all threads) and
 // the wall time per update() until the call returned.  --ranks-probe N forks N processes that run the u8 mode concurrently (scenes 0..N-1, device
 // rank % device_count) and reports each one's rate and CPU time: what N ranks cost the host (profiles/r05_nranks/).
@@ -107,8 +108,17 @@ Result run_mode(const Sequence& q, const std::string& mode, int steps, int warmu
       dev.push_back(im); dev_ptr.push_back(static_cast<const float*>(p));
     }
   }
+  unsigned char* pinned = nullptr;  // mode "pinned": the whole sequence in ONE block of pinned host memory, as a producer would leave it there
+  const size_t frame_bytes = static_cast<size_t>(q.w) * q.h;
+  if (mode == "pinned") {
+    check(rmd_hip_host_alloc(reinterpret_cast<void**>(&pinned), frame_bytes * q.n), "host_alloc");
+    for (int k = 0; k < q.n; ++k) memcpy(pinned + frame_bytes * k, q.gray[k].data(), frame_bytes);
+  }
   auto one_pass = [&]() {
-    if (mode == "u8") {
+    if (mode == "pinned") {
+      check(rmd_hip_seeds_set_reference_u8(h, q.gray[0].data(), q.pose[0].data(), q.min_depth, q.max_depth), "set_reference_u8");
+      for (int k = 1; k < q.n; ++k) check(rmd_hip_seeds_update_u8_pinned(h, pinned + frame_bytes * k, q.pose[k].data(), nullptr), "update_u8_pinned");
+    } else if (mode == "u8") {
       check(rmd_hip_seeds_set_reference_u8(h, q.gray[0].data(), q.pose[0].data(), q.min_depth, q.max_depth), "set_reference_u8");
       for (int k = 1; k < q.n; ++k) check(rmd_hip_seeds_update_u8(h, q.gray[k].data(), q.pose[k].data()), "update_u8");
     } else if (mode == "resident") {
@@ -141,6 +151,7 @@ Result run_mode(const Sequence& q, const std::string& mode, int steps, int warmu
   check(rmd_hip_seeds_set_option(h, RMD_HIP_OPT_TIMING, 0), "set_option");
   r.converged = seeds.getConvergedCount();
   for (rmd_hip_image_t* im : dev) rmd_hip_image_destroy(im);
+  if (pinned) check(rmd_hip_host_free(pinned), "host_free");
   return r;
 }
 
@@ -172,7 +183,7 @@ int main(int argc, char** argv) {
     else if (a == "--ranks-probe") ranks = atoi(next());
     else if (a == "--render-threads") threads = atoi(next());
     else if (a == "--unit-target") g_unit_target = atoi(next());
-    else { fprintf(stderr, "usage: bench_main [--size WxH] [--frames F] [--steps K] [--warmup W] [--scene S] [--modes u8,resident,float] [--ranks-probe N]\n"); return 1; }
+    else { fprintf(stderr, "usage: bench_main [--size WxH] [--frames F] [--steps K] [--warmup W] [--scene S] [--modes u8,resident,float,pinned] [--ranks-probe N]\n"); return 1; }
   }
   rmd_synth_set_threads(threads);
   int rank = 0;
@@ -191,7 +202,7 @@ int main(int argc, char** argv) {
     const size_t e = modes.find(',', pos);
     const std::string mode = modes.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
     pos = e == std::string::npos ? modes.size() : e + 1;
-    if (mode != "u8" && mode != "resident" && mode != "float") { fprintf(stderr, "unknown mode %s\n", mode.c_str()); return 1; }
+    if (mode != "u8" && mode != "resident" && mode != "float" && mode != "pinned") { fprintf(stderr, "unknown mode %s\n", mode.c_str()); return 1; }
     print_line(q, mode, steps, warmup, run_mode(q, mode, steps, warmup), rank);
   }
   if (ranks > 1 && rank == 0)

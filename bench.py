@@ -377,6 +377,19 @@ def measure_config(api, synth, label, Wc, Hc, Fc, tv_iters, passes=1):
     u8 = timed(pass_u8)
     u8["frames_on_copy_engines_addressed_directly"], u8["frames_on_the_copy_stream"] = s.stagedFrames()
     res = timed(pass_res)
+    pinned = None
+    if hasattr(api, "PinnedFrames"):  # frames the caller keeps in pinned host memory (rmd_hip_seeds_update_u8_pinned): no memcpy into the ring
+        pf = api.PinnedFrames(Fc, Hc, Wc)
+        for k in range(Fc):
+            pf.frames[k][:] = gray[k]
+
+        def pass_pinned():
+            s.setReferenceImageU8(gray[0], poses[0], lo, hi)
+            for k in range(1, Fc):
+                s.updateU8Pinned(pf.frames[k], poses[k])
+        pinned = timed(pass_pinned)
+        s.sync()
+        pf.close()
     avg_s = u8["us_per_update_device"] / 1e6
     ach = FUSED_BYTES_PER_PIXEL * Wc * Hc / avg_s / 1e9
     den = api.DepthmapDenoiser(Wc, Hc)
@@ -390,6 +403,7 @@ def measure_config(api, synth, label, Wc, Hc, Fc, tv_iters, passes=1):
     tv_bw = TV_BYTES_PER_PIXEL_ITER * Wc * Hc * tv_iters / (tv_ms / 1e3) / 1e9 if tv_ms > 0 else 0.0
     out = {"workload": f"{label}: {Wc}x{Hc}, {Fc} frames ({Fc - 1} updates per pass), patch side {SIDE}, TV-L1 {tv_iters} iterations; 8-bit host frames inside update()",
            "value": u8["value"], "unit": "Mpix/s", "u8_host_frames": u8, "resident": res, "u8_over_resident": round(u8["value"] / res["value"], 4),
+           "caller_pinned_frames": pinned, "caller_pinned_over_resident": round(pinned["value"] / res["value"], 4) if pinned else None,
            "converged_seeds_at_end": s.getConvergedCount(),
            "roofline": {"bound": "hbm", "kernel": "seed_update (fused)", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                         "frac_resident": round(FUSED_BYTES_PER_PIXEL * Wc * Hc / (res["us_per_update_device"] / 1e6) / 1e9 / HBM_PEAK_GBS, 5),
@@ -625,7 +639,7 @@ def main():
                        "denoise_wall_ms": round(denoise_wall_ms, 3), "iterations": tv_iters, "depth_maps_per_launch": B}
 
         search_stats, cpu, glibc, resident, floats, heavy, batched, other_path = None, None, None, None, None, None, None, None
-        floats_other, other_configs, live = None, None, None
+        floats_other, other_configs, live, pinned = None, None, None, None
         extra_passes = max(1, min(args.steps, 3))
         if not args.no_extras and bm is None:
             # search statistics of the timed workload (separate pass over the same sequence, diagnostics counters on)
@@ -655,6 +669,27 @@ def main():
                 other_path = dict(rate(pass_u8), path="rmd_hip_seeds_update_u8: 8-bit frames in pageable host memory (SURVEY.md 8d: the upload inside update())")
             else:
                 resident = dict(rate(pass_resident), path="rmd_hip_seeds_update_device: frames already resident in HBM, read in place")
+
+            if hasattr(api, "PinnedFrames"):
+                # frames the CALLER keeps in pinned host memory (rmd_hip_seeds_update_u8_pinned, not in the reference): the copy engine reads them where
+                # they lie -- update() without the memcpy into the library's ring
+                pf = api.PinnedFrames(F, H, W)
+                for k in range(F):
+                    pf.frames[k][:] = gray[k]
+
+                def pass_pinned(s):
+                    s.setReferenceImageU8(gray[0], poses[0], min_depth, max_depth)
+                    for k in range(1, F):
+                        s.updateU8Pinned(pf.frames[k], poses[k])
+                ru_a = resource.getrusage(resource.RUSAGE_SELF)
+                t_a = time.perf_counter()
+                pinned = rate(pass_pinned)
+                t_b = time.perf_counter()
+                ru_b = resource.getrusage(resource.RUSAGE_SELF)
+                pinned = dict(pinned, path="rmd_hip_seeds_update_u8_pinned: 8-bit frames the caller keeps in pinned host memory, read by the copy engine where they lie "
+                              "(an extension: the reference's update() takes pageable memory)",
+                              host_cores_busy_incl_warmup_pass=round(((ru_b.ru_utime + ru_b.ru_stime) - (ru_a.ru_utime + ru_a.ru_stime)) / (t_b - t_a), 3))
+                pf.close()
 
             if F <= 500:
                 fimgs = [synth.to_float_image(g) for g in gray]
@@ -844,7 +879,7 @@ def main():
             "roofline_valu": valu_roofline(avg_kernel_s, counters, n_sequences=B, ncc_evals_per_update=search_stats["ncc_evals"] if search_stats else None) if headline else None,
             "roofline_flops": flops_roofline(avg_kernel_s, search_stats["ncc_evals"] if search_stats else None, SIDE),
             "roofline_denoiser": roofline_tv, "cpu_baseline": cpu,
-            "resident": resident, "h2d_inclusive": other_path, "float_frames": floats, "float_frames_not_8bit_levels": floats_other, "heavy_prefix": heavy, "batched_per_gpu": batched,
+            "resident": resident, "h2d_inclusive": other_path, "caller_pinned_frames": pinned, "float_frames": floats, "float_frames_not_8bit_levels": floats_other, "heavy_prefix": heavy, "batched_per_gpu": batched,
             "configs": other_configs, "live": live,
             "parity": PARITY_NOTE, "parity_vs_glibc_reference": glibc, "tolerance_vs_cuda_build_model": cuda_build_tolerance() if headline else None,
             "per_rank": [dict(rank_record(r), device=i % max(torch.cuda.device_count(), 1)) for i, r in enumerate(per_rank)],

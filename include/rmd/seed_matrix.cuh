@@ -49,6 +49,19 @@ class SeedMatrix {
     detail::throw_on_error(rmd_hip_seeds_update(handle_, host_curr_img_align_row_maj, T_curr_world.data.data), "SeedMatrix: update failed");
     return true;
   }
+  // not in the reference: an 8-bit frame the caller keeps in pinned host memory (rmd_hip_host_alloc) is read where it lies; it must stay
+  // unchanged until pinnedFramesDone() has reached the ticket returned here (include/rmd_hip.h)
+  unsigned long long updatePinned(const unsigned char* pinned_gray_align_row_maj, const SE3<float>& T_curr_world) {
+    unsigned long long ticket = 0;
+    detail::throw_on_error(rmd_hip_seeds_update_u8_pinned(handle_, pinned_gray_align_row_maj, T_curr_world.data.data, &ticket),
+                           "SeedMatrix: updatePinned failed");
+    return ticket;
+  }
+  unsigned long long pinnedFramesDone() {
+    unsigned long long done = 0;
+    detail::throw_on_error(rmd_hip_seeds_pinned_frames_done(handle_, &done), "SeedMatrix: pinnedFramesDone failed");
+    return done;
+  }
 
   void downloadDepthmap(float* host_depthmap_align_row_maj) const { download(RMD_HIP_PLANE_MU, host_depthmap_align_row_maj); }
   void downloadConvergence(int* host_align_row_maj) const { download(RMD_HIP_PLANE_CONVERGENCE, host_align_row_maj); }

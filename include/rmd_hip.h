@@ -159,12 +159,23 @@ int rmd_hip_seeds_update_device(rmd_hip_seeds_t* s, const float* dev_img, size_t
 /* same two calls for an 8-bit gray frame (contiguous W x H bytes): what rmd::Depthmap::inputImage does on the host
  * (src/depthmap.cpp:95-106: cv::remap through the undistortion maps if rmd_hip_seeds_init_undistortion_map was called, then
  * cv::Mat::convertTo(CV_32F, 1.0f/255.0f)) happens on the device, bit for bit.  A quarter of the bytes of a float frame cross the bus;
- * update_u8 returns as soon as the frame has been copied into one of four pinned buffers; the conversion runs inside the PREVIOUS update's
- * search kernel when the frame has arrived by then, else inside the update's own first kernel (no extra launch, no synchronisation between
- * the upload and the compute queue): 97 % of the rate of frames that are already resident. */
+ * update_u8 returns as soon as the frame has been copied into one of four pinned buffers; copy engines bring it into HBM and the update's own
+ * first kernel converts it (no extra launch, no synchronisation between the upload and the compute queue): 97-99 % of the rate of frames that
+ * are already resident. */
 int rmd_hip_seeds_set_reference_u8(rmd_hip_seeds_t* s, const unsigned char* host_gray, const float* T_curr_world,
                                    float min_depth, float max_depth);
 int rmd_hip_seeds_update_u8(rmd_hip_seeds_t* s, const unsigned char* host_gray, const float* T_curr_world);
+/* Not in the reference: 8-bit frames the caller KEEPS in pinned host memory (rmd_hip_host_alloc, hipHostMalloc) -- the producer writes them there,
+ * e.g. a capture driver or a decoder -- are read by the copy engine where they lie: update() without the copy into the library's ring (at
+ * 1920x1080 the 2 MB per frame that keep one to two host cores busy).  The frame must stay unchanged until it has been read:
+ * rmd_hip_seeds_pinned_frames_done returns the newest ticket up to which every frame handed over this way has been read (tickets count these
+ * calls from 1; after rmd_hip_seeds_sync all are done).  Rows dense (width bytes apart).  Where the engine cannot take the frame from there (copy
+ * engines not addressable, RMD_HIP_TUNE_COPY_ENGINES = 0, another RMD_HIP_TUNE_HOST_FRAMES mode, lens undistortion, a batch member's reference)
+ * the call copies like rmd_hip_seeds_update_u8 and the ticket is done when it returns.  Results are those of rmd_hip_seeds_update_u8, bit for bit. */
+int rmd_hip_host_alloc(void** ptr, size_t bytes);
+int rmd_hip_host_free(void* ptr);
+int rmd_hip_seeds_update_u8_pinned(rmd_hip_seeds_t* s, const unsigned char* pinned_gray, const float* T_curr_world, unsigned long long* ticket);
+int rmd_hip_seeds_pinned_frames_done(rmd_hip_seeds_t* s, unsigned long long* ticket_done);
 /* downloadDepthmap/downloadConvergence :160-168 and the RMD_BUILD_TESTS downloads :205-230 */
 int rmd_hip_seeds_download(const rmd_hip_seeds_t* s, int plane, void* host_dst);
 /* test hook: overwrite mu / sigma_sq / a / b (planes 0..3) */

@@ -51,6 +51,10 @@ SIGNATURES = {
     "rmd_hip_seeds_update_device": (_i, [_p, _p, _sz, _p]),
     "rmd_hip_seeds_set_reference_u8": (_i, [_p, _p, _p, _f, _f]),
     "rmd_hip_seeds_update_u8": (_i, [_p, _p, _p]),
+    "rmd_hip_host_alloc": (_i, [_c.POINTER(_p), _sz]),
+    "rmd_hip_host_free": (_i, [_p]),
+    "rmd_hip_seeds_update_u8_pinned": (_i, [_p, _p, _p, _c.POINTER(_c.c_ulonglong)]),
+    "rmd_hip_seeds_pinned_frames_done": (_i, [_p, _c.POINTER(_c.c_ulonglong)]),
     "rmd_hip_seeds_download": (_i, [_p, _i, _p]),
     "rmd_hip_seeds_upload": (_i, [_p, _i, _p]),
     "rmd_hip_seeds_plane": (_i, [_p, _i, _pp]),

@@ -251,6 +251,31 @@ class ImageReducer:
         return int(out.value)
 
 
+class PinnedFrames:
+    """count frames of height x width bytes in ONE block of pinned host memory (rmd_hip_host_alloc): .frames[i] are numpy views a producer writes
+    into and SeedMatrix.updateU8Pinned reads from without a copy"""
+
+    def __init__(self, count, height, width):
+        self.ptr = ctypes.c_void_p()
+        self.nbytes = int(count) * int(height) * int(width)
+        check(_lib.lib().rmd_hip_host_alloc(ctypes.byref(self.ptr), self.nbytes))
+        buf = (ctypes.c_ubyte * self.nbytes).from_address(self.ptr.value)
+        self.block = np.frombuffer(buf, np.uint8).reshape(count, height, width)
+        self.frames = [self.block[i] for i in range(count)]
+
+    def close(self):
+        if self.ptr:
+            self.frames, self.block = [], None
+            _lib.lib().rmd_hip_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class SeedMatrix:
     def __init__(self, width, height, cam, patch_side=5, max_extent=100, _member_of=None, _ptr=None):
         self.width, self.height, self.patch_side = int(width), int(height), int(patch_side)
@@ -310,6 +335,21 @@ class SeedMatrix:
         T = _as_pose(T_curr_world)
         check(_lib.lib().rmd_hip_seeds_update_u8(self.ptr, _ptr(img), _ptr(T)))
         return True
+
+    def updateU8Pinned(self, pinned_gray_u8, T_curr_world):
+        """rmd_hip_seeds_update_u8_pinned: an 8-bit frame the caller KEEPS in pinned host memory (a view of a PinnedFrames block) is read by the copy
+        engine where it lies; it must stay unchanged until pinnedFramesDone() has reached the ticket this returns"""
+        img = pinned_gray_u8
+        assert img.dtype == np.uint8 and img.shape == (self.height, self.width) and img.flags["C_CONTIGUOUS"]
+        T = _as_pose(T_curr_world)
+        ticket = ctypes.c_ulonglong()
+        check(_lib.lib().rmd_hip_seeds_update_u8_pinned(self.ptr, img.ctypes.data, _ptr(T), ctypes.byref(ticket)))
+        return int(ticket.value)
+
+    def pinnedFramesDone(self):
+        out = ctypes.c_ulonglong()
+        check(_lib.lib().rmd_hip_seeds_pinned_frames_done(self.ptr, ctypes.byref(out)))
+        return int(out.value)
 
     def setReferenceImageDevice(self, dev_ptr, stride_elems, T_curr_world, min_depth, max_depth):
         T = _as_pose(T_curr_world)

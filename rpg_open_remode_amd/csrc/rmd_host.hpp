@@ -306,6 +306,11 @@ struct rmd_hip_seeds {
   int engine_route = 0;
   uint64_t sig_frame[8] = {}, sig_flag[8] = {};  // [RING_MAX]
   unsigned long staged_by_engines = 0, staged_by_stream = 0;  // diagnostics (RMD_HIP_INGEST_PROFILE)
+  // frames the caller keeps in pinned memory (rmd_hip_seeds_update_u8_pinned): the next frame is one (set by the entry point, taken by
+  // ingest_current_fused), tickets issued, and per ring slot the ticket of the caller's frame an engine may still be reading (0: none)
+  bool next_frame_pinned = false;
+  unsigned long long pinned_issued = 0, slot_ticket[8] = {};
+  CopyEngines* engines_used = nullptr;  // = engines, kept when those are given up: the signals are still waited for
   void* cur_planes[SLOTS] = {};             // current-image planes (pitch of planes[CURR_IMG]), used in rotation; [0] is the handle's own
   int u8_pitch = 0, ingest_slot = 0;
   // fused ingest (tile pipeline): the caller's frame is copied into one of SLOTS pinned buffers, a copy engine moves it to a staging buffer

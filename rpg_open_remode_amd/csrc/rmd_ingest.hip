@@ -104,6 +104,7 @@ int ingest_init(rmd_hip_seeds* s) {
   s->engine_route = s->batch ? 0 : T.v[RMD_HIP_TUNE_COPY_ENGINES];
   if (s->engine_route < 0) s->engine_route = static_cast<long long>(s->width) * s->height >= 1500000ll ? 3 : 2;
   if (s->engine_route > 0 && (s->engines = CopyEngines::for_device(s->device, s->engine_route)) != nullptr) {
+    s->engines_used = s->engines;
     for (int q = 0; q < rmd_hip_seeds::RING_MAX; ++q) {
       s->sig_frame[q] = s->engines->create_signal();
       s->sig_flag[q] = s->engines->create_signal();
@@ -314,11 +315,15 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
   }
   const bool as_u8 = host_gray != nullptr || packed;
   const bool remap = host_gray != nullptr && s->d_undist_map1 != nullptr;
+  // a frame the caller keeps in pinned memory: the engine reads it where it lies (rmd_hip_seeds_update_u8_pinned)
+  const bool from_caller = s->next_frame_pinned && host_gray && !remap && s->engines && s->u8_pitch == s->width && !frame_in_place(false,
+      remap);
+  s->next_frame_pinned = false;
   in.no_remap = packed;
   if (as_u8) {
     const size_t bytes = static_cast<size_t>(s->u8_pitch) * s->height;
     TRY(ensure_u8_ring());
-    if (packed) {
+    if (packed || from_caller) {
     } else if (s->u8_pitch == s->width) host_copy(s->h_zc_u8[k], host_gray, bytes);
     else
       for (int y = 0; y < s->height; ++y)
@@ -329,7 +334,8 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
       HIP_TRY(hipHostGetDevicePointer(&dev, s->h_zc_u8[k], 0));
       in.u8 = static_cast<const unsigned int*>(dev);
     } else {
-      stage_src = s->h_zc_u8[k]; stage_dst = s->d_zc_u8[k]; stage_bytes = bytes;
+      stage_src = from_caller ? const_cast<unsigned char*>(host_gray) : s->h_zc_u8[k];
+      stage_dst = s->d_zc_u8[k]; stage_bytes = bytes;
       in.u8 = reinterpret_cast<const unsigned int*>(s->d_zc_u8[k]);
     }
     in.common.kind = 1;
@@ -370,11 +376,13 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
       if (!s->engines->wait_idle(s->sig_frame[k], 2e6) || !s->engines->wait_idle(s->sig_flag[k], 2e6))
         return fail(RMD_HIP_ERR_RUNTIME, "a copy engine has not completed ring slot %d's previous frame after 2 s", k);
       s->h_seq[k * FLAG_SLOT_WORDS] = n;
+      if (!from_caller) s->slot_ticket[k] = 0ull;  // (whatever frame of the caller's the slot stood for has been read: its signal is idle)
       // frames rotate over engine_route engines (1..4); a frame's flag is the next command of its own engine
       const unsigned de = static_cast<unsigned>(n64 % static_cast<unsigned long long>(s->engine_route)), fe = de;
       sent = s->engines->submit(de, fe, stage_dst, stage_src, stage_bytes,
                                 s->sig_frame[k], withhold ? nullptr : slot_flag, s->h_seq + k * FLAG_SLOT_WORDS, sizeof(unsigned int),
                                 s->sig_flag[k]);
+      if (sent && from_caller) s->slot_ticket[k] = s->pinned_issued;  // (the entry point has counted this frame already)
       if (!sent) {  // refused: this frame and every later one take the copy stream
         if (s->ingest_profile) fprintf(stderr, "[rmd_hip ingest] copy engines given up: %s\n", s->engines->last_error());
         s->engines = nullptr;
@@ -390,6 +398,7 @@ static int ingest_current_fused(rmd_hip_seeds* s, const unsigned char* host_gray
       fill_flag_block(s->h_seq + k * FLAG_SLOT_WORDS, n, fw);
       if (!withhold)
         HIP_TRY(hipMemcpyAsync(slot_flag, s->h_seq + k * FLAG_SLOT_WORDS, fw * sizeof(unsigned int), hipMemcpyHostToDevice, cs));
+      if (from_caller) HIP_TRY(hipStreamSynchronize(cs));  // (the engines were given up on this very frame: its ticket is done on return)
     }
     in.common.flag = slot_flag;
   }
@@ -495,6 +504,50 @@ int rmd_hip_seeds_set_reference_u8(rmd_hip_seeds_t* s, const unsigned char* host
   if (!s || !host_gray || !T_curr_world) return fail(RMD_HIP_ERR_INVALID_ARG, "set_reference_u8: null argument");
   TRY(seeds_bind_device(s));
   return ingest_reference(s, host_gray, nullptr, T_curr_world, min_depth, max_depth);
+}
+
+int rmd_hip_host_alloc(void** ptr, size_t bytes) {
+  if (!ptr || !bytes) return fail(RMD_HIP_ERR_INVALID_ARG, "host_alloc: null argument");
+  HIP_TRY(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_host_free(void* ptr) {
+  if (ptr) HIP_TRY(hipHostFree(ptr));
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_seeds_pinned_frames_done(rmd_hip_seeds_t* s, unsigned long long* ticket_done) {
+  if (!s || !ticket_done) return fail(RMD_HIP_ERR_INVALID_ARG, "pinned_frames_done: null argument");
+  unsigned long long done = s->pinned_issued;
+  for (int k = 0; k < rmd_hip_seeds::RING_MAX; ++k) {
+    const unsigned long long t = s->slot_ticket[k];
+    if (!t) continue;
+    if (s->engines_used && s->engines_used->idle(s->sig_frame[k])) s->slot_ticket[k] = 0ull;  // read: the caller may write the frame again
+    else if (t - 1ull < done) done = t - 1ull;
+  }
+  *ticket_done = done;
+  return RMD_HIP_OK;
+}
+
+int rmd_hip_seeds_update_u8_pinned(rmd_hip_seeds_t* s, const unsigned char* pinned_gray, const float* T_curr_world,
+                                   unsigned long long* ticket) {
+  if (!s || !pinned_gray || !T_curr_world) return fail(RMD_HIP_ERR_INVALID_ARG, "update_u8_pinned: null argument");
+  if (s->batch) return fail(RMD_HIP_ERR_INVALID_ARG,
+      "update_u8_pinned: this SeedMatrix is a member of a batch; its updates are issued with rmd_hip_batch_update*");
+  if (!s->has_reference) return fail(RMD_HIP_ERR_NOT_READY, "update_u8_pinned: setReferenceImage has not been called");
+  TRY(seeds_bind_device(s));
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, pinned_gray) != hipSuccess || attr.type != hipMemoryTypeHost) {
+    (void)hipGetLastError();
+    return fail(RMD_HIP_ERR_INVALID_ARG, "update_u8_pinned: the frame is not in pinned host memory (rmd_hip_host_alloc, hipHostMalloc)");
+  }
+  ++s->pinned_issued;
+  if (ticket) *ticket = s->pinned_issued;
+  s->next_frame_pinned = true;
+  const int rc = ingest_current(s, pinned_gray, nullptr, T_curr_world);
+  s->next_frame_pinned = false;  // (a path that copies the frame -- another matcher, lens undistortion -- never looks at it)
+  return rc;
 }
 
 int rmd_hip_seeds_update_u8(rmd_hip_seeds_t* s, const unsigned char* host_gray, const float* T_curr_world) {
