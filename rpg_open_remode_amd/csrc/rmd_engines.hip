@@ -103,7 +103,8 @@ bool CopyEngines::find_agents(int hip_device) {
   gpu_ = S.gpu.handle; cpu_ = S.cpu.handle;
   // (one process per GPU on a node of eight: an engine of the WRONG agent would write this device's memory from another one)
   if (tunables().v[RMD_HIP_TUNE_INGEST_PROFILE])
-    fprintf(stderr, "[rmd_hip ingest] copy engines of HIP device %d: the HSA agent at PCI %04x:%02x:%02x, %s (%d GPU agent%s in the process)\n",
+    fprintf(stderr,
+        "[rmd_hip ingest] copy engines of HIP device %d: the HSA agent at PCI %04x:%02x:%02x, %s (%d GPU agent%s in the process)\n",
             hip_device, domain, bus, dev, by_address ? "matched by address" : "the only GPU agent", S.n_gpus, S.n_gpus == 1 ? "" : "s");
   // The order frames rotate in: 0x1, 0x4, 0x2, 0x8 -- not 0x1, 0x2: two frames in flight with their flags behind them take 41 us per
   // 1920x1080 frame on 0x1 / 0x4 and 48 us on 0x1 / 0x2 (as on 0x4 / 0x8: neighbours share something; tools/link_probe.cpp, route G).
