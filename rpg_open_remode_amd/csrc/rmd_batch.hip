@@ -137,15 +137,8 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
       ++n_segs;
     }
   }
-  // The frames of the step go into the pinned block, spread over the copy threads.  STAGED frames are brought in by the copy engine and
-  // their setup kernels wait for the arrival flag themselves: nothing the host queues for the compute streams depends on the pinned block,
-  // so the step's launches are queued WHILE the helpers copy (the caller's share of the copy follows them) -- per step the host spends
-  // max(copy, launches) instead of their sum, which is what lets it stay a step or more ahead of the device on the light two thirds of a
-  // sequence (batch of 8: 50 + 30 us against a 100-us step).  Frames read IN PLACE must be complete before the kernels that read them
-  // start.
-  const bool overlap = !in_place && n_segs > 0;
-  if (n_segs && !overlap) CopyPool::instance().copy_many(segs, n_segs, frame_bytes);
-  if (overlap) CopyPool::instance().begin_copy_many(segs, n_segs, frame_bytes);
+  // The frames of the step go into the pinned block, spread over the copy threads.
+  if (n_segs) CopyPool::instance().copy_many(segs, n_segs, frame_bytes);
   const double t_c = b->ingest_profile ? host_now_us() : 0.0;
   const unsigned char* frames_dev = b->d_stage[k];
   rmdk::IngestArgs in;
@@ -179,9 +172,12 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
     rmd_hip_batch::Group& G = b->groups[g];
     if ((active >> G.first) & ((1u << G.n) - 1u)) { G.slot_step[k] = n64; G.last_step = n64; }
   }
-  const int rc = batch_launch(b, active, &in, frames_dev, frame_bytes);
-  if (overlap) CopyPool::instance().finish_copy_many();  // (also after a failed launch: the pool must be released)
-  if (rc == RMD_HIP_OK && !in_place) {
+  // A staged step's copy is handed to the engine BEFORE its kernels are launched, never after: a setup kernel that is running waits
+  // (bounded: 0.13 s) for the arrival flag, and a host thread between "launched" and "copy submitted" can be held up for as long as ANOTHER
+  // thread of the process sits in a runtime call that waits for the device to drain (hipFree, hipMalloc ...) -- which the spinning kernel
+  // keeps from draining.  (Until the end of round 6 the launches were queued while the helper threads copied, to save the host 25 us per
+  // step: four handles on four threads, one of them a batch, timed out in every second run.)
+  if (!in_place) {
     const size_t off = static_cast<size_t>(first) * frame_bytes, len = static_cast<size_t>(last - first + 1) * frame_bytes;
     bool sent = false;
     if (deep) {
@@ -200,6 +196,7 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
       if (deep) HIP_TRY(hipStreamSynchronize(b->copy_stream));
     }
   }
+  const int rc = batch_launch(b, active, &in, frames_dev, frame_bytes);
   if (b->ingest_profile) {
     const double t_d = host_now_us();
     b->ingest_us[0] += t_b - t_a; b->ingest_us[1] += t_c - t_b; b->ingest_us[2] += t_d - t_c; b->ingest_us[3] += 1.0;

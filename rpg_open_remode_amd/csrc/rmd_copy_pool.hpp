@@ -62,25 +62,6 @@ class CopyPool {
     wait();
     segs_ = nullptr; n_segs_ = 0;
   }
-  // The same in two halves, so that the caller can do something else while the helpers copy (rmd_batch.hip queues a step's kernel launches
-  // in between): begin_copy_many wakes the helpers and returns; finish_copy_many copies the caller's share and waits for theirs.  `segs`
-  // must stay valid in between; every begin is followed by exactly one finish on the same thread (the pool is held in between).
-  void begin_copy_many(const Segment* segs, int n, size_t bytes) {
-    call_mutex_.lock();
-    split_ = n_workers_ != 0 && n > 1 && bytes * static_cast<size_t>(n) >= kMinBytes;
-    segs_ = segs; n_segs_ = n; bytes_ = bytes;
-    if (split_) post();
-  }
-  void finish_copy_many() {
-    if (split_) {
-      for (int i = n_workers_; i < n_segs_; i += n_workers_ + 1) memcpy(segs_[i].dst, segs_[i].src, bytes_);  // the caller's share
-      wait();
-    } else {
-      for (int i = 0; i < n_segs_; ++i) memcpy(segs_[i].dst, segs_[i].src, bytes_);
-    }
-    segs_ = nullptr; n_segs_ = 0;
-    call_mutex_.unlock();
-  }
   // pack_float_rows_u8 over the rows of one frame, split over the participants; true if every row was accepted
   bool pack(const float* src, unsigned char* dst, int w, int h, int pitch) {
     // an image of other floats is turned down before anybody is woken
@@ -194,7 +175,6 @@ class CopyPool {
   const float* pack_src_ = nullptr; unsigned char* pack_dst_ = nullptr;
   int pack_w_ = 0, pack_h_ = 0, pack_pitch_ = 0, pack_rows_ = 0, pack_ok_ = 1;
   int pending_ = 0;
-  bool split_ = false;
 };
 // (A/B: RMD_HIP_TUNE_FLOAT_AS_BYTES = 0 sends every float frame as floats)
 inline bool float_frames_as_bytes() { return tunables().v[RMD_HIP_TUNE_FLOAT_AS_BYTES] != 0; }
