@@ -88,7 +88,8 @@ typedef struct rmd_hip_batch rmd_hip_batch_t;
 #define RMD_HIP_TUNE_AHEAD_WGS 2      /* workgroups that convert a host frame one step ahead (128) */
 #define RMD_HIP_TUNE_PACK_BACKOFF 3   /* after a float frame that is not made of 8-bit levels the next n frames are not examined (15; tests use 0) */
 #define RMD_HIP_TUNE_FLOAT_AS_BYTES 4 /* 1 (default): float frames of 8-bit levels travel as bytes; 0: always as floats */
-#define RMD_HIP_TUNE_COPY_THREADS 5   /* host threads that copy a large frame into the pinned ring, 1..16 (4); read when the first large frame arrives */
+#define RMD_HIP_TUNE_COPY_THREADS 5   /* host threads that examine a large float frame / copy the frames of a batch step into the pinned ring, 1..16 (4); one
+                                         large frame is copied by two threads whatever this says (by one if it is 1); read when the first large frame arrives */
 #define RMD_HIP_TUNE_FUSED_INGEST 6   /* 1 (default): host frames are converted by the update's own kernels; 0: upload + conversion kernel on the copy stream */
 #define RMD_HIP_TUNE_INGEST_PROFILE 7 /* 1: a handle prints the host time per frame it spent waiting / copying / submitting when it is destroyed */
 #define RMD_HIP_TUNE_HOST_WAIT 8      /* how update() waits for a free slot of its pinned frame ring (the device is up to three frames behind the caller): 1

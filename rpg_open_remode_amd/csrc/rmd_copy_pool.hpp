@@ -43,14 +43,23 @@ RMD_HOST_SIMD_CLONES static bool pack_float_rows_u8(const float* src, unsigned c
 
 class CopyPool {
  public:
+  // the pool (RMD_HIP_TUNE_COPY_THREADS participants): examination of float frames (pack) and the frames of a batch step (copy_many)
   static CopyPool& instance() {
-    static CopyPool pool;
+    static CopyPool pool(tunables().v[RMD_HIP_TUNE_COPY_THREADS] - 1);
+    return pool;
+  }
+  // ... and a pool of ONE helper for the plain copy of one frame (copy): that is bound by waking the helpers, not by bandwidth --
+  // 1920x1080 (2 MB per 60 us) with two participants 31 900-33 300 Mpix/s at 1.1 host cores, with four 29 700-31 000 at 2.0, with eight
+  // 28 900-31 100 at 3.1-3.7, and one alone (73 us per frame) cannot keep up -- whereas the examination is arithmetic and wants them all
+  // (1280x960 float frames: 11 300-12 300 Mpix/s with four, 9 060 with two).
+  static CopyPool& pair() {
+    static CopyPool pool(tunables().v[RMD_HIP_TUNE_COPY_THREADS] > 1 ? 1 : 0);
     return pool;
   }
   struct Segment { void* dst; const void* src; };
   // several buffers of `bytes` each (the frames of one batch step): the participants take whole buffers in turn
   void copy_many(const Segment* segs, int n, size_t bytes) {
-    if (n == 1) { copy(segs[0].dst, segs[0].src, bytes); return; }
+    if (n == 1) { pair().copy(segs[0].dst, segs[0].src, bytes); return; }
     if (n_workers_ == 0 || bytes * static_cast<size_t>(n) < kMinBytes) {
       for (int i = 0; i < n; ++i) memcpy(segs[i].dst, segs[i].src, bytes);
       return;
@@ -113,8 +122,7 @@ class CopyPool {
   // the copy of a float frame three times faster, but four busy threads per stream ran the process into its container's CPU quota on
   // the measurement box: one run in four lost 50 - 70 ms to a throttled thread (RMD_HIP_INGEST_PROFILE: "longest wait 58945 us").
   static constexpr double kPollUs = 0.0;
-  CopyPool() {
-    int n = tunables().v[RMD_HIP_TUNE_COPY_THREADS] - 1;  // (read when the pool is created: at the first large host frame)
+  explicit CopyPool(int n) {  // n helpers (the tunable is read when a pool is created: at the first large host frame)
     const unsigned hw = std::thread::hardware_concurrency();
     if (hw != 0 && static_cast<unsigned>(n + 1) > hw) n = static_cast<int>(hw) - 1;
     if (n < 0) n = 0;
@@ -178,7 +186,7 @@ class CopyPool {
 };
 // (A/B: RMD_HIP_TUNE_FLOAT_AS_BYTES = 0 sends every float frame as floats)
 inline bool float_frames_as_bytes() { return tunables().v[RMD_HIP_TUNE_FLOAT_AS_BYTES] != 0; }
-inline void host_copy(void* dst, const void* src, size_t bytes) { CopyPool::instance().copy(dst, src, bytes); }
+inline void host_copy(void* dst, const void* src, size_t bytes) { CopyPool::pair().copy(dst, src, bytes); }
 }  // namespace rmdh
 
 #endif  // RMD_COPY_POOL_HPP
