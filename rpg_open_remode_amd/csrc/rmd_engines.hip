@@ -184,9 +184,8 @@ bool CopyEngines::submit(unsigned data_engine, unsigned flag_engine, void* dst, 
   const unsigned de = engine_[data_engine % n_ready], fe = engine_[flag_engine % n_ready];
   const hsa_signal_t fs = as_signal(frame_sig);
   hsa_signal_store_relaxed(fs, 1);
-  hsa_status_t st = hsa_amd_memory_async_copy_on_engine(dst, gpu, src, cpu, bytes, 0, nullptr, fs,
-      static_cast<hsa_amd_sdma_engine_id_t>(de),
-                                                        false);
+  hsa_status_t st =
+      hsa_amd_memory_async_copy_on_engine(dst, gpu, src, cpu, bytes, 0, nullptr, fs, static_cast<hsa_amd_sdma_engine_id_t>(de), false);
   if (st != HSA_STATUS_SUCCESS) {
     hsa_signal_store_relaxed(fs, 0);
     snprintf(tl_submit_error, sizeof tl_submit_error, "hsa_amd_memory_async_copy_on_engine (frame, engine 0x%x): %s", de, status_text(st));
@@ -196,8 +195,8 @@ bool CopyEngines::submit(unsigned data_engine, unsigned flag_engine, void* dst, 
   const hsa_signal_t gs = as_signal(flag_sig);
   hsa_signal_store_relaxed(gs, 1);
   // (the dependency is named on the frame's own engine as well: its queue is served in order, the engine finds the signal at zero)
-  st = hsa_amd_memory_async_copy_on_engine(flag_dst, gpu, flag_src, cpu, flag_bytes, 1, &fs, gs, static_cast<hsa_amd_sdma_engine_id_t>(fe),
-                                           false);
+  st = hsa_amd_memory_async_copy_on_engine(flag_dst, gpu, flag_src, cpu, flag_bytes, 1, &fs, gs,
+                                           static_cast<hsa_amd_sdma_engine_id_t>(fe), false);
   if (st != HSA_STATUS_SUCCESS) {
     hsa_signal_store_relaxed(gs, 0);
     snprintf(tl_submit_error, sizeof tl_submit_error, "hsa_amd_memory_async_copy_on_engine (flag, engine 0x%x): %s", fe, status_text(st));
