@@ -82,7 +82,7 @@ typedef struct rmd_hip_batch rmd_hip_batch_t;
                                          buffer in HBM), 1 staged_ahead (... and the frame is converted during the previous update's search kernel), 2 inplace
                                          (the kernels read the pinned ring themselves), 3 inplace_ahead; -1 (default) = staged for a SeedMatrix (staged_ahead
                                          when RMD_HIP_TUNE_COPY_ENGINES is 0); a batch: staged (on one copy engine, eight staging buffers deep) while a step
-                                         is at most 3 MB and the engines can be addressed, else inplace; frames with lens undistortion are always staged.
+                                         is at most 5 MB and the engines can be addressed, else inplace; frames with lens undistortion are always staged.
                                          Environment: the names or the numbers */
 #define RMD_HIP_TUNE_BATCH_GROUPS 1   /* stream groups of a batch, 1..4; 0 (default) = min(n, 3) */
 #define RMD_HIP_TUNE_AHEAD_WGS 2      /* workgroups that convert a host frame one step ahead (128) */

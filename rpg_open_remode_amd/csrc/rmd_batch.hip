@@ -51,15 +51,15 @@ int batch_update_host(rmd_hip_batch* b, const unsigned char* const* gray, const 
     ++n_active;
     any_maps = any_maps || (gray && b->members[i]->d_undist_map1);
   }
-  // In place or staged?  What RMD_HIP_TUNE_HOST_FRAMES says; left alone (-1): staged on the engine while a step is at most 3 MB (eight
-  // 640x480 frames: 16 180-16 380 against 14 980-15 020 Mpix/s in place, four: 14 780-14 990 against 13 100-13 570; sixteen: 15 150-15 190
-  // against 15 630-16 070 -- 4.9 MB are 180 us on one engine and 80 us of memcpy in front of it), else in place.  Frames that go through
-  // the lens-undistortion maps are always staged (the remap gathers single bytes).
+  // In place or staged?  What RMD_HIP_TUNE_HOST_FRAMES says; left alone (-1): staged on the engine while a step is at most 5 MB (sixteen
+  // 640x480 frames; Mpix/s staged against in place: 2 frames 12 140-12 200 / 11 040-11 070, 4: 14 890-15 080 / 13 370-13 440, 8: 16 220-
+  // 16 630 / 15 510-15 540, 12: 16 400 / 14 770-16 080, 16: 15 920-16 290 / 15 610-16 150), else in place.  Frames that go through the
+  // lens-undistortion maps are always staged (the remap gathers single bytes).
   const bool in_place = [&] {
     if (any_maps) return false;
     const int forced = tunables().v[RMD_HIP_TUNE_HOST_FRAMES];
     if (forced != HOST_FRAMES_DEFAULT) return forced == HOST_FRAMES_INPLACE || forced == HOST_FRAMES_INPLACE_AHEAD;
-    return !(b->engines && static_cast<size_t>(n_active) * (gray ? bytes_u8 : frame_bytes) <= (size_t(3) << 20));
+    return !(b->engines && static_cast<size_t>(n_active) * (gray ? bytes_u8 : frame_bytes) <= (size_t(5) << 20));
   }();
   const bool deep = b->engines != nullptr && !in_place;
   const int kp = static_cast<int>(n64 % static_cast<unsigned long long>(b->slots));

@@ -189,7 +189,7 @@ struct rmd_hip_image {
 // and staged + ahead where its frames travel on the copy stream (RMD_HIP_TUNE_COPY_ENGINES = 0; profiles/r03_h2d.txt) -- the copy engines
 // do not touch the CUs, whereas link reads issued by a CU delay the loads of the workgroups it shares its memory pipeline with (in place +
 // ahead: search +4.5 us per update).  A batch (rmd_batch.hip decides per step) is staged on one engine, eight staging buffers deep, while a
-// step is at most 3 MB, and read in place beyond that or without the engines -- its setup kernels are long enough to hide most of the link
+// step is at most 5 MB, and read in place beyond that or without the engines -- its setup kernels are long enough to hide most of the link
 // time.  Frames that go through the lens-undistortion maps are always staged, without ahead (the remap gathers single bytes). A/B:
 // RMD_HIP_TUNE_HOST_FRAMES.
 enum { HOST_FRAMES_DEFAULT = -1, HOST_FRAMES_STAGED = 0, HOST_FRAMES_STAGED_AHEAD = 1, HOST_FRAMES_INPLACE = 2,
