@@ -103,6 +103,9 @@ int ingest_init(rmd_hip_seeds* s) {
   // share a device: profiles/r06_ab_copy_engines.txt)
   s->engine_route = s->batch ? 0 : T.v[RMD_HIP_TUNE_COPY_ENGINES];
   if (s->engine_route < 0) s->engine_route = static_cast<long long>(s->width) * s->height >= 1500000ll ? 3 : 2;
+  // (an engine beyond the first that refuses its first copy -- a node whose runtime keeps it for something else -- leaves the handle with
+  // the engines that work: one engine is still a frame and its flag without a second command's fixed cost on hipMemcpyAsync's engine)
+  while (s->engine_route > 1 && CopyEngines::for_device(s->device, s->engine_route) == nullptr) --s->engine_route;
   if (s->engine_route > 0 && (s->engines = CopyEngines::for_device(s->device, s->engine_route)) != nullptr) {
     s->engines_used = s->engines;
     for (int q = 0; q < rmd_hip_seeds::RING_MAX; ++q) {
