@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: copy-engine routes 0 / 2 / 3 (RMD_HIP_COPY_ENGINES) -- tests, probe, rates per size, batches staged on an engine against in place, and the 8-rank rehearsal per route.
+# GPU box: copy engines in rotation (RMD_HIP_COPY_ENGINES = 2 / 3 / 4; writes gpurun_out/r06_x) -- host-frame tests, probe, rates per size and route, the 8-rank rehearsal per route (incl. 0).
 set -u
 export TMPDIR=/tmp
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/r06_x; mkdir -p $OUT/nranks
