@@ -15,7 +15,7 @@ import sys, numpy as np
 sys.path.insert(0, sys.argv[1])
 from rpg_open_remode_amd import api, synth
 from rpg_open_remode_amd._lib import RmdHipError
-w, h, side, n = 320, 240, 7, 14
+w, h, side, n = int(sys.argv[3]), int(sys.argv[4]), 7, 14
 seq = synth.Sequence(w, h, n, 0)
 cam = api.PinholeCamera(*seq.K)
 def bits(st): return [np.ascontiguousarray(st[p]).view(np.uint32).copy() for p in sorted(st)]
@@ -62,10 +62,11 @@ print("PINNED-OK")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env_extra, how", [({}, "direct"), ({"RMD_HIP_COPY_ENGINES": "0"}, "copied"), ({"RMD_HIP_HOST_FRAMES": "inplace"}, "copied"),
-                                            ({"RMD_HIP_COPY_ENGINES": "1"}, "direct")])
-def test_frames_kept_in_pinned_memory(env_extra, how):
+@pytest.mark.parametrize("env_extra, how, size", [({}, "direct", (320, 240)), ({"RMD_HIP_COPY_ENGINES": "0"}, "copied", (320, 240)),
+                                                  ({"RMD_HIP_HOST_FRAMES": "inplace"}, "copied", (320, 240)), ({"RMD_HIP_COPY_ENGINES": "1"}, "direct", (320, 240)),
+                                                  ({}, "copied", (322, 242))])  # (rows that are no multiple of 4 bytes: the ring's rows are padded, the frame is copied row by row)
+def test_frames_kept_in_pinned_memory(env_extra, how, size):
     env = {k: v for k, v in os.environ.items() if not k.startswith("RMD_HIP_") or k == "RMD_HIP_LIB"}
     env.update(env_extra)
-    res = subprocess.run([sys.executable, "-c", CHILD, ROOT, how], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    res = subprocess.run([sys.executable, "-c", CHILD, ROOT, how, str(size[0]), str(size[1])], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert res.returncode == 0 and "PINNED-OK" in res.stdout, res.stdout[-2500:]
