@@ -41,6 +41,38 @@ RMD_HOST_SIMD_CLONES static bool pack_float_rows_u8(const float* src, unsigned c
   return true;
 }
 
+// A frame's way into a pinned buffer that a copy engine reads next: streaming stores.  memcpy's ordinary stores first READ every line of
+// the destination into the cache (write-allocate) and leave the frame there for the engine to snoop out again; 32-byte non-temporal stores
+// write it to memory once (glibc switches to them only above ~3/4 of the shared cache, tens of megabytes).  For the large copies only (1 MB
+// and more per frame or batch step: 1920x1080 27 400-28 400 -> 28 800-32 900 Mpix/s, a batch of 16 16 250-16 330 -> 16 450-16 510): a 307-KB
+// frame that is read by the engine microseconds later is better left in the cache (640x480: 9.5-10.4 us per copy against 11.5 streamed).
+// `dst` 32-byte aligned (pinned buffers are page-aligned, the pool's chunks multiples of 4 KB), else memcpy.
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+typedef long long rmd_v4di __attribute__((vector_size(32), aligned(32)));
+typedef long long rmd_v4di_u __attribute__((vector_size(32), aligned(1)));
+__attribute__((target("avx2"))) static void frame_copy_avx2(char* dst, const char* src, size_t n) {
+  size_t i = 0;
+  for (; i + 128 <= n; i += 128) {
+    const rmd_v4di a = *reinterpret_cast<const rmd_v4di_u*>(src + i), b = *reinterpret_cast<const rmd_v4di_u*>(src + i + 32);
+    const rmd_v4di c = *reinterpret_cast<const rmd_v4di_u*>(src + i + 64), d = *reinterpret_cast<const rmd_v4di_u*>(src + i + 96);
+    __builtin_nontemporal_store(a, reinterpret_cast<rmd_v4di*>(dst + i));
+    __builtin_nontemporal_store(b, reinterpret_cast<rmd_v4di*>(dst + i + 32));
+    __builtin_nontemporal_store(c, reinterpret_cast<rmd_v4di*>(dst + i + 64));
+    __builtin_nontemporal_store(d, reinterpret_cast<rmd_v4di*>(dst + i + 96));
+  }
+  for (; i + 32 <= n; i += 32) __builtin_nontemporal_store(*reinterpret_cast<const rmd_v4di_u*>(src + i), reinterpret_cast<rmd_v4di*>(dst + i));
+  if (i < n) memcpy(dst + i, src + i, n - i);
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);  // (the streamed lines are globally visible before the engine is told to read them)
+}
+inline void frame_copy(void* dst, const void* src, size_t n, bool stream) {
+  static const bool avx2 = __builtin_cpu_supports("avx2") != 0;
+  if (stream && avx2 && (reinterpret_cast<uintptr_t>(dst) & 31u) == 0) frame_copy_avx2(static_cast<char*>(dst), static_cast<const char*>(src), n);
+  else memcpy(dst, src, n);
+}
+#else
+inline void frame_copy(void* dst, const void* src, size_t n, bool) { memcpy(dst, src, n); }
+#endif
+
 class CopyPool {
  public:
   // the pool (RMD_HIP_TUNE_COPY_THREADS participants): examination of float frames (pack) and the frames of a batch step (copy_many)
@@ -61,13 +93,13 @@ class CopyPool {
   void copy_many(const Segment* segs, int n, size_t bytes) {
     if (n == 1) { pair().copy(segs[0].dst, segs[0].src, bytes); return; }
     if (n_workers_ == 0 || bytes * static_cast<size_t>(n) < kMinBytes) {
-      for (int i = 0; i < n; ++i) memcpy(segs[i].dst, segs[i].src, bytes);
+      for (int i = 0; i < n; ++i) frame_copy(segs[i].dst, segs[i].src, bytes, bytes * static_cast<size_t>(n) >= kMinBytes);
       return;
     }
     std::lock_guard<std::mutex> one_copy_at_a_time(call_mutex_);
     segs_ = segs; n_segs_ = n; bytes_ = bytes;
     post();
-    for (int i = n_workers_; i < n; i += n_workers_ + 1) memcpy(segs[i].dst, segs[i].src, bytes);  // the caller's share
+    for (int i = n_workers_; i < n; i += n_workers_ + 1) frame_copy(segs[i].dst, segs[i].src, bytes, true);  // the caller's share
     wait();
     segs_ = nullptr; n_segs_ = 0;
   }
@@ -90,7 +122,7 @@ class CopyPool {
   void copy(void* dst, const void* src, size_t bytes) {
     const int parts = n_workers_ + 1;
     if (n_workers_ == 0 || bytes < kMinBytes) {
-      memcpy(dst, src, bytes);
+      frame_copy(dst, src, bytes, bytes >= kMinBytes);
       return;
     }
     std::lock_guard<std::mutex> one_copy_at_a_time(call_mutex_);
@@ -98,7 +130,7 @@ class CopyPool {
     dst_ = static_cast<char*>(dst); src_ = static_cast<const char*>(src); bytes_ = bytes; chunk_ = chunk;
     post();
     const size_t mine = static_cast<size_t>(n_workers_) * chunk;  // the caller takes the last part
-    if (mine < bytes) memcpy(dst_ + mine, src_ + mine, bytes - mine);
+    if (mine < bytes) frame_copy(dst_ + mine, src_ + mine, bytes - mine, true);
     wait();
   }
 
@@ -161,10 +193,10 @@ class CopyPool {
         if (y0 < y1 && !pack_float_rows_u8(pack_src_, pack_dst_, pack_w_, pack_pitch_, y0, y1)) __atomic_store_n(&pack_ok_, 0,
             __ATOMIC_RELAXED);
       } else if (segs_) {
-        for (int i = index; i < n_segs_; i += n_workers_ + 1) memcpy(segs_[i].dst, segs_[i].src, bytes_);
+        for (int i = index; i < n_segs_; i += n_workers_ + 1) frame_copy(segs_[i].dst, segs_[i].src, bytes_, true);
       } else {
         const size_t off = static_cast<size_t>(index) * chunk_;
-        if (off < bytes_) memcpy(dst_ + off, src_ + off, bytes_ - off < chunk_ ? bytes_ - off : chunk_);
+        if (off < bytes_) frame_copy(dst_ + off, src_ + off, bytes_ - off < chunk_ ? bytes_ - off : chunk_, true);
       }
       __atomic_fetch_sub(&pending_, 1, __ATOMIC_RELEASE);
     }
