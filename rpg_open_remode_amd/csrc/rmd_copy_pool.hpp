@@ -44,9 +44,9 @@ RMD_HOST_SIMD_CLONES static bool pack_float_rows_u8(const float* src, unsigned c
 // A frame's way into a pinned buffer that a copy engine reads next: streaming stores.  memcpy's ordinary stores first READ every line of
 // the destination into the cache (write-allocate) and leave the frame there for the engine to snoop out again; 32-byte non-temporal stores
 // write it to memory once (glibc switches to them only above ~3/4 of the shared cache, tens of megabytes).  For the large copies only (1 MB
-// and more per frame or batch step: 1920x1080 27 400-28 400 -> 28 800-32 900 Mpix/s, a batch of 16 16 250-16 330 -> 16 450-16 510): a 307-KB
-// frame that is read by the engine microseconds later is better left in the cache (640x480: 9.5-10.4 us per copy against 11.5 streamed).
-// `dst` 32-byte aligned (pinned buffers are page-aligned, the pool's chunks multiples of 4 KB), else memcpy.
+// and more per frame or batch step: 1920x1080 27 400-28 400 -> 28 800-32 900 Mpix/s, a batch of 16 16 250-16 330 -> 16 450-16 510): a
+// 307-KB frame that is read by the engine microseconds later is better left in the cache (640x480: 9.5-10.4 us per copy against 11.5
+// streamed). `dst` 32-byte aligned (pinned buffers are page-aligned, the pool's chunks multiples of 4 KB), else memcpy.
 #if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
 typedef long long rmd_v4di __attribute__((vector_size(32), aligned(32)));
 typedef long long rmd_v4di_u __attribute__((vector_size(32), aligned(1)));
@@ -60,14 +60,19 @@ __attribute__((target("avx2"))) static void frame_copy_avx2(char* dst, const cha
     __builtin_nontemporal_store(c, reinterpret_cast<rmd_v4di*>(dst + i + 64));
     __builtin_nontemporal_store(d, reinterpret_cast<rmd_v4di*>(dst + i + 96));
   }
-  for (; i + 32 <= n; i += 32) __builtin_nontemporal_store(*reinterpret_cast<const rmd_v4di_u*>(src + i), reinterpret_cast<rmd_v4di*>(dst + i));
+  for (; i + 32 <= n; i += 32) {
+    const rmd_v4di a = *reinterpret_cast<const rmd_v4di_u*>(src + i);
+    __builtin_nontemporal_store(a, reinterpret_cast<rmd_v4di*>(dst + i));
+  }
   if (i < n) memcpy(dst + i, src + i, n - i);
   __atomic_thread_fence(__ATOMIC_SEQ_CST);  // (the streamed lines are globally visible before the engine is told to read them)
 }
 inline void frame_copy(void* dst, const void* src, size_t n, bool stream) {
   static const bool avx2 = __builtin_cpu_supports("avx2") != 0;
-  if (stream && avx2 && (reinterpret_cast<uintptr_t>(dst) & 31u) == 0) frame_copy_avx2(static_cast<char*>(dst), static_cast<const char*>(src), n);
-  else memcpy(dst, src, n);
+  if (stream && avx2 && (reinterpret_cast<uintptr_t>(dst) & 31u) == 0)
+    frame_copy_avx2(static_cast<char*>(dst), static_cast<const char*>(src), n);
+  else
+    memcpy(dst, src, n);
 }
 #else
 inline void frame_copy(void* dst, const void* src, size_t n, bool) { memcpy(dst, src, n); }
